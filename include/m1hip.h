@@ -1,0 +1,192 @@
+/* m1hip.h -- C ABI of the MI355X-native M1 hot path (libm1hip.so, gfx950 only).
+ *
+ * The reference (DIAGNijmegen/prostateMR_3D-CAD-csPCa, tf2.5/) owns NO native code: every op below is,
+ * in the reference, a call into a TensorFlow / TF-Addons / TF-Probability layer.  Each entry point
+ * cites the reference call site(s) whose arithmetic it replaces, relative to
+ * tf2.5/scripts/model/unets/  (N: = networks.py, B: = network_blocks.py).
+ *
+ * Conventions
+ *   - plain pointers and sizes only; the caller (PyTorch, or any host) owns every buffer, including
+ *     workspaces; no allocation, no global mutable state (except the opt-in profiler), no hidden
+ *     synchronisation; every launch goes to the caller's hipStream_t (graph-capturable).
+ *   - activations are NDHWC, C-contiguous; `dtype` selects their storage type
+ *     (M1_F32 / M1_BF16); parameters, statistics, reductions and gradients of parameters are fp32.
+ *   - every function returns 0 on success or a negative m1_status.
+ *   - `void* stream` is a hipStream_t.
+ */
+#ifndef M1HIP_H
+#define M1HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum m1_dtype { M1_F32 = 0, M1_BF16 = 1 };
+
+enum m1_status {
+    M1_OK = 0,
+    M1_ERR_BAD_ARG = -1,
+    M1_ERR_UNSUPPORTED = -2,
+    M1_ERR_LAUNCH = -3,
+    M1_ERR_WORKSPACE = -4
+};
+
+#define M1_MAX_SRC 6
+
+/* One member of a virtual channel-concat (tf.concat(axis=-1), N:596,604,606,613,615,621,623,653,677,
+ * 701,725).  The concat is never materialised: kernels walk the list. */
+typedef struct {
+    const void* ptr; /* (N, D, H, W, C) */
+    int C;
+    int _pad;
+} m1_src_t;
+
+/* Geometry of one Conv3D(padding='same') or Conv3DTranspose(padding='same').
+ * For Conv3D:           (D,H,W) = input extent,  output = ceil(in/s)       
+ * For Conv3DTranspose:  (D,H,W) = input extent,  output = in*s              */
+typedef struct {
+    int N, D, H, W;
+    int Cin, Cout;
+    int kd, kh, kw;
+    int sd, sh, sw;
+    int dtype;
+    int nsrc;                 /* number of concat members forming the Cin axis */
+    m1_src_t src[M1_MAX_SRC]; /* sum of C == Cin */
+} m1_conv_desc_t;
+
+const char* m1_status_name(int status);
+int m1_abi_version(void);
+
+/* ---- Conv3D(padding='same') + bias : B:37,39,41,43,100-103 ; N:472,526,529-531,534-537 ; B:275 ----
+ * w: Keras layout (kd,kh,kw,Cin,Cout) fp32; bias (Cout) fp32 or NULL; y: (N,OD,OH,OW,Cout). */
+int m1_conv3d_fwd(const m1_conv_desc_t* d, const float* w, const float* bias, void* y, void* stream);
+/* dx[i]: gradient buffer of concat member i (same shape/dtype as src[i]) or NULL to skip it. */
+int m1_conv3d_dgrad(const m1_conv_desc_t* d, const float* w, const void* dy, void* const* dx, void* stream);
+/* dw (kd,kh,kw,Cin,Cout) and db (Cout) are OVERWRITTEN (zeroed inside, then accumulated). */
+/* ws: fp32 workspace of m1_reduce_ws_floats(N, OD*OH*OW, Cout, 1) floats (bias-gradient reduction); may be
+ * NULL when db is NULL. */
+int m1_conv3d_wgrad(const m1_conv_desc_t* d, const void* dy, float* dw, float* db, float* ws, void* stream);
+
+/* ---- Conv3DTranspose(padding='same') + bias : N:496-499,505-507,513-514,520,546-553 ----
+ * w: Keras layout (kd,kh,kw,Cout,Cin) fp32; y: (N, D*sd, H*sh, W*sw, Cout). */
+int m1_convT3d_fwd(const m1_conv_desc_t* d, const float* w, const float* bias, void* y, void* stream);
+int m1_convT3d_dgrad(const m1_conv_desc_t* d, const float* w, const void* dy, void* const* dx, void* stream);
+int m1_convT3d_wgrad(const m1_conv_desc_t* d, const void* dy, float* dw, float* db, float* ws, void* stream);
+
+/* ---- tfa.layers.InstanceNormalization (eps 1e-3) [+ LeakyReLU(slope)] : B:38,40,42,44,54-60,104,128;
+ *      N:473,575-576.  x,y: (N,V,C).  stats: (N,C,2) fp32 = {mean, rstd}.
+ *      ws: fp32 workspace of m1_reduce_ws_floats(N,V,C,nsums) floats. ---- */
+size_t m1_reduce_ws_floats(int N, long long V, int C, int nsums);
+int m1_instnorm_stats(const void* x, int N, long long V, int C, int dtype, float eps, float* stats, float* ws,
+                      void* stream);
+int m1_instnorm_apply(const void* x, const float* stats, const float* gamma, const float* beta, float slope,
+                      void* y, int N, long long V, int C, int dtype, void* stream);
+/* dy = grad wrt the (activated) output; writes dx (grad wrt raw x), dgamma, dbeta (C, overwritten). */
+int m1_instnorm_bwd(const void* x, const float* stats, const float* gamma, const float* beta, float slope,
+                    const void* dy, void* dx, float* dgamma, float* dbeta, int N, long long V, int C, int dtype,
+                    float* ws, void* stream);
+
+/* ---- SE gate + multiplicative residual combine : B:68-78 ----
+ * gate: g = sigmoid(W7 . lrelu(W6 . beta3 + b6) + b7)  (GAP(IN3(.)) == beta3 exactly).
+ * W6: (F,Fr) W7: (Fr,F) Keras (1,1,1,Cin,Cout) layout.  hidden: (Fr) pre-activation, saved for bwd. */
+int m1_se_gate_fwd(const float* beta3, const float* W6, const float* b6, const float* W7, const float* b7,
+                   int F, int Fr, float* hidden, float* g, void* stream);
+int m1_se_gate_bwd(const float* beta3, const float* W6, const float* W7, const float* hidden, const float* g,
+                   const float* dg, int F, int Fr, float* dbeta3_add, float* dW6, float* db6, float* dW7,
+                   float* db7, void* stream);
+/* out = dropout( lrelu( IN3(y3) * g * IN4(y4) ) ); y3,y4 raw conv outputs (N,V,F); stats3/4 (N,F,2).
+ * Dropout state is DEVICE resident so a captured graph can be replayed: rng[0] = seed, rng[1] = step
+ * counter (advanced by m1_step_advance); layer_id separates the streams of different layers. The mask is
+ * a pure function of (rng, layer_id, element index): backward regenerates it, no mask tensor exists. */
+int m1_se_combine_fwd(const void* y3, const void* y4, const float* stats3, const float* stats4,
+                      const float* gamma3, const float* beta3, const float* gamma4, const float* beta4,
+                      const float* g, void* out, int N, long long V, int F, int dtype, float drop_rate,
+                      const uint64_t* rng, uint64_t layer_id, void* stream);
+/* writes dy3, dy4 (grads wrt the RAW conv outputs, i.e. through both InstanceNorms), and overwrites
+ * dgamma3,dbeta3,dgamma4,dbeta4,dg (F each).  ws: m1_reduce_ws_floats(N,V,F,5). */
+int m1_se_combine_bwd(const void* y3, const void* y4, const float* stats3, const float* stats4,
+                      const float* gamma3, const float* beta3, const float* gamma4, const float* beta4,
+                      const float* g, const void* dout, void* dy3, void* dy4, float* dgamma3, float* dbeta3,
+                      float* dgamma4, float* dbeta4, float* dg, int N, long long V, int F, int dtype,
+                      float drop_rate, const uint64_t* rng, uint64_t layer_id, float* ws, void* stream);
+
+/* ---- grid attention gate pieces : B:113-124 ----
+ * theta: (N, Dt,Ht,Wt, C) ; phi: (N, Dp,Hp,Wp, C) nearest-upsampled by (Dt/Dp,...) ;
+ * sigma[n,v] = sigmoid( sum_c lrelu(theta+phi_up)[c]*wpsi[c] + bpsi ) : (N,Dt,Ht,Wt) stored as dtype */
+int m1_gate_sigma_fwd(const void* theta, const void* phi, const float* wpsi, const float* bpsi, void* sigma,
+                      int N, int Dt, int Ht, int Wt, int Dp, int Hp, int Wp, int C, int dtype, void* stream);
+/* dtheta (like theta) is written; dphi (like phi) = window-sum of dtheta; dwpsi (C), dbpsi (1) overwritten.
+ * ws: m1_reduce_ws_floats(N, Dt*Ht*Wt, C, 1) + 64 floats */
+int m1_gate_sigma_bwd(const void* theta, const void* phi, const float* wpsi, const void* sigma,
+                      const void* dsigma, void* dtheta, void* dphi, float* dwpsi, float* dbpsi, int N, int Dt,
+                      int Ht, int Wt, int Dp, int Hp, int Wp, int C, int dtype, float* ws, void* stream);
+/* y = sigma_up * x : x (N,D,H,W,C), sigma (N,D/ss0,H/ss1,W/ss2) */
+int m1_mul_sigma_fwd(const void* x, const void* sigma, void* y, int N, int D, int H, int W, int C, int s0,
+                     int s1, int s2, int dtype, void* stream);
+int m1_mul_sigma_bwd(const void* x, const void* sigma, const void* dy, void* dx, void* dsigma, int N, int D,
+                     int H, int W, int C, int s0, int s1, int s2, int dtype, void* stream);
+
+/* ---- latent head : N:640-647 (x4 levels) and KL N:373-385 ----
+ * ml: (N,V,2L) = [mu | logsigma]; z = mu + exp(clip(logsigma,+-0.1))*eps  (mode 0) or mu (mode 1). */
+int m1_latent_sample_fwd(const void* ml, const void* eps, void* z, int N, long long V, int L, int mode,
+                         int dtype, void* stream);
+int m1_latent_sample_bwd(const void* ml, const void* eps, const void* dz, void* dml, int N, long long V, int L,
+                         int mode, int dtype, void* stream);
+/* kl[0] = mean_n sum_v KL(q||p) (fp32, overwritten). */
+int m1_kl_fwd(const void* ml_q, const void* ml_p, float* kl, int N, long long V, int L, int dtype, void* stream);
+/* dml_q, dml_p = dkl[0] * dKL/d(ml_*)  */
+int m1_kl_bwd(const void* ml_q, const void* ml_p, const float* dkl, void* dml_q, void* dml_p, int N,
+              long long V, int L, int dtype, void* stream);
+
+/* ---- output heads : softmax(logits) (N:754, N:388-390) with deep-supervision heads upsampled by
+ *      nearest repeat (N:739-741,751).  logits_h: (N, D/u0, H/u1, W/u2, nc) per head;
+ *      probs: (N,D,H,W,nheads*nc) fp32. ---- */
+typedef struct {
+    const void* logits;
+    void* dlogits;
+    int u0, u1, u2;
+    int _pad;
+} m1_head_t;
+int m1_softmax_heads_fwd(const m1_head_t* heads, int nheads, float* probs, int N, int D, int H, int W, int nc,
+                         int dtype, void* stream);
+int m1_softmax_heads_bwd(const m1_head_t* heads, int nheads, const float* probs, const float* dprobs, int N,
+                         int D, int H, int W, int nc, int dtype, void* stream);
+
+/* ---- MonteCarloDropout / Dropout : B:142-143 ; N:462-463 (Philox4x32-10, mask regenerated in bwd) ---- */
+int m1_dropout(const void* x, void* y, long long n, float rate, const uint64_t* rng, uint64_t layer_id, int dtype,
+               void* stream);
+
+/* ---- dtype conversion of activations (fp32 <-> bf16) ---- */
+int m1_cast(const void* x, int src_dtype, void* y, int dst_dtype, long long n, void* stream);
+
+/* ---- Keras Adam(amsgrad=True) + L2 regulariser gradient : train_model.py:120 ; N:456-460 ----
+ * p,g,m,v,vhat: flat fp32 of n elements; g += 2*lambda*p first (lambda per contiguous range:
+ * [0,n_kernel) -> l2_kernel, [n_kernel,n_kernel+n_bias) -> l2_bias, rest -> 0); grad_scale multiplies g
+ * (1/world_size after a sum all-reduce). lr_dev[0] = learning rate and step_dev[0] = 1-based step, both in
+ * device memory (graph replay). All five buffers 16-byte aligned. */
+int m1_adam_amsgrad(float* p, const float* g, float* m, float* v, float* vhat, long long n, long long n_kernel,
+                    long long n_bias, float l2_kernel, float l2_bias, float grad_scale, const float* lr_dev,
+                    float beta1, float beta2, float eps, const int* step_dev, void* stream);
+/* step_dev[0] += 1 (may be NULL); rng_dev[1] += 1 (may be NULL). */
+int m1_step_advance(int* step_dev, uint64_t* rng_dev, void* stream);
+
+/* ---- opt-in per-kernel-family timing with hipEvents on the launch stream (bench.py roofline) ---- */
+int m1_prof_enable(int on);
+int m1_prof_reset(void);
+/* after a stream sync: fills up to max_n records; returns count. */
+typedef struct {
+    char name[48];
+    double total_ms;
+    double flops; /* algorithmic flops summed over launches */
+    double bytes; /* algorithmic bytes summed over launches */
+    long long launches;
+} m1_prof_rec_t;
+int m1_prof_read(m1_prof_rec_t* out, int max_n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* M1HIP_H */

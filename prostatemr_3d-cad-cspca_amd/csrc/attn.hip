@@ -1,0 +1,298 @@
+// attn.hip -- the non-GEMM pieces of GridAttentionBlock3D (network_blocks.py:113-124), fwd + bwd:
+//   sigma  = sigmoid( psi . lrelu(theta + upsample(phi)) + b_psi )       (B:113-119)
+//   y      = upsample(sigma) * x                                           (B:120-124)
+// The nearest-neighbour UpSampling3D is index arithmetic; its backward is a window sum.
+// The three 1x1x1 convolutions (theta, phi, W) go through the conv entry points.
+#include "common.h"
+#include "reduce.h"
+
+struct Geo {
+    int N, Dt, Ht, Wt, Dp, Hp, Wp, C, ud, uh, uw;
+};
+
+__device__ __forceinline__ long long phi_voxel(const Geo& g, long long v /* fine voxel within sample */) {
+    const int w = (int)(v % g.Wt); long long r = v / g.Wt;
+    const int h = (int)(r % g.Ht); const int d = (int)(r / g.Ht);
+    return ((long long)(d / g.ud) * g.Hp + (h / g.uh)) * g.Wp + (w / g.uw);
+}
+
+// lanes-per-voxel: power of two <= 64 covering C/VEC
+static inline int lanes_per_voxel(int C, int VEC) { int l = 1; while (l < 64 && l * VEC < C) l <<= 1; return l; }
+
+template <typename T, int VEC>
+__global__ void __launch_bounds__(256) gate_sigma_fwd_kernel(const T* __restrict__ theta, const T* __restrict__ phi,
+                                                             const float* __restrict__ wpsi, const float* __restrict__ bpsi,
+                                                             T* __restrict__ sigma, Geo g, int lpv) {
+    const long long Vt = (long long)g.Dt * g.Ht * g.Wt, Vp = (long long)g.Dp * g.Hp * g.Wp;
+    const long long total = Vt * g.N;
+    const int vpb = 256 / lpv, sub = threadIdx.x % lpv, vloc = threadIdx.x / lpv;
+    for (long long gv = (long long)blockIdx.x * vpb + vloc; gv < total + vloc; gv += (long long)gridDim.x * vpb) {
+        const bool ok = gv < total;   // keep all lanes in the shuffle
+        float s = 0.f;
+        if (ok) {
+            const int n = (int)(gv / Vt); const long long v = gv % Vt;
+            const T* tp = theta + (size_t)gv * g.C;
+            const T* pp = phi + ((size_t)n * Vp + phi_voxel(g, v)) * g.C;
+            for (int c = sub * VEC; c < g.C; c += lpv * VEC) {
+                float a[VEC], b[VEC];
+                VecIO<T, VEC>::ld(tp + c, a); VecIO<T, VEC>::ld(pp + c, b);
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) s = fmaf(lrelu_f(a[k] + b[k], 0.1f), wpsi[c + k], s);
+            }
+        }
+        for (int o = lpv >> 1; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+        if (ok && sub == 0) Act<T>::st(sigma + gv, sigmoid_f(s + bpsi[0]));
+    }
+}
+
+template <typename T, int VEC>
+__global__ void __launch_bounds__(256) gate_dtheta_kernel(const T* __restrict__ theta, const T* __restrict__ phi,
+                                                          const float* __restrict__ wpsi, const T* __restrict__ sigma,
+                                                          const T* __restrict__ dsigma, T* __restrict__ dtheta, Geo g) {
+    const long long Vt = (long long)g.Dt * g.Ht * g.Wt, Vp = (long long)g.Dp * g.Hp * g.Wp;
+    const int cg = g.C / VEC;
+    const long long per = Vt * g.N * cg;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < per; i += (long long)gridDim.x * blockDim.x) {
+        const int c0 = (int)(i % cg) * VEC; const long long gv = i / cg;
+        const int n = (int)(gv / Vt); const long long v = gv % Vt;
+        const float sg = Act<T>::ld(sigma + gv);
+        const float dpsi = Act<T>::ld(dsigma + gv) * sg * (1.f - sg);
+        float a[VEC], b[VEC];
+        VecIO<T, VEC>::ld(theta + (size_t)gv * g.C + c0, a);
+        VecIO<T, VEC>::ld(phi + ((size_t)n * Vp + phi_voxel(g, v)) * g.C + c0, b);
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) a[k] = dpsi * wpsi[c0 + k] * lrelu_g(a[k] + b[k], 0.1f);
+        VecIO<T, VEC>::st(dtheta + (size_t)gv * g.C + c0, a);
+    }
+}
+
+// dwpsi[c] = sum_{n,v} dpsi * f[c];  dbpsi = sum dpsi  (second accumulator; read back from channel 0)
+template <typename T>
+struct GateWF {
+    const T* theta; const T* phi; const T* sigma; const T* dsigma; Geo g;
+    __device__ void operator()(int n, long long v, int c, float* acc) const {
+        const long long Vt = (long long)g.Dt * g.Ht * g.Wt, Vp = (long long)g.Dp * g.Hp * g.Wp;
+        const long long gv = (long long)n * Vt + v;
+        const float sg = Act<T>::ld(sigma + gv);
+        const float dpsi = Act<T>::ld(dsigma + gv) * sg * (1.f - sg);
+        const float f = lrelu_f(Act<T>::ld(theta + (size_t)gv * g.C + c) +
+                                Act<T>::ld(phi + ((size_t)n * Vp + phi_voxel(g, v)) * g.C + c), 0.1f);
+        acc[0] += dpsi * f; acc[1] += dpsi;
+    }
+};
+__global__ void gate_w_finalize_kernel(const float* __restrict__ sums /*[N][C][2]*/, int N, int C,
+                                       float* __restrict__ dwpsi, float* __restrict__ dbpsi) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0, b = 0.0;
+    for (int n = 0; n < N; ++n) { s += sums[((size_t)n * C + c) * 2]; b += sums[((size_t)n * C + c) * 2 + 1]; }
+    dwpsi[c] = (float)s;
+    if (c == 0) dbpsi[0] = (float)b;
+}
+
+// dphi[n,p,c] = sum_{v in window(p)} dtheta[n,v,c]
+template <typename T, int VEC>
+__global__ void __launch_bounds__(256) window_sum_kernel(const T* __restrict__ dtheta, T* __restrict__ dphi, Geo g) {
+    const long long Vp = (long long)g.Dp * g.Hp * g.Wp;
+    const int cg = g.C / VEC;
+    const long long per = Vp * g.N * cg;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < per; i += (long long)gridDim.x * blockDim.x) {
+        const int c0 = (int)(i % cg) * VEC; const long long gp = i / cg;
+        const int n = (int)(gp / Vp); long long r = gp % Vp;
+        const int pw = (int)(r % g.Wp); r /= g.Wp; const int ph = (int)(r % g.Hp); const int pd = (int)(r / g.Hp);
+        float s[VEC];
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) s[k] = 0.f;
+        for (int a = 0; a < g.ud; ++a)
+            for (int b = 0; b < g.uh; ++b)
+                for (int e = 0; e < g.uw; ++e) {
+                    const long long v = (((long long)n * g.Dt + pd * g.ud + a) * g.Ht + ph * g.uh + b) * g.Wt + pw * g.uw + e;
+                    float t[VEC];
+                    VecIO<T, VEC>::ld(dtheta + (size_t)v * g.C + c0, t);
+#pragma unroll
+                    for (int k = 0; k < VEC; ++k) s[k] += t[k];
+                }
+        VecIO<T, VEC>::st(dphi + (size_t)gp * g.C + c0, s);
+    }
+}
+
+static inline int gx_for(long long per) { long long b = cdiv_ll(per, 256); return (int)(b > 8192 ? 8192 : (b < 1 ? 1 : b)); }
+
+template <typename T>
+static int gate_fwd_impl(const void* theta, const void* phi, const float* wpsi, const float* bpsi, void* sigma, const Geo& g,
+                         hipStream_t st) {
+    constexpr int VW = sizeof(T) == 2 ? 8 : 4;
+    const long long total = (long long)g.N * g.Dt * g.Ht * g.Wt;
+    if (g.C % VW == 0) {
+        const int lpv = lanes_per_voxel(g.C, VW);
+        hipLaunchKernelGGL((gate_sigma_fwd_kernel<T, VW>), dim3(gx_for(total * lpv)), dim3(256), 0, st, (const T*)theta,
+                           (const T*)phi, wpsi, bpsi, (T*)sigma, g, lpv);
+    } else {
+        const int lpv = lanes_per_voxel(g.C, 1);
+        hipLaunchKernelGGL((gate_sigma_fwd_kernel<T, 1>), dim3(gx_for(total * lpv)), dim3(256), 0, st, (const T*)theta,
+                           (const T*)phi, wpsi, bpsi, (T*)sigma, g, lpv);
+    }
+    return m1_check_launch();
+}
+
+template <typename T>
+static int gate_bwd_impl(const void* theta, const void* phi, const float* wpsi, const void* sigma, const void* dsigma,
+                         void* dtheta, void* dphi, float* dwpsi, float* dbpsi, const Geo& g, float* ws, hipStream_t st) {
+    constexpr int VW = sizeof(T) == 2 ? 8 : 4;
+    const long long Vt = (long long)g.Dt * g.Ht * g.Wt, Vp = (long long)g.Dp * g.Hp * g.Wp;
+    if (g.C % VW == 0) {
+        hipLaunchKernelGGL((gate_dtheta_kernel<T, VW>), dim3(gx_for(Vt * g.N * (g.C / VW))), dim3(256), 0, st, (const T*)theta,
+                           (const T*)phi, wpsi, (const T*)sigma, (const T*)dsigma, (T*)dtheta, g);
+        hipLaunchKernelGGL((window_sum_kernel<T, VW>), dim3(gx_for(Vp * g.N * (g.C / VW))), dim3(256), 0, st, (const T*)dtheta,
+                           (T*)dphi, g);
+    } else {
+        hipLaunchKernelGGL((gate_dtheta_kernel<T, 1>), dim3(gx_for(Vt * g.N * g.C)), dim3(256), 0, st, (const T*)theta,
+                           (const T*)phi, wpsi, (const T*)sigma, (const T*)dsigma, (T*)dtheta, g);
+        hipLaunchKernelGGL((window_sum_kernel<T, 1>), dim3(gx_for(Vp * g.N * g.C)), dim3(256), 0, st, (const T*)dtheta,
+                           (T*)dphi, g);
+    }
+    int rc = m1_check_launch(); if (rc) return rc;
+    GateWF<T> f{(const T*)theta, (const T*)phi, (const T*)sigma, (const T*)dsigma, g};
+    rc = m1_reduce_nc_launch<2>(f, g.N, Vt, g.C, ws, st); if (rc) return rc;
+    const int nchunks = m1_red_nchunks(Vt, g.C);
+    float* sums = ws + (size_t)g.N * nchunks * g.C * 2;
+    hipLaunchKernelGGL((m1_reduce_finalize_kernel<2>), dim3((g.N * g.C + 255) / 256), dim3(256), 0, st, ws, g.N, g.C, nchunks, sums);
+    hipLaunchKernelGGL(gate_w_finalize_kernel, dim3((g.C + 255) / 256), dim3(256), 0, st, sums, g.N, g.C, dwpsi, dbpsi);
+    return m1_check_launch();
+}
+
+static int make_geo(Geo& g, int N, int Dt, int Ht, int Wt, int Dp, int Hp, int Wp, int C) {
+    if (N <= 0 || Dt <= 0 || Ht <= 0 || Wt <= 0 || Dp <= 0 || Hp <= 0 || Wp <= 0 || C <= 0) return M1_ERR_BAD_ARG;
+    if (Dt % Dp || Ht % Hp || Wt % Wp) return M1_ERR_UNSUPPORTED;   // UpSampling3D(size=shape//shape) then add must match
+    g = Geo{N, Dt, Ht, Wt, Dp, Hp, Wp, C, Dt / Dp, Ht / Hp, Wt / Wp};
+    return M1_OK;
+}
+
+extern "C" int m1_gate_sigma_fwd(const void* theta, const void* phi, const float* wpsi, const float* bpsi, void* sigma,
+                                 int N, int Dt, int Ht, int Wt, int Dp, int Hp, int Wp, int C, int dtype, void* stream) {
+    if (!theta || !phi || !wpsi || !bpsi || !sigma) return M1_ERR_BAD_ARG;
+    Geo g; int rc = make_geo(g, N, Dt, Ht, Wt, Dp, Hp, Wp, C); if (rc) return rc;
+    M1ProfScope ps("gate_sigma_fwd", 0.0, (double)N * Dt * Ht * Wt * C * (dtype == M1_BF16 ? 2 : 4), (hipStream_t)stream);
+    return dtype == M1_BF16 ? gate_fwd_impl<bf16_t>(theta, phi, wpsi, bpsi, sigma, g, (hipStream_t)stream)
+                            : gate_fwd_impl<float>(theta, phi, wpsi, bpsi, sigma, g, (hipStream_t)stream);
+}
+
+extern "C" int m1_gate_sigma_bwd(const void* theta, const void* phi, const float* wpsi, const void* sigma,
+                                 const void* dsigma, void* dtheta, void* dphi, float* dwpsi, float* dbpsi, int N, int Dt,
+                                 int Ht, int Wt, int Dp, int Hp, int Wp, int C, int dtype, float* ws, void* stream) {
+    if (!theta || !phi || !wpsi || !sigma || !dsigma || !dtheta || !dphi || !dwpsi || !dbpsi || !ws) return M1_ERR_BAD_ARG;
+    Geo g; int rc = make_geo(g, N, Dt, Ht, Wt, Dp, Hp, Wp, C); if (rc) return rc;
+    M1ProfScope ps("gate_sigma_bwd", 0.0, 4.0 * N * Dt * Ht * Wt * C * (dtype == M1_BF16 ? 2 : 4), (hipStream_t)stream);
+    return dtype == M1_BF16
+               ? gate_bwd_impl<bf16_t>(theta, phi, wpsi, sigma, dsigma, dtheta, dphi, dwpsi, dbpsi, g, ws, (hipStream_t)stream)
+               : gate_bwd_impl<float>(theta, phi, wpsi, sigma, dsigma, dtheta, dphi, dwpsi, dbpsi, g, ws, (hipStream_t)stream);
+}
+
+// ------------------------------------------------------------------------------------------------
+// y = upsample(sigma) * x
+// ------------------------------------------------------------------------------------------------
+struct MulGeo { int N, D, H, W, C, s0, s1, s2, Ds, Hs, Ws; };
+
+__device__ __forceinline__ long long sig_index(const MulGeo& g, long long gv) {
+    const long long V = (long long)g.D * g.H * g.W;
+    const int n = (int)(gv / V); long long r = gv % V;
+    const int w = (int)(r % g.W); r /= g.W; const int h = (int)(r % g.H); const int d = (int)(r / g.H);
+    return (((long long)n * g.Ds + d / g.s0) * g.Hs + h / g.s1) * g.Ws + w / g.s2;
+}
+
+template <typename T, int VEC>
+__global__ void __launch_bounds__(256) mul_sigma_kernel(const T* __restrict__ x, const T* __restrict__ sigma,
+                                                        T* __restrict__ y, MulGeo g) {
+    const int cg = g.C / VEC;
+    const long long per = (long long)g.N * g.D * g.H * g.W * cg;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < per; i += (long long)gridDim.x * blockDim.x) {
+        const long long gv = i / cg;
+        const float s = Act<T>::ld(sigma + sig_index(g, gv));
+        float a[VEC];
+        VecIO<T, VEC>::ld(x + i * VEC, a);
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) a[k] *= s;
+        VecIO<T, VEC>::st(y + i * VEC, a);
+    }
+}
+
+// dsigma[n,p] = sum_{v in window(p)} sum_c dy*x   (lpv lanes per coarse voxel)
+template <typename T, int VEC>
+__global__ void __launch_bounds__(256) mul_sigma_dsig_kernel(const T* __restrict__ x, const T* __restrict__ dy,
+                                                             T* __restrict__ dsigma, MulGeo g, int lpv) {
+    const long long Vs = (long long)g.Ds * g.Hs * g.Ws, total = Vs * g.N;
+    const int vpb = 256 / lpv, sub = threadIdx.x % lpv, vloc = threadIdx.x / lpv;
+    for (long long gp = (long long)blockIdx.x * vpb + vloc; gp < total + vloc; gp += (long long)gridDim.x * vpb) {
+        const bool ok = gp < total;
+        float s = 0.f;
+        if (ok) {
+            const int n = (int)(gp / Vs); long long r = gp % Vs;
+            const int pw = (int)(r % g.Ws); r /= g.Ws; const int ph = (int)(r % g.Hs); const int pd = (int)(r / g.Hs);
+            for (int a = 0; a < g.s0; ++a)
+                for (int b = 0; b < g.s1; ++b)
+                    for (int e = 0; e < g.s2; ++e) {
+                        const long long v = (((long long)n * g.D + pd * g.s0 + a) * g.H + ph * g.s1 + b) * g.W + pw * g.s2 + e;
+                        for (int c = sub * VEC; c < g.C; c += lpv * VEC) {
+                            float xv[VEC], dv[VEC];
+                            VecIO<T, VEC>::ld(x + (size_t)v * g.C + c, xv); VecIO<T, VEC>::ld(dy + (size_t)v * g.C + c, dv);
+#pragma unroll
+                            for (int k = 0; k < VEC; ++k) s = fmaf(xv[k], dv[k], s);
+                        }
+                    }
+        }
+        for (int o = lpv >> 1; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+        if (ok && sub == 0) Act<T>::st(dsigma + gp, s);
+    }
+}
+
+static int make_mulgeo(MulGeo& g, int N, int D, int H, int W, int C, int s0, int s1, int s2) {
+    if (N <= 0 || D <= 0 || H <= 0 || W <= 0 || C <= 0 || s0 <= 0 || s1 <= 0 || s2 <= 0) return M1_ERR_BAD_ARG;
+    if (D % s0 || H % s1 || W % s2) return M1_ERR_UNSUPPORTED;
+    g = MulGeo{N, D, H, W, C, s0, s1, s2, D / s0, H / s1, W / s2};
+    return M1_OK;
+}
+
+template <typename T>
+static int mul_fwd_impl(const void* x, const void* sigma, void* y, const MulGeo& g, hipStream_t st) {
+    constexpr int VW = sizeof(T) == 2 ? 8 : 4;
+    const long long V = (long long)g.N * g.D * g.H * g.W;
+    if (g.C % VW == 0)
+        hipLaunchKernelGGL((mul_sigma_kernel<T, VW>), dim3(gx_for(V * (g.C / VW))), dim3(256), 0, st, (const T*)x, (const T*)sigma, (T*)y, g);
+    else
+        hipLaunchKernelGGL((mul_sigma_kernel<T, 1>), dim3(gx_for(V * g.C)), dim3(256), 0, st, (const T*)x, (const T*)sigma, (T*)y, g);
+    return m1_check_launch();
+}
+
+extern "C" int m1_mul_sigma_fwd(const void* x, const void* sigma, void* y, int N, int D, int H, int W, int C, int s0, int s1,
+                                int s2, int dtype, void* stream) {
+    if (!x || !sigma || !y) return M1_ERR_BAD_ARG;
+    MulGeo g; int rc = make_mulgeo(g, N, D, H, W, C, s0, s1, s2); if (rc) return rc;
+    M1ProfScope ps("mul_sigma_fwd", 0.0, 2.0 * N * D * H * W * C * (dtype == M1_BF16 ? 2 : 4), (hipStream_t)stream);
+    return dtype == M1_BF16 ? mul_fwd_impl<bf16_t>(x, sigma, y, g, (hipStream_t)stream)
+                            : mul_fwd_impl<float>(x, sigma, y, g, (hipStream_t)stream);
+}
+
+template <typename T>
+static int mul_bwd_impl(const void* x, const void* sigma, const void* dy, void* dx, void* dsigma, const MulGeo& g, hipStream_t st) {
+    int rc = mul_fwd_impl<T>(dy, sigma, dx, g, st);   // dx = sigma_up * dy
+    if (rc) return rc;
+    constexpr int VW = sizeof(T) == 2 ? 8 : 4;
+    const long long total = (long long)g.N * g.Ds * g.Hs * g.Ws;
+    if (g.C % VW == 0) {
+        const int lpv = lanes_per_voxel(g.C, VW);
+        hipLaunchKernelGGL((mul_sigma_dsig_kernel<T, VW>), dim3(gx_for(total * lpv)), dim3(256), 0, st, (const T*)x, (const T*)dy, (T*)dsigma, g, lpv);
+    } else {
+        const int lpv = lanes_per_voxel(g.C, 1);
+        hipLaunchKernelGGL((mul_sigma_dsig_kernel<T, 1>), dim3(gx_for(total * lpv)), dim3(256), 0, st, (const T*)x, (const T*)dy, (T*)dsigma, g, lpv);
+    }
+    return m1_check_launch();
+}
+
+extern "C" int m1_mul_sigma_bwd(const void* x, const void* sigma, const void* dy, void* dx, void* dsigma, int N, int D, int H,
+                                int W, int C, int s0, int s1, int s2, int dtype, void* stream) {
+    if (!x || !sigma || !dy || !dx || !dsigma) return M1_ERR_BAD_ARG;
+    MulGeo g; int rc = make_mulgeo(g, N, D, H, W, C, s0, s1, s2); if (rc) return rc;
+    M1ProfScope ps("mul_sigma_bwd", 0.0, 4.0 * N * D * H * W * C * (dtype == M1_BF16 ? 2 : 4), (hipStream_t)stream);
+    return dtype == M1_BF16 ? mul_bwd_impl<bf16_t>(x, sigma, dy, dx, dsigma, g, (hipStream_t)stream)
+                            : mul_bwd_impl<float>(x, sigma, dy, dx, dsigma, g, (hipStream_t)stream);
+}

@@ -1,0 +1,146 @@
+// common.h -- shared device/host helpers for libm1hip (gfx950 / CDNA4 only, wave = 64).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/m1hip.h"
+
+#define M1_WAVE 64
+#define M1_LRELU_EPS_UNUSED 0
+
+typedef unsigned short bf16_t;  // raw bf16 storage
+
+// ---- bf16 <-> f32 (round-to-nearest-even, NaN preserved) ----
+__device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((unsigned)v) << 16); }
+__device__ __forceinline__ bf16_t f2bf(float f) {
+    unsigned u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);  // quiet NaN
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (bf16_t)(u >> 16);
+}
+
+template <typename T> struct Act;
+template <> struct Act<float> {
+    static __device__ __forceinline__ float ld(const float* p) { return *p; }
+    static __device__ __forceinline__ void st(float* p, float v) { *p = v; }
+};
+template <> struct Act<bf16_t> {
+    static __device__ __forceinline__ float ld(const bf16_t* p) { return bf2f(*p); }
+    static __device__ __forceinline__ void st(bf16_t* p, float v) { *p = f2bf(v); }
+};
+
+// ---- vector load/store of VEC consecutive channels as floats (16 B per lane when VEC = 4 (f32) / 8 (bf16)) ----
+template <typename T, int VEC> struct VecIO;
+template <> struct VecIO<float, 1> {
+    static __device__ __forceinline__ void ld(const float* p, float* o) { o[0] = p[0]; }
+    static __device__ __forceinline__ void st(float* p, const float* o) { p[0] = o[0]; }
+};
+template <> struct VecIO<float, 4> {
+    static __device__ __forceinline__ void ld(const float* p, float* o) {
+        float4 v = *reinterpret_cast<const float4*>(p);
+        o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
+    }
+    static __device__ __forceinline__ void st(float* p, const float* o) {
+        *reinterpret_cast<float4*>(p) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+};
+template <> struct VecIO<float, 8> {
+    static __device__ __forceinline__ void ld(const float* p, float* o) {
+        VecIO<float, 4>::ld(p, o); VecIO<float, 4>::ld(p + 4, o + 4);
+    }
+    static __device__ __forceinline__ void st(float* p, const float* o) {
+        VecIO<float, 4>::st(p, o); VecIO<float, 4>::st(p + 4, o + 4);
+    }
+};
+template <> struct VecIO<bf16_t, 1> {
+    static __device__ __forceinline__ void ld(const bf16_t* p, float* o) { o[0] = bf2f(p[0]); }
+    static __device__ __forceinline__ void st(bf16_t* p, const float* o) { p[0] = f2bf(o[0]); }
+};
+template <> struct VecIO<bf16_t, 4> {
+    static __device__ __forceinline__ void ld(const bf16_t* p, float* o) {
+        uint2 v = *reinterpret_cast<const uint2*>(p);
+        o[0] = __uint_as_float(v.x << 16); o[1] = __uint_as_float(v.x & 0xffff0000u);
+        o[2] = __uint_as_float(v.y << 16); o[3] = __uint_as_float(v.y & 0xffff0000u);
+    }
+    static __device__ __forceinline__ void st(bf16_t* p, const float* o) {
+        uint2 v;
+        v.x = (unsigned)f2bf(o[0]) | ((unsigned)f2bf(o[1]) << 16);
+        v.y = (unsigned)f2bf(o[2]) | ((unsigned)f2bf(o[3]) << 16);
+        *reinterpret_cast<uint2*>(p) = v;
+    }
+};
+template <> struct VecIO<bf16_t, 8> {
+    static __device__ __forceinline__ void ld(const bf16_t* p, float* o) {
+        uint4 v = *reinterpret_cast<const uint4*>(p);
+        o[0] = __uint_as_float(v.x << 16); o[1] = __uint_as_float(v.x & 0xffff0000u);
+        o[2] = __uint_as_float(v.y << 16); o[3] = __uint_as_float(v.y & 0xffff0000u);
+        o[4] = __uint_as_float(v.z << 16); o[5] = __uint_as_float(v.z & 0xffff0000u);
+        o[6] = __uint_as_float(v.w << 16); o[7] = __uint_as_float(v.w & 0xffff0000u);
+    }
+    static __device__ __forceinline__ void st(bf16_t* p, const float* o) {
+        uint4 v;
+        v.x = (unsigned)f2bf(o[0]) | ((unsigned)f2bf(o[1]) << 16);
+        v.y = (unsigned)f2bf(o[2]) | ((unsigned)f2bf(o[3]) << 16);
+        v.z = (unsigned)f2bf(o[4]) | ((unsigned)f2bf(o[5]) << 16);
+        v.w = (unsigned)f2bf(o[6]) | ((unsigned)f2bf(o[7]) << 16);
+        *reinterpret_cast<uint4*>(p) = v;
+    }
+};
+
+__device__ __forceinline__ float lrelu_f(float x, float slope) { return x >= 0.f ? x : slope * x; }
+__device__ __forceinline__ float lrelu_g(float x, float slope) { return x >= 0.f ? 1.f : slope; }
+__device__ __forceinline__ float sigmoid_f(float x) { return 1.f / (1.f + __expf(-x)); }
+
+// ---- wave / block reductions (wave64 shuffles) ----
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// ---- Philox4x32-10 (counter-based RNG; the keep-mask is a pure function of (seed, element index)) ----
+__device__ __forceinline__ void philox_round(uint32_t& c0, uint32_t& c1, uint32_t& c2, uint32_t& c3, uint32_t k0,
+                                             uint32_t k1) {
+    const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u;
+    uint32_t hi0 = __umulhi(M0, c0), lo0 = M0 * c0;
+    uint32_t hi1 = __umulhi(M1, c2), lo1 = M1 * c2;
+    uint32_t n0 = hi1 ^ c1 ^ k0, n1 = lo1, n2 = hi0 ^ c3 ^ k1, n3 = lo0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+}
+__device__ __forceinline__ uint4 philox4x32_10(uint64_t seed, uint64_t ctr) {
+    uint32_t c0 = (uint32_t)ctr, c1 = (uint32_t)(ctr >> 32), c2 = 0x243F6A88u, c3 = 0x85A308D3u;
+    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+    for (int i = 0; i < 10; ++i) {
+        philox_round(c0, c1, c2, c3, k0, k1);
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    return make_uint4(c0, c1, c2, c3);
+}
+// keep-decision of element `idx` of the dropout stream (seed, base): U[0,1) >= rate  
+__device__ __forceinline__ bool philox_keep(uint64_t seed, uint64_t base, uint64_t idx, float rate) {
+    uint64_t e = base + idx;
+    uint4 r = philox4x32_10(seed, e >> 2);
+    uint32_t w = (e & 3) == 0 ? r.x : (e & 3) == 1 ? r.y : (e & 3) == 2 ? r.z : r.w;
+    float u = (float)(w >> 8) * (1.0f / 16777216.0f);
+    return u >= rate;
+}
+
+// ---- host helpers ----
+static inline int m1_check_launch() {
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? M1_OK : M1_ERR_LAUNCH;
+}
+static inline long long cdiv_ll(long long a, long long b) { return (a + b - 1) / b; }
+
+// profiler hooks (prof.hip)
+struct M1ProfScope {
+    int slot;
+    hipStream_t s;
+    M1ProfScope(const char* name, double flops, double bytes, hipStream_t stream);
+    ~M1ProfScope();
+};

@@ -1,0 +1,239 @@
+// norm.hip -- InstanceNormalization (eps inside rsqrt, biased variance) [+ LeakyReLU], forward and backward.
+// Replaces tfa.layers.InstanceNormalization + relu(alpha=0.1) at network_blocks.py:38-44,54-60,104,128 and
+// networks.py:473,575-576.  Backward math: SURVEY.md App. F.
+#include "common.h"
+#include "reduce.h"
+
+extern "C" size_t m1_reduce_ws_floats(int N, long long V, int C, int nsums) {
+    return (size_t)N * m1_red_nchunks(V, C) * C * nsums + (size_t)N * C * nsums + 64;
+}
+
+// ------------------------------------------------------------------------------------------------
+// statistics: mean and rstd per (n,c)
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+struct StatsF {
+    const T* x; long long V; int C;
+    __device__ void operator()(int n, long long v, int c, float* acc) const {
+        float xv = Act<T>::ld(x + ((size_t)n * V + v) * C + c);
+        acc[0] += xv; acc[1] += xv * xv;
+    }
+};
+
+__global__ void stats_finalize_kernel(const float* __restrict__ partial, int N, int C, int nchunks, long long V,
+                                      float eps, float* __restrict__ stats) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N * C) return;
+    int n = i / C, c = i % C;
+    double s = 0.0, ss = 0.0;
+    for (int j = 0; j < nchunks; ++j) {
+        const float* p = partial + (((size_t)n * nchunks + j) * C + c) * 2;
+        s += (double)p[0]; ss += (double)p[1];
+    }
+    double mean = s / (double)V;
+    double var = ss / (double)V - mean * mean;
+    if (var < 0.0) var = 0.0;
+    stats[(size_t)i * 2 + 0] = (float)mean;
+    stats[(size_t)i * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+}
+
+template <typename T>
+static int stats_impl(const void* x, int N, long long V, int C, float eps, float* stats, float* ws, hipStream_t st) {
+    StatsF<T> f{(const T*)x, V, C};
+    int rc = m1_reduce_nc_launch<2>(f, N, V, C, ws, st);
+    if (rc) return rc;
+    int tot = N * C;
+    hipLaunchKernelGGL(stats_finalize_kernel, dim3((tot + 255) / 256), dim3(256), 0, st, ws, N, C,
+                       m1_red_nchunks(V, C), V, eps, stats);
+    return m1_check_launch();
+}
+
+extern "C" int m1_instnorm_stats(const void* x, int N, long long V, int C, int dtype, float eps, float* stats,
+                                 float* ws, void* stream) {
+    if (!x || !stats || !ws || N <= 0 || V <= 0 || C <= 0) return M1_ERR_BAD_ARG;
+    M1ProfScope ps("instnorm_stats", 0.0, (double)N * V * C * (dtype == M1_BF16 ? 2 : 4), (hipStream_t)stream);
+    return dtype == M1_BF16 ? stats_impl<bf16_t>(x, N, V, C, eps, stats, ws, (hipStream_t)stream)
+                            : stats_impl<float>(x, N, V, C, eps, stats, ws, (hipStream_t)stream);
+}
+
+// ------------------------------------------------------------------------------------------------
+// apply: y = lrelu( (x-mean)*rstd*gamma + beta )
+// ------------------------------------------------------------------------------------------------
+template <typename T, int VEC>
+__global__ void __launch_bounds__(256) in_apply_kernel(const T* __restrict__ x, const float* __restrict__ stats,
+                                                       const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, float slope,
+                                                       T* __restrict__ y, long long V, int C) {
+    const int n = blockIdx.y;
+    const long long per = V * (C / VEC);
+    const T* xn = x + (size_t)n * V * C;
+    T* yn = y + (size_t)n * V * C;
+    const int cg = C / VEC;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < per;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int c0 = (int)(i % cg) * VEC;
+        float v[VEC];
+        VecIO<T, VEC>::ld(xn + i * VEC, v);
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) {
+            const int c = c0 + k;
+            const float mean = stats[((size_t)n * C + c) * 2], rstd = stats[((size_t)n * C + c) * 2 + 1];
+            float t = (v[k] - mean) * rstd * gamma[c] + beta[c];
+            v[k] = lrelu_f(t, slope);
+        }
+        VecIO<T, VEC>::st(yn + i * VEC, v);
+    }
+}
+
+template <typename T>
+static int apply_impl(const void* x, const float* stats, const float* gamma, const float* beta, float slope, void* y,
+                      int N, long long V, int C, hipStream_t st) {
+    constexpr int VW = sizeof(T) == 2 ? 8 : 4;
+    long long per;
+    if (C % VW == 0) {
+        per = V * (C / VW);
+        int gx = (int)(cdiv_ll(per, 256) > 4096 ? 4096 : cdiv_ll(per, 256));
+        hipLaunchKernelGGL((in_apply_kernel<T, VW>), dim3(gx, N), dim3(256), 0, st, (const T*)x, stats, gamma, beta,
+                           slope, (T*)y, V, C);
+    } else {
+        per = V * C;
+        int gx = (int)(cdiv_ll(per, 256) > 4096 ? 4096 : cdiv_ll(per, 256));
+        hipLaunchKernelGGL((in_apply_kernel<T, 1>), dim3(gx, N), dim3(256), 0, st, (const T*)x, stats, gamma, beta,
+                           slope, (T*)y, V, C);
+    }
+    return m1_check_launch();
+}
+
+extern "C" int m1_instnorm_apply(const void* x, const float* stats, const float* gamma, const float* beta,
+                                 float slope, void* y, int N, long long V, int C, int dtype, void* stream) {
+    if (!x || !stats || !gamma || !beta || !y || N <= 0 || V <= 0 || C <= 0) return M1_ERR_BAD_ARG;
+    M1ProfScope ps("instnorm_apply", 0.0, 2.0 * N * V * C * (dtype == M1_BF16 ? 2 : 4), (hipStream_t)stream);
+    return dtype == M1_BF16 ? apply_impl<bf16_t>(x, stats, gamma, beta, slope, y, N, V, C, (hipStream_t)stream)
+                            : apply_impl<float>(x, stats, gamma, beta, slope, y, N, V, C, (hipStream_t)stream);
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward (App. F):  a = lrelu(y), y = gamma*xh + beta, xh = (x-mean)*rstd
+//   dy = da * lrelu'(y);  dbeta = sum dy;  dgamma = sum dy*xh;  dx = gamma*rstd*(dy - dbeta/V - xh*dgamma/V)
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+struct InBwdF {
+    const T* x; const T* da; const float* stats; const float* gamma; const float* beta; float slope;
+    long long V; int C;
+    __device__ void operator()(int n, long long v, int c, float* acc) const {
+        const size_t idx = ((size_t)n * V + v) * C + c;
+        const float mean = stats[((size_t)n * C + c) * 2], rstd = stats[((size_t)n * C + c) * 2 + 1];
+        const float xh = (Act<T>::ld(x + idx) - mean) * rstd;
+        const float yv = gamma[c] * xh + beta[c];
+        const float dy = Act<T>::ld(da + idx) * lrelu_g(yv, slope);
+        acc[0] += dy; acc[1] += dy * xh;
+    }
+};
+
+template <typename T, int VEC>
+__global__ void __launch_bounds__(256) in_bwd_apply_kernel(const T* __restrict__ x, const T* __restrict__ da,
+                                                           const float* __restrict__ stats,
+                                                           const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, float slope,
+                                                           const float* __restrict__ sums /*[N][C][2]*/,
+                                                           T* __restrict__ dx, long long V, int C) {
+    const int n = blockIdx.y;
+    const int cg = C / VEC;
+    const long long per = V * cg;
+    const size_t base = (size_t)n * V * C;
+    const float invV = 1.0f / (float)V;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < per;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int c0 = (int)(i % cg) * VEC;
+        float xv[VEC], dv[VEC];
+        VecIO<T, VEC>::ld(x + base + i * VEC, xv);
+        VecIO<T, VEC>::ld(da + base + i * VEC, dv);
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) {
+            const int c = c0 + k;
+            const float mean = stats[((size_t)n * C + c) * 2], rstd = stats[((size_t)n * C + c) * 2 + 1];
+            const float xh = (xv[k] - mean) * rstd;
+            const float yv = gamma[c] * xh + beta[c];
+            const float dy = dv[k] * lrelu_g(yv, slope);
+            const float s0 = sums[((size_t)n * C + c) * 2], s1 = sums[((size_t)n * C + c) * 2 + 1];
+            dv[k] = gamma[c] * rstd * (dy - s0 * invV - xh * s1 * invV);
+        }
+        VecIO<T, VEC>::st(dx + base + i * VEC, dv);
+    }
+}
+
+// dgamma[c] = sum_n sums[n][c][1], dbeta[c] = sum_n sums[n][c][0]
+__global__ void in_bwd_param_kernel(const float* __restrict__ sums, int N, int C, float* __restrict__ dgamma,
+                                    float* __restrict__ dbeta) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double g = 0.0, b = 0.0;
+    for (int n = 0; n < N; ++n) { b += sums[((size_t)n * C + c) * 2]; g += sums[((size_t)n * C + c) * 2 + 1]; }
+    dgamma[c] = (float)g; dbeta[c] = (float)b;
+}
+
+template <typename T>
+static int bwd_impl(const void* x, const float* stats, const float* gamma, const float* beta, float slope,
+                    const void* dy, void* dx, float* dgamma, float* dbeta, int N, long long V, int C, float* ws,
+                    hipStream_t st) {
+    InBwdF<T> f{(const T*)x, (const T*)dy, stats, gamma, beta, slope, V, C};
+    int rc = m1_reduce_nc_launch<2>(f, N, V, C, ws, st);
+    if (rc) return rc;
+    const int nchunks = m1_red_nchunks(V, C);
+    float* sums = ws + (size_t)N * nchunks * C * 2;
+    int tot = N * C;
+    hipLaunchKernelGGL((m1_reduce_finalize_kernel<2>), dim3((tot + 255) / 256), dim3(256), 0, st, ws, N, C, nchunks,
+                       sums);
+    hipLaunchKernelGGL(in_bwd_param_kernel, dim3((C + 255) / 256), dim3(256), 0, st, sums, N, C, dgamma, dbeta);
+    constexpr int VW = sizeof(T) == 2 ? 8 : 4;
+    if (C % VW == 0) {
+        long long per = V * (C / VW);
+        int gx = (int)(cdiv_ll(per, 256) > 4096 ? 4096 : cdiv_ll(per, 256));
+        hipLaunchKernelGGL((in_bwd_apply_kernel<T, VW>), dim3(gx, N), dim3(256), 0, st, (const T*)x, (const T*)dy,
+                           stats, gamma, beta, slope, sums, (T*)dx, V, C);
+    } else {
+        long long per = V * C;
+        int gx = (int)(cdiv_ll(per, 256) > 4096 ? 4096 : cdiv_ll(per, 256));
+        hipLaunchKernelGGL((in_bwd_apply_kernel<T, 1>), dim3(gx, N), dim3(256), 0, st, (const T*)x, (const T*)dy,
+                           stats, gamma, beta, slope, sums, (T*)dx, V, C);
+    }
+    return m1_check_launch();
+}
+
+extern "C" int m1_instnorm_bwd(const void* x, const float* stats, const float* gamma, const float* beta, float slope,
+                               const void* dy, void* dx, float* dgamma, float* dbeta, int N, long long V, int C,
+                               int dtype, float* ws, void* stream) {
+    if (!x || !stats || !gamma || !beta || !dy || !dx || !dgamma || !dbeta || !ws) return M1_ERR_BAD_ARG;
+    M1ProfScope ps("instnorm_bwd", 0.0, 5.0 * N * V * C * (dtype == M1_BF16 ? 2 : 4), (hipStream_t)stream);
+    return dtype == M1_BF16
+               ? bwd_impl<bf16_t>(x, stats, gamma, beta, slope, dy, dx, dgamma, dbeta, N, V, C, ws, (hipStream_t)stream)
+               : bwd_impl<float>(x, stats, gamma, beta, slope, dy, dx, dgamma, dbeta, N, V, C, ws, (hipStream_t)stream);
+}
+
+// ------------------------------------------------------------------------------------------------
+// column sum over all (n, v): out[c] = sum x[n,v,c]  (bias gradients). ws as for nsums=1.
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+struct ColSumF {
+    const T* x; long long V; int C;
+    __device__ void operator()(int n, long long v, int c, float* acc) const {
+        acc[0] += Act<T>::ld(x + ((size_t)n * V + v) * C + c);
+    }
+};
+__global__ void colsum_finalize_kernel(const float* __restrict__ partial, int rows, int C, float* __restrict__ out) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0;
+    for (int r = 0; r < rows; ++r) s += partial[(size_t)r * C + c];
+    out[c] = (float)s;
+}
+// Internal (used by conv wgrad): ws must hold N*nchunks*C floats.
+int m1_colsum_internal(const void* x, int N, long long V, int C, int dtype, float* out, float* ws, hipStream_t st) {
+    int rc;
+    if (dtype == M1_BF16) { ColSumF<bf16_t> f{(const bf16_t*)x, V, C}; rc = m1_reduce_nc_launch<1>(f, N, V, C, ws, st); }
+    else { ColSumF<float> f{(const float*)x, V, C}; rc = m1_reduce_nc_launch<1>(f, N, V, C, ws, st); }
+    if (rc) return rc;
+    hipLaunchKernelGGL(colsum_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, st, ws, N * m1_red_nchunks(V, C),
+                       C, out);
+    return m1_check_launch();
+}

@@ -1,0 +1,61 @@
+// prof.hip -- opt-in per-kernel-family timing with hipEvents recorded on the launch stream.
+// Off by default (zero overhead: one predictable branch per entry point).  Not for use under stream capture.
+#include "common.h"
+#include <string.h>
+#include <vector>
+#include <mutex>
+
+namespace {
+struct Rec { char name[48]; double flops, bytes; long long launches; };
+struct Pair { hipEvent_t a, b; int slot; };
+bool g_on = false;
+std::vector<Rec> g_recs;
+std::vector<Pair> g_pairs;
+size_t g_used = 0;
+std::mutex g_mu;
+}
+
+M1ProfScope::M1ProfScope(const char* name, double flops, double bytes, hipStream_t stream) : slot(-1), s(stream) {
+    if (!g_on) return;
+    std::lock_guard<std::mutex> lk(g_mu);
+    int idx = -1;
+    for (size_t i = 0; i < g_recs.size(); ++i) if (!strcmp(g_recs[i].name, name)) { idx = (int)i; break; }
+    if (idx < 0) { Rec r{}; strncpy(r.name, name, 47); g_recs.push_back(r); idx = (int)g_recs.size() - 1; }
+    g_recs[idx].flops += flops; g_recs[idx].bytes += bytes; g_recs[idx].launches += 1;
+    if (g_used == g_pairs.size()) {
+        Pair p{}; 
+        if (hipEventCreate(&p.a) != hipSuccess || hipEventCreate(&p.b) != hipSuccess) return;
+        g_pairs.push_back(p);
+    }
+    slot = (int)g_used++;
+    g_pairs[slot].slot = idx;
+    (void)hipEventRecord(g_pairs[slot].a, s);
+}
+M1ProfScope::~M1ProfScope() {
+    if (slot < 0) return;
+    std::lock_guard<std::mutex> lk(g_mu);
+    (void)hipEventRecord(g_pairs[slot].b, s);
+}
+
+extern "C" int m1_prof_enable(int on) { std::lock_guard<std::mutex> lk(g_mu); g_on = on != 0; return M1_OK; }
+extern "C" int m1_prof_reset(void) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    g_recs.clear(); g_used = 0;
+    return M1_OK;
+}
+extern "C" int m1_prof_read(m1_prof_rec_t* out, int max_n) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    std::vector<double> ms(g_recs.size(), 0.0);
+    for (size_t i = 0; i < g_used; ++i) {
+        float t = 0.f;
+        if (hipEventSynchronize(g_pairs[i].b) != hipSuccess) continue;
+        if (hipEventElapsedTime(&t, g_pairs[i].a, g_pairs[i].b) == hipSuccess) ms[g_pairs[i].slot] += t;
+    }
+    int n = 0;
+    for (size_t i = 0; i < g_recs.size() && n < max_n; ++i, ++n) {
+        memset(&out[n], 0, sizeof(out[n]));
+        strncpy(out[n].name, g_recs[i].name, 47);
+        out[n].total_ms = ms[i]; out[n].flops = g_recs[i].flops; out[n].bytes = g_recs[i].bytes; out[n].launches = g_recs[i].launches;
+    }
+    return n;
+}

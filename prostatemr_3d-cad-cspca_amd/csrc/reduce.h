@@ -1,0 +1,82 @@
+// reduce.h -- per-(n,c) reductions over the voxel axis of an (N,V,C) NDHWC tensor.
+//
+// Stage 1: grid (chunks, N). Each 256-thread block owns `chunkV` consecutive voxels of one sample and
+//          ALL channels; lanes run along C (coalesced, channel-contiguous HBM reads), partial sums stay
+//          in registers, then one LDS pass folds the voxel-sub-lanes. Output: fp32 partials
+//          [N][nchunks][C][NS] -- deterministic (no atomics).
+// Stage 2: finalize kernel folds the chunks in fp64 (tiny).
+#pragma once
+#include "common.h"
+
+#define M1_RED_THREADS 256
+
+static inline int m1_red_chunkV(long long V, int C) {
+    // aim for >= ~8 elements per thread-channel and enough blocks to fill 256 CUs
+    long long per_block = (long long)M1_RED_THREADS * 16 / (C < 256 ? (C < 1 ? 1 : C) : 256);
+    if (per_block < 16) per_block = 16;
+    if (per_block > 4096) per_block = 4096;
+    long long chunk = per_block;
+    if (chunk > V) chunk = V;
+    return (int)chunk;
+}
+static inline int m1_red_nchunks(long long V, int C) { return (int)cdiv_ll(V, m1_red_chunkV(V, C)); }
+
+static inline int m1_pow2_ge(int c) { int p = 1; while (p < c) p <<= 1; return p; }
+
+// Functor contract:  __device__ void operator()(int n, long long v, int c, float* acc) const;   acc[NS] += ...
+template <int NS, typename F>
+__global__ void __launch_bounds__(M1_RED_THREADS) m1_reduce_nc_kernel(F f, long long V, int C, int chunkV,
+                                                                      int nchunks, float* __restrict__ partial) {
+    __shared__ float red[M1_RED_THREADS * NS];
+    const int n = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
+    const long long v0 = (long long)chunk * chunkV;
+    long long v1 = v0 + chunkV; if (v1 > V) v1 = V;
+    int cpad = 1; while (cpad < C && cpad < M1_RED_THREADS) cpad <<= 1;   // lanes along C
+    const int vs = tid / cpad, nvs = M1_RED_THREADS / cpad, cl = tid % cpad;
+    for (int cbase = 0; cbase < C; cbase += cpad) {
+        const int c = cbase + cl;
+        float acc[NS];
+#pragma unroll
+        for (int k = 0; k < NS; ++k) acc[k] = 0.f;
+        if (c < C)
+            for (long long v = v0 + vs; v < v1; v += nvs) f(n, v, c, acc);
+#pragma unroll
+        for (int k = 0; k < NS; ++k) red[tid * NS + k] = acc[k];
+        __syncthreads();
+        if (vs == 0 && c < C) {
+#pragma unroll
+            for (int k = 0; k < NS; ++k) {
+                float s = 0.f;
+                for (int j = 0; j < nvs; ++j) s += red[(j * cpad + cl) * NS + k];
+                partial[(((size_t)n * nchunks + chunk) * C + c) * NS + k] = s;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// out[n][c][k] = sum_chunks partial (fp64 accumulate) -> float
+template <int NS>
+__global__ void m1_reduce_finalize_kernel(const float* __restrict__ partial, int N, int C, int nchunks,
+                                          float* __restrict__ out) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N * C) return;
+    int n = i / C, c = i % C;
+    double s[NS];
+#pragma unroll
+    for (int k = 0; k < NS; ++k) s[k] = 0.0;
+    for (int j = 0; j < nchunks; ++j)
+#pragma unroll
+        for (int k = 0; k < NS; ++k) s[k] += (double)partial[(((size_t)n * nchunks + j) * C + c) * NS + k];
+#pragma unroll
+    for (int k = 0; k < NS; ++k) out[(size_t)i * NS + k] = (float)s[k];
+}
+
+template <int NS, typename F>
+static inline int m1_reduce_nc_launch(const F& f, int N, long long V, int C, float* partial, hipStream_t st) {
+    const int chunkV = m1_red_chunkV(V, C), nchunks = m1_red_nchunks(V, C);
+    dim3 grid(nchunks, N);
+    hipLaunchKernelGGL((m1_reduce_nc_kernel<NS, F>), grid, dim3(M1_RED_THREADS), 0, st, f, V, C, chunkV, nchunks,
+                       partial);
+    return m1_check_launch();
+}

@@ -1,0 +1,254 @@
+// se.hip -- squeeze-excitation gate and the multiplicative-residual combine of SEResNetBottleNeck
+// (network_blocks.py:68-78), forward and backward, with the block's dropout
+// (networks.py:579-582,597,607,616,624; network_blocks.py:142-143) fused into the epilogue.
+//
+//   x_  = IN3(y3)            rho = IN4(y4)            g = sigmoid(W7 . lrelu(W6 . GAP(x_) + b6) + b7)
+//   out = dropout( lrelu( x_ * g * rho ) )
+// GAP(IN3(.)) over D,H,W equals beta3 exactly, so g depends on parameters only.
+#include "common.h"
+#include "reduce.h"
+
+#define SE_MAX_F 1024
+#define SE_MAX_FR 256
+
+// ---------------- gate (one block) ----------------
+__global__ void __launch_bounds__(256) se_gate_fwd_kernel(const float* __restrict__ beta3, const float* __restrict__ W6,
+                                                          const float* __restrict__ b6, const float* __restrict__ W7,
+                                                          const float* __restrict__ b7, int F, int Fr,
+                                                          float* __restrict__ hidden, float* __restrict__ g) {
+    __shared__ float h_s[SE_MAX_FR];
+    for (int j = threadIdx.x; j < Fr; j += blockDim.x) {
+        float s = b6[j];
+        for (int c = 0; c < F; ++c) s = fmaf(beta3[c], W6[(size_t)c * Fr + j], s);
+        hidden[j] = s;
+        h_s[j] = lrelu_f(s, 0.1f);
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < F; c += blockDim.x) {
+        float s = b7[c];
+        for (int j = 0; j < Fr; ++j) s = fmaf(h_s[j], W7[(size_t)j * F + c], s);
+        g[c] = 1.f / (1.f + expf(-s));
+    }
+}
+
+__global__ void __launch_bounds__(256) se_gate_bwd_kernel(const float* __restrict__ beta3, const float* __restrict__ W6,
+                                                          const float* __restrict__ W7, const float* __restrict__ hidden,
+                                                          const float* __restrict__ g, const float* __restrict__ dg, int F,
+                                                          int Fr, float* __restrict__ dbeta3_add, float* __restrict__ dW6,
+                                                          float* __restrict__ db6, float* __restrict__ dW7,
+                                                          float* __restrict__ db7) {
+    __shared__ float dgp_s[SE_MAX_F];
+    __shared__ float dh_s[SE_MAX_FR];
+    for (int c = threadIdx.x; c < F; c += blockDim.x) {
+        const float t = dg[c] * g[c] * (1.f - g[c]);
+        dgp_s[c] = t; db7[c] = t;
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < Fr; j += blockDim.x) {
+        const float h = lrelu_f(hidden[j], 0.1f);
+        float s = 0.f;
+        for (int c = 0; c < F; ++c) {
+            s = fmaf(W7[(size_t)j * F + c], dgp_s[c], s);
+            dW7[(size_t)j * F + c] = h * dgp_s[c];
+        }
+        const float dhid = s * lrelu_g(hidden[j], 0.1f);
+        dh_s[j] = dhid; db6[j] = dhid;
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < F; c += blockDim.x) {
+        float s = 0.f;
+        for (int j = 0; j < Fr; ++j) {
+            s = fmaf(W6[(size_t)c * Fr + j], dh_s[j], s);
+            dW6[(size_t)c * Fr + j] = beta3[c] * dh_s[j];
+        }
+        dbeta3_add[c] += s;
+    }
+}
+
+extern "C" int m1_se_gate_fwd(const float* beta3, const float* W6, const float* b6, const float* W7, const float* b7,
+                              int F, int Fr, float* hidden, float* g, void* stream) {
+    if (!beta3 || !W6 || !b6 || !W7 || !b7 || !hidden || !g || F <= 0 || Fr <= 0) return M1_ERR_BAD_ARG;
+    if (F > SE_MAX_F || Fr > SE_MAX_FR) return M1_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(se_gate_fwd_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, beta3, W6, b6, W7, b7, F, Fr, hidden, g);
+    return m1_check_launch();
+}
+extern "C" int m1_se_gate_bwd(const float* beta3, const float* W6, const float* W7, const float* hidden, const float* g,
+                              const float* dg, int F, int Fr, float* dbeta3_add, float* dW6, float* db6, float* dW7,
+                              float* db7, void* stream) {
+    if (!beta3 || !W6 || !W7 || !hidden || !g || !dg || !dbeta3_add || !dW6 || !db6 || !dW7 || !db7) return M1_ERR_BAD_ARG;
+    if (F > SE_MAX_F || Fr > SE_MAX_FR) return M1_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(se_gate_bwd_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, beta3, W6, W7, hidden, g, dg, F, Fr,
+                       dbeta3_add, dW6, db6, dW7, db7);
+    return m1_check_launch();
+}
+
+// ---------------- combine forward ----------------
+struct SeParams {
+    const float *stats3, *stats4, *gamma3, *beta3, *gamma4, *beta4, *g;
+    long long V; int F;
+    float drop_rate; const uint64_t* rng; uint64_t layer_id;
+};
+
+__device__ __forceinline__ void se_rng(const SeParams& p, uint64_t& seed, uint64_t& base) {
+    seed = 0; base = 0;
+    if (p.drop_rate > 0.f) { seed = p.rng[0] + p.layer_id * 0x9E3779B97F4A7C15ull; base = p.rng[1] << 36; }
+}
+
+template <typename T, int VEC>
+__global__ void __launch_bounds__(256) se_combine_fwd_kernel(const T* __restrict__ y3, const T* __restrict__ y4, SeParams p,
+                                                             T* __restrict__ out) {
+    const int n = blockIdx.y, F = p.F, cg = F / VEC;
+    const long long per = p.V * cg;
+    const size_t base = (size_t)n * p.V * F;
+    uint64_t seed, rbase; se_rng(p, seed, rbase);
+    const float keep_scale = p.drop_rate > 0.f ? 1.f / (1.f - p.drop_rate) : 1.f;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < per; i += (long long)gridDim.x * blockDim.x) {
+        const int c0 = (int)(i % cg) * VEC;
+        float a[VEC], b[VEC];
+        VecIO<T, VEC>::ld(y3 + base + i * VEC, a);
+        VecIO<T, VEC>::ld(y4 + base + i * VEC, b);
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) {
+            const int c = c0 + k; const size_t sc = ((size_t)n * F + c) * 2;
+            const float x_ = (a[k] - p.stats3[sc]) * p.stats3[sc + 1] * p.gamma3[c] + p.beta3[c];
+            const float rho = (b[k] - p.stats4[sc]) * p.stats4[sc + 1] * p.gamma4[c] + p.beta4[c];
+            float o = lrelu_f(x_ * p.g[c] * rho, 0.1f);
+            if (p.drop_rate > 0.f) o = philox_keep(seed, rbase, base + i * VEC + k, p.drop_rate) ? o * keep_scale : 0.f;
+            a[k] = o;
+        }
+        VecIO<T, VEC>::st(out + base + i * VEC, a);
+    }
+}
+
+// ---------------- combine backward ----------------
+template <typename T>
+struct SeBwdF {
+    const T* y3; const T* y4; const T* dout; SeParams p;
+    __device__ void operator()(int n, long long v, int c, float* acc) const {
+        const int F = p.F;
+        const size_t idx = ((size_t)n * p.V + v) * F + c; const size_t sc = ((size_t)n * F + c) * 2;
+        const float xh3 = (Act<T>::ld(y3 + idx) - p.stats3[sc]) * p.stats3[sc + 1];
+        const float xh4 = (Act<T>::ld(y4 + idx) - p.stats4[sc]) * p.stats4[sc + 1];
+        const float x_ = xh3 * p.gamma3[c] + p.beta3[c], rho = xh4 * p.gamma4[c] + p.beta4[c];
+        const float g = p.g[c], u = x_ * g * rho;
+        float d = Act<T>::ld(dout + idx);
+        if (p.drop_rate > 0.f) {
+            uint64_t seed, rbase; se_rng(p, seed, rbase);
+            d = philox_keep(seed, rbase, idx, p.drop_rate) ? d / (1.f - p.drop_rate) : 0.f;
+        }
+        const float du = d * lrelu_g(u, 0.1f);
+        const float dx_ = du * g * rho, drho = du * g * x_;
+        acc[0] += dx_; acc[1] += dx_ * xh3; acc[2] += drho; acc[3] += drho * xh4; acc[4] += du * x_ * rho;
+    }
+};
+
+template <typename T, int VEC>
+__global__ void __launch_bounds__(256) se_combine_bwd_apply_kernel(const T* __restrict__ y3, const T* __restrict__ y4,
+                                                                   const T* __restrict__ dout, SeParams p,
+                                                                   const float* __restrict__ sums /*[N][F][5]*/,
+                                                                   T* __restrict__ dy3, T* __restrict__ dy4) {
+    const int n = blockIdx.y, F = p.F, cg = F / VEC;
+    const long long per = p.V * cg;
+    const size_t base = (size_t)n * p.V * F;
+    const float invV = 1.f / (float)p.V;
+    uint64_t seed, rbase; se_rng(p, seed, rbase);
+    const float keep_scale = p.drop_rate > 0.f ? 1.f / (1.f - p.drop_rate) : 1.f;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < per; i += (long long)gridDim.x * blockDim.x) {
+        const int c0 = (int)(i % cg) * VEC;
+        float a[VEC], b[VEC], d[VEC];
+        VecIO<T, VEC>::ld(y3 + base + i * VEC, a);
+        VecIO<T, VEC>::ld(y4 + base + i * VEC, b);
+        VecIO<T, VEC>::ld(dout + base + i * VEC, d);
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) {
+            const int c = c0 + k; const size_t sc = ((size_t)n * F + c) * 2;
+            const float r3 = p.stats3[sc + 1], r4 = p.stats4[sc + 1];
+            const float xh3 = (a[k] - p.stats3[sc]) * r3, xh4 = (b[k] - p.stats4[sc]) * r4;
+            const float x_ = xh3 * p.gamma3[c] + p.beta3[c], rho = xh4 * p.gamma4[c] + p.beta4[c];
+            const float g = p.g[c], u = x_ * g * rho;
+            float dd = d[k];
+            if (p.drop_rate > 0.f) dd = philox_keep(seed, rbase, base + i * VEC + k, p.drop_rate) ? dd * keep_scale : 0.f;
+            const float du = dd * lrelu_g(u, 0.1f);
+            const float dx_ = du * g * rho, drho = du * g * x_;
+            const float* s = sums + ((size_t)n * F + c) * 5;
+            a[k] = p.gamma3[c] * r3 * (dx_ - s[0] * invV - xh3 * s[1] * invV);
+            b[k] = p.gamma4[c] * r4 * (drho - s[2] * invV - xh4 * s[3] * invV);
+        }
+        VecIO<T, VEC>::st(dy3 + base + i * VEC, a);
+        VecIO<T, VEC>::st(dy4 + base + i * VEC, b);
+    }
+}
+
+__global__ void se_bwd_param_kernel(const float* __restrict__ sums, int N, int F, float* __restrict__ dgamma3,
+                                    float* __restrict__ dbeta3, float* __restrict__ dgamma4, float* __restrict__ dbeta4,
+                                    float* __restrict__ dg) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= F) return;
+    double s[5] = {0, 0, 0, 0, 0};
+    for (int n = 0; n < N; ++n)
+        for (int k = 0; k < 5; ++k) s[k] += sums[((size_t)n * F + c) * 5 + k];
+    dbeta3[c] = (float)s[0]; dgamma3[c] = (float)s[1]; dbeta4[c] = (float)s[2]; dgamma4[c] = (float)s[3]; dg[c] = (float)s[4];
+}
+
+static inline int grid_x(long long per) { long long g = cdiv_ll(per, 256); return (int)(g > 4096 ? 4096 : (g < 1 ? 1 : g)); }
+
+template <typename T>
+static int se_fwd_impl(const void* y3, const void* y4, const SeParams& p, void* out, int N, hipStream_t st) {
+    constexpr int VW = sizeof(T) == 2 ? 8 : 4;
+    if (p.F % VW == 0)
+        hipLaunchKernelGGL((se_combine_fwd_kernel<T, VW>), dim3(grid_x(p.V * (p.F / VW)), N), dim3(256), 0, st, (const T*)y3,
+                           (const T*)y4, p, (T*)out);
+    else
+        hipLaunchKernelGGL((se_combine_fwd_kernel<T, 1>), dim3(grid_x(p.V * p.F), N), dim3(256), 0, st, (const T*)y3,
+                           (const T*)y4, p, (T*)out);
+    return m1_check_launch();
+}
+
+template <typename T>
+static int se_bwd_impl(const void* y3, const void* y4, const void* dout, const SeParams& p, void* dy3, void* dy4,
+                       float* dgamma3, float* dbeta3, float* dgamma4, float* dbeta4, float* dg, int N, float* ws,
+                       hipStream_t st) {
+    SeBwdF<T> f{(const T*)y3, (const T*)y4, (const T*)dout, p};
+    int rc = m1_reduce_nc_launch<5>(f, N, p.V, p.F, ws, st);
+    if (rc) return rc;
+    const int nchunks = m1_red_nchunks(p.V, p.F);
+    float* sums = ws + (size_t)N * nchunks * p.F * 5;
+    hipLaunchKernelGGL((m1_reduce_finalize_kernel<5>), dim3((N * p.F + 255) / 256), dim3(256), 0, st, ws, N, p.F, nchunks, sums);
+    hipLaunchKernelGGL(se_bwd_param_kernel, dim3((p.F + 255) / 256), dim3(256), 0, st, sums, N, p.F, dgamma3, dbeta3, dgamma4,
+                       dbeta4, dg);
+    constexpr int VW = sizeof(T) == 2 ? 8 : 4;
+    if (p.F % VW == 0)
+        hipLaunchKernelGGL((se_combine_bwd_apply_kernel<T, VW>), dim3(grid_x(p.V * (p.F / VW)), N), dim3(256), 0, st,
+                           (const T*)y3, (const T*)y4, (const T*)dout, p, sums, (T*)dy3, (T*)dy4);
+    else
+        hipLaunchKernelGGL((se_combine_bwd_apply_kernel<T, 1>), dim3(grid_x(p.V * p.F), N), dim3(256), 0, st, (const T*)y3,
+                           (const T*)y4, (const T*)dout, p, sums, (T*)dy3, (T*)dy4);
+    return m1_check_launch();
+}
+
+extern "C" int m1_se_combine_fwd(const void* y3, const void* y4, const float* stats3, const float* stats4,
+                                 const float* gamma3, const float* beta3, const float* gamma4, const float* beta4,
+                                 const float* g, void* out, int N, long long V, int F, int dtype, float drop_rate,
+                                 const uint64_t* rng, uint64_t layer_id, void* stream) {
+    if (!y3 || !y4 || !stats3 || !stats4 || !gamma3 || !beta3 || !gamma4 || !beta4 || !g || !out) return M1_ERR_BAD_ARG;
+    if (drop_rate > 0.f && !rng) return M1_ERR_BAD_ARG;
+    if (drop_rate < 0.f || drop_rate >= 1.f) return M1_ERR_BAD_ARG;
+    SeParams p{stats3, stats4, gamma3, beta3, gamma4, beta4, g, V, F, drop_rate, rng, layer_id};
+    M1ProfScope ps("se_combine_fwd", 0.0, 3.0 * N * V * F * (dtype == M1_BF16 ? 2 : 4), (hipStream_t)stream);
+    return dtype == M1_BF16 ? se_fwd_impl<bf16_t>(y3, y4, p, out, N, (hipStream_t)stream)
+                            : se_fwd_impl<float>(y3, y4, p, out, N, (hipStream_t)stream);
+}
+
+extern "C" int m1_se_combine_bwd(const void* y3, const void* y4, const float* stats3, const float* stats4,
+                                 const float* gamma3, const float* beta3, const float* gamma4, const float* beta4,
+                                 const float* g, const void* dout, void* dy3, void* dy4, float* dgamma3, float* dbeta3,
+                                 float* dgamma4, float* dbeta4, float* dg, int N, long long V, int F, int dtype,
+                                 float drop_rate, const uint64_t* rng, uint64_t layer_id, float* ws, void* stream) {
+    if (!y3 || !y4 || !dout || !dy3 || !dy4 || !dgamma3 || !dbeta3 || !dgamma4 || !dbeta4 || !dg || !ws) return M1_ERR_BAD_ARG;
+    if (drop_rate > 0.f && !rng) return M1_ERR_BAD_ARG;
+    SeParams p{stats3, stats4, gamma3, beta3, gamma4, beta4, g, V, F, drop_rate, rng, layer_id};
+    M1ProfScope ps("se_combine_bwd", 0.0, 8.0 * N * V * F * (dtype == M1_BF16 ? 2 : 4), (hipStream_t)stream);
+    return dtype == M1_BF16
+               ? se_bwd_impl<bf16_t>(y3, y4, dout, p, dy3, dy4, dgamma3, dbeta3, dgamma4, dbeta4, dg, N, ws, (hipStream_t)stream)
+               : se_bwd_impl<float>(y3, y4, dout, p, dy3, dy4, dgamma3, dbeta3, dgamma4, dbeta4, dg, N, ws, (hipStream_t)stream);
+}

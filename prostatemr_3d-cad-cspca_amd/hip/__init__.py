@@ -1,0 +1,2 @@
+from . import lib    # noqa: F401
+from . import ops    # noqa: F401

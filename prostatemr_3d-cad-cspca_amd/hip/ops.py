@@ -1,0 +1,476 @@
+"""torch.autograd.Function shims over the C ABI (include/m1hip.h): PyTorch supplies device memory, the
+current HIP stream and the autograd tape; every FLOP of the M1 hot path runs in libm1hip.so.
+
+All activations are NDHWC, contiguous, float32 or bfloat16, on a CUDA(HIP) device.  There is no CPU
+path: ops raise RuntimeError on non-GPU tensors.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+
+from . import lib as L
+
+IN_EPS = 1e-3
+
+
+def _dt(t: torch.Tensor) -> int:
+    if t.dtype == torch.float32:
+        return L.M1_F32
+    if t.dtype == torch.bfloat16:
+        return L.M1_BF16
+    raise RuntimeError(f"unsupported activation dtype {t.dtype} (float32 / bfloat16 only)")
+
+
+def _req(*ts):
+    for t in ts:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise RuntimeError("M1 HIP ops need tensors on a GPU (cuda/HIP) device: the HIP extension is the only "
+                               "compute path of this package; there is no CPU fallback")
+        if not t.is_contiguous():
+            raise RuntimeError("M1 HIP ops need contiguous NDHWC tensors")
+
+
+def _p(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ws(N: int, V: int, Cn: int, nsums: int, device) -> torch.Tensor:
+    n = L.load().m1_reduce_ws_floats(int(N), int(V), int(Cn), int(nsums))
+    return torch.empty(int(n), dtype=torch.float32, device=device)
+
+
+def _desc(srcs: Sequence[torch.Tensor], cout: int, k, s) -> L.m1_conv_desc_t:
+    d = L.m1_conv_desc_t()
+    x0 = srcs[0]
+    d.N, d.D, d.H, d.W = int(x0.shape[0]), int(x0.shape[1]), int(x0.shape[2]), int(x0.shape[3])
+    d.Cin = int(sum(int(t.shape[4]) for t in srcs))
+    d.Cout = int(cout)
+    d.kd, d.kh, d.kw = (int(v) for v in k)
+    d.sd, d.sh, d.sw = (int(v) for v in s)
+    d.dtype = _dt(x0)
+    d.nsrc = len(srcs)
+    if len(srcs) > L.M1_MAX_SRC:
+        raise RuntimeError("too many concat members")
+    for i, t in enumerate(srcs):
+        if t.shape[:4] != x0.shape[:4] or t.dtype != x0.dtype:
+            raise RuntimeError("concat members must agree in N,D,H,W and dtype")
+        d.src[i].ptr = t.data_ptr()
+        d.src[i].C = int(t.shape[4])
+    return d
+
+
+def same_out(size: int, s: int) -> int:
+    return -(-size // s)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# Conv3D / Conv3DTranspose (padding='same') over a virtual channel concat
+# ---------------------------------------------------------------------------------------------------------
+class _Conv3d(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, w, b, k, s, transposed, *srcs):
+        _req(w, b, *srcs)
+        lib = L.load()
+        x0 = srcs[0]
+        cout = int(w.shape[3] if transposed else w.shape[4])
+        cin = int(w.shape[4] if transposed else w.shape[3])
+        d = _desc(srcs, cout, k, s)
+        if d.Cin != cin or tuple(w.shape[:3]) != tuple(k):
+            raise RuntimeError(f"kernel {tuple(w.shape)} does not match inputs (Cin={d.Cin}, k={k})")
+        if transposed:
+            osz = (d.N, d.D * d.sd, d.H * d.sh, d.W * d.sw, cout)
+        else:
+            osz = (d.N, same_out(d.D, d.sd), same_out(d.H, d.sh), same_out(d.W, d.sw), cout)
+        y = torch.empty(osz, dtype=x0.dtype, device=x0.device)
+        fn = lib.m1_convT3d_fwd if transposed else lib.m1_conv3d_fwd
+        L.check(fn(C.byref(d), _p(w), _p(b), _p(y), _stream()), "m1_convT3d_fwd" if transposed else "m1_conv3d_fwd")
+        ctx.save_for_backward(w, *srcs)
+        ctx.k, ctx.s, ctx.transposed, ctx.has_bias, ctx.cout = tuple(k), tuple(s), transposed, b is not None, cout
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = L.load()
+        w, *srcs = ctx.saved_tensors
+        dy = dy.contiguous()
+        _req(dy)
+        d = _desc(srcs, ctx.cout, ctx.k, ctx.s)
+        st = _stream()
+        name = "convT3d" if ctx.transposed else "conv3d"
+        dw = db = None
+        if ctx.needs_input_grad[0] or (ctx.has_bias and ctx.needs_input_grad[1]):
+            dw = torch.empty_like(w)
+            db = torch.empty(ctx.cout, dtype=torch.float32, device=w.device) if ctx.has_bias else None
+            V = dy.shape[1] * dy.shape[2] * dy.shape[3]
+            ws = _ws(d.N, V, ctx.cout, 1, w.device) if db is not None else None
+            fn = lib.m1_convT3d_wgrad if ctx.transposed else lib.m1_conv3d_wgrad
+            L.check(fn(C.byref(d), _p(dy), _p(dw), _p(db), _p(ws), st), f"m1_{name}_wgrad")
+        dsrc: List[Optional[torch.Tensor]] = []
+        ptrs = (C.c_void_p * len(srcs))()
+        any_d = False
+        for i, t in enumerate(srcs):
+            if ctx.needs_input_grad[5 + i]:
+                g = torch.empty_like(t)
+                dsrc.append(g)
+                ptrs[i] = g.data_ptr()
+                any_d = True
+            else:
+                dsrc.append(None)
+                ptrs[i] = None
+        if any_d:
+            fn = lib.m1_convT3d_dgrad if ctx.transposed else lib.m1_conv3d_dgrad
+            L.check(fn(C.byref(d), _p(w), _p(dy), ptrs, st), f"m1_{name}_dgrad")
+        return (dw, db, None, None, None, *dsrc)
+
+
+def conv3d_same(srcs, w, b, k, s):
+    """tf.keras.layers.Conv3D(padding='same') on the channel-concat of ``srcs`` (never materialised)."""
+    if isinstance(srcs, torch.Tensor):
+        srcs = [srcs]
+    return _Conv3d.apply(w, b, tuple(k), tuple(s), False, *srcs)
+
+
+def conv3d_transpose_same(srcs, w, b, k, s):
+    """tf.keras.layers.Conv3DTranspose(padding='same') on the channel-concat of ``srcs``."""
+    if isinstance(srcs, torch.Tensor):
+        srcs = [srcs]
+    return _Conv3d.apply(w, b, tuple(k), tuple(s), True, *srcs)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# InstanceNormalization (+ LeakyReLU)
+# ---------------------------------------------------------------------------------------------------------
+def instnorm_stats(x: torch.Tensor) -> torch.Tensor:
+    _req(x)
+    N, Cn = int(x.shape[0]), int(x.shape[-1])
+    V = x.numel() // (N * Cn)
+    stats = torch.empty((N, Cn, 2), dtype=torch.float32, device=x.device)
+    ws = _ws(N, V, Cn, 2, x.device)
+    L.check(L.load().m1_instnorm_stats(_p(x), N, V, Cn, _dt(x), IN_EPS, _p(stats), _p(ws), _stream()), "m1_instnorm_stats")
+    return stats
+
+
+class _InstNormAct(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, slope):
+        _req(x, gamma, beta)
+        N, Cn = int(x.shape[0]), int(x.shape[-1])
+        V = x.numel() // (N * Cn)
+        stats = instnorm_stats(x)
+        y = torch.empty_like(x)
+        L.check(L.load().m1_instnorm_apply(_p(x), _p(stats), _p(gamma), _p(beta), float(slope), _p(y), N, V, Cn, _dt(x),
+                                           _stream()), "m1_instnorm_apply")
+        ctx.save_for_backward(x, stats, gamma, beta)
+        ctx.slope = float(slope)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, stats, gamma, beta = ctx.saved_tensors
+        dy = dy.contiguous()
+        N, Cn = int(x.shape[0]), int(x.shape[-1])
+        V = x.numel() // (N * Cn)
+        dx = torch.empty_like(x)
+        dg = torch.empty_like(gamma)
+        db = torch.empty_like(beta)
+        ws = _ws(N, V, Cn, 2, x.device)
+        L.check(L.load().m1_instnorm_bwd(_p(x), _p(stats), _p(gamma), _p(beta), ctx.slope, _p(dy), _p(dx), _p(dg), _p(db),
+                                         N, V, Cn, _dt(x), _p(ws), _stream()), "m1_instnorm_bwd")
+        return dx, dg, db, None
+
+
+def instnorm_act(x, gamma, beta, slope: float = 1.0):
+    """tfa InstanceNormalization (eps 1e-3) followed by LeakyReLU(slope) (slope=1 -> no activation)."""
+    return _InstNormAct.apply(x, gamma, beta, slope)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# SE gate + multiplicative combine (+ fused dropout)
+# ---------------------------------------------------------------------------------------------------------
+class _SECombine(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, y3, y4, g3, b3, g4, b4, W6, b6, W7, b7, drop_rate, rng, layer_id):
+        _req(y3, y4, g3, b3, g4, b4, W6, b6, W7, b7)
+        lib = L.load()
+        N, Fn = int(y3.shape[0]), int(y3.shape[-1])
+        V = y3.numel() // (N * Fn)
+        Fr = int(W6.shape[-1])
+        st = _stream()
+        s3, s4 = instnorm_stats(y3), instnorm_stats(y4)
+        hidden = torch.empty(Fr, dtype=torch.float32, device=y3.device)
+        g = torch.empty(Fn, dtype=torch.float32, device=y3.device)
+        L.check(lib.m1_se_gate_fwd(_p(b3), _p(W6), _p(b6), _p(W7), _p(b7), Fn, Fr, _p(hidden), _p(g), st), "m1_se_gate_fwd")
+        out = torch.empty_like(y3)
+        L.check(lib.m1_se_combine_fwd(_p(y3), _p(y4), _p(s3), _p(s4), _p(g3), _p(b3), _p(g4), _p(b4), _p(g), _p(out), N, V, Fn,
+                                      _dt(y3), float(drop_rate), _p(rng), int(layer_id), st), "m1_se_combine_fwd")
+        ctx.save_for_backward(y3, y4, s3, s4, g3, b3, g4, b4, W6, W7, hidden, g)
+        ctx.rng, ctx.drop_rate, ctx.layer_id = rng, float(drop_rate), int(layer_id)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        lib = L.load()
+        y3, y4, s3, s4, g3, b3, g4, b4, W6, W7, hidden, g = ctx.saved_tensors
+        dout = dout.contiguous()
+        N, Fn = int(y3.shape[0]), int(y3.shape[-1])
+        V = y3.numel() // (N * Fn)
+        Fr = int(W6.shape[-1])
+        st = _stream()
+        dev = y3.device
+        dy3, dy4 = torch.empty_like(y3), torch.empty_like(y4)
+        dg3, db3, dg4, db4, dg = (torch.empty(Fn, dtype=torch.float32, device=dev) for _ in range(5))
+        ws = _ws(N, V, Fn, 5, dev)
+        L.check(lib.m1_se_combine_bwd(_p(y3), _p(y4), _p(s3), _p(s4), _p(g3), _p(b3), _p(g4), _p(b4), _p(g), _p(dout),
+                                      _p(dy3), _p(dy4), _p(dg3), _p(db3), _p(dg4), _p(db4), _p(dg), N, V, Fn, _dt(y3),
+                                      ctx.drop_rate, _p(ctx.rng), ctx.layer_id, _p(ws), st), "m1_se_combine_bwd")
+        dW6, dW7 = torch.empty_like(W6), torch.empty_like(W7)
+        db6 = torch.empty(Fr, dtype=torch.float32, device=dev)
+        db7 = torch.empty(Fn, dtype=torch.float32, device=dev)
+        L.check(lib.m1_se_gate_bwd(_p(b3), _p(W6), _p(W7), _p(hidden), _p(g), _p(dg), Fn, Fr, _p(db3), _p(dW6), _p(db6),
+                                   _p(dW7), _p(db7), st), "m1_se_gate_bwd")
+        return dy3, dy4, dg3, db3, dg4, db4, dW6, db6, dW7, db7, None, None, None
+
+
+def se_combine(y3, y4, g3, b3, g4, b4, W6, b6, W7, b7, drop_rate=0.0, rng=None, layer_id=0):
+    """dropout(lrelu(IN3(y3) * sigmoid(W7.lrelu(W6.beta3+b6)+b7) * IN4(y4)))  (network_blocks.py:60-78)."""
+    return _SECombine.apply(y3, y4, g3, b3, g4, b4, W6, b6, W7, b7, drop_rate, rng, layer_id)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# attention-gate pieces
+# ---------------------------------------------------------------------------------------------------------
+class _GateSigma(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, theta, phi, wpsi, bpsi):
+        _req(theta, phi, wpsi, bpsi)
+        N, Dt, Ht, Wt, Cn = (int(v) for v in theta.shape)
+        Dp, Hp, Wp = (int(v) for v in phi.shape[1:4])
+        sigma = torch.empty((N, Dt, Ht, Wt), dtype=theta.dtype, device=theta.device)
+        L.check(L.load().m1_gate_sigma_fwd(_p(theta), _p(phi), _p(wpsi), _p(bpsi), _p(sigma), N, Dt, Ht, Wt, Dp, Hp, Wp, Cn,
+                                           _dt(theta), _stream()), "m1_gate_sigma_fwd")
+        ctx.save_for_backward(theta, phi, wpsi, sigma)
+        return sigma
+
+    @staticmethod
+    def backward(ctx, dsigma):
+        theta, phi, wpsi, sigma = ctx.saved_tensors
+        dsigma = dsigma.contiguous()
+        N, Dt, Ht, Wt, Cn = (int(v) for v in theta.shape)
+        Dp, Hp, Wp = (int(v) for v in phi.shape[1:4])
+        dtheta, dphi = torch.empty_like(theta), torch.empty_like(phi)
+        dw = torch.empty_like(wpsi)
+        db = torch.empty(1, dtype=torch.float32, device=theta.device)
+        ws = _ws(N, Dt * Ht * Wt, Cn, 2, theta.device)
+        L.check(L.load().m1_gate_sigma_bwd(_p(theta), _p(phi), _p(wpsi), _p(sigma), _p(dsigma), _p(dtheta), _p(dphi), _p(dw),
+                                           _p(db), N, Dt, Ht, Wt, Dp, Hp, Wp, Cn, _dt(theta), _p(ws), _stream()),
+                "m1_gate_sigma_bwd")
+        return dtheta, dphi, dw, db
+
+
+def gate_sigma(theta, phi, wpsi, bpsi):
+    return _GateSigma.apply(theta, phi, wpsi, bpsi)
+
+
+class _MulSigma(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, sigma, ss):
+        _req(x, sigma)
+        N, D, H, W, Cn = (int(v) for v in x.shape)
+        y = torch.empty_like(x)
+        L.check(L.load().m1_mul_sigma_fwd(_p(x), _p(sigma), _p(y), N, D, H, W, Cn, int(ss[0]), int(ss[1]), int(ss[2]), _dt(x),
+                                          _stream()), "m1_mul_sigma_fwd")
+        ctx.save_for_backward(x, sigma)
+        ctx.ss = tuple(int(v) for v in ss)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, sigma = ctx.saved_tensors
+        dy = dy.contiguous()
+        N, D, H, W, Cn = (int(v) for v in x.shape)
+        dx, dsig = torch.empty_like(x), torch.empty_like(sigma)
+        L.check(L.load().m1_mul_sigma_bwd(_p(x), _p(sigma), _p(dy), _p(dx), _p(dsig), N, D, H, W, Cn, *ctx.ss, _dt(x),
+                                          _stream()), "m1_mul_sigma_bwd")
+        return dx, dsig, None
+
+
+def mul_sigma(x, sigma, ss=(1, 1, 1)):
+    return _MulSigma.apply(x, sigma, tuple(ss))
+
+
+# ---------------------------------------------------------------------------------------------------------
+# latent sample / KL
+# ---------------------------------------------------------------------------------------------------------
+class _LatentSample(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, ml, eps, mode):
+        _req(ml, eps)
+        N = int(ml.shape[0]); Lc = int(ml.shape[-1]) // 2
+        V = ml.numel() // (N * 2 * Lc)
+        z = torch.empty((*ml.shape[:-1], Lc), dtype=ml.dtype, device=ml.device)
+        L.check(L.load().m1_latent_sample_fwd(_p(ml), _p(eps), _p(z), N, V, Lc, int(mode), _dt(ml), _stream()),
+                "m1_latent_sample_fwd")
+        ctx.save_for_backward(ml, eps if eps is not None else ml.new_empty(0))
+        ctx.mode = int(mode)
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        ml, eps = ctx.saved_tensors
+        dz = dz.contiguous()
+        N = int(ml.shape[0]); Lc = int(ml.shape[-1]) // 2
+        V = ml.numel() // (N * 2 * Lc)
+        dml = torch.empty_like(ml)
+        L.check(L.load().m1_latent_sample_bwd(_p(ml), _p(eps) if eps.numel() else None, _p(dz), _p(dml), N, V, Lc, ctx.mode,
+                                              _dt(ml), _stream()), "m1_latent_sample_bwd")
+        return dml, None, None
+
+
+def latent_sample(ml, eps, mean: bool):
+    """z = mu + exp(clip(logsigma,+-0.1))*eps, or mu when ``mean`` (networks.py:640-647)."""
+    return _LatentSample.apply(ml, eps, 1 if mean else 0)
+
+
+class _KL(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, mq, mp):
+        _req(mq, mp)
+        N = int(mq.shape[0]); Lc = int(mq.shape[-1]) // 2
+        V = mq.numel() // (N * 2 * Lc)
+        kl = torch.empty(1, dtype=torch.float32, device=mq.device)
+        L.check(L.load().m1_kl_fwd(_p(mq), _p(mp), _p(kl), N, V, Lc, _dt(mq), _stream()), "m1_kl_fwd")
+        ctx.save_for_backward(mq, mp)
+        return kl
+
+    @staticmethod
+    def backward(ctx, dkl):
+        mq, mp = ctx.saved_tensors
+        dkl = dkl.contiguous().float()
+        N = int(mq.shape[0]); Lc = int(mq.shape[-1]) // 2
+        V = mq.numel() // (N * 2 * Lc)
+        dq, dp = torch.empty_like(mq), torch.empty_like(mp)
+        L.check(L.load().m1_kl_bwd(_p(mq), _p(mp), _p(dkl), _p(dq), _p(dp), N, V, Lc, _dt(mq), _stream()), "m1_kl_bwd")
+        return dq, dp
+
+
+def kl_mvn_diag(ml_q, ml_p):
+    """mean_b sum_voxels KL(q||p) of one level (networks.py:375-377) -> tensor of shape (1,)."""
+    return _KL.apply(ml_q, ml_p)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# softmax heads
+# ---------------------------------------------------------------------------------------------------------
+class _SoftmaxHeads(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, ups, *logits):
+        _req(*logits)
+        l0 = logits[0]
+        N, D, H, W, nc = (int(v) for v in l0.shape)
+        heads = (L.m1_head_t * len(logits))()
+        for i, (t, u) in enumerate(zip(logits, ups)):
+            heads[i].logits = t.data_ptr(); heads[i].dlogits = None
+            heads[i].u0, heads[i].u1, heads[i].u2 = (int(v) for v in u)
+        probs = torch.empty((N, D, H, W, nc * len(logits)), dtype=torch.float32, device=l0.device)
+        L.check(L.load().m1_softmax_heads_fwd(heads, len(logits), _p(probs), N, D, H, W, nc, _dt(l0), _stream()),
+                "m1_softmax_heads_fwd")
+        ctx.save_for_backward(probs, *logits)
+        ctx.ups = ups
+        return probs
+
+    @staticmethod
+    def backward(ctx, dprobs):
+        probs, *logits = ctx.saved_tensors
+        dprobs = dprobs.contiguous().float()
+        l0 = logits[0]
+        N, D, H, W, nc = (int(v) for v in l0.shape)
+        heads = (L.m1_head_t * len(logits))()
+        grads = []
+        for i, (t, u) in enumerate(zip(logits, ctx.ups)):
+            g = torch.empty_like(t)
+            grads.append(g)
+            heads[i].logits = t.data_ptr(); heads[i].dlogits = g.data_ptr()
+            heads[i].u0, heads[i].u1, heads[i].u2 = (int(v) for v in u)
+        L.check(L.load().m1_softmax_heads_bwd(heads, len(logits), _p(probs), _p(dprobs), N, D, H, W, nc, _dt(l0), _stream()),
+                "m1_softmax_heads_bwd")
+        return (None, *grads)
+
+
+def softmax_heads(logits: Sequence[torch.Tensor], ups: Sequence[Tuple[int, int, int]]):
+    """concat_h softmax(upsample_nearest(logits_h, ups_h)) -> fp32 (N,D,H,W,nheads*nc) (networks.py:751-754)."""
+    return _SoftmaxHeads.apply(tuple(tuple(int(v) for v in u) for u in ups), *logits)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# dropout (standalone), cast
+# ---------------------------------------------------------------------------------------------------------
+class _Dropout(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, rate, rng, layer_id):
+        _req(x, rng)
+        y = torch.empty_like(x)
+        L.check(L.load().m1_dropout(_p(x), _p(y), x.numel(), float(rate), _p(rng), int(layer_id), _dt(x), _stream()), "m1_dropout")
+        ctx.rate, ctx.rng, ctx.layer_id = float(rate), rng, int(layer_id)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = dy.contiguous()
+        dx = torch.empty_like(dy)
+        L.check(L.load().m1_dropout(_p(dy), _p(dx), dy.numel(), ctx.rate, _p(ctx.rng), ctx.layer_id, _dt(dy), _stream()),
+                "m1_dropout")
+        return dx, None, None, None
+
+
+def dropout(x, rate, rng, layer_id):
+    if rate == 0.0:
+        return x
+    return _Dropout.apply(x, rate, rng, layer_id)
+
+
+def cast(x: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
+    """fp32 <-> bf16 activation cast (no autograd: used on network inputs only)."""
+    _req(x)
+    if x.dtype == dtype:
+        return x
+    y = torch.empty(x.shape, dtype=dtype, device=x.device)
+    L.check(L.load().m1_cast(_p(x), _dt(x), _p(y), _dt(y), x.numel(), _stream()), "m1_cast")
+    return y
+
+
+# ---------------------------------------------------------------------------------------------------------
+# optimizer / profiler
+# ---------------------------------------------------------------------------------------------------------
+def adam_amsgrad_(p, g, m, v, vhat, n_kernel, n_bias, l2_kernel, l2_bias, grad_scale, lr_dev, beta1, beta2, eps, step_dev):
+    _req(p, g, m, v, vhat, lr_dev, step_dev)
+    L.check(L.load().m1_adam_amsgrad(_p(p), _p(g), _p(m), _p(v), _p(vhat), p.numel(), int(n_kernel), int(n_bias),
+                                     float(l2_kernel), float(l2_bias), float(grad_scale), _p(lr_dev), float(beta1), float(beta2),
+                                     float(eps), _p(step_dev), _stream()), "m1_adam_amsgrad")
+
+
+def step_advance(step_dev, rng_dev):
+    L.check(L.load().m1_step_advance(_p(step_dev), _p(rng_dev), _stream()), "m1_step_advance")
+
+
+def prof_enable(on: bool):
+    L.load().m1_prof_enable(1 if on else 0)
+
+
+def prof_reset():
+    L.load().m1_prof_reset()
+
+
+def prof_read():
+    arr = (L.m1_prof_rec_t * 64)()
+    n = L.load().m1_prof_read(arr, 64)
+    return [dict(name=arr[i].name.decode(), total_ms=arr[i].total_ms, flops=arr[i].flops, bytes=arr[i].bytes,
+                 launches=arr[i].launches) for i in range(n)]

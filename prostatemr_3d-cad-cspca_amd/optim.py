@@ -1,0 +1,139 @@
+"""Optimiser plumbing: Keras-flavoured ``Adam(amsgrad=True)`` (train_model.py:120; README.md:58; semantics
+SURVEY.md App. B-8) on ONE flat fp32 parameter buffer, updated by the fused HIP kernel ``m1_adam_amsgrad``
+which also adds the L2-regulariser gradient 2*lambda*w (networks.py:456-460), and the
+``CosineDecayRestarts`` schedule (train_model.py:114-116; README.md:53-55).
+"""
+from __future__ import annotations
+
+import math
+from typing import List, Optional
+
+import torch
+
+from .hip import ops
+
+
+class CosineDecayRestarts:
+    """tf.keras.optimizers.schedules.CosineDecayRestarts(initial_learning_rate, first_decay_steps, t_mul, m_mul, alpha)."""
+
+    def __init__(self, initial_learning_rate, first_decay_steps, t_mul=2.0, m_mul=1.0, alpha=0.0):
+        self.initial_learning_rate, self.first_decay_steps = float(initial_learning_rate), float(first_decay_steps)
+        self.t_mul, self.m_mul, self.alpha = float(t_mul), float(m_mul), float(alpha)
+
+    def __call__(self, step: int) -> float:
+        completed = step / self.first_decay_steps
+        if self.t_mul == 1.0:
+            i_restart = math.floor(completed)
+            frac = completed - i_restart
+        else:
+            i_restart = math.floor(math.log(1.0 - completed * (1.0 - self.t_mul)) / math.log(self.t_mul))
+            sum_r = (1.0 - self.t_mul ** i_restart) / (1.0 - self.t_mul)
+            frac = (completed - sum_r) / self.t_mul ** i_restart
+        m_fac = self.m_mul ** i_restart
+        cosine = 0.5 * m_fac * (1.0 + math.cos(math.pi * frac))
+        return self.initial_learning_rate * ((1 - self.alpha) * cosine + self.alpha)
+
+
+class FlatParams:
+    """All parameters of a model as views into one flat fp32 buffer ordered
+    [regularised kernels | regularised biases | everything else] so the optimiser kernel can apply the right
+    L2 coefficient by range, and one flat gradient buffer for bucketed all-reduce (ddp.py)."""
+
+    def __init__(self, model):
+        ks, bs = model.regularized_parameters() if hasattr(model, "regularized_parameters") else ([], [])
+        kid, bid = {id(p) for p in ks}, {id(p) for p in bs}
+        rest = [p for p in model.parameters() if id(p) not in kid and id(p) not in bid]
+        self.params: List[torch.nn.Parameter] = list(ks) + list(bs) + rest
+        self.n_kernel = sum(p.numel() for p in ks)
+        self.n_bias = sum(p.numel() for p in bs)
+        self.n = sum(p.numel() for p in self.params)
+        dev = self.params[0].device
+        n_pad = (self.n + 3) // 4 * 4
+        self.flat = torch.zeros(n_pad, dtype=torch.float32, device=dev)
+        self.grad = torch.zeros(n_pad, dtype=torch.float32, device=dev)
+        self.views, self.gviews = [], []
+        off = 0
+        with torch.no_grad():
+            for p in self.params:
+                n = p.numel()
+                v = self.flat[off:off + n].view(p.shape)
+                v.copy_(p.data)
+                p.data = v
+                self.views.append(v)
+                self.gviews.append(self.grad[off:off + n].view(p.shape))
+                off += n
+
+    def gather_grads(self):
+        """Copy the autograd .grad tensors into the flat gradient buffer (zeros where a parameter got none)."""
+        self.grad.zero_()
+        dst, src = [], []
+        for p, gv in zip(self.params, self.gviews):
+            if p.grad is not None:
+                dst.append(gv); src.append(p.grad)
+        if dst:
+            torch._foreach_copy_(dst, src)
+
+
+class Adam:
+    """tf.keras.optimizers.Adam(learning_rate, beta_1, beta_2, epsilon=1e-7, amsgrad=True).
+
+    ``w -= lr*sqrt(1-b2^t)/(1-b1^t) * m/(sqrt(vhat)+eps)`` with ``vhat = max(vhat, v)`` -- epsilon OUTSIDE the
+    bias-corrected sqrt, unlike torch.optim.Adam.  Only amsgrad=True (the reference's setting) is implemented."""
+    handles_l2 = True
+
+    def __init__(self, learning_rate=1e-3, beta_1=0.9, beta_2=0.999, epsilon=1e-7, amsgrad=True):
+        if not amsgrad:
+            raise NotImplementedError("the reference trains with amsgrad=True (train_model.py:120); only that is built")
+        self.learning_rate = learning_rate
+        self.beta_1, self.beta_2, self.epsilon = float(beta_1), float(beta_2), float(epsilon)
+        self.flatp: Optional[FlatParams] = None
+        self.iterations = 0
+        self.grad_scale = 1.0
+        self.reducer = None          # ddp.GradReducer, optional
+        self._lr_override: Optional[float] = None
+
+    # Keras: optimizer.lr readable / assignable (callbacks.py:99,117,179)
+    @property
+    def lr(self) -> float:
+        if self._lr_override is not None:
+            return self._lr_override
+        return float(self.learning_rate(self.iterations)) if callable(self.learning_rate) else float(self.learning_rate)
+
+    @lr.setter
+    def lr(self, v):
+        self._lr_override = float(v)
+
+    def bind(self, model):
+        self.model = model
+        self.flatp = FlatParams(model)
+        dev = self.flatp.flat.device
+        self.m = torch.zeros_like(self.flatp.flat)
+        self.v = torch.zeros_like(self.flatp.flat)
+        self.vhat = torch.zeros_like(self.flatp.flat)
+        self.lr_dev = torch.zeros(1, dtype=torch.float32, device=dev)
+        self.step_dev = torch.ones(1, dtype=torch.int32, device=dev)
+        self.l2_kernel = float(getattr(model, "l2_kernel", 0.0))
+        self.l2_bias = float(getattr(model, "l2_bias", 0.0))
+        return self
+
+    def zero_grad(self):
+        for p in self.flatp.params:
+            p.grad = None
+
+    def set_lr_device(self):
+        self.lr_dev.fill_(self.lr)
+
+    def apply_flat(self):
+        """Fused update from the flat gradient buffer (already gathered / all-reduced)."""
+        f = self.flatp
+        ops.adam_amsgrad_(f.flat, f.grad, self.m, self.v, self.vhat, f.n_kernel, f.n_bias, self.l2_kernel, self.l2_bias,
+                          self.grad_scale, self.lr_dev, self.beta_1, self.beta_2, self.epsilon, self.step_dev)
+        ops.step_advance(self.step_dev, None)
+
+    def step(self):
+        self.set_lr_device()
+        self.flatp.gather_grads()
+        if self.reducer is not None:
+            self.reducer.all_reduce(self.flatp.grad)
+        self.apply_flat()
+        self.iterations += 1

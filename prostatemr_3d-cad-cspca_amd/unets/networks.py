@@ -1,0 +1,692 @@
+"""``M1`` / ``m1`` / ``M1Core`` with the constructor surface of the reference's networks.py
+(tf2.5/scripts/model/unets/networks.py:24-223, 232-392, 402-783), running on libm1hip.so.
+
+    unet_model = unets.networks.M1(input_spatial_dims=(20,160,160), input_channels=3, num_classes=2, ...)
+
+keeps the reference's keyword names and order (networks.py:34-55; call sites train_model.py:189-207,
+README.md:30-50).  Documented deviations (harness bugs are not reproduced):
+  * C-1: the deterministic branch calls ``core(inputs, prob_mean=False, prob_z_q=None)`` and ``core.summary()``.
+  * C-3: default ``att_sub_samp`` / ``prob_latent_dims`` are 4-tuples (the reference's 3-tuples violate its
+    own asserts at networks.py:467 / the index at networks.py:537).
+  * initializer / regularizer kwargs take the value objects of ``..initializers`` (TF meanings, App. B-7).
+Numerics quirks ARE reproduced: label slice off-by-one (networks.py:301), multiplicative residual
+(network_blocks.py:77), deep supervision being a no-op in probabilistic mode (networks.py:304-335,389),
+dropd0 at rate/2 (networks.py:523), log-sigma clip +-0.1 (networks.py:642).
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .. import initializers as init
+from ..hip import ops
+from .modelio import LoadableModel, store_config_args
+from .network_blocks import (Conv3D, Conv3DTranspose, Dropout, GridAttentionBlock3D, InstanceNormalization,
+                             MonteCarloDropout, SEResNetBottleNeck, StitchingProbDecoder, _DropoutBase)
+
+
+class Input:
+    """Stand-in for tf.keras.Input(shape=(D,H,W,C), name=...) (networks.py:64)."""
+
+    def __init__(self, shape, name="image"):
+        self.shape = (None, *tuple(int(s) for s in shape))
+        self.name = name
+
+
+def _same_out(size, s):
+    return -(-int(size) // int(s))
+
+
+# ============================================================================================================
+# M1Core (networks.py:402-783)
+# ============================================================================================================
+class M1Core(nn.Module):
+    """Attention gates + nested decoder + SE-ResNet blocks (+ hierarchical latent branch).
+
+    U-Net schematic (networks.py:411-416):
+        Resol. 0  (x)------------->(att_conv0)-->(deconv2_up2)-->(deconv1_up1)-->(deconv0)-->(uconv0_)-->(uconv0)-->(y__)
+        Resol. 1   |---->(conv1)-->(att_conv1)-->(deconv3_up2)-->(deconv2_up1)-->(deconv1)-->(uconv1_)-->(uconv1)
+        Resol. 2            |----->(conv2)------>(att_conv2)---->(deconv3_up1)-->(deconv2)-->(uconv2_)-->(uconv2)
+        Resol. 3                      |--------->(conv3)-------->(att_conv3)---->(deconv3)-->(uconv3_)-->(uconv3)
+        Resol. 4                                    |----------->(convm)-------------|
+    """
+
+    def __init__(self,
+                 num_classes=2,
+                 dropout_mode='standard',
+                 dropout_rate=0.50,
+                 filters=(32, 64, 128, 256, 512),
+                 strides=((1, 1, 1), (1, 2, 2), (1, 2, 2), (2, 2, 2), (1, 2, 2)),
+                 kernel_sizes=((1, 3, 3), (1, 3, 3), (3, 3, 3), (3, 3, 3), (3, 3, 3)),
+                 se_reduction=(8, 8, 8, 8, 8),
+                 att_sub_samp=((1, 1, 1), (1, 1, 1), (1, 1, 1), (1, 1, 1)),
+                 kernel_initializer=None,
+                 bias_initializer=None,
+                 kernel_regularizer=None,
+                 bias_regularizer=None,
+                 dense_skip=False,
+                 deep_supervision=False,
+                 probabilistic=False,
+                 prob_latent_dims=(1, 1, 1, 1),
+                 input_channels=None):
+        super().__init__()
+        if input_channels is None:
+            raise TypeError("M1Core needs input_channels (torch builds weights eagerly)")
+        self.num_classes, self.dropout_mode, self.dropout_rate = int(num_classes), dropout_mode, float(dropout_rate)
+        self.filters = tuple(int(f) for f in filters)
+        self.strides = tuple(tuple(int(v) for v in s) for s in strides)
+        self.kernel_sizes = tuple(tuple(int(v) for v in k) for k in kernel_sizes)
+        self.se_reduction = tuple(int(r) for r in se_reduction)
+        self.att_sub_samp = tuple(tuple(int(v) for v in a) for a in att_sub_samp)
+        self.kernel_initializer = kernel_initializer if kernel_initializer is not None else init.Orthogonal(gain=1.0)
+        self.bias_initializer = bias_initializer if bias_initializer is not None else init.TruncatedNormal(mean=0.0, stddev=0.001)
+        self.kernel_regularizer = kernel_regularizer if kernel_regularizer is not None else init.l2(1e-4)
+        self.bias_regularizer = bias_regularizer if bias_regularizer is not None else init.l2(1e-4)
+        self.dense_skip, self.deep_supervision, self.probabilistic = bool(dense_skip), bool(deep_supervision), bool(probabilistic)
+        self.prob_latent_dims = tuple(int(v) for v in prob_latent_dims)
+        self.input_channels = int(input_channels)
+
+        # networks.py:456-460
+        self.conv_params = {'padding': 'same',
+                            'kernel_initializer': self.kernel_initializer,
+                            'bias_initializer': self.bias_initializer,
+                            'kernel_regularizer': self.kernel_regularizer,
+                            'bias_regularizer': self.bias_regularizer}
+        if self.dropout_mode == 'standard':
+            DropoutFunc = Dropout
+        elif self.dropout_mode == 'monte-carlo':
+            DropoutFunc = MonteCarloDropout
+        else:
+            raise ValueError("dropout_mode must be 'standard' or 'monte-carlo'")
+
+        # networks.py:465-469 (identical messages)
+        assert len(self.filters) == 5, "ERROR: Expected Tuple/Array with 5 Values (One Per Resolution)."
+        assert len(self.se_reduction) == 5, "ERROR: Expected Tuple/Array with 5 Values (One Per Resolution)."
+        assert [len(a) for a in self.att_sub_samp] == [3, 3, 3, 3], "ERROR: Expected 4x3 Tuple/Array (3D Sub-Sampling Factors for 4 Attention Gates)."
+        assert [len(s) for s in self.strides] == [3, 3, 3, 3, 3], "ERROR: Expected 5x3 Tuple/Array (3D Strides for 5 Resolutions)."
+        assert [len(k) for k in self.kernel_sizes] == [3, 3, 3, 3, 3], "ERROR: Expected 5x3 Tuple/Array (3D Kernels for 5 Resolutions)."
+
+        F, S, K, R = self.filters, self.strides, self.kernel_sizes, self.se_reduction
+        cp = {k: v for k, v in self.conv_params.items() if k != 'padding'}
+        dn = self.dense_skip
+
+        def SE(cin, f, k, s, r):
+            return SEResNetBottleNeck(filters=f, kernel_size=k, strides=s, reduction=r, conv_params=self.conv_params, in_channels=cin)
+
+        # networks.py:472-473
+        self.conve0 = Conv3D(self.input_channels, F[0], K[0], S[0], **cp)
+        self.norme0 = InstanceNormalization(F[0])
+        # networks.py:476-487
+        self.serse1 = SE(F[0], F[1], K[1], S[1], R[1]); self.drope1 = DropoutFunc(self.dropout_rate)
+        self.serse2 = SE(F[1], F[2], K[2], S[2], R[2]); self.drope2 = DropoutFunc(self.dropout_rate)
+        self.serse3 = SE(F[2], F[3], K[3], S[3], R[3]); self.drope3 = DropoutFunc(self.dropout_rate)
+        self.serse4 = SE(F[3], F[4], K[4], S[4], R[4]); self.drope4 = DropoutFunc(self.dropout_rate)
+        # networks.py:490-493
+        for i in range(4):
+            setattr(self, f"att{i}", GridAttentionBlock3D(inter_channels=F[i], sub_samp=self.att_sub_samp[i],
+                                                          conv_params=self.conv_params, in_channels=F[i], gating_channels=F[4]))
+        # networks.py:496-502
+        self.convtd3 = Conv3DTranspose(F[4], F[3], K[4], S[4], **cp)
+        if dn:
+            self.convtd3_up1 = Conv3DTranspose(F[3], F[2], K[3], S[3], **cp)
+            self.convtd3_up2 = Conv3DTranspose(F[2], F[1], K[2], S[2], **cp)
+            self.convtd3_up3 = Conv3DTranspose(F[1], F[0], K[1], S[1], **cp)
+        self.sersd3 = SE(2 * F[3], F[3], K[3], (1, 1, 1), R[3]); self.dropd3 = DropoutFunc(self.dropout_rate)
+        # networks.py:505-510
+        self.convtd2 = Conv3DTranspose(F[3], F[2], K[3], S[3], **cp)
+        if dn:
+            self.convtd2_up1 = Conv3DTranspose(F[2], F[1], K[2], S[2], **cp)
+            self.convtd2_up2 = Conv3DTranspose(F[1], F[0], K[1], S[1], **cp)
+        self.sersd2 = SE((3 if dn else 2) * F[2], F[2], K[2], (1, 1, 1), R[2]); self.dropd2 = DropoutFunc(self.dropout_rate)
+        # networks.py:513-517
+        self.convtd1 = Conv3DTranspose(F[2], F[1], K[2], S[2], **cp)
+        if dn:
+            self.convtd1_up1 = Conv3DTranspose(F[1], F[0], K[1], S[1], **cp)
+        self.sersd1 = SE((4 if dn else 2) * F[1], F[1], K[1], (1, 1, 1), R[1]); self.dropd1 = DropoutFunc(self.dropout_rate)
+        # networks.py:520-523
+        self.convtd0 = Conv3DTranspose(F[1], F[0], K[1], S[1], **cp)
+        self.sersd0 = SE((5 if dn else 2) * F[0], F[0], K[0], (1, 1, 1), R[0]); self.dropd0 = DropoutFunc(self.dropout_rate / 2)
+        # networks.py:526
+        self.logits = Conv3D(F[0], self.num_classes, (1, 1, 1), (1, 1, 1), **cp)
+        # networks.py:529-531 -- Keras creates weights only for layers that are called: heads exist iff used
+        if self.deep_supervision:
+            self.dsy1_logits = Conv3D(F[1], self.num_classes, (1, 1, 1), (1, 1, 1), **cp)
+            self.dsy2_logits = Conv3D(F[2], self.num_classes, (1, 1, 1), (1, 1, 1), **cp)
+            self.dsy3_logits = Conv3D(F[3], self.num_classes, (1, 1, 1), (1, 1, 1), **cp)
+        # networks.py:534-565
+        if self.probabilistic:
+            assert len(self.prob_latent_dims) == 4, "prob_latent_dims needs 4 entries (networks.py:534-537)"
+            nz = [v != 0 for v in self.prob_latent_dims]
+            assert all(nz[i] or not any(nz[i:]) for i in range(4)), \
+                "prob_latent_dims must have its zeros at the tail: prob_z_q is indexed by level (networks.py:645,669,693,717)"
+            fr, kr, sr, rr = F[::-1], K[::-1], S[::-1], R[::-1]
+            skipc = [2 * F[3], (3 if dn else 2) * F[2], (4 if dn else 2) * F[1], (5 if dn else 2) * F[0]]
+            for lvl in range(4):
+                sfx = str(3 - lvl)
+                Ld = self.prob_latent_dims[lvl]
+                if Ld != 0:
+                    setattr(self, "mu_logsig" + sfx, Conv3D(fr[lvl], 2 * Ld, (1, 1, 1), (1, 1, 1), **cp))
+                setattr(self, "dec_hi" + sfx, Conv3DTranspose(fr[lvl] + Ld, fr[lvl + 1], kr[lvl], sr[lvl], **cp))
+                setattr(self, "sersp" + sfx, SE(fr[lvl + 1] + skipc[lvl], fr[lvl + 1], kr[lvl + 1], (1, 1, 1), rr[lvl + 1]))
+                setattr(self, "dropp" + sfx, DropoutFunc(self.dropout_rate))
+        self._shapes: Dict[str, tuple] = {}
+
+    # ---------------------------------------------------------------------------------------------------------
+    def forward(self, inputs, prob_mean=False, prob_z_q=None, eps: Optional[List[torch.Tensor]] = None):
+        """M1Core.__call__(inputs, prob_mean, prob_z_q) (networks.py:568-759).  ``inputs`` is an NDHWC tensor or
+        a list of tensors forming a virtual channel concat.  ``eps``: optional injected N(0,1) draws per level
+        (MultivariateNormalDiag.sample() = mu + sigma*eps)."""
+        outputs = {}
+        S = self.strides
+        # networks.py:574-576
+        x = self.norme0(self.conve0(inputs), 0.1)
+        # networks.py:579-582 (dropout fused into the block's last kernel)
+        conv1 = self.serse1(x, dropout=self.drope1)
+        conv2 = self.serse2(conv1, dropout=self.drope2)
+        conv3 = self.serse3(conv2, dropout=self.drope3)
+        convm = self.serse4(conv3, dropout=self.drope4)
+        # networks.py:585-588
+        att_conv0, _ = self.att0(x, convm)
+        att_conv1, _ = self.att1(conv1, convm)
+        att_conv2, _ = self.att2(conv2, convm)
+        att_conv3, _ = self.att3(conv3, convm)
+        # networks.py:591-597
+        deconv3 = self.convtd3(convm)
+        if self.dense_skip:
+            deconv3_up1 = self.convtd3_up1(deconv3)
+            deconv3_up2 = self.convtd3_up2(deconv3_up1)
+            deconv3_up3 = self.convtd3_up3(deconv3_up2)
+        uconv3_ = [deconv3, att_conv3]
+        uconv3 = self.sersd3(uconv3_, dropout=self.dropd3)
+        # networks.py:600-607
+        deconv2 = self.convtd2(uconv3)
+        if self.dense_skip:
+            deconv2_up1 = self.convtd2_up1(deconv2)
+            deconv2_up2 = self.convtd2_up2(deconv2_up1)
+            uconv2_ = [deconv2, deconv3_up1, att_conv2]
+        else:
+            uconv2_ = [deconv2, att_conv2]
+        uconv2 = self.sersd2(uconv2_, dropout=self.dropd2)
+        # networks.py:610-616
+        deconv1 = self.convtd1(uconv2)
+        if self.dense_skip:
+            deconv1_up1 = self.convtd1_up1(deconv1)
+            uconv1_ = [deconv1, deconv2_up1, deconv3_up2, att_conv1]
+        else:
+            uconv1_ = [deconv1, att_conv1]
+        uconv1 = self.sersd1(uconv1_, dropout=self.dropd1)
+        # networks.py:619-624
+        deconv0 = self.convtd0(uconv1)
+        if self.dense_skip:
+            uconv0_ = [deconv0, deconv1_up1, deconv2_up2, deconv3_up3, att_conv0]
+        else:
+            uconv0_ = [deconv0, att_conv0]
+
+        cat_c = lambda ts: sum(int(t.shape[-1]) for t in ts)
+        self._shapes = {"inputs": tuple(inputs.shape) if isinstance(inputs, torch.Tensor) else (*inputs[0].shape[:-1], cat_c(inputs)),
+                        "x": tuple(x.shape), "att_conv0": tuple(att_conv0.shape), "conv1": tuple(conv1.shape),
+                        "att_conv1": tuple(att_conv1.shape), "conv2": tuple(conv2.shape), "att_conv2": tuple(att_conv2.shape),
+                        "conv3": tuple(conv3.shape), "att_conv3": tuple(att_conv3.shape), "convm": tuple(convm.shape),
+                        "uconv3_": (*deconv3.shape[:-1], cat_c(uconv3_)), "uconv3": tuple(uconv3.shape),
+                        "uconv2_": (*deconv2.shape[:-1], cat_c(uconv2_)), "uconv2": tuple(uconv2.shape),
+                        "uconv1_": (*deconv1.shape[:-1], cat_c(uconv1_)), "uconv1": tuple(uconv1.shape),
+                        "uconv0_": (*deconv0.shape[:-1], cat_c(uconv0_))}
+
+        # In the probabilistic training graph nothing downstream of sersd0/logits reaches an output
+        # (networks.py:389 takes an empty slice): the deterministic head is skipped there.
+        y__ = None
+        if not self.probabilistic:
+            uconv0 = self.sersd0(uconv0_, dropout=self.dropd0)                     # networks.py:624
+            y__ = self.logits(uconv0)                                              # networks.py:627
+            self._shapes["uconv0"] = tuple(uconv0.shape); self._shapes["y__"] = tuple(y__.shape)
+
+        ds_ops = []
+        if self.probabilistic:                                                     # networks.py:633-734
+            distributions, used_latents = [], []
+            skips = [uconv3_, uconv2_, uconv1_, uconv0_]
+            feats = convm
+            zi = 0
+            for lvl in range(4):
+                sfx = str(3 - lvl)
+                Ld = self.prob_latent_dims[lvl]
+                if Ld != 0:
+                    ml = getattr(self, "mu_logsig" + sfx)(feats)                   # networks.py:639 (mu | logsigma)
+                    if prob_z_q is not None:                                       # networks.py:645
+                        z = prob_z_q[lvl]
+                    elif prob_mean:                                                # networks.py:646
+                        z = ops.latent_sample(ml, None, True)
+                    else:                                                          # networks.py:647
+                        e = eps[zi] if eps is not None else torch.randn((*ml.shape[:-1], Ld), device=ml.device,
+                                                                         dtype=torch.float32).to(ml.dtype)
+                        z = ops.latent_sample(ml, e.contiguous(), False)
+                    zi += 1
+                    distributions.append(ml)
+                    used_latents.append(z)
+                    up = getattr(self, "dec_hi" + sfx)([z, feats])                 # networks.py:652-653
+                else:
+                    up = getattr(self, "dec_hi" + sfx)(feats)                      # networks.py:655-656
+                feats = getattr(self, "sersp" + sfx)([up, *skips[lvl]], dropout=getattr(self, "dropp" + sfx))
+                if lvl < 3:
+                    ds_ops.append(feats)                                           # networks.py:657,681,705
+            outputs['prob_distributions'] = distributions      # raw (mu|logsigma) maps; sigma = exp(clip(logsigma,+-0.1))
+            outputs['prob_used_latents'] = used_latents
+            outputs['prob_decoder_features'] = feats
+
+        # networks.py:737-757
+        if y__ is not None:
+            heads, ups = [y__], [(1, 1, 1)]
+            if self.deep_supervision:
+                s1 = S[1]
+                s12 = tuple(a * b for a, b in zip(S[1], S[2]))
+                s123 = tuple(a * b * c for a, b, c in zip(S[1], S[2], S[3]))
+                heads += [self.dsy1_logits(uconv1), self.dsy2_logits(uconv2), self.dsy3_logits(uconv3)]
+                ups += [s1, s12, s123]
+            outputs['y_softmax'] = ops.softmax_heads(heads, ups)
+            outputs['logits'] = y__
+            outputs['_heads'] = heads
+            outputs['_ups'] = ups
+        return outputs
+
+    def summary(self):
+        """Stage-shape printout of networks.py:761-782 (uses the shapes of the last forward)."""
+        s = self._shapes
+        if not s:
+            print('(run a forward pass first)')
+            return
+        rows = [('Input Volume:-----------------------------------------------', 'inputs'),
+                ('Initial Convolutional Layer (Stage 0):----------------------', 'x'),
+                ('Attention Gating: Stage 0:----------------------------------', 'att_conv0'),
+                ('Encoder: Stage 1; SE-Residual Block:------------------------', 'conv1'),
+                ('Attention Gating: Stage 1:----------------------------------', 'att_conv1'),
+                ('Encoder: Stage 2; SE-Residual Block:------------------------', 'conv2'),
+                ('Attention Gating: Stage 2:----------------------------------', 'att_conv2'),
+                ('Encoder: Stage 3; SE-Residual Block:------------------------', 'conv3'),
+                ('Attention Gating: Stage 3:----------------------------------', 'att_conv3'),
+                ('Middle: High-Dim Latent Features:---------------------------', 'convm'),
+                ('Decoder: Stage 3; Nested U-Net Concat.:---------------------', 'uconv3_'),
+                ('Decoder: Stage 3; Nested U-Net End:-------------------------', 'uconv3'),
+                ('Decoder: Stage 2; Nested U-Net Concat.:---------------------', 'uconv2_'),
+                ('Decoder: Stage 2; Nested U-Net End:-------------------------', 'uconv2'),
+                ('Decoder: Stage 1; Nested U-Net Concat.:---------------------', 'uconv1_'),
+                ('Decoder: Stage 1; Nested U-Net End:-------------------------', 'uconv1'),
+                ('Decoder: Stage 0; Nested U-Net Concat.:---------------------', 'uconv0_'),
+                ('Decoder: Stage 0; Nested U-Net End:-------------------------', 'uconv0')]
+        for label, key in rows:
+            if key in s:
+                print(label, s[key])
+        if not self.probabilistic and 'y__' in s:
+            print('Prob. 3D U-Net (Type: M1) [Logits]:---------------------------', s['y__'])
+
+
+# ============================================================================================================
+# m1 (networks.py:232-392)
+# ============================================================================================================
+class M1Net(nn.Module):
+    """The graph ``m1(...)`` builds: deterministic (one core) or hierarchical probabilistic (prior core,
+    posterior core, StitchingProbDecoder, 4 core passes per training step + KL).  Calling it returns the
+    reference's ``outputs`` dict; ``net['logits']`` etc. index the outputs of the last call."""
+
+    def __init__(self, input_channels, num_classes, dropout_mode, dropout_rate, filters, strides, kernel_sizes, se_reduction,
+                 att_sub_samp, kernel_initializer, bias_initializer, kernel_regularizer, bias_regularizer, dense_skip,
+                 deep_supervision, probabilistic, prob_latent_dims, summary):
+        super().__init__()
+        self.num_classes, self.probabilistic, self.deep_supervision = int(num_classes), bool(probabilistic), bool(deep_supervision)
+        self.show_summary = bool(summary)
+        self._summarised = False
+        self.last: Dict[str, torch.Tensor] = {}
+        common = dict(num_classes=num_classes, dropout_mode=dropout_mode, dropout_rate=dropout_rate, filters=filters,
+                      strides=strides, kernel_sizes=kernel_sizes, se_reduction=se_reduction, att_sub_samp=att_sub_samp,
+                      kernel_initializer=kernel_initializer, bias_initializer=bias_initializer,
+                      kernel_regularizer=kernel_regularizer, bias_regularizer=bias_regularizer, dense_skip=dense_skip)
+        nc = self.num_classes
+        if not self.probabilistic:                                                 # networks.py:266-281
+            self.core = M1Core(**common, deep_supervision=deep_supervision, probabilistic=False,
+                               input_channels=input_channels)
+        else:                                                                      # networks.py:297-345
+            c_img = input_channels - (nc - 1)                                      # networks.py:300
+            c_lab = nc - 1                                                         # networks.py:301
+            # deep_supervision is NOT forwarded (networks.py:304-335)
+            self.prior = M1Core(**common, probabilistic=True, prob_latent_dims=prob_latent_dims, input_channels=c_img)
+            self.posterior = M1Core(**common, probabilistic=True, prob_latent_dims=prob_latent_dims,
+                                    input_channels=c_img + c_lab)
+            self.stitch = StitchingProbDecoder(num_classes=num_classes, filters=filters, strides=strides,
+                                               kernel_sizes=kernel_sizes, kernel_initializer=kernel_initializer,
+                                               bias_initializer=bias_initializer, kernel_regularizer=kernel_regularizer,
+                                               bias_regularizer=bias_regularizer)
+
+    def __getitem__(self, key):
+        return self.last[key]
+
+    def forward(self, inputs: torch.Tensor, eps_q=None, eps_p=None, with_infer=False, train_outputs=True):
+        outputs: Dict[str, torch.Tensor] = {}
+        nc = self.num_classes
+        if not self.probabilistic:
+            o = self.core(inputs, prob_mean=False, prob_z_q=None)                  # networks.py:281 (+ App. C-1)
+            outputs['y_softmax'] = o['y_softmax']
+            outputs['logits'] = o['logits']
+            outputs['_heads'], outputs['_ups'] = o['_heads'], o['_ups']
+            if self.show_summary and not self._summarised:
+                print('--------------------------------------------------------------------')
+                print('Deterministic 3D U-Net (Type: M1)')
+                print('--------------------------------------------------------------------')
+                self.core.summary()
+                print('--------------------------------------------------------------------')
+                self._summarised = True
+        else:
+            C = int(inputs.shape[-1])
+            # networks.py:300-301 -- channel slices as contiguous tensors (off-by-one reproduced, App. C-2)
+            image = inputs[..., :C - (nc - 1)].contiguous()
+            label = inputs[..., C - (nc - 1) - 1:C - 1].contiguous()
+            post_in = [image, label]                                               # tf.concat([image,label]) virtual
+            if train_outputs:
+                q_sample = self.posterior(post_in, prob_mean=False, prob_z_q=None, eps=eps_q)          # networks.py:348
+                q_mean = self.posterior(post_in, prob_mean=True, prob_z_q=None)                          # networks.py:349
+                p_z_q = self.prior(image, prob_mean=False, prob_z_q=q_sample['prob_used_latents'])      # networks.py:351
+                p_z_qm = self.prior(image, prob_mean=False, prob_z_q=q_mean['prob_used_latents'])       # networks.py:352
+                train_conv = self.stitch(p_z_qm['prob_decoder_features'])                               # networks.py:356
+                kl = None                                                                               # networks.py:373-385
+                for q, p in zip(q_sample['prob_distributions'], p_z_q['prob_distributions']):
+                    k = ops.kl_mvn_diag(q, p)
+                    kl = k if kl is None else kl + k
+                outputs['prob_train_conv'] = train_conv
+                outputs['prob_kl'] = kl
+                # networks.py:388-390: with deep_supervision the concat partner y_softmax[..., nc:] is EMPTY
+                outputs['prob_softmax'] = ops.softmax_heads([train_conv], [(1, 1, 1)])
+                outputs['_heads'], outputs['_ups'] = [train_conv], [(1, 1, 1)]
+            if with_infer or not train_outputs:
+                p_sample = self.prior(image, prob_mean=False, prob_z_q=None, eps=eps_p)                 # networks.py:350
+                outputs['prob_infer_conv'] = self.stitch(p_sample['prob_decoder_features'])             # networks.py:355
+            if self.show_summary and not self._summarised:
+                print('-------------------------------------------------------------------------------------')
+                print('Hierarchical Prob. 3D U-Net (Type: M1) - Prior Network')
+                print('-------------------------------------------------------------------------------------')
+                self.prior.summary()
+                print('-------------------------------------------------------------------------------------')
+                print('Hierarchical Prob. 3D U-Net (Type: M1) - Posterior Network')
+                print('-------------------------------------------------------------------------------------')
+                self.posterior.summary()
+                print('-------------------------------------------------------------------------------------')
+                self._summarised = True
+        self.last = outputs
+        return outputs
+
+
+def m1(inputs, num_classes,
+       dropout_mode='standard',
+       dropout_rate=0.50,
+       filters=(32, 64, 128, 256, 512),
+       strides=((1, 1, 1), (1, 2, 2), (1, 2, 2), (2, 2, 2), (1, 2, 2)),
+       kernel_sizes=((1, 3, 3), (1, 3, 3), (3, 3, 3), (3, 3, 3), (3, 3, 3)),
+       se_reduction=(8, 8, 8, 8, 8),
+       att_sub_samp=((1, 1, 1), (1, 1, 1), (1, 1, 1), (1, 1, 1)),
+       kernel_initializer=None,
+       bias_initializer=None,
+       kernel_regularizer=None,
+       bias_regularizer=None,
+       dense_skip=False,
+       deep_supervision=False,
+       probabilistic=False,
+       prob_latent_dims=(1, 1, 1, 1),
+       summary=True) -> M1Net:
+    """Mid-level wrapper (networks.py:232-392).  ``inputs`` is an ``Input`` placeholder (or anything with a
+    ``.shape`` whose last entry is the channel count); returns the callable graph ``M1Net``."""
+    cin = int(inputs.shape[-1])
+    return M1Net(cin, num_classes, dropout_mode, dropout_rate, filters, strides, kernel_sizes, se_reduction, att_sub_samp,
+                 kernel_initializer, bias_initializer, kernel_regularizer, bias_regularizer, dense_skip, deep_supervision,
+                 probabilistic, prob_latent_dims, summary)
+
+
+# ============================================================================================================
+# M1 (networks.py:24-223)
+# ============================================================================================================
+class M1(LoadableModel):
+    '''
+    [1] Z. Zhou et al. (2019), "UNet++: A Nested U-Net Architecture for Medical Image Segmentation", IEEE TMI.
+    [2] J. Hu et al.(2019), "Squeeze-and-Excitation Networks", IEEE TPAMI.
+    [3] S. Kohl et al. (2019), "A Hierarchical Probabilistic U-Net for Modeling Multi-Scale Ambiguities", NeurIPS.
+    [4] O. Oktay et al. (2018), "Attention U-Net: Learning Where to Look for the Pancreas", MIDL.
+    '''
+    @store_config_args
+    def __init__(self,
+                 input_spatial_dims,
+                 input_channels,
+                 num_classes,
+                 dropout_rate=0.50,
+                 dropout_mode='standard',
+                 filters=(32, 64, 128, 256, 512),
+                 strides=((1, 1, 1), (1, 2, 2), (1, 2, 2), (2, 2, 2), (1, 2, 2)),
+                 kernel_sizes=((1, 3, 3), (1, 3, 3), (3, 3, 3), (3, 3, 3), (3, 3, 3)),
+                 se_reduction=(8, 8, 8, 8, 8),
+                 att_sub_samp=((1, 1, 1), (1, 1, 1), (1, 1, 1), (1, 1, 1)),
+                 kernel_initializer=None,
+                 bias_initializer=None,
+                 kernel_regularizer=None,
+                 bias_regularizer=None,
+                 cascaded=False,
+                 dense_skip=False,
+                 deep_supervision=False,
+                 probabilistic=False,
+                 prob_latent_dims=(3, 2, 1, 0),
+                 summary=True,
+                 name='UNET-TYPE-M1'):
+        super().__init__(name=name)
+        kernel_initializer = kernel_initializer if kernel_initializer is not None else init.Orthogonal(gain=1.0)
+        bias_initializer = bias_initializer if bias_initializer is not None else init.TruncatedNormal(mean=0.0, stddev=0.001)
+        kernel_regularizer = kernel_regularizer if kernel_regularizer is not None else init.l2(1e-4)
+        bias_regularizer = bias_regularizer if bias_regularizer is not None else init.l2(1e-4)
+
+        # networks.py:58-59
+        ndims = len(input_spatial_dims)
+        assert ndims in [1, 2, 3], 'Variable (ndims) should be  1, 2 or 3. Found: %d.' % ndims
+        if ndims != 3:
+            raise NotImplementedError("the HIP path implements the 3D model only")
+        self.input_spatial_dims = tuple(int(v) for v in input_spatial_dims)
+        self.input_channels, self.num_classes = int(input_channels), int(num_classes)
+        self.l2_kernel = float(getattr(kernel_regularizer, "l2", 0.0))
+        self.l2_bias = float(getattr(bias_regularizer, "l2", 0.0))
+        self.compute_dtype = torch.float32
+        self.references = LoadableModel.ReferenceContainer()
+        kw = dict(num_classes=num_classes, dropout_mode=dropout_mode, dropout_rate=dropout_rate, filters=filters,
+                  strides=strides, kernel_sizes=kernel_sizes, se_reduction=se_reduction, att_sub_samp=att_sub_samp,
+                  kernel_initializer=kernel_initializer, bias_initializer=bias_initializer,
+                  kernel_regularizer=kernel_regularizer, bias_regularizer=bias_regularizer, dense_skip=dense_skip,
+                  deep_supervision=deep_supervision, probabilistic=probabilistic, prob_latent_dims=prob_latent_dims,
+                  summary=summary)
+
+        if cascaded == False:  # noqa: E712 -- mirrors networks.py:62
+            image = Input(shape=(*self.input_spatial_dims, input_channels), name='image')       # networks.py:64
+            self.m1_model = m1(inputs=image, **kw)                                              # networks.py:67-84
+            self.inputs = [image]
+            self.output_names = ['detection', 'KL'] if probabilistic else ['detection']         # networks.py:89-90,99
+            self.references.cascaded = cascaded
+            self.references.probabilistic = probabilistic
+            self.references.m1_model = self.m1_model
+            self.references.num_classes = num_classes
+        else:
+            if cascaded not in ('identity', 'noisy-or', 'bayes'):
+                raise ValueError("cascaded must be False, 'identity', 'noisy-or' or 'bayes' (networks.py:209-216)")
+            image_v1 = Input(shape=(*self.input_spatial_dims, input_channels), name='image_1')  # networks.py:111
+            image_v2 = Input(shape=(*self.input_spatial_dims, input_channels), name='image_2')  # networks.py:112
+            self.m1_stage1 = m1(inputs=image_v1, **kw)                                          # networks.py:115-132
+            stage2_in = Input(shape=(*self.input_spatial_dims, input_channels + num_classes - 1))
+            self.m1_stage2 = m1(inputs=stage2_in, **kw)                                         # networks.py:135-153
+            self.inputs = [image_v1, image_v2]
+            self.output_names = (['detection_1', 'detection_2', 'KL_1', 'KL_2'] if probabilistic
+                                 else ['detection_1', 'detection_2'])                           # networks.py:168-171,181-182
+            self.references.m1_stage1 = self.m1_stage1
+            self.references.m1_stage2 = self.m1_stage2
+            self.references.cascaded = cascaded
+            self.references.probabilistic = probabilistic
+            self.references.num_classes = num_classes
+
+        # device-resident dropout / sampling stream state {seed, step}; re-created by .to(device) via buffer
+        self.register_buffer("rng_state", torch.tensor([0x1234ABCD, 0], dtype=torch.int64), persistent=False)
+        self._attach_rng()
+
+    # ---- plumbing ------------------------------------------------------------------------------------------
+    def _attach_rng(self):
+        for m in self.modules():
+            if isinstance(m, _DropoutBase):
+                m.rng = self.rng_state
+
+    def _apply(self, fn, *a, **k):
+        r = super()._apply(fn, *a, **k)
+        self._attach_rng()
+        return r
+
+    def set_compute_dtype(self, dtype: torch.dtype):
+        """Activation storage type of the HIP path: torch.float32 (parity mode) or torch.bfloat16 (bf16 storage,
+        fp32 accumulation and statistics).  Parameters stay fp32."""
+        assert dtype in (torch.float32, torch.bfloat16)
+        self.compute_dtype = dtype
+        return self
+
+    def seed_dropout(self, seed: int):
+        with torch.no_grad():
+            self.rng_state[0] = int(seed)
+            self.rng_state[1] = 0
+
+    def advance_rng(self):
+        """Move the dropout stream to the next step (so consecutive forward passes draw fresh masks)."""
+        ops.step_advance(None, self.rng_state)
+
+    def _prep(self, x) -> torch.Tensor:
+        if isinstance(x, dict):
+            x = x[self.inputs[0].name]
+        if isinstance(x, (list, tuple)) and len(x) == 1:
+            x = x[0]
+        if not isinstance(x, torch.Tensor):
+            x = torch.as_tensor(np.asarray(x))
+        if not x.is_cuda:
+            raise RuntimeError("M1 runs on the HIP extension only: move the model and inputs to a GPU device "
+                               "(no CPU fallback exists in this package)")
+        want = (*self.input_spatial_dims, self.input_channels)
+        if tuple(x.shape[1:]) != want:
+            raise ValueError(f"expected input of shape (B,{','.join(map(str, want))}), got {tuple(x.shape)}")
+        x = x.contiguous()
+        if x.dtype != self.compute_dtype:
+            x = ops.cast(x.float() if x.dtype not in (torch.float32, torch.bfloat16) else x, self.compute_dtype)
+        return x
+
+    # ---- forward: returns the Keras outputs (networks.py:89-90,99) ----------------------------------------------
+    def forward(self, x, training: Optional[bool] = None, eps_q=None):
+        if self.references.cascaded != False:  # noqa: E712
+            return self._forward_cascaded(x)
+        o = self.m1_model(self._prep(x), eps_q=eps_q)
+        if self.references.probabilistic:
+            return [o['prob_softmax'], o['prob_kl']]
+        return o['y_softmax']
+
+    def _forward_cascaded(self, x):
+        """networks.py:109-193.  Stage 2 sees cat[stage-1 softmax[..., :nc-1], image_2]; fusion per decision_fusion."""
+        if isinstance(x, dict):
+            x1, x2 = x[self.inputs[0].name], x[self.inputs[1].name]
+        else:
+            x1, x2 = x
+        nc, prob = self.num_classes, self.references.probabilistic
+        key = 'prob_softmax' if prob else 'y_softmax'
+        o1 = self.m1_stage1(self._prep(x1))
+        p1 = o1[key]
+        prior_in = ops.cast(p1[..., :nc - 1].contiguous(), self.compute_dtype)                   # networks.py:135-136
+        o2 = self.m1_stage2(torch.cat([prior_in, self._prep(x2)], dim=-1).contiguous())
+        p2 = o2[key]
+        prior_pred, joint_pred = self.decision_fusion(p1[..., nc - 1], p2[..., nc - 1], strategy=self.references.cascaded)
+        if prob:
+            return [prior_pred, joint_pred, o1['prob_kl'], o2['prob_kl']]
+        return [prior_pred, joint_pred]
+
+    # ---- networks.py:196-206 ---------------------------------------------------------------------------------
+    def get_detect_model(self):
+        """Model reconfigured to predict segment probabilities only: probabilistic -> softmax(prob_infer_conv)
+        with z ~ P at every level; deterministic -> y_softmax[..., :num_classes]."""
+        outer = self
+
+        class _Detect(nn.Module):
+            def forward(self, x):
+                nc = outer.references.num_classes
+                if outer.references.cascaded != False:  # noqa: E712
+                    raise NotImplementedError("cascaded detect model: use M1.forward outputs")
+                with torch.no_grad():
+                    if outer.references.probabilistic:
+                        o = outer.m1_model(outer._prep(x), train_outputs=False)
+                        return ops.softmax_heads([o['prob_infer_conv']], [(1, 1, 1)])
+                    o = outer.m1_model(outer._prep(x))
+                    return o['y_softmax'][..., :nc]
+
+            def predict(self, x):
+                return self.forward(x)
+        return _Detect()
+
+    # ---- networks.py:209-223 ---------------------------------------------------------------------------------
+    def decision_fusion(self, prior_softmax, follow_up_softmax, strategy='identity'):
+        if strategy == 'identity':
+            joint_pred = follow_up_softmax.unsqueeze(-1)
+        elif strategy == 'noisy-or':
+            joint_pred = (1 - ((1 - prior_softmax) * (1 - follow_up_softmax))).unsqueeze(-1)
+        elif strategy == 'bayes':
+            joint_pred = (((prior_softmax * follow_up_softmax) + 1e-9)
+                          / ((prior_softmax * follow_up_softmax) + 1e-9 + ((1 - prior_softmax) * (1 - follow_up_softmax)))).unsqueeze(-1)
+        else:
+            raise ValueError(strategy)
+        prior_pred = torch.cat(((1 - prior_softmax).unsqueeze(-1), prior_softmax.unsqueeze(-1)), dim=-1)
+        joint_pred = torch.cat((1 - joint_pred, joint_pred), dim=-1)
+        return prior_pred, joint_pred
+
+    # ---- regulariser terms (networks.py:456-460; Keras adds them to the compiled loss) ---------------------------
+    def regularized_parameters(self):
+        """(kernels, biases) of every layer built with conv_params; never conv6/conv7 or IN (App. B-7, C-7)."""
+        ks, bs = [], []
+        for mod in self.modules():
+            if isinstance(mod, Conv3D) and mod.kernel_regularizer is not None:
+                ks.append(mod.kernel)
+            if isinstance(mod, Conv3D) and mod.bias_regularizer is not None:
+                bs.append(mod.bias)
+        return ks, bs
+
+    def regularization_loss(self) -> torch.Tensor:
+        ks, bs = self.regularized_parameters()
+        tot = torch.zeros((), dtype=torch.float32, device=self.rng_state.device)
+        if self.l2_kernel:
+            tot = tot + self.l2_kernel * sum((k.float() ** 2).sum() for k in ks)
+        if self.l2_bias:
+            tot = tot + self.l2_bias * sum((b.float() ** 2).sum() for b in bs)
+        return tot
+
+    # ---- one optimisation step of the compiled model (Keras train_step; train_model.py:231,253) --------------------
+    def compute_loss(self, outputs, y):
+        c = self._compiled
+        outs = outputs if isinstance(outputs, (list, tuple)) else [outputs]
+        if isinstance(y, dict):
+            ys = [y.get(n) for n in self.output_names]
+        elif isinstance(y, (list, tuple)):
+            ys = list(y) + [None] * (len(outs) - len(y))
+        else:
+            ys = [y] + [None] * (len(outs) - 1)
+        parts, total = {}, None
+        for name, lf, w, yt, yp in zip(self.output_names, c["losses"], c["weights"], ys, outs):
+            if lf is None:
+                continue
+            v = lf(yt, yp)
+            parts[name + "_loss"] = v
+            total = w * v if total is None else total + w * v
+        return total, parts
+
+    def train_step(self, x, y):
+        c = self._compiled
+        opt = c["optimizer"]
+        self.train()
+        outputs = self(x)
+        total, parts = self.compute_loss(outputs, y)
+        fused_l2 = bool(getattr(opt, "handles_l2", False))
+        reg = self.regularization_loss()
+        loss = total if fused_l2 else total + reg
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        self.advance_rng()
+        logs = {"loss": float((total + reg).detach())}
+        logs.update({k: float(v.detach()) for k, v in parts.items()})
+        return logs
