@@ -1,0 +1,265 @@
+#!/usr/bin/env python3
+"""bench.py -- train-step throughput of M1 on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus 1 --steps K --warmup W                   (driver, N=1)
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+One "step" = forward (all core passes) + Focal (+10*KL) loss + backward + gradient all-reduce (N>1) +
+fused Adam-amsgrad/L2 update, on synthetic volumes already resident in HBM.
+Rank 0 prints ONE JSON line; `value` = volumes/s over all ranks; `roofline` describes the dominant kernel
+(algorithmic work / hipEvent-measured duration on the launch stream); `cpu_baseline` is the CPU oracle
+(stand-in for the TF 2.5 CPU path, which cannot be installed) timed on this box's host cores.
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+README_STRIDES = ((1, 1, 1), (1, 2, 2), (1, 2, 2), (2, 2, 2), (2, 2, 2))
+WORKLOADS = {
+    # name: (spatial, filters, probabilistic, dense_skip, deep_supervision)   -- BASELINE.json configs
+    "C1": ((8, 64, 64), (8, 16, 32, 64, 128), False, False, False),
+    "C2": ((20, 160, 160), (32, 64, 128, 256, 512), False, False, False),
+    "C3": ((20, 160, 160), (32, 64, 128, 256, 512), True, True, True),
+    "C5": ((32, 256, 256), (32, 64, 128, 256, 512), False, False, False),
+}
+PEAK_HBM_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+PEAK_MFMA_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default=os.environ.get("M1_BENCH_WORKLOAD", "C2"), choices=sorted(WORKLOADS))
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--batch", type=int, default=None, help="volumes per GPU (default 1; C4 = C3 with --batch 2)")
+    ap.add_argument("--dropout", type=float, default=0.5)
+    ap.add_argument("--no-graph", action="store_true", help="do not capture the step in a hipGraph")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--prof-steps", type=int, default=2)
+    return ap.parse_args()
+
+
+def ball_targets(B, dims, seed, device):
+    import numpy as np
+    import torch
+    D, H, W = dims
+    rng = np.random.default_rng(seed)
+    zz, yy, xx = np.meshgrid(np.arange(D), np.arange(H), np.arange(W), indexing="ij")
+    t = np.zeros((B, D, H, W, 2), dtype=np.float32)
+    for b in range(B):
+        c = [rng.integers(1, max(2, D - 1)), rng.integers(6, H - 6), rng.integers(6, W - 6)]
+        m = ((zz - c[0]) ** 2 + (yy - c[1]) ** 2 + (xx - c[2]) ** 2) <= 36
+        t[b, ..., 1] = m
+        t[b, ..., 0] = 1 - t[b, ..., 1]
+    return torch.from_numpy(t).to(device)
+
+
+def cpu_baseline(workload, prob, dense, deep, dims, filters, kl_w):
+    """The CPU oracle's full train step (fwd + Focal [+10 KL] + L2 + bwd, torch-CPU fp32, all host cores) on a
+    bounded sample: the same model on a quarter-area volume; throughput is scaled by the voxel ratio (the
+    path is convolutional, i.e. linear in voxels)."""
+    import torch
+    from oracle import m1_oracle as O
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    D, H, W = dims
+    sd = (D, H // 2, W // 2) if H >= 64 else dims
+    frac = (sd[0] * sd[1] * sd[2]) / float(D * H * W)
+    cfg = O.M1Config(input_spatial_dims=sd, filters=filters, strides=README_STRIDES, probabilistic=prob, dense_skip=dense,
+                     deep_supervision=deep, prob_latent_dims=(3, 2, 1, 0))
+    g = torch.Generator().manual_seed(0)
+    P = {k: v.requires_grad_(True) for k, v in O.fixture_params(cfg, 0).items()}
+    x = torch.randn(1, *sd, 3, generator=g)
+    tgt = ball_targets(1, sd, 1, "cpu")
+    eps = [torch.randn(1, *s, generator=g) for s in O.latent_shapes(cfg)] if prob else None
+    times = []
+    for it in range(2):
+        t0 = time.time()
+        loss, _, _ = O.train_loss(P, cfg, x, tgt, eps_q=eps, kl_weight=kl_w)
+        loss.backward()
+        for p in P.values():
+            p.grad = None
+        times.append(time.time() - t0)
+        if times[-1] > 40:
+            break
+    t = min(times)
+    return {"value": frac / t, "unit": "volumes/s", "cores": cores, "kind": "port",
+            "sample": f"oracle (torch-CPU fp32 restatement of the TF2.5 path, stand-in: TF cannot be installed) full train "
+                      f"step fwd+loss+bwd of {workload} on a ({sd[0]},{sd[1]},{sd[2]}) sub-volume = {frac:.3f} of a volume, "
+                      f"{t:.2f} s/step, scaled by voxel ratio"}
+
+
+def main():
+    a = parse()
+    import torch
+    import torch.distributed as dist
+    pkg = importlib.import_module("prostatemr_3d-cad-cspca_amd")
+    ops = pkg.hip.ops
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus and world > 1:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
+
+    dims, filters, prob, dense, deep = WORKLOADS[a.workload]
+    B = a.batch or 1
+    act_dtype = torch.bfloat16 if a.dtype == "bf16" else torch.float32
+    kl_w = 10.0
+
+    pkg.unets.network_blocks.set_init_seed(0)
+    init = pkg.initializers
+    model = pkg.unets.networks.M1(
+        input_spatial_dims=dims, input_channels=3, num_classes=2, filters=filters, strides=README_STRIDES,
+        kernel_sizes=((1, 3, 3), (1, 3, 3), (3, 3, 3), (3, 3, 3), (3, 3, 3)), prob_latent_dims=(3, 2, 1, 0),
+        dropout_rate=a.dropout, dropout_mode="monte-carlo", se_reduction=(8, 8, 8, 8, 8), att_sub_samp=((1, 1, 1),) * 4,
+        kernel_initializer=init.Orthogonal(gain=1.0), bias_initializer=init.TruncatedNormal(mean=0.0, stddev=1e-3),
+        kernel_regularizer=init.l2(1e-4), bias_regularizer=init.l2(1e-4), cascaded=False, dense_skip=dense,
+        probabilistic=prob, deep_supervision=deep, summary=False).to(dev)
+    model.set_compute_dtype(act_dtype)
+    model.seed_dropout(2 + rank)
+    nparams = sum(p.numel() for p in model.parameters())
+
+    g = torch.Generator().manual_seed(1 + rank)
+    x = torch.randn(B, *dims, 3, generator=g).to(dev)
+    tgt = ball_targets(B, dims, 100 + rank, dev)
+    if prob:
+        x[..., 2] = tgt[..., 1]                                          # label channel (data_generators.py:82)
+    x = ops.cast(x.contiguous(), act_dtype)
+
+    focal = pkg.losses.Focal(alpha=[0.75, 0.25], gamma=2.0).loss
+    elbo = pkg.losses.EvidenceLowerBound().loss
+    losses, weights = ([focal, elbo], [1.0, kl_w]) if prob else ([focal], [1.0])
+    opt = pkg.optim.Adam(learning_rate=1e-3, amsgrad=True)
+    model.compile(optimizer=opt, loss=losses, loss_weights=weights)
+    if world > 1:
+        opt.reducer = pkg.ddp.GradReducer(world_size=world)
+        opt.grad_scale = opt.reducer.grad_scale
+    opt.set_lr_device()
+    model.train()
+    loss_buf = torch.zeros(1, device=dev)
+
+    def step():
+        outs = model(x)
+        total, _ = model.compute_loss(outs, {"detection": tgt})
+        opt.zero_grad()
+        total.backward()
+        opt.flatp.gather_grads()
+        if opt.reducer is not None:
+            opt.reducer.all_reduce(opt.flatp.grad)
+        opt.apply_flat()
+        ops.step_advance(None, model.rng_state)
+        loss_buf.copy_(total.detach().reshape(1))
+
+    # ---- eager warm-up (also primes the allocator), then optional whole-step hipGraph ----
+    for _ in range(max(1, min(a.warmup, 2))):
+        step()
+    torch.cuda.synchronize()
+    use_graph, graph, graph_err = (not a.no_graph), None, None
+    if use_graph:
+        try:
+            s = torch.cuda.Stream()
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s):
+                step()
+            torch.cuda.current_stream().wait_stream(s)
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                step()
+            torch.cuda.synchronize()
+        except Exception as e:  # noqa: BLE001 -- fall back to eager launches, report it
+            graph, graph_err = None, f"{type(e).__name__}: {str(e)[:200]}"
+            torch.cuda.synchronize()
+    run = (lambda: graph.replay()) if graph is not None else step
+
+    for _ in range(a.warmup):
+        run()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        run()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt)
+    final_loss = float(loss_buf)
+
+    # ---- per-kernel-family hipEvent timing on the launch stream (eager launches of the same step) ----
+    roof = None
+    if not a.no_roofline and rank == 0:
+        ops.prof_reset(); ops.prof_enable(True)
+        for _ in range(a.prof_steps):
+            step()
+        torch.cuda.synchronize()
+        recs = ops.prof_read()
+        ops.prof_enable(False)
+        recs = [r for r in recs if r["total_ms"] > 0]
+        recs.sort(key=lambda r: -r["total_ms"])
+        if recs:
+            r = recs[0]
+            sec = r["total_ms"] * 1e-3
+            tf_ach, gb_ach = r["flops"] / sec / 1e12, r["bytes"] / sec / 1e9
+            f_m, f_h = tf_ach / PEAK_MFMA_TFLOPS[a.dtype], gb_ach / PEAK_HBM_GBS
+            if f_m >= f_h:
+                roof = {"bound": "mfma", "achieved": tf_ach, "peak": PEAK_MFMA_TFLOPS[a.dtype], "unit": "TFLOP/s", "frac": f_m}
+            else:
+                roof = {"bound": "hbm", "achieved": gb_ach, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": f_h}
+            roof.update({"traffic": None, "kernel": r["name"], "launches_per_step": r["launches"] / a.prof_steps,
+                         "avg_launch_ms": r["total_ms"] / r["launches"],
+                         "kernel_ms_per_step": r["total_ms"] / a.prof_steps,
+                         "all_kernels_ms_per_step": {q["name"]: round(q["total_ms"] / a.prof_steps, 4) for q in recs}})
+
+    if world > 1:
+        dist.barrier()
+    if rank == 0:
+        cpu = None
+        if not a.no_cpu_baseline and world == 1:
+            try:
+                cpu = cpu_baseline(a.workload, prob, dense, deep, dims, filters, kl_w)
+            except Exception as e:  # noqa: BLE001
+                cpu = {"value": None, "unit": "volumes/s", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {e}"}
+        vols = B * world * a.steps
+        out = {
+            "metric": "train-step volumes/sec (whole job), M1 (20,160,160,3)" if a.workload in ("C2", "C3") else
+                      f"train-step volumes/sec (whole job), M1 {dims}",
+            "value": vols / dt, "unit": "volumes/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": a.dtype, "data": "synthetic",
+            "config": {"workload": {"C1": "C1 tiny deterministic (8,64,64,3) filters (8..128)",
+                                    "C2": "C2 M1 deterministic Attention-U-Net (20,160,160,3) filters (32..512)",
+                                    "C3": "C3 M1 full hierarchical-probabilistic dense_skip+deep_supervision latents (3,2,1,0) (20,160,160,3)",
+                                    "C5": "C5 M1 deterministic high-res (32,256,256,3)"}[a.workload],
+                       "batch_per_gpu": B, "global_batch": B * world, "params": nparams, "dropout": a.dropout,
+                       "parallelism": f"dp{world}", "hip_graph": graph is not None, "graph_error": graph_err,
+                       "loss": final_loss},
+            "roofline": roof, "cpu_baseline": cpu,
+        }
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -11,6 +11,10 @@ int m1_convT3d_dgrad_direct(const m1_conv_desc_t*, const float*, const void*, vo
 int m1_convT3d_wgrad_direct(const m1_conv_desc_t*, const void*, float*, float*, float*, void*);
 }
 
+static inline bool desc_ok(const m1_conv_desc_t* d) {
+    return d && d->N > 0 && d->D > 0 && d->H > 0 && d->W > 0 && d->Cin > 0 && d->Cout > 0 && d->kd > 0 && d->kh > 0 &&
+           d->kw > 0 && d->sd > 0 && d->sh > 0 && d->sw > 0 && d->nsrc >= 1 && d->nsrc <= M1_MAX_SRC;
+}
 static inline double esz(int dt) { return dt == M1_BF16 ? 2.0 : 4.0; }
 static inline void conv_out_dims(const m1_conv_desc_t* d, int* od, int* oh, int* ow) {
     *od = (d->D + d->sd - 1) / d->sd; *oh = (d->H + d->sh - 1) / d->sh; *ow = (d->W + d->sw - 1) / d->sw;
@@ -42,32 +46,32 @@ extern "C" const char* m1_status_name(int s) {
 extern "C" int m1_abi_version(void) { return 1; }
 
 extern "C" int m1_conv3d_fwd(const m1_conv_desc_t* d, const float* w, const float* bias, void* y, void* stream) {
-    if (!d) return M1_ERR_BAD_ARG;
+    if (!desc_ok(d)) return M1_ERR_BAD_ARG;
     M1ProfScope ps("conv3d_fwd", 2.0 * conv_macs(d, 0), (conv_in_elems(d) + conv_out_elems(d, 0)) * esz(d->dtype), (hipStream_t)stream);
     return m1_conv3d_fwd_direct(d, w, bias, y, stream);
 }
 extern "C" int m1_conv3d_dgrad(const m1_conv_desc_t* d, const float* w, const void* dy, void* const* dx, void* stream) {
-    if (!d) return M1_ERR_BAD_ARG;
+    if (!desc_ok(d)) return M1_ERR_BAD_ARG;
     M1ProfScope ps("conv3d_dgrad", 2.0 * conv_macs(d, 0), (conv_in_elems(d) + conv_out_elems(d, 0)) * esz(d->dtype), (hipStream_t)stream);
     return m1_conv3d_dgrad_direct(d, w, dy, dx, stream);
 }
 extern "C" int m1_conv3d_wgrad(const m1_conv_desc_t* d, const void* dy, float* dw, float* db, float* ws, void* stream) {
-    if (!d) return M1_ERR_BAD_ARG;
+    if (!desc_ok(d)) return M1_ERR_BAD_ARG;
     M1ProfScope ps("conv3d_wgrad", 2.0 * conv_macs(d, 0), (conv_in_elems(d) + conv_out_elems(d, 0)) * esz(d->dtype), (hipStream_t)stream);
     return m1_conv3d_wgrad_direct(d, dy, dw, db, ws, stream);
 }
 extern "C" int m1_convT3d_fwd(const m1_conv_desc_t* d, const float* w, const float* bias, void* y, void* stream) {
-    if (!d) return M1_ERR_BAD_ARG;
+    if (!desc_ok(d)) return M1_ERR_BAD_ARG;
     M1ProfScope ps("convT3d_fwd", 2.0 * conv_macs(d, 1), (conv_in_elems(d) + conv_out_elems(d, 1)) * esz(d->dtype), (hipStream_t)stream);
     return m1_convT3d_fwd_direct(d, w, bias, y, stream);
 }
 extern "C" int m1_convT3d_dgrad(const m1_conv_desc_t* d, const float* w, const void* dy, void* const* dx, void* stream) {
-    if (!d) return M1_ERR_BAD_ARG;
+    if (!desc_ok(d)) return M1_ERR_BAD_ARG;
     M1ProfScope ps("convT3d_dgrad", 2.0 * conv_macs(d, 1), (conv_in_elems(d) + conv_out_elems(d, 1)) * esz(d->dtype), (hipStream_t)stream);
     return m1_convT3d_dgrad_direct(d, w, dy, dx, stream);
 }
 extern "C" int m1_convT3d_wgrad(const m1_conv_desc_t* d, const void* dy, float* dw, float* db, float* ws, void* stream) {
-    if (!d) return M1_ERR_BAD_ARG;
+    if (!desc_ok(d)) return M1_ERR_BAD_ARG;
     M1ProfScope ps("convT3d_wgrad", 2.0 * conv_macs(d, 1), (conv_in_elems(d) + conv_out_elems(d, 1)) * esz(d->dtype), (hipStream_t)stream);
     return m1_convT3d_wgrad_direct(d, dy, dw, db, ws, stream);
 }

@@ -30,7 +30,7 @@ class Orthogonal(Initializer):
         q = q * torch.sign(torch.diagonal(r))
         if rows < cols:
             q = q.t()
-        return (self.gain * q.reshape(shape)).to(torch.float32)
+        return (self.gain * q.contiguous().reshape(shape)).to(torch.float32).contiguous()
 
 
 class TruncatedNormal(Initializer):

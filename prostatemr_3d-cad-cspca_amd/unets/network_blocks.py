@@ -47,8 +47,8 @@ class Conv3D(nn.Module):
         self.kernel_regularizer, self.bias_regularizer = kernel_regularizer, bias_regularizer
         kinit = kernel_initializer if kernel_initializer is not None else init.GlorotUniform()
         binit = bias_initializer if bias_initializer is not None else init.Zeros()
-        self.kernel = nn.Parameter(kinit(self._kernel_shape(), _GEN))
-        self.bias = nn.Parameter(binit((self.filters,), _GEN))
+        self.kernel = nn.Parameter(kinit(self._kernel_shape(), _GEN).contiguous())
+        self.bias = nn.Parameter(binit((self.filters,), _GEN).contiguous())
 
     def _kernel_shape(self):
         return (*self.kernel_size, self.in_channels, self.filters)

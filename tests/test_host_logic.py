@@ -1,0 +1,207 @@
+"""CPU tests of the host side: constructor surface / config capture, initialisers, schedule, flat parameter
+buffer, regulariser bookkeeping, loud failure without a GPU, and the N>1 gradient exchange over gloo."""
+import math
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import m1_oracle as O
+from util import C1_FILTERS, C1_STRIDES, PKG, ROOT
+
+N = PKG.unets.networks
+init = PKG.initializers
+
+
+def _m1(**kw):
+    base = dict(input_spatial_dims=(8, 64, 64), input_channels=3, num_classes=2, filters=C1_FILTERS, strides=C1_STRIDES,
+                summary=False)
+    base.update(kw)
+    return N.M1(**base)
+
+
+def test_reference_import_path_and_ctor_kwargs():
+    import inspect
+    import model.unets as unets
+    import model.losses as losses
+    assert unets.networks.M1 is N.M1 and hasattr(losses, "Focal") and hasattr(losses, "EvidenceLowerBound")
+    names = list(inspect.signature(N.M1.__init__).parameters)[1:]
+    assert names == ["input_spatial_dims", "input_channels", "num_classes", "dropout_rate", "dropout_mode", "filters", "strides",
+                     "kernel_sizes", "se_reduction", "att_sub_samp", "kernel_initializer", "bias_initializer",
+                     "kernel_regularizer", "bias_regularizer", "cascaded", "dense_skip", "deep_supervision", "probabilistic",
+                     "prob_latent_dims", "summary", "name"]                           # networks.py:34-55
+    core = list(inspect.signature(N.M1Core.__init__).parameters)[1:]
+    assert core[:16] == ["num_classes", "dropout_mode", "dropout_rate", "filters", "strides", "kernel_sizes", "se_reduction",
+                         "att_sub_samp", "kernel_initializer", "bias_initializer", "kernel_regularizer", "bias_regularizer",
+                         "dense_skip", "deep_supervision", "probabilistic", "prob_latent_dims"]   # networks.py:418-434
+
+
+def test_parameter_names_shapes_and_counts_match_oracle_inventory():
+    for kw in (dict(), dict(deep_supervision=True), dict(probabilistic=True, dense_skip=True, deep_supervision=True)):
+        m = _m1(**kw)
+        cfg = O.M1Config(input_spatial_dims=(8, 64, 64), filters=C1_FILTERS, strides=C1_STRIDES, **kw)
+        want = O.m1_param_shapes(cfg)
+        got = {k.replace("m1_model.", ""): tuple(v.shape) for k, v in m.state_dict().items()}
+        assert got == {k: tuple(v) for k, v in want.items()}
+        assert all(p.is_contiguous() for p in m.parameters())
+    assert sum(p.numel() for p in _m1().parameters()) == 1_098_523                     # KAT-9
+
+
+def test_shape_asserts_have_the_reference_messages():
+    with pytest.raises(AssertionError, match="Expected Tuple/Array with 5 Values"):
+        _m1(filters=(8, 16, 32))
+    with pytest.raises(AssertionError, match="Expected 4x3 Tuple/Array"):
+        _m1(att_sub_samp=((1, 1, 1),) * 3)
+    with pytest.raises(AssertionError, match=r"Variable \(ndims\) should be  1, 2 or 3"):
+        _m1(input_spatial_dims=(1, 2, 3, 4))
+
+
+def test_store_config_args_and_from_config_roundtrip(tmp_path):
+    m = _m1(dense_skip=True, kernel_regularizer=init.l2(3e-5))
+    cfg = m.get_config()
+    assert cfg["dense_skip"] is True and cfg["filters"] == C1_FILTERS and cfg["name"] == "UNET-TYPE-M1"
+    m2 = N.M1.from_config(cfg)
+    assert sum(p.numel() for p in m2.parameters()) == sum(p.numel() for p in m.parameters())
+    path = str(tmp_path / "w.npz")
+    m.save_weights(path)
+    m3 = N.M1.load(path)
+    assert m3.l2_kernel == pytest.approx(3e-5)
+    for (k, a), (_, b) in zip(m.state_dict().items(), m3.state_dict().items()):
+        assert torch.equal(a, b), k
+
+    class Bad(PKG.unets.modelio.LoadableModel):
+        def __init__(self):
+            super().__init__()
+    with pytest.raises(RuntimeError, match="store_config_args"):
+        Bad().get_config()
+
+
+def test_keras_surface_present():
+    m = _m1(probabilistic=True, dense_skip=True)
+    assert m.output_names == ["detection", "KL"] and m.inputs[0].name == "image"
+    assert m.references.probabilistic is True and m.references.cascaded is False and m.references.num_classes == 2
+    assert len(m.layers) > 50 and callable(m.get_detect_model) and callable(m.decision_fusion)
+    opt = PKG.optim.Adam(learning_rate=1e-3, amsgrad=True)
+    m.compile(optimizer=opt, loss=[PKG.losses.Focal().loss, PKG.losses.EvidenceLowerBound().loss], loss_weights=[1.0, 10.0])
+    assert m.optimizer.lr == pytest.approx(1e-3)
+    m.optimizer.lr = 5e-4
+    assert opt.lr == pytest.approx(5e-4)
+
+
+def test_forward_fails_loudly_without_gpu():
+    m = _m1()
+    with pytest.raises(RuntimeError, match="HIP extension only"):
+        m(torch.zeros(1, 8, 64, 64, 3))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        PKG.hip.ops.conv3d_same([torch.zeros(1, 2, 2, 2, 4)], torch.zeros(1, 1, 1, 4, 4), None, (1, 1, 1), (1, 1, 1))
+
+
+def test_product_never_imports_the_oracle():
+    pkgdir = os.path.join(ROOT, "prostatemr_3d-cad-cspca_amd")
+    for dp, _, fs in os.walk(pkgdir):
+        for f in fs:
+            if f.endswith((".py", ".hip", ".h")):
+                txt = open(os.path.join(dp, f)).read()
+                assert "import oracle" not in txt and "from oracle" not in txt, f
+
+
+def test_initializers_have_tf_semantics():
+    g = torch.Generator().manual_seed(0)
+    w = init.Orthogonal(gain=1.0)((3, 3, 3, 16, 8), g)
+    m = w.reshape(-1, 8)
+    assert w.is_contiguous() and float((m.t() @ m - torch.eye(8)).abs().max()) < 1e-5       # orthonormal columns
+    w = init.Orthogonal(gain=2.0)((1, 1, 1, 4, 32), g).reshape(4, 32)
+    assert float((w @ w.t() - 4 * torch.eye(4)).abs().max()) < 1e-4                          # rows < cols: orthonormal rows * gain
+    t = init.TruncatedNormal(0.0, 1e-3)((10000,), g)
+    assert float(t.abs().max()) <= 2e-3 and 0.7e-3 < float(t.std()) < 1.0e-3
+    u = init.GlorotUniform()((1, 1, 1, 32, 4), g)
+    assert float(u.abs().max()) <= math.sqrt(6 / 36) + 1e-6
+    assert float(init.l2(1e-4)(torch.ones(10))) == pytest.approx(1e-3)
+
+
+def test_regularised_parameter_partition_matches_reference_rule():
+    m = _m1()
+    ks, bs = m.regularized_parameters()
+    names = {id(p): n for n, p in m.named_parameters()}
+    assert all(".conv6." not in names[id(p)] and ".conv7." not in names[id(p)] for p in ks + bs)
+    nreg = sum(p.numel() for p in ks) + sum(p.numel() for p in bs)
+    se_fc = sum(p.numel() for n, p in m.named_parameters() if ".conv6." in n or ".conv7." in n)
+    inorm = sum(p.numel() for n, p in m.named_parameters() if n.endswith("gamma") or n.endswith("beta"))
+    assert nreg + se_fc + inorm == 1_098_523
+    cfg = O.M1Config(input_spatial_dims=(8, 64, 64), filters=C1_FILTERS, strides=C1_STRIDES)
+    P = {k.replace("m1_model.", ""): v.detach() for k, v in m.state_dict().items()}
+    assert float(m.regularization_loss()) == pytest.approx(float(O.l2_regularisation(P, cfg)), rel=1e-5)
+
+
+def test_flat_params_layout_and_views():
+    m = _m1()
+    ref = {n: p.detach().clone() for n, p in m.named_parameters()}
+    fp = PKG.optim.FlatParams(m)
+    assert fp.n == 1_098_523 and fp.flat.numel() % 4 == 0
+    for n, p in m.named_parameters():
+        assert torch.equal(p.detach(), ref[n]) and p.data_ptr() >= fp.flat.data_ptr()
+    fp.flat.zero_()
+    assert all(float(p.abs().sum()) == 0.0 for p in m.parameters())                      # parameters ARE views
+    for p in fp.params[:3]:
+        p.grad = torch.ones_like(p)
+    fp.gather_grads()
+    k = sum(p.numel() for p in fp.params[:3])
+    assert float(fp.grad[:k].sum()) == k and float(fp.grad[k:].abs().sum()) == 0.0
+
+
+def test_cosine_decay_restarts_matches_tf_formula():
+    s = PKG.optim.CosineDecayRestarts(1e-3, 100, t_mul=2.0, m_mul=1.0, alpha=1e-3)
+    assert s(0) == pytest.approx(1e-3)
+    assert s(50) == pytest.approx(1e-3 * ((1 - 1e-3) * 0.5 + 1e-3))
+    assert s(100) == pytest.approx(1e-3)                                                  # restart
+    assert s(200) == pytest.approx(1e-3 * ((1 - 1e-3) * 0.5 + 1e-3))                      # second period is 200 long
+    s2 = PKG.optim.CosineDecayRestarts(1.0, 10, t_mul=1.0, m_mul=0.5, alpha=0.0)
+    assert s2(10) == pytest.approx(0.5) and s2(25) == pytest.approx(0.25 * 0.5)
+
+
+def test_bucket_bounds_cover_exactly():
+    bb = PKG.ddp.bucket_bounds(1_000_003, 250_000)
+    assert bb[0][0] == 0 and bb[-1][1] == 1_000_003 and all(a[1] == b[0] for a, b in zip(bb, bb[1:]))
+    assert PKG.ddp.bucket_bounds(10, 1 << 20) == [(0, 10)] and PKG.ddp.bucket_bounds(0, 4) == []
+    assert list(PKG.ddp.shard_batch(16, 3, 8)) == [6, 7]
+    with pytest.raises(AssertionError, match="multiple of the number of GPUs"):
+        PKG.ddp.shard_batch(3, 0, 2)
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _ddp_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import importlib
+    pkg = importlib.import_module("prostatemr_3d-cad-cspca_amd")
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    assert pkg.ddp.init_process_group_from_env("gloo") == world
+    red = pkg.ddp.GradReducer(bucket_mb=0.001)                 # forces several buckets
+    g = torch.Generator().manual_seed(rank)
+    flat = torch.randn(5003, generator=g)
+    mine = flat.clone()
+    red.all_reduce(flat)
+    q.put((rank, mine.numpy(), flat.numpy(), red.grad_scale))
+    dist.barrier(); dist.destroy_process_group()
+
+
+def test_two_rank_gloo_gradient_exchange_equals_global_batch_mean():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_ddp_worker, args=(r, world, port, q)) for r in range(world)]
+    [p.start() for p in ps]
+    res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])
+    [p.join(60) for p in ps]
+    assert all(p.exitcode == 0 for p in ps)
+    total = res[0][1] + res[1][1]
+    for _, _, reduced, scale in res:
+        assert np.allclose(reduced, total, atol=1e-6) and scale == 0.5
+        assert np.allclose(reduced * scale, total / 2, atol=1e-6)           # what the optimiser kernel consumes
