@@ -62,19 +62,22 @@ int m1_abi_version(void);
 
 /* ---- Conv3D(padding='same') + bias : B:37,39,41,43,100-103 ; N:472,526,529-531,534-537 ; B:275 ----
  * w: Keras layout (kd,kh,kw,Cin,Cout) fp32; bias (Cout) fp32 or NULL; y: (N,OD,OH,OW,Cout). */
-int m1_conv3d_fwd(const m1_conv_desc_t* d, const float* w, const float* bias, void* y, void* stream);
+/* ws: caller-owned scratch of m1_conv_ws_bytes(d, transposed, role) bytes, 256-byte aligned (packed bf16/fp32
+ * weight panels for the matrix-core kernels; bias-gradient partials for wgrad). role: 0 fwd, 1 dgrad, 2 wgrad. */
+size_t m1_conv_ws_bytes(const m1_conv_desc_t* d, int transposed, int role);
+int m1_conv3d_fwd(const m1_conv_desc_t* d, const float* w, const float* bias, void* y, void* ws, void* stream);
 /* dx[i]: gradient buffer of concat member i (same shape/dtype as src[i]) or NULL to skip it. */
-int m1_conv3d_dgrad(const m1_conv_desc_t* d, const float* w, const void* dy, void* const* dx, void* stream);
+int m1_conv3d_dgrad(const m1_conv_desc_t* d, const float* w, const void* dy, void* const* dx, void* ws, void* stream);
 /* dw (kd,kh,kw,Cin,Cout) and db (Cout) are OVERWRITTEN (zeroed inside, then accumulated). */
-/* ws: fp32 workspace of m1_reduce_ws_floats(N, OD*OH*OW, Cout, 1) floats (bias-gradient reduction); may be
- * NULL when db is NULL. */
-int m1_conv3d_wgrad(const m1_conv_desc_t* d, const void* dy, float* dw, float* db, float* ws, void* stream);
+int m1_conv3d_wgrad(const m1_conv_desc_t* d, const void* dy, float* dw, float* db, void* ws, void* stream);
+/* test hook: 1 = route every conv through the generic direct kernels (no matrix cores). */
+int m1_set_force_direct(int on);
 
 /* ---- Conv3DTranspose(padding='same') + bias : N:496-499,505-507,513-514,520,546-553 ----
  * w: Keras layout (kd,kh,kw,Cout,Cin) fp32; y: (N, D*sd, H*sh, W*sw, Cout). */
-int m1_convT3d_fwd(const m1_conv_desc_t* d, const float* w, const float* bias, void* y, void* stream);
-int m1_convT3d_dgrad(const m1_conv_desc_t* d, const float* w, const void* dy, void* const* dx, void* stream);
-int m1_convT3d_wgrad(const m1_conv_desc_t* d, const void* dy, float* dw, float* db, float* ws, void* stream);
+int m1_convT3d_fwd(const m1_conv_desc_t* d, const float* w, const float* bias, void* y, void* ws, void* stream);
+int m1_convT3d_dgrad(const m1_conv_desc_t* d, const float* w, const void* dy, void* const* dx, void* ws, void* stream);
+int m1_convT3d_wgrad(const m1_conv_desc_t* d, const void* dy, float* dw, float* db, void* ws, void* stream);
 
 /* ---- tfa.layers.InstanceNormalization (eps 1e-3) [+ LeakyReLU(slope)] : B:38,40,42,44,54-60,104,128;
  *      N:473,575-576.  x,y: (N,V,C).  stats: (N,C,2) fp32 = {mean, rstd}.
@@ -119,7 +122,7 @@ int m1_se_combine_bwd(const void* y3, const void* y4, const float* stats3, const
 int m1_gate_sigma_fwd(const void* theta, const void* phi, const float* wpsi, const float* bpsi, void* sigma,
                       int N, int Dt, int Ht, int Wt, int Dp, int Hp, int Wp, int C, int dtype, void* stream);
 /* dtheta (like theta) is written; dphi (like phi) = window-sum of dtheta; dwpsi (C), dbpsi (1) overwritten.
- * ws: m1_reduce_ws_floats(N, Dt*Ht*Wt, C, 1) + 64 floats */
+ * ws: m1_reduce_ws_floats(N, Dt*Ht*Wt, C, 2) floats */
 int m1_gate_sigma_bwd(const void* theta, const void* phi, const float* wpsi, const void* sigma,
                       const void* dsigma, void* dtheta, void* dphi, float* dwpsi, float* dbpsi, int N, int Dt,
                       int Ht, int Wt, int Dp, int Hp, int Wp, int C, int dtype, float* ws, void* stream);

@@ -156,7 +156,7 @@ static int gate_bwd_impl(const void* theta, const void* phi, const float* wpsi, 
     rc = m1_reduce_nc_launch<2>(f, g.N, Vt, g.C, ws, st); if (rc) return rc;
     const int nchunks = m1_red_nchunks(Vt, g.C);
     float* sums = ws + (size_t)g.N * nchunks * g.C * 2;
-    hipLaunchKernelGGL((m1_reduce_finalize_kernel<2>), dim3((g.N * g.C + 255) / 256), dim3(256), 0, st, ws, g.N, g.C, nchunks, sums);
+    rc = m1_reduce_finalize_launch<2>(ws, g.N, g.C, nchunks, sums, 0, 0.f, st); if (rc) return rc;
     hipLaunchKernelGGL(gate_w_finalize_kernel, dim3((g.C + 255) / 256), dim3(256), 0, st, sums, g.N, g.C, dwpsi, dbpsi);
     return m1_check_launch();
 }

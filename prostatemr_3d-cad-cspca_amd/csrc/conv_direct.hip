@@ -12,8 +12,7 @@
 // implicit-GEMM path in conv_mfma.hip takes the wide layers.
 #include "common.h"
 #include "reduce.h"
-
-int m1_colsum_internal(const void* x, int N, long long V, int C, int dtype, float* out, float* ws, hipStream_t st);
+#include "gather.h"
 
 struct GatherP {
     const void* src[M1_MAX_SRC];
@@ -28,7 +27,7 @@ struct GatherP {
     int N;
     const float* w;
     long long wST, wSC, wSO;  // w[tap*wST + cc*wSC + (oc+oc_off)*wSO]
-    int oc_off;
+    int oc_off, cc_off, accumulate;
     const float* bias;
     int kd, kh, kw;
     int mode;
@@ -132,7 +131,7 @@ __global__ void __launch_bounds__(256) conv_gather_kernel(GatherP p) {
                         const int cw = e >> 6, ow = e & 63;
                         const int c = c0 + cw, oc = oc0 + ow;
                         float val = 0.f;
-                        if (c < p.CC && oc < p.OC) val = p.w[tap * p.wST + (long long)c * p.wSC + (long long)(oc + p.oc_off) * p.wSO];
+                        if (c < p.CC && oc < p.OC) val = p.w[tap * p.wST + (long long)(c + p.cc_off) * p.wSC + (long long)(oc + p.oc_off) * p.wSO];
                         W_s[cw][ow] = val;
                     }
                     __syncthreads();
@@ -168,6 +167,7 @@ __global__ void __launch_bounds__(256) conv_gather_kernel(GatherP p) {
             if (oc < p.OC) {
                 float r = acc[i][j];
                 if (p.bias) r += p.bias[oc + p.oc_off];
+                if (p.accumulate) r += Act<T>::ld(out + o * p.OC + oc);
                 Act<T>::st(out + o * p.OC + oc, r);
             }
         }
@@ -191,12 +191,7 @@ static int launch_gather(const GatherP& p, int dtype, hipStream_t st) {
 // ------------------------------------------------------------------------------------------------
 // weight gradient:  R[tap][a+a_off][b+b_off] += sum_{n,v} A[n, v*s + k - p][a] * B[n, v][b]
 // ------------------------------------------------------------------------------------------------
-struct WgradP {
-    const void* A; int CA; int AD, AH, AW;
-    const void* B; int CB; int BD, BH, BW;
-    int N;
-    float* R; long long RT, RSA; int a_off, b_off;
-    int kd, kh, kw, sd, sh, sw, pd, ph, pw;
+struct WgradP : WgradSpec {
     long long vox_per_split;
 };
 
@@ -276,7 +271,9 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(WgradP p) {
     }
 }
 
-static int launch_wgrad(WgradP p, int dtype, hipStream_t st) {
+int m1_direct_wgrad(const WgradSpec& spec, hipStream_t st) {
+    WgradP p; static_cast<WgradSpec&>(p) = spec; p.vox_per_split = 0;
+    const int dtype = spec.dtype;
     const int aTiles = (p.CA + WG_T - 1) / WG_T, bTiles = (p.CB + WG_T - 1) / WG_T;
     const int taps = p.kd * p.kh * p.kw;
     const long long TV = (long long)p.N * p.BD * p.BH * p.BW;
@@ -295,153 +292,20 @@ static int launch_wgrad(WgradP p, int dtype, hipStream_t st) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// geometry helpers
+// spec-based entry (dispatch.hip builds the specs)
 // ------------------------------------------------------------------------------------------------
-static inline void same_pad(int in, int k, int s, int* out, int* pb) {
-    int o = (in + s - 1) / s;
-    int tot = (o - 1) * s + k - in; if (tot < 0) tot = 0;
-    *out = o; *pb = tot / 2;
-}
-static inline int convT_pb(int k, int s) { return (k - s > 0 ? k - s : 0) / 2; }
-
-static int check_desc(const m1_conv_desc_t* d) {
-    if (!d || d->nsrc < 1 || d->nsrc > M1_MAX_SRC) return M1_ERR_BAD_ARG;
-    int c = 0;
-    for (int i = 0; i < d->nsrc; ++i) { if (!d->src[i].ptr || d->src[i].C <= 0) return M1_ERR_BAD_ARG; c += d->src[i].C; }
-    if (c != d->Cin || d->Cout <= 0 || d->N <= 0 || d->D <= 0 || d->H <= 0 || d->W <= 0) return M1_ERR_BAD_ARG;
-    if (d->kd <= 0 || d->kh <= 0 || d->kw <= 0 || d->sd <= 0 || d->sh <= 0 || d->sw <= 0) return M1_ERR_BAD_ARG;
-    if (d->dtype != M1_F32 && d->dtype != M1_BF16) return M1_ERR_UNSUPPORTED;
-    return M1_OK;
-}
-static void fill_srcs(GatherP& p, const m1_conv_desc_t* d) {
-    p.nsrc = d->nsrc; int off = 0;
+int m1_direct_gather(const GatherSpec& g, hipStream_t st) {
+    GatherP p{};
+    int off = 0;
+    p.nsrc = g.nsrc;
     for (int i = 0; i < M1_MAX_SRC; ++i) {
-        if (i < d->nsrc) { p.src[i] = d->src[i].ptr; p.srcC[i] = d->src[i].C; p.srcOff[i] = off; off += d->src[i].C; }
+        if (i < g.nsrc) { p.src[i] = g.src[i]; p.srcC[i] = g.srcC[i]; p.srcOff[i] = off; off += g.srcC[i]; }
         else { p.src[i] = nullptr; p.srcC[i] = 0; p.srcOff[i] = off; }
     }
-    p.srcOff[M1_MAX_SRC] = off;
-    p.CC = off;
-}
-static void single_src(GatherP& p, const void* ptr, int C) {
-    p.nsrc = 1;
-    for (int i = 0; i < M1_MAX_SRC; ++i) { p.src[i] = i == 0 ? ptr : nullptr; p.srcC[i] = i == 0 ? C : 0; p.srcOff[i] = i == 0 ? 0 : C; }
-    p.srcOff[M1_MAX_SRC] = C; p.CC = C;
-}
-static inline double esz(int dtype) { return dtype == M1_BF16 ? 2.0 : 4.0; }
-
-// ------------------------------------------------------------------------------------------------
-// C ABI: direct-path implementations (the dispatchers in dispatch.hip pick direct vs MFMA)
-// ------------------------------------------------------------------------------------------------
-extern "C" int m1_conv3d_fwd_direct(const m1_conv_desc_t* d, const float* w, const float* bias, void* y, void* stream) {
-    int rc = check_desc(d); if (rc) return rc;
-    if (!w || !y) return M1_ERR_BAD_ARG;
-    GatherP p{}; fill_srcs(p, d);
-    p.ID = d->D; p.IH = d->H; p.IW = d->W; p.N = d->N;
-    same_pad(d->D, d->kd, d->sd, &p.OD, &p.pd); same_pad(d->H, d->kh, d->sh, &p.OH, &p.ph); same_pad(d->W, d->kw, d->sw, &p.OW, &p.pw);
-    p.out = y; p.OC = d->Cout; p.w = w; p.wST = (long long)d->Cin * d->Cout; p.wSC = d->Cout; p.wSO = 1; p.oc_off = 0;
-    p.bias = bias; p.kd = d->kd; p.kh = d->kh; p.kw = d->kw; p.mode = 0; p.sd = d->sd; p.sh = d->sh; p.sw = d->sw;
-    return launch_gather(p, d->dtype, (hipStream_t)stream);
-}
-
-extern "C" int m1_conv3d_dgrad_direct(const m1_conv_desc_t* d, const float* w, const void* dy, void* const* dx, void* stream) {
-    int rc = check_desc(d); if (rc) return rc;
-    if (!w || !dy || !dx) return M1_ERR_BAD_ARG;
-    int OD, OH, OW, pd, ph, pw;
-    same_pad(d->D, d->kd, d->sd, &OD, &pd); same_pad(d->H, d->kh, d->sh, &OH, &ph); same_pad(d->W, d->kw, d->sw, &OW, &pw);
-    int off = 0;
-    for (int i = 0; i < d->nsrc; ++i) {
-        if (dx[i]) {
-            GatherP p{}; single_src(p, dy, d->Cout);
-            p.ID = OD; p.IH = OH; p.IW = OW; p.N = d->N;
-            p.OD = d->D; p.OH = d->H; p.OW = d->W; p.pd = pd; p.ph = ph; p.pw = pw;
-            p.out = dx[i]; p.OC = d->src[i].C; p.w = w; p.wST = (long long)d->Cin * d->Cout; p.wSC = 1; p.wSO = d->Cout;
-            p.oc_off = off; p.bias = nullptr; p.kd = d->kd; p.kh = d->kh; p.kw = d->kw; p.mode = 1;
-            p.sd = d->sd; p.sh = d->sh; p.sw = d->sw;
-            rc = launch_gather(p, d->dtype, (hipStream_t)stream); if (rc) return rc;
-        }
-        off += d->src[i].C;
-    }
-    return M1_OK;
-}
-
-extern "C" int m1_conv3d_wgrad_direct(const m1_conv_desc_t* d, const void* dy, float* dw, float* db, float* ws, void* stream) {
-    int rc = check_desc(d); if (rc) return rc;
-    if (!dy || !dw) return M1_ERR_BAD_ARG;
-    hipStream_t st = (hipStream_t)stream;
-    int OD, OH, OW, pd, ph, pw;
-    same_pad(d->D, d->kd, d->sd, &OD, &pd); same_pad(d->H, d->kh, d->sh, &OH, &ph); same_pad(d->W, d->kw, d->sw, &OW, &pw);
-    const size_t nw = (size_t)d->kd * d->kh * d->kw * d->Cin * d->Cout;
-    if (hipMemsetAsync(dw, 0, nw * sizeof(float), st) != hipSuccess) return M1_ERR_LAUNCH;
-    int off = 0;
-    for (int i = 0; i < d->nsrc; ++i) {
-        WgradP p{};
-        p.A = d->src[i].ptr; p.CA = d->src[i].C; p.AD = d->D; p.AH = d->H; p.AW = d->W;
-        p.B = dy; p.CB = d->Cout; p.BD = OD; p.BH = OH; p.BW = OW; p.N = d->N;
-        p.R = dw; p.RT = (long long)d->Cin * d->Cout; p.RSA = d->Cout; p.a_off = off; p.b_off = 0;
-        p.kd = d->kd; p.kh = d->kh; p.kw = d->kw; p.sd = d->sd; p.sh = d->sh; p.sw = d->sw; p.pd = pd; p.ph = ph; p.pw = pw;
-        rc = launch_wgrad(p, d->dtype, st); if (rc) return rc;
-        off += d->src[i].C;
-    }
-    if (db) {
-        if (!ws) return M1_ERR_WORKSPACE;
-        rc = m1_colsum_internal(dy, d->N, (long long)OD * OH * OW, d->Cout, d->dtype, db, ws, st); if (rc) return rc;
-    }
-    return M1_OK;
-}
-
-extern "C" int m1_convT3d_fwd_direct(const m1_conv_desc_t* d, const float* w, const float* bias, void* y, void* stream) {
-    int rc = check_desc(d); if (rc) return rc;
-    if (!w || !y) return M1_ERR_BAD_ARG;
-    GatherP p{}; fill_srcs(p, d);
-    p.ID = d->D; p.IH = d->H; p.IW = d->W; p.N = d->N;
-    p.OD = d->D * d->sd; p.OH = d->H * d->sh; p.OW = d->W * d->sw;
-    p.pd = convT_pb(d->kd, d->sd); p.ph = convT_pb(d->kh, d->sh); p.pw = convT_pb(d->kw, d->sw);
-    p.out = y; p.OC = d->Cout; p.w = w; p.wST = (long long)d->Cout * d->Cin; p.wSC = 1; p.wSO = d->Cin; p.oc_off = 0;
-    p.bias = bias; p.kd = d->kd; p.kh = d->kh; p.kw = d->kw; p.mode = 1; p.sd = d->sd; p.sh = d->sh; p.sw = d->sw;
-    return launch_gather(p, d->dtype, (hipStream_t)stream);
-}
-
-extern "C" int m1_convT3d_dgrad_direct(const m1_conv_desc_t* d, const float* w, const void* dy, void* const* dx, void* stream) {
-    int rc = check_desc(d); if (rc) return rc;
-    if (!w || !dy || !dx) return M1_ERR_BAD_ARG;
-    int off = 0;
-    for (int i = 0; i < d->nsrc; ++i) {
-        if (dx[i]) {
-            GatherP p{}; single_src(p, dy, d->Cout);
-            p.ID = d->D * d->sd; p.IH = d->H * d->sh; p.IW = d->W * d->sw; p.N = d->N;
-            p.OD = d->D; p.OH = d->H; p.OW = d->W;
-            p.pd = convT_pb(d->kd, d->sd); p.ph = convT_pb(d->kh, d->sh); p.pw = convT_pb(d->kw, d->sw);
-            p.out = dx[i]; p.OC = d->src[i].C; p.w = w; p.wST = (long long)d->Cout * d->Cin; p.wSC = d->Cin; p.wSO = 1;
-            p.oc_off = off; p.bias = nullptr; p.kd = d->kd; p.kh = d->kh; p.kw = d->kw; p.mode = 0;
-            p.sd = d->sd; p.sh = d->sh; p.sw = d->sw;
-            rc = launch_gather(p, d->dtype, (hipStream_t)stream); if (rc) return rc;
-        }
-        off += d->src[i].C;
-    }
-    return M1_OK;
-}
-
-extern "C" int m1_convT3d_wgrad_direct(const m1_conv_desc_t* d, const void* dy, float* dw, float* db, float* ws, void* stream) {
-    int rc = check_desc(d); if (rc) return rc;
-    if (!dy || !dw) return M1_ERR_BAD_ARG;
-    hipStream_t st = (hipStream_t)stream;
-    const size_t nw = (size_t)d->kd * d->kh * d->kw * d->Cin * d->Cout;
-    if (hipMemsetAsync(dw, 0, nw * sizeof(float), st) != hipSuccess) return M1_ERR_LAUNCH;
-    int off = 0;
-    for (int i = 0; i < d->nsrc; ++i) {
-        WgradP p{};
-        p.A = dy; p.CA = d->Cout; p.AD = d->D * d->sd; p.AH = d->H * d->sh; p.AW = d->W * d->sw;
-        p.B = d->src[i].ptr; p.CB = d->src[i].C; p.BD = d->D; p.BH = d->H; p.BW = d->W; p.N = d->N;
-        p.R = dw; p.RT = (long long)d->Cout * d->Cin; p.RSA = d->Cin; p.a_off = 0; p.b_off = off;
-        p.kd = d->kd; p.kh = d->kh; p.kw = d->kw; p.sd = d->sd; p.sh = d->sh; p.sw = d->sw;
-        p.pd = convT_pb(d->kd, d->sd); p.ph = convT_pb(d->kh, d->sh); p.pw = convT_pb(d->kw, d->sw);
-        rc = launch_wgrad(p, d->dtype, st); if (rc) return rc;
-        off += d->src[i].C;
-    }
-    if (db) {
-        if (!ws) return M1_ERR_WORKSPACE;
-        rc = m1_colsum_internal(dy, d->N, (long long)d->D * d->sd * d->H * d->sh * d->W * d->sw, d->Cout, d->dtype, db, ws, st);
-        if (rc) return rc;
-    }
-    return M1_OK;
+    p.srcOff[M1_MAX_SRC] = off; p.CC = off;
+    p.ID = g.ID; p.IH = g.IH; p.IW = g.IW; p.out = g.out; p.OC = g.OC; p.OD = g.OD; p.OH = g.OH; p.OW = g.OW; p.N = g.N;
+    p.w = g.w; p.wST = g.wST; p.wSC = g.wSC; p.wSO = g.wSO; p.oc_off = g.oc_off; p.cc_off = g.cc_off; p.accumulate = g.accumulate;
+    p.bias = g.bias; p.kd = g.kd; p.kh = g.kh; p.kw = g.kw; p.mode = g.mode;
+    p.sd = g.sd; p.sh = g.sh; p.sw = g.sw; p.pd = g.pd; p.ph = g.ph; p.pw = g.pw;
+    return launch_gather(p, g.dtype, st);
 }

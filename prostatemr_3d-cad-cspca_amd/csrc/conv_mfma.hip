@@ -1,0 +1,388 @@
+// conv_mfma.hip -- implicit-GEMM Conv3D / Conv3DTranspose (TF 'same') on the CDNA4 matrix cores.
+//
+//   D[voxel][oc] = sum_{tap} sum_{c} X[voxel (+) tap][c] * Wp[oc][tap][c]        M = voxels, N = oc, K = taps*C
+//
+// * One kernel serves conv forward / convT dgrad (mode 0, in = o*s + k - p) and conv dgrad / convT forward
+//   (mode 1, in = (o + p - k)/s, one output PARITY CLASS per blockIdx.y with only its own taps).
+// * A operand: im2col gathered on the fly, 16-byte segments (8 bf16 / 4 fp32 channels) straight from the NDHWC
+//   tensors of the virtual concat (never materialised); zero fill outside the volume (TF 'same' padding).
+// * B operand: weights pre-packed K-contiguous per output channel ([oc][tap][c], same dtype as activations).
+// * LDS tiles are 64-byte rows (one K-chunk = 32 bf16 / 16 fp32) with the segment XOR-swizzle
+//   seg' = seg ^ ((-(row>>2))&3), which makes every ds_read_b128 fragment read conflict-free on gfx950's
+//   16-lane b128 groups; double buffered, global loads for chunk i+1 are in flight while chunk i is on the MFMAs.
+// * wave64 tiles of 16x16: bf16 -> v_mfma_f32_16x16x32_bf16 (one per tile per chunk), fp32 ->
+//   4 x v_mfma_f32_16x16x4_f32 (exact fp32).  fp32 accumulation in both.
+// * epilogue: + bias, convert, stage the block tile in LDS, 16-byte coalesced NDHWC stores.
+#include "common.h"
+#include "gather.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+
+#define MF_MAX_TAPS 27
+#define MF_MAX_CLASSES 8
+
+struct MfmaP {
+    const void* src[M1_MAX_SRC];
+    int srcC[M1_MAX_SRC];
+    int nsrc, CC;               // CC = contraction channels per tap (sum srcC)
+    int ID, IH, IW;             // gathered tensor extent
+    void* out;
+    int OC, OCn;                // out row stride (channels) / channels computed by this launch
+    int OD, OH, OW, N;
+    const void* wp;             // packed weights
+    const float* bias;
+    int mode, sd, sh, sw, pd, ph, pw;
+    int nclasses;
+    int cls_ntaps[MF_MAX_CLASSES], cls_first[MF_MAX_CLASSES], cls_kpad[MF_MAX_CLASSES];
+    long long cls_woff[MF_MAX_CLASSES];     // element offset of the class matrix in wp
+    signed char tdd[MF_MAX_TAPS], tdh[MF_MAX_TAPS], tdw[MF_MAX_TAPS];   // gather offsets per (class-ordered) tap
+    int accumulate;             // out += result (used when another kernel already wrote the other concat members)
+};
+
+template <typename T> struct MT;
+template <> struct MT<bf16_t> { static constexpr int SEG = 8; };
+template <> struct MT<float> { static constexpr int SEG = 4; };
+
+__device__ __forceinline__ int swz(int row, int seg) { return seg ^ ((-(row >> 2)) & 3); }
+
+template <typename T, int BM, int BN, int WM, int WN>
+__global__ void __launch_bounds__(256) conv_mfma_kernel(MfmaP p) {
+    constexpr int SEG = MT<T>::SEG;
+    constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
+    constexpr int A_BYTES = BM * 64, B_BYTES = BN * 64;
+    constexpr int A_LD = BM / 64;                       // 16-B loads per thread per chunk for A (BM*4/256)
+    constexpr int B_LD = (BN * 4 + 255) / 256;          // for B
+    static_assert(WM * WN == 4 && BM % 64 == 0 && BN % 16 == 0, "tile config");
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    // tables first (they must survive the epilogue tile, which reuses the pipeline buffers)
+    int4* rowinfo = reinterpret_cast<int4*>(smem);                                 // [BM] {n, bd, bh, bw}
+    int* outrow = reinterpret_cast<int*>(rowinfo + BM);                            // [BM] output voxel index or -1
+    const T** s_src = reinterpret_cast<const T**>(outrow + BM);                    // [6]
+    int* s_srcC = reinterpret_cast<int*>(s_src + M1_MAX_SRC);                      // [6]
+    int* s_tap = s_srcC + M1_MAX_SRC;                                              // [27] packed dd|dh|dw
+    constexpr int TBL_BYTES = (BM * 20 + M1_MAX_SRC * 12 + MF_MAX_TAPS * 4 + 15) / 16 * 16;
+    unsigned char* A_s = smem + TBL_BYTES;               // [2][BM][64]
+    unsigned char* B_s = A_s + 2 * A_BYTES;              // [2][BN][64]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int cls = blockIdx.y;
+    const int oc0 = blockIdx.z * BN;
+
+    int pdc = 0, phc = 0, pwc = 0, QD = p.OD, QH = p.OH, QW = p.OW;
+    if (p.mode == 1) {
+        pwc = cls % p.sw; phc = (cls / p.sw) % p.sh; pdc = cls / (p.sw * p.sh);
+        QD = p.OD > pdc ? (p.OD - pdc + p.sd - 1) / p.sd : 0;
+        QH = p.OH > phc ? (p.OH - phc + p.sh - 1) / p.sh : 0;
+        QW = p.OW > pwc ? (p.OW - pwc + p.sw - 1) / p.sw : 0;
+    }
+    const long long QV = (long long)QD * QH * QW, Mtot = QV * p.N;
+    const long long m0 = (long long)blockIdx.x * BM;
+    if (m0 >= Mtot) return;
+
+    for (int r = tid; r < BM; r += 256) {
+        const long long m = m0 + r;
+        int4 ri = make_int4(-1, 0, 0, 0); int orow = -1;
+        if (m < Mtot) {
+            const int n = (int)(m / QV); long long lin = m % QV;
+            const int qw = (int)(lin % QW); lin /= QW; const int qh = (int)(lin % QH); const int qd = (int)(lin / QH);
+            if (p.mode == 0) {
+                ri = make_int4(n, qd * p.sd - p.pd, qh * p.sh - p.ph, qw * p.sw - p.pw);
+                orow = (int)m;
+            } else {
+                ri = make_int4(n, qd, qh, qw);
+                orow = (int)((((long long)n * p.OD + qd * p.sd + pdc) * p.OH + qh * p.sh + phc) * p.OW + qw * p.sw + pwc);
+            }
+        }
+        rowinfo[r] = ri; outrow[r] = orow;
+    }
+    if (tid < M1_MAX_SRC) { s_src[tid] = (const T*)p.src[tid]; s_srcC[tid] = p.srcC[tid]; }
+    const int ntaps = p.cls_ntaps[cls], tfirst = p.cls_first[cls];
+    if (tid < ntaps) {
+        const int t = tfirst + tid;
+        s_tap[tid] = ((int)p.tdd[t] & 0xff) | (((int)p.tdh[t] & 0xff) << 8) | (((int)p.tdw[t] & 0xff) << 16);
+    }
+    __syncthreads();
+
+    const int spt = p.CC / SEG;                          // segments per tap
+    const int nseg = ntaps * spt;
+    const int nchunks = (nseg + 3) >> 2;
+    const int kpad = p.cls_kpad[cls];
+    const T* wp = (const T*)p.wp + p.cls_woff[cls];
+
+    f32x4_t acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+    uint4 ra[A_LD], rb[B_LD];
+    const int lseg = tid & 3, lrow = tid >> 2;           // loader: 4 lanes cover one 64-byte row
+
+    auto prefetch = [&](int chunk) {
+        // ---- A: gathered activations ----
+        const int kseg = chunk * 4 + lseg;
+        const T* sp = nullptr; int sC = 0, coff = 0, dd = 0, dh = 0, dw = 0;
+        const bool kvalid = kseg < nseg;
+        if (kvalid) {
+            const int tap_i = kseg / spt;
+            int c = (kseg - tap_i * spt) * SEG, s = 0;
+            while (c >= s_srcC[s]) { c -= s_srcC[s]; ++s; }
+            sp = s_src[s]; sC = s_srcC[s]; coff = c;
+            const int tp = s_tap[tap_i];
+            dd = (signed char)(tp & 0xff); dh = (signed char)((tp >> 8) & 0xff); dw = (signed char)((tp >> 16) & 0xff);
+        }
+#pragma unroll
+        for (int i = 0; i < A_LD; ++i) {
+            const int4 ri = rowinfo[lrow + 64 * i];
+            uint4 v = make_uint4(0, 0, 0, 0);
+            const int id = ri.y + dd, ih = ri.z + dh, iw = ri.w + dw;
+            if (kvalid && ri.x >= 0 && id >= 0 && id < p.ID && ih >= 0 && ih < p.IH && iw >= 0 && iw < p.IW) {
+                const long long vox = (((long long)ri.x * p.ID + id) * p.IH + ih) * p.IW + iw;
+                v = *reinterpret_cast<const uint4*>(sp + vox * sC + coff);
+            }
+            ra[i] = v;
+        }
+        // ---- B: packed weights, rows = output channels ----
+#pragma unroll
+        for (int i = 0; i < B_LD; ++i) {
+            const int e = tid + 256 * i;                 // (row, seg) = (e>>2, e&3)
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (e < BN * 4) {
+                const int brow = e >> 2;
+                v = *reinterpret_cast<const uint4*>(wp + (long long)(oc0 + brow) * kpad + (long long)(chunk * 4 + (e & 3)) * SEG);
+            }
+            rb[i] = v;
+        }
+    };
+    auto stage = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < A_LD; ++i) {
+            const int row = lrow + 64 * i;
+            *reinterpret_cast<uint4*>(A_s + buf * A_BYTES + row * 64 + swz(row, lseg) * 16) = ra[i];
+        }
+#pragma unroll
+        for (int i = 0; i < B_LD; ++i) {
+            const int e = tid + 256 * i;
+            if (e < BN * 4) {
+                const int row = e >> 2;
+                *reinterpret_cast<uint4*>(B_s + buf * B_BYTES + row * 64 + swz(row, e & 3) * 16) = rb[i];
+            }
+        }
+    };
+
+    prefetch(0);
+    stage(0);
+    __syncthreads();
+    const int fr = lane & 15, fs = lane >> 4;
+    for (int it = 0; it < nchunks; ++it) {
+        const int buf = it & 1;
+        if (it + 1 < nchunks) prefetch(it + 1);
+        uint4 af[TM], bfr[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int row = wm * (BM / WM) + i * 16 + fr;
+            af[i] = *reinterpret_cast<const uint4*>(A_s + buf * A_BYTES + row * 64 + swz(row, fs) * 16);
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int row = wn * (BN / WN) + j * 16 + fr;
+            bfr[j] = *reinterpret_cast<const uint4*>(B_s + buf * B_BYTES + row * 64 + swz(row, fs) * 16);
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                if constexpr (sizeof(T) == 2) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, af[i]),
+                                                                        __builtin_bit_cast(bf16x8_t, bfr[j]), acc[i][j], 0, 0, 0);
+                } else {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(af[i].x), __uint_as_float(bfr[j].x), acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(af[i].y), __uint_as_float(bfr[j].y), acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(af[i].z), __uint_as_float(bfr[j].z), acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(af[i].w), __uint_as_float(bfr[j].w), acc[i][j], 0, 0, 0);
+                }
+            }
+        if (it + 1 < nchunks) stage(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: acc (+bias) -> T -> LDS tile [BM][BN] (row pitch BN+SEG to spread banks) -> 16-B stores ----
+    constexpr int CP = BN + SEG;                          // pitch in elements
+    T* C_s = reinterpret_cast<T*>(A_s);                   // reuses the A/B buffers (all waves are past the last sync)
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int col = wn * (BN / WN) + j * 16 + fr;
+            const float bv = (p.bias && oc0 + col < p.OCn) ? p.bias[oc0 + col] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = wm * (BM / WM) + i * 16 + fs * 4 + r;
+                Act<T>::st(C_s + row * CP + col, acc[i][j][r] + bv);
+            }
+        }
+    __syncthreads();
+    constexpr int SPR = BN / SEG;                         // 16-B segments per tile row
+    T* out = (T*)p.out;
+    for (int e = tid; e < BM * SPR; e += 256) {
+        const int row = e / SPR, cs = e % SPR;
+        const int orow = outrow[row];
+        const int oc = oc0 + cs * SEG;
+        if (orow < 0 || oc >= p.OCn) continue;
+        uint4 v = *reinterpret_cast<const uint4*>(C_s + row * CP + cs * SEG);
+        T* dst = out + (long long)orow * p.OC + oc;
+        if (p.accumulate) {
+            float a[SEG], b[SEG];
+            VecIO<T, SEG>::ld(reinterpret_cast<const T*>(&v), a);
+            VecIO<T, SEG>::ld(dst, b);
+#pragma unroll
+            for (int k = 0; k < SEG; ++k) a[k] += b[k];
+            VecIO<T, SEG>::st(dst, a);
+        } else {
+            *reinterpret_cast<uint4*>(dst) = v;
+        }
+    }
+}
+
+template <typename T, int BM, int BN>
+static constexpr size_t mfma_smem_bytes() {
+    size_t tbl = (BM * 20 + M1_MAX_SRC * 12 + MF_MAX_TAPS * 4 + 15) / 16 * 16;
+    size_t pipe = 2 * BM * 64 + 2 * BN * 64;
+    size_t epi = (size_t)BM * (BN + MT<T>::SEG) * sizeof(T);
+    return tbl + (pipe > epi ? pipe : epi);
+}
+
+// ------------------------------------------------------------------------------------------------
+// weight packing:  wp[class][oc][tap_i*CC + c] = w[wtap*wST + c*wSC + (oc+oc_off)*wSO]   (zero padded)
+// ------------------------------------------------------------------------------------------------
+struct PackP {
+    const float* w; long long wST, wSC, wSO; int oc_off, cc_off, OCn, OCpad, CC;
+    int nclasses; int cls_ntaps[MF_MAX_CLASSES], cls_first[MF_MAX_CLASSES], cls_kpad[MF_MAX_CLASSES];
+    long long cls_woff[MF_MAX_CLASSES];
+    unsigned char wtap[MF_MAX_TAPS];
+};
+template <typename T>
+__global__ void pack_weights_kernel(PackP p, T* __restrict__ out) {
+    const int cls = blockIdx.y;
+    const int kpad = p.cls_kpad[cls], ntaps = p.cls_ntaps[cls];
+    const long long tot = (long long)p.OCpad * kpad;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < tot; i += (long long)gridDim.x * blockDim.x) {
+        const int oc = (int)(i / kpad), k = (int)(i % kpad);
+        const int tap_i = k / p.CC, c = k % p.CC;
+        float v = 0.f;
+        if (oc < p.OCn && tap_i < ntaps)
+            v = p.w[(long long)p.wtap[p.cls_first[cls] + tap_i] * p.wST + (long long)(c + p.cc_off) * p.wSC + (long long)(oc + p.oc_off) * p.wSO];
+        Act<T>::st(out + p.cls_woff[cls] + i, v);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------
+static inline int seg_of(int dtype) { return dtype == M1_BF16 ? 8 : 4; }
+static inline int pick_bn(int ocn) { return ocn > 64 ? 128 : (ocn > 32 ? 64 : (ocn > 16 ? 32 : 16)); }
+
+bool m1_mfma_supported(const GatherSpec& g) {
+    const int SEG = seg_of(g.dtype);
+    if (g.OC % SEG) return false;
+    for (int i = 0; i < g.nsrc; ++i) if (g.srcC[i] % SEG) return false;
+    if (g.kd * g.kh * g.kw > MF_MAX_TAPS) return false;
+    if (g.mode == 1 && g.sd * g.sh * g.sw > MF_MAX_CLASSES) return false;
+    return true;
+}
+
+static void build_classes(const GatherSpec& g, int CC, int SEG, int OCpad, MfmaP* mp, PackP* pp, long long* total_elems) {
+    const int ncls = g.mode == 1 ? g.sd * g.sh * g.sw : 1;
+    int t = 0; long long woff = 0;
+    for (int c = 0; c < ncls; ++c) {
+        const int pwc = g.mode == 1 ? c % g.sw : 0, phc = g.mode == 1 ? (c / g.sw) % g.sh : 0, pdc = g.mode == 1 ? c / (g.sw * g.sh) : 0;
+        const int first = t;
+        for (int a = 0; a < g.kd; ++a) {
+            int od;
+            if (g.mode == 0) od = a - 0; else { int v = pdc + g.pd - a; if (v % g.sd) continue; od = v / g.sd; }
+            for (int b = 0; b < g.kh; ++b) {
+                int oh;
+                if (g.mode == 0) oh = b; else { int v = phc + g.ph - b; if (v % g.sh) continue; oh = v / g.sh; }
+                for (int e = 0; e < g.kw; ++e) {
+                    int ow;
+                    if (g.mode == 0) ow = e; else { int v = pwc + g.pw - e; if (v % g.sw) continue; ow = v / g.sw; }
+                    if (mp) { mp->tdd[t] = (signed char)od; mp->tdh[t] = (signed char)oh; mp->tdw[t] = (signed char)ow; }
+                    if (pp) pp->wtap[t] = (unsigned char)((a * g.kh + b) * g.kw + e);
+                    ++t;
+                }
+            }
+        }
+        const int nt = t - first;
+        const int nseg = nt * (CC / SEG);
+        const int kpad = ((nseg + 3) / 4) * 4 * SEG;
+        if (mp) { mp->cls_ntaps[c] = nt; mp->cls_first[c] = first; mp->cls_kpad[c] = kpad; mp->cls_woff[c] = woff; }
+        if (pp) { pp->cls_ntaps[c] = nt; pp->cls_first[c] = first; pp->cls_kpad[c] = kpad; pp->cls_woff[c] = woff; }
+        woff += (long long)OCpad * kpad;
+    }
+    if (mp) mp->nclasses = ncls;
+    if (pp) pp->nclasses = ncls;
+    *total_elems = woff;
+}
+
+size_t m1_mfma_ws_bytes(const GatherSpec& g) {
+    const int SEG = seg_of(g.dtype);
+    int CC = 0; for (int i = 0; i < g.nsrc; ++i) CC += g.srcC[i];
+    const int BN = pick_bn(g.OC), OCpad = (g.OC + BN - 1) / BN * BN;
+    long long tot = 0;
+    build_classes(g, CC, SEG, OCpad, nullptr, nullptr, &tot);
+    return (size_t)tot * (g.dtype == M1_BF16 ? 2 : 4) + 256;
+}
+
+template <typename T, int BM, int BN, int WM, int WN>
+static int launch_cfg(const MfmaP& mp, long long maxM, int OCpad, hipStream_t st) {
+    dim3 grid((unsigned)cdiv_ll(maxM, BM), mp.nclasses, OCpad / BN);
+    const size_t smem = mfma_smem_bytes<T, BM, BN>();
+    auto kern = conv_mfma_kernel<T, BM, BN, WM, WN>;
+    static bool attr_set = false;     // per instantiation
+    if (smem > 48 * 1024 && !attr_set) {
+        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) return M1_ERR_LAUNCH;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, grid, dim3(256), smem, st, mp);
+    return m1_check_launch();
+}
+
+template <typename T>
+static int run_mfma(const GatherSpec& g, void* ws, hipStream_t st) {
+    constexpr int SEG = MT<T>::SEG;
+    MfmaP mp{}; PackP pp{};
+    int CC = 0;
+    for (int i = 0; i < M1_MAX_SRC; ++i) {
+        mp.src[i] = i < g.nsrc ? g.src[i] : nullptr; mp.srcC[i] = i < g.nsrc ? g.srcC[i] : (1 << 30);
+        if (i < g.nsrc) CC += g.srcC[i];
+    }
+    mp.nsrc = g.nsrc; mp.CC = CC; mp.ID = g.ID; mp.IH = g.IH; mp.IW = g.IW; mp.out = g.out; mp.OC = g.OC; mp.OCn = g.OC;
+    mp.OD = g.OD; mp.OH = g.OH; mp.OW = g.OW; mp.N = g.N; mp.wp = ws; mp.bias = g.bias; mp.mode = g.mode;
+    mp.sd = g.sd; mp.sh = g.sh; mp.sw = g.sw; mp.pd = g.pd; mp.ph = g.ph; mp.pw = g.pw; mp.accumulate = g.accumulate;
+    const int BN = pick_bn(g.OC), OCpad = (g.OC + BN - 1) / BN * BN;
+    long long tot = 0;
+    build_classes(g, CC, SEG, OCpad, &mp, &pp, &tot);
+    pp.w = g.w; pp.wST = g.wST; pp.wSC = g.wSC; pp.wSO = g.wSO; pp.oc_off = g.oc_off; pp.cc_off = g.cc_off; pp.OCn = g.OC; pp.OCpad = OCpad; pp.CC = CC;
+    int maxk = 0; for (int c = 0; c < pp.nclasses; ++c) maxk = pp.cls_kpad[c] > maxk ? pp.cls_kpad[c] : maxk;
+    long long pblocks = cdiv_ll((long long)OCpad * maxk, 256); if (pblocks > 2048) pblocks = 2048; if (pblocks < 1) pblocks = 1;
+    hipLaunchKernelGGL(pack_weights_kernel<T>, dim3((unsigned)pblocks, pp.nclasses), dim3(256), 0, st, pp, (T*)ws);
+    int rc = m1_check_launch(); if (rc) return rc;
+
+    long long maxM;
+    if (g.mode == 0) maxM = (long long)g.N * g.OD * g.OH * g.OW;
+    else maxM = (long long)g.N * ((g.OD + g.sd - 1) / g.sd) * ((g.OH + g.sh - 1) / g.sh) * ((g.OW + g.sw - 1) / g.sw);
+    switch (BN) {
+        case 128: return launch_cfg<T, 128, 128, 2, 2>(mp, maxM, OCpad, st);
+        case 64:  return launch_cfg<T, 128, 64, 4, 1>(mp, maxM, OCpad, st);
+        case 32:  return launch_cfg<T, 128, 32, 4, 1>(mp, maxM, OCpad, st);
+        default:  return launch_cfg<T, 128, 16, 4, 1>(mp, maxM, OCpad, st);
+    }
+}
+
+int m1_mfma_gather(const GatherSpec& g, void* ws, hipStream_t st) {
+    if (!ws) return M1_ERR_WORKSPACE;
+    return g.dtype == M1_BF16 ? run_mfma<bf16_t>(g, ws, st) : run_mfma<float>(g, ws, st);
+}

@@ -1,36 +1,47 @@
-// dispatch.hip -- public conv entry points: choose the MFMA implicit-GEMM path (conv_mfma.hip) when the
-// layer shape allows it, else the generic direct path (conv_direct.hip).  Also status strings.
+// dispatch.hip -- the six public conv entry points.  Each builds the logical problem (gather.h) for its role and
+// runs it on the matrix-core kernels when the channel counts allow 16-byte segments, else on the generic
+// direct kernels.  A concat whose members are partly unaligned (the latent z of 1..3 channels in front of the
+// feature map, networks.py:652-653) is split: aligned members -> MFMA, the rest -> direct kernel accumulating
+// into the same output.
 #include "common.h"
-
-extern "C" {
-int m1_conv3d_fwd_direct(const m1_conv_desc_t*, const float*, const float*, void*, void*);
-int m1_conv3d_dgrad_direct(const m1_conv_desc_t*, const float*, const void*, void* const*, void*);
-int m1_conv3d_wgrad_direct(const m1_conv_desc_t*, const void*, float*, float*, float*, void*);
-int m1_convT3d_fwd_direct(const m1_conv_desc_t*, const float*, const float*, void*, void*);
-int m1_convT3d_dgrad_direct(const m1_conv_desc_t*, const float*, const void*, void* const*, void*);
-int m1_convT3d_wgrad_direct(const m1_conv_desc_t*, const void*, float*, float*, float*, void*);
-}
+#include "gather.h"
 
 static inline bool desc_ok(const m1_conv_desc_t* d) {
-    return d && d->N > 0 && d->D > 0 && d->H > 0 && d->W > 0 && d->Cin > 0 && d->Cout > 0 && d->kd > 0 && d->kh > 0 &&
-           d->kw > 0 && d->sd > 0 && d->sh > 0 && d->sw > 0 && d->nsrc >= 1 && d->nsrc <= M1_MAX_SRC;
+    if (!(d && d->N > 0 && d->D > 0 && d->H > 0 && d->W > 0 && d->Cin > 0 && d->Cout > 0 && d->kd > 0 && d->kh > 0 &&
+          d->kw > 0 && d->sd > 0 && d->sh > 0 && d->sw > 0 && d->nsrc >= 1 && d->nsrc <= M1_MAX_SRC)) return false;
+    if (d->dtype != M1_F32 && d->dtype != M1_BF16) return false;
+    int c = 0;
+    for (int i = 0; i < d->nsrc; ++i) { if (!d->src[i].ptr || d->src[i].C <= 0) return false; c += d->src[i].C; }
+    return c == d->Cin;
 }
 static inline double esz(int dt) { return dt == M1_BF16 ? 2.0 : 4.0; }
-static inline void conv_out_dims(const m1_conv_desc_t* d, int* od, int* oh, int* ow) {
-    *od = (d->D + d->sd - 1) / d->sd; *oh = (d->H + d->sh - 1) / d->sh; *ow = (d->W + d->sw - 1) / d->sw;
+static inline void same_pad(int in, int k, int s, int* out, int* pb) {
+    int o = (in + s - 1) / s;
+    int tot = (o - 1) * s + k - in; if (tot < 0) tot = 0;
+    *out = o; *pb = tot / 2;
 }
-// algorithmic work: flops = 2*MAC; bytes = read each logical input once + write output once
-static inline double conv_macs(const m1_conv_desc_t* d, int transposed) {
-    int od, oh, ow; conv_out_dims(d, &od, &oh, &ow);
+static inline int convT_pb(int k, int s) { return (k - s > 0 ? k - s : 0) / 2; }
+
+struct Geo { int OD, OH, OW, pd, ph, pw; };
+static inline Geo conv_geo(const m1_conv_desc_t* d) {
+    Geo g; same_pad(d->D, d->kd, d->sd, &g.OD, &g.pd); same_pad(d->H, d->kh, d->sh, &g.OH, &g.ph); same_pad(d->W, d->kw, d->sw, &g.OW, &g.pw);
+    return g;
+}
+static inline Geo convT_geo(const m1_conv_desc_t* d) {
+    Geo g; g.OD = d->D * d->sd; g.OH = d->H * d->sh; g.OW = d->W * d->sw;
+    g.pd = convT_pb(d->kd, d->sd); g.ph = convT_pb(d->kh, d->sh); g.pw = convT_pb(d->kw, d->sw);
+    return g;
+}
+// algorithmic work: flops = 2*MAC; bytes = every logical input read once + output written once
+static inline double conv_macs(const m1_conv_desc_t* d, bool T) {
+    Geo g = T ? convT_geo(d) : conv_geo(d);
     const double taps = (double)d->kd * d->kh * d->kw;
-    const double vox = transposed ? (double)d->D * d->H * d->W : (double)od * oh * ow;   // coarse-grid voxels
+    const double vox = T ? (double)d->D * d->H * d->W : (double)g.OD * g.OH * g.OW;
     return (double)d->N * vox * taps * d->Cin * d->Cout;
 }
-static inline double conv_in_elems(const m1_conv_desc_t* d) { return (double)d->N * d->D * d->H * d->W * d->Cin; }
-static inline double conv_out_elems(const m1_conv_desc_t* d, int transposed) {
-    if (transposed) return (double)d->N * d->D * d->sd * d->H * d->sh * d->W * d->sw * d->Cout;
-    int od, oh, ow; conv_out_dims(d, &od, &oh, &ow);
-    return (double)d->N * od * oh * ow * d->Cout;
+static inline double conv_bytes(const m1_conv_desc_t* d, bool T) {
+    Geo g = T ? convT_geo(d) : conv_geo(d);
+    return ((double)d->N * d->D * d->H * d->W * d->Cin + (double)d->N * g.OD * g.OH * g.OW * d->Cout) * esz(d->dtype);
 }
 
 extern "C" const char* m1_status_name(int s) {
@@ -45,33 +56,154 @@ extern "C" const char* m1_status_name(int s) {
 }
 extern "C" int m1_abi_version(void) { return 1; }
 
-extern "C" int m1_conv3d_fwd(const m1_conv_desc_t* d, const float* w, const float* bias, void* y, void* stream) {
-    if (!desc_ok(d)) return M1_ERR_BAD_ARG;
-    M1ProfScope ps("conv3d_fwd", 2.0 * conv_macs(d, 0), (conv_in_elems(d) + conv_out_elems(d, 0)) * esz(d->dtype), (hipStream_t)stream);
-    return m1_conv3d_fwd_direct(d, w, bias, y, stream);
+static int g_force_direct = 0;
+extern "C" int m1_set_force_direct(int on) { g_force_direct = on; return M1_OK; }
+
+// ---- spec builders -------------------------------------------------------------------------------------------
+// forward-type problems: the concat `d->src` is the CONTRACTION axis, `out` has all Cout channels
+static GatherSpec fwd_spec(const m1_conv_desc_t* d, bool T, const float* w, const float* bias, void* y) {
+    GatherSpec g{}; Geo q = T ? convT_geo(d) : conv_geo(d);
+    g.nsrc = d->nsrc;
+    for (int i = 0; i < d->nsrc; ++i) { g.src[i] = d->src[i].ptr; g.srcC[i] = d->src[i].C; }
+    g.ID = d->D; g.IH = d->H; g.IW = d->W; g.out = y; g.OC = d->Cout; g.OD = q.OD; g.OH = q.OH; g.OW = q.OW; g.N = d->N;
+    g.w = w; g.bias = bias; g.kd = d->kd; g.kh = d->kh; g.kw = d->kw; g.sd = d->sd; g.sh = d->sh; g.sw = d->sw;
+    g.pd = q.pd; g.ph = q.ph; g.pw = q.pw; g.dtype = d->dtype;
+    if (!T) { g.mode = 0; g.wST = (long long)d->Cin * d->Cout; g.wSC = d->Cout; g.wSO = 1; }     // w[tap][ci][co]
+    else    { g.mode = 1; g.wST = (long long)d->Cout * d->Cin; g.wSC = 1; g.wSO = d->Cin; }      // w[tap][co][ci]
+    return g;
 }
-extern "C" int m1_conv3d_dgrad(const m1_conv_desc_t* d, const float* w, const void* dy, void* const* dx, void* stream) {
-    if (!desc_ok(d)) return M1_ERR_BAD_ARG;
-    M1ProfScope ps("conv3d_dgrad", 2.0 * conv_macs(d, 0), (conv_in_elems(d) + conv_out_elems(d, 0)) * esz(d->dtype), (hipStream_t)stream);
-    return m1_conv3d_dgrad_direct(d, w, dy, dx, stream);
+// data-gradient problems: dy (Cout channels) is the contraction axis, one spec per concat member
+static GatherSpec dgrad_spec(const m1_conv_desc_t* d, bool T, const float* w, const void* dy, void* dx, int member, int ch_off) {
+    GatherSpec g{}; Geo q = T ? convT_geo(d) : conv_geo(d);
+    g.nsrc = 1; g.src[0] = dy; g.srcC[0] = d->Cout;
+    g.ID = q.OD; g.IH = q.OH; g.IW = q.OW; g.out = dx; g.OC = d->src[member].C; g.OD = d->D; g.OH = d->H; g.OW = d->W; g.N = d->N;
+    g.w = w; g.bias = nullptr; g.oc_off = ch_off; g.kd = d->kd; g.kh = d->kh; g.kw = d->kw; g.sd = d->sd; g.sh = d->sh; g.sw = d->sw;
+    g.pd = q.pd; g.ph = q.ph; g.pw = q.pw; g.dtype = d->dtype;
+    if (!T) { g.mode = 1; g.wST = (long long)d->Cin * d->Cout; g.wSC = 1; g.wSO = d->Cout; }     // out = ci, contraction = co
+    else    { g.mode = 0; g.wST = (long long)d->Cout * d->Cin; g.wSC = d->Cin; g.wSO = 1; }
+    return g;
 }
-extern "C" int m1_conv3d_wgrad(const m1_conv_desc_t* d, const void* dy, float* dw, float* db, float* ws, void* stream) {
-    if (!desc_ok(d)) return M1_ERR_BAD_ARG;
-    M1ProfScope ps("conv3d_wgrad", 2.0 * conv_macs(d, 0), (conv_in_elems(d) + conv_out_elems(d, 0)) * esz(d->dtype), (hipStream_t)stream);
-    return m1_conv3d_wgrad_direct(d, dy, dw, db, ws, stream);
+
+static inline size_t align256(size_t v) { return (v + 255) / 256 * 256; }
+
+// splits a forward-type spec into an MFMA part (aligned members) and a direct part (the rest)
+static void split_members(const GatherSpec& g, GatherSpec* mf, GatherSpec* dr) {
+    const int SEG = g.dtype == M1_BF16 ? 8 : 4;
+    *mf = g; *dr = g; mf->nsrc = 0; dr->nsrc = 0;
+    if (g_force_direct || g.OC % SEG) { *dr = g; return; }
+    // members must stay contiguous on the weight's contraction axis: MFMA takes the longest aligned SUFFIX
+    int first_aligned = g.nsrc;
+    for (int i = g.nsrc - 1; i >= 0 && g.srcC[i] % SEG == 0; --i) first_aligned = i;
+    int off = 0;
+    for (int i = 0; i < g.nsrc; ++i) {
+        GatherSpec* t = i >= first_aligned ? mf : dr;
+        if (t->nsrc == 0) t->cc_off = g.cc_off + off;
+        t->src[t->nsrc] = g.src[i]; t->srcC[t->nsrc] = g.srcC[i]; ++t->nsrc;
+        off += g.srcC[i];
+    }
+    if (mf->nsrc && !m1_mfma_supported(*mf)) { *dr = g; mf->nsrc = 0; }
 }
-extern "C" int m1_convT3d_fwd(const m1_conv_desc_t* d, const float* w, const float* bias, void* y, void* stream) {
-    if (!desc_ok(d)) return M1_ERR_BAD_ARG;
-    M1ProfScope ps("convT3d_fwd", 2.0 * conv_macs(d, 1), (conv_in_elems(d) + conv_out_elems(d, 1)) * esz(d->dtype), (hipStream_t)stream);
-    return m1_convT3d_fwd_direct(d, w, bias, y, stream);
+
+static size_t gather_ws_bytes(const GatherSpec& g) {
+    GatherSpec mf, dr; split_members(g, &mf, &dr);
+    return mf.nsrc ? align256(m1_mfma_ws_bytes(mf)) : 0;
 }
-extern "C" int m1_convT3d_dgrad(const m1_conv_desc_t* d, const float* w, const void* dy, void* const* dx, void* stream) {
-    if (!desc_ok(d)) return M1_ERR_BAD_ARG;
-    M1ProfScope ps("convT3d_dgrad", 2.0 * conv_macs(d, 1), (conv_in_elems(d) + conv_out_elems(d, 1)) * esz(d->dtype), (hipStream_t)stream);
-    return m1_convT3d_dgrad_direct(d, w, dy, dx, stream);
+
+static int run_gather(const GatherSpec& g, void* ws, hipStream_t st) {
+    GatherSpec mf, dr; split_members(g, &mf, &dr);
+    int rc = M1_OK;
+    if (mf.nsrc) {
+        if (!ws) return M1_ERR_WORKSPACE;
+        rc = m1_mfma_gather(mf, ws, st); if (rc) return rc;
+        if (dr.nsrc) { dr.accumulate = 1; dr.bias = nullptr; rc = m1_direct_gather(dr, st); }
+        return rc;
+    }
+    return m1_direct_gather(dr, st);
 }
-extern "C" int m1_convT3d_wgrad(const m1_conv_desc_t* d, const void* dy, float* dw, float* db, float* ws, void* stream) {
-    if (!desc_ok(d)) return M1_ERR_BAD_ARG;
-    M1ProfScope ps("convT3d_wgrad", 2.0 * conv_macs(d, 1), (conv_in_elems(d) + conv_out_elems(d, 1)) * esz(d->dtype), (hipStream_t)stream);
-    return m1_convT3d_wgrad_direct(d, dy, dw, db, ws, stream);
+
+// ---- workspace query ---------------------------------------------------------------------------------------------
+extern "C" size_t m1_conv_ws_bytes(const m1_conv_desc_t* d, int transposed, int role) {
+    if (!desc_ok(d)) return 0;
+    const bool T = transposed != 0;
+    if (role == 0) return gather_ws_bytes(fwd_spec(d, T, nullptr, nullptr, nullptr)) + 256;
+    if (role == 1) {
+        size_t m = 0; int off = 0;
+        for (int i = 0; i < d->nsrc; ++i) {
+            size_t b = gather_ws_bytes(dgrad_spec(d, T, nullptr, nullptr, nullptr, i, off));
+            m = b > m ? b : m; off += d->src[i].C;
+        }
+        return m + 256;
+    }
+    Geo q = T ? convT_geo(d) : conv_geo(d);
+    return m1_reduce_ws_floats(d->N, (long long)q.OD * q.OH * q.OW, d->Cout, 1) * sizeof(float) + 256;
+}
+
+// ---- Conv3D ------------------------------------------------------------------------------------------------------
+extern "C" int m1_conv3d_fwd(const m1_conv_desc_t* d, const float* w, const float* bias, void* y, void* ws, void* stream) {
+    if (!desc_ok(d) || !w || !y) return M1_ERR_BAD_ARG;
+    M1ProfScope ps("conv3d_fwd", 2.0 * conv_macs(d, false), conv_bytes(d, false), (hipStream_t)stream);
+    return run_gather(fwd_spec(d, false, w, bias, y), ws, (hipStream_t)stream);
+}
+extern "C" int m1_convT3d_fwd(const m1_conv_desc_t* d, const float* w, const float* bias, void* y, void* ws, void* stream) {
+    if (!desc_ok(d) || !w || !y) return M1_ERR_BAD_ARG;
+    M1ProfScope ps("convT3d_fwd", 2.0 * conv_macs(d, true), conv_bytes(d, true), (hipStream_t)stream);
+    return run_gather(fwd_spec(d, true, w, bias, y), ws, (hipStream_t)stream);
+}
+static int dgrad_common(const m1_conv_desc_t* d, bool T, const float* w, const void* dy, void* const* dx, void* ws, hipStream_t st) {
+    int off = 0;
+    for (int i = 0; i < d->nsrc; ++i) {
+        if (dx[i]) { int rc = run_gather(dgrad_spec(d, T, w, dy, dx[i], i, off), ws, st); if (rc) return rc; }
+        off += d->src[i].C;
+    }
+    return M1_OK;
+}
+extern "C" int m1_conv3d_dgrad(const m1_conv_desc_t* d, const float* w, const void* dy, void* const* dx, void* ws, void* stream) {
+    if (!desc_ok(d) || !w || !dy || !dx) return M1_ERR_BAD_ARG;
+    M1ProfScope ps("conv3d_dgrad", 2.0 * conv_macs(d, false), conv_bytes(d, false), (hipStream_t)stream);
+    return dgrad_common(d, false, w, dy, dx, ws, (hipStream_t)stream);
+}
+extern "C" int m1_convT3d_dgrad(const m1_conv_desc_t* d, const float* w, const void* dy, void* const* dx, void* ws, void* stream) {
+    if (!desc_ok(d) || !w || !dy || !dx) return M1_ERR_BAD_ARG;
+    M1ProfScope ps("convT3d_dgrad", 2.0 * conv_macs(d, true), conv_bytes(d, true), (hipStream_t)stream);
+    return dgrad_common(d, true, w, dy, dx, ws, (hipStream_t)stream);
+}
+
+// ---- weight gradients ------------------------------------------------------------------------------------------
+static int wgrad_common(const m1_conv_desc_t* d, bool T, const void* dy, float* dw, float* db, void* ws, hipStream_t st) {
+    Geo q = T ? convT_geo(d) : conv_geo(d);
+    const size_t nw = (size_t)d->kd * d->kh * d->kw * d->Cin * d->Cout;
+    if (hipMemsetAsync(dw, 0, nw * sizeof(float), st) != hipSuccess) return M1_ERR_LAUNCH;
+    int off = 0;
+    for (int i = 0; i < d->nsrc; ++i) {
+        WgradSpec g{};
+        g.N = d->N; g.R = dw; g.kd = d->kd; g.kh = d->kh; g.kw = d->kw; g.sd = d->sd; g.sh = d->sh; g.sw = d->sw;
+        g.pd = q.pd; g.ph = q.ph; g.pw = q.pw; g.dtype = d->dtype;
+        if (!T) {   // dw[tap][ci][co] = sum X[v*s+tap-p][ci] * dY[v][co]
+            g.A = d->src[i].ptr; g.CA = d->src[i].C; g.AD = d->D; g.AH = d->H; g.AW = d->W;
+            g.B = dy; g.CB = d->Cout; g.BD = q.OD; g.BH = q.OH; g.BW = q.OW;
+            g.RT = (long long)d->Cin * d->Cout; g.RSA = d->Cout; g.a_off = off; g.b_off = 0;
+        } else {    // dw[tap][co][ci] = sum dOut[i*s+tap-pb][co] * In[i][ci]
+            g.A = dy; g.CA = d->Cout; g.AD = q.OD; g.AH = q.OH; g.AW = q.OW;
+            g.B = d->src[i].ptr; g.CB = d->src[i].C; g.BD = d->D; g.BH = d->H; g.BW = d->W;
+            g.RT = (long long)d->Cout * d->Cin; g.RSA = d->Cin; g.a_off = 0; g.b_off = off;
+        }
+        int rc = (!g_force_direct && m1_mfma_wgrad_supported(g)) ? m1_mfma_wgrad(g, st) : m1_direct_wgrad(g, st);
+        if (rc) return rc;
+        off += d->src[i].C;
+    }
+    if (db) {
+        if (!ws) return M1_ERR_WORKSPACE;
+        return m1_colsum_internal(dy, d->N, (long long)q.OD * q.OH * q.OW, d->Cout, d->dtype, db, (float*)ws, st);
+    }
+    return M1_OK;
+}
+extern "C" int m1_conv3d_wgrad(const m1_conv_desc_t* d, const void* dy, float* dw, float* db, void* ws, void* stream) {
+    if (!desc_ok(d) || !dy || !dw) return M1_ERR_BAD_ARG;
+    M1ProfScope ps("conv3d_wgrad", 2.0 * conv_macs(d, false), conv_bytes(d, false), (hipStream_t)stream);
+    return wgrad_common(d, false, dy, dw, db, ws, (hipStream_t)stream);
+}
+extern "C" int m1_convT3d_wgrad(const m1_conv_desc_t* d, const void* dy, float* dw, float* db, void* ws, void* stream) {
+    if (!desc_ok(d) || !dy || !dw) return M1_ERR_BAD_ARG;
+    M1ProfScope ps("convT3d_wgrad", 2.0 * conv_macs(d, true), conv_bytes(d, true), (hipStream_t)stream);
+    return wgrad_common(d, true, dy, dw, db, ws, (hipStream_t)stream);
 }

@@ -1,0 +1,37 @@
+// gather.h -- the logical problems behind the six conv entry points, shared by the direct (conv_direct.hip)
+// and matrix-core (conv_mfma.hip, wgrad_mfma.hip) implementations.  dispatch.hip builds these specs.
+#pragma once
+#include "common.h"
+
+// out[o][oc] = bias[oc+oc_off] + sum_tap sum_c  X[gather(o,tap)][c] * w[tap*wST + (c+cc_off)*wSC + (oc+oc_off)*wSO]
+//   mode 0: gather = o*s + tap - p  (Conv3D forward, Conv3DTranspose dgrad)
+//   mode 1: gather = (o + p - tap)/s when divisible (Conv3D dgrad, Conv3DTranspose forward)
+struct GatherSpec {
+    const void* src[M1_MAX_SRC]; int srcC[M1_MAX_SRC]; int nsrc;   // virtual concat of the contraction axis
+    int ID, IH, IW;            // extent of the gathered tensors
+    void* out; int OC;         // output tensor and its channel count
+    int OD, OH, OW, N;
+    const float* w; long long wST, wSC, wSO; int oc_off, cc_off;
+    const float* bias;
+    int kd, kh, kw, mode, sd, sh, sw, pd, ph, pw;
+    int dtype, accumulate;
+};
+
+// R[tap*RT + (a+a_off)*RSA + (b+b_off)] += sum_{n,v} A[n, v*s + tap - p][a] * B[n, v][b]
+struct WgradSpec {
+    const void* A; int CA; int AD, AH, AW;
+    const void* B; int CB; int BD, BH, BW;
+    int N;
+    float* R; long long RT, RSA; int a_off, b_off;
+    int kd, kh, kw, sd, sh, sw, pd, ph, pw;
+    int dtype;
+};
+
+int m1_direct_gather(const GatherSpec& g, hipStream_t st);
+int m1_direct_wgrad(const WgradSpec& g, hipStream_t st);
+bool m1_mfma_supported(const GatherSpec& g);
+size_t m1_mfma_ws_bytes(const GatherSpec& g);
+int m1_mfma_gather(const GatherSpec& g, void* ws, hipStream_t st);
+bool m1_mfma_wgrad_supported(const WgradSpec& g);
+int m1_mfma_wgrad(const WgradSpec& g, hipStream_t st);
+int m1_colsum_internal(const void* x, int N, long long V, int C, int dtype, float* out, float* ws, hipStream_t st);

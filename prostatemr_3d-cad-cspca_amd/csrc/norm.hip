@@ -20,32 +20,12 @@ struct StatsF {
     }
 };
 
-__global__ void stats_finalize_kernel(const float* __restrict__ partial, int N, int C, int nchunks, long long V,
-                                      float eps, float* __restrict__ stats) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= N * C) return;
-    int n = i / C, c = i % C;
-    double s = 0.0, ss = 0.0;
-    for (int j = 0; j < nchunks; ++j) {
-        const float* p = partial + (((size_t)n * nchunks + j) * C + c) * 2;
-        s += (double)p[0]; ss += (double)p[1];
-    }
-    double mean = s / (double)V;
-    double var = ss / (double)V - mean * mean;
-    if (var < 0.0) var = 0.0;
-    stats[(size_t)i * 2 + 0] = (float)mean;
-    stats[(size_t)i * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
-}
-
 template <typename T>
 static int stats_impl(const void* x, int N, long long V, int C, float eps, float* stats, float* ws, hipStream_t st) {
     StatsF<T> f{(const T*)x, V, C};
     int rc = m1_reduce_nc_launch<2>(f, N, V, C, ws, st);
     if (rc) return rc;
-    int tot = N * C;
-    hipLaunchKernelGGL(stats_finalize_kernel, dim3((tot + 255) / 256), dim3(256), 0, st, ws, N, C,
-                       m1_red_nchunks(V, C), V, eps, stats);
-    return m1_check_launch();
+    return m1_reduce_finalize_launch<2>(ws, N, C, m1_red_nchunks(V, C), stats, V, eps, st);
 }
 
 extern "C" int m1_instnorm_stats(const void* x, int N, long long V, int C, int dtype, float eps, float* stats,
@@ -181,9 +161,8 @@ static int bwd_impl(const void* x, const float* stats, const float* gamma, const
     if (rc) return rc;
     const int nchunks = m1_red_nchunks(V, C);
     float* sums = ws + (size_t)N * nchunks * C * 2;
-    int tot = N * C;
-    hipLaunchKernelGGL((m1_reduce_finalize_kernel<2>), dim3((tot + 255) / 256), dim3(256), 0, st, ws, N, C, nchunks,
-                       sums);
+    rc = m1_reduce_finalize_launch<2>(ws, N, C, nchunks, sums, 0, 0.f, st);
+    if (rc) return rc;
     hipLaunchKernelGGL(in_bwd_param_kernel, dim3((C + 255) / 256), dim3(256), 0, st, sums, N, C, dgamma, dbeta);
     constexpr int VW = sizeof(T) == 2 ? 8 : 4;
     if (C % VW == 0) {
@@ -220,20 +199,12 @@ struct ColSumF {
         acc[0] += Act<T>::ld(x + ((size_t)n * V + v) * C + c);
     }
 };
-__global__ void colsum_finalize_kernel(const float* __restrict__ partial, int rows, int C, float* __restrict__ out) {
-    int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    double s = 0.0;
-    for (int r = 0; r < rows; ++r) s += partial[(size_t)r * C + c];
-    out[c] = (float)s;
-}
 // Internal (used by conv wgrad): ws must hold N*nchunks*C floats.
 int m1_colsum_internal(const void* x, int N, long long V, int C, int dtype, float* out, float* ws, hipStream_t st) {
     int rc;
     if (dtype == M1_BF16) { ColSumF<bf16_t> f{(const bf16_t*)x, V, C}; rc = m1_reduce_nc_launch<1>(f, N, V, C, ws, st); }
     else { ColSumF<float> f{(const float*)x, V, C}; rc = m1_reduce_nc_launch<1>(f, N, V, C, ws, st); }
     if (rc) return rc;
-    hipLaunchKernelGGL(colsum_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, st, ws, N * m1_red_nchunks(V, C),
-                       C, out);
-    return m1_check_launch();
+    // partial is [N*nchunks][C][1]: fold all rows as one sample
+    return m1_reduce_finalize_launch<1>(ws, 1, C, N * m1_red_nchunks(V, C), out, 0, 0.f, st);
 }

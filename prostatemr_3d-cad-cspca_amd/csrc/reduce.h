@@ -11,11 +11,12 @@
 #define M1_RED_THREADS 256
 
 static inline int m1_red_chunkV(long long V, int C) {
-    // aim for >= ~8 elements per thread-channel and enough blocks to fill 256 CUs
+    // >= ~16 elements per thread, and at most ~1024 chunks per sample (the finalize folds them per wave)
     long long per_block = (long long)M1_RED_THREADS * 16 / (C < 256 ? (C < 1 ? 1 : C) : 256);
     if (per_block < 16) per_block = 16;
-    if (per_block > 4096) per_block = 4096;
     long long chunk = per_block;
+    const long long cap = cdiv_ll(V, 1024);
+    if (chunk < cap) chunk = cap;
     if (chunk > V) chunk = V;
     return (int)chunk;
 }
@@ -55,21 +56,42 @@ __global__ void __launch_bounds__(M1_RED_THREADS) m1_reduce_nc_kernel(F f, long 
     }
 }
 
-// out[n][c][k] = sum_chunks partial (fp64 accumulate) -> float
+// out[n][c][k] = sum_chunks partial (fp64 accumulate) -> float.  ONE WAVE per (n,c): lanes stride the chunks.
+// Launch with 256 threads (4 waves) per block and ceil(N*C/4) blocks (m1_reduce_finalize_launch).
+// stats_V > 0 (NS == 2 only): writes {mean, rstd} computed in fp64 from (sum, sum of squares) instead.
 template <int NS>
-__global__ void m1_reduce_finalize_kernel(const float* __restrict__ partial, int N, int C, int nchunks,
-                                          float* __restrict__ out) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ void __launch_bounds__(256) m1_reduce_finalize_kernel(const float* __restrict__ partial, int N, int C, int nchunks,
+                                                                 float* __restrict__ out, long long stats_V, float eps) {
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (i >= N * C) return;
-    int n = i / C, c = i % C;
+    const int n = i / C, c = i % C;
     double s[NS];
 #pragma unroll
     for (int k = 0; k < NS; ++k) s[k] = 0.0;
-    for (int j = 0; j < nchunks; ++j)
+    for (int j = lane; j < nchunks; j += 64)
 #pragma unroll
         for (int k = 0; k < NS; ++k) s[k] += (double)partial[(((size_t)n * nchunks + j) * C + c) * NS + k];
 #pragma unroll
-    for (int k = 0; k < NS; ++k) out[(size_t)i * NS + k] = (float)s[k];
+    for (int k = 0; k < NS; ++k) s[k] = wave_sum_d(s[k]);
+    if (lane == 0) {
+        if (stats_V > 0 && NS == 2) {
+            const double mean = s[0] / (double)stats_V;
+            double var = s[NS - 1] / (double)stats_V - mean * mean;
+            if (var < 0.0) var = 0.0;
+            out[(size_t)i * NS + 0] = (float)mean;
+            out[(size_t)i * NS + NS - 1] = (float)(1.0 / sqrt(var + (double)eps));
+        } else {
+#pragma unroll
+            for (int k = 0; k < NS; ++k) out[(size_t)i * NS + k] = (float)s[k];
+        }
+    }
+}
+template <int NS>
+static inline int m1_reduce_finalize_launch(const float* partial, int N, int C, int nchunks, float* out, long long stats_V,
+                                            float eps, hipStream_t st) {
+    hipLaunchKernelGGL((m1_reduce_finalize_kernel<NS>), dim3((N * C + 3) / 4), dim3(256), 0, st, partial, N, C, nchunks, out,
+                       stats_V, eps);
+    return m1_check_launch();
 }
 
 template <int NS, typename F>

@@ -213,7 +213,8 @@ static int se_bwd_impl(const void* y3, const void* y4, const void* dout, const S
     if (rc) return rc;
     const int nchunks = m1_red_nchunks(p.V, p.F);
     float* sums = ws + (size_t)N * nchunks * p.F * 5;
-    hipLaunchKernelGGL((m1_reduce_finalize_kernel<5>), dim3((N * p.F + 255) / 256), dim3(256), 0, st, ws, N, p.F, nchunks, sums);
+    rc = m1_reduce_finalize_launch<5>(ws, N, p.F, nchunks, sums, 0, 0.f, st);
+    if (rc) return rc;
     hipLaunchKernelGGL(se_bwd_param_kernel, dim3((p.F + 255) / 256), dim3(256), 0, st, sums, N, p.F, dgamma3, dbeta3, dgamma4,
                        dbeta4, dg);
     constexpr int VW = sizeof(T) == 2 ? 8 : 4;

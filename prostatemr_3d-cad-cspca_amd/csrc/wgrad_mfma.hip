@@ -1,0 +1,203 @@
+// wgrad_mfma.hip -- weight gradients of Conv3D / Conv3DTranspose on the matrix cores.
+//
+//   R[tap][a][b] += sum_{n,v} A[n, v*s + tap - p][a] * B[n, v][b]        M = a, N = b, K = voxels (split-K)
+//
+// Both operands are voxel-major in memory (NDHWC) while the MFMA wants K(=voxel)-contiguous fragments, so the
+// staging path transposes SEG x SEG blocks IN REGISTERS (8x8 bf16 via 16-bit interleaves, 4x4 fp32 for free by
+// register renaming) and writes K-contiguous 16-byte segments into the same swizzled 64-byte-row LDS image the
+// forward kernel uses; the fragment reads / MFMA issue are then identical to conv_mfma.hip.
+// One block = one (tap, a-tile, b-tile, voxel-split); partial results are combined with fp32 atomics in L2.
+#include "common.h"
+#include "gather.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+
+template <typename T> struct WT;
+template <> struct WT<bf16_t> { static constexpr int SEG = 8; };
+template <> struct WT<float> { static constexpr int SEG = 4; };
+
+__device__ __forceinline__ int wswz(int row, int seg) { return seg ^ ((-(row >> 2)) & 3); }
+
+struct WgP : WgradSpec { long long vox_per_split; };
+
+// r[j] = 16 bytes of voxel j (SEG channels); returns o[c] = 16 bytes of channel c (SEG voxels)
+__device__ __forceinline__ void transpose_unit(const uint4 (&r)[8], uint4 (&o)[8], bf16_t) {
+    // 8x8 of 16-bit: pairwise interleave rows (2i,2i+1) per dword, then a register-only 4x4 dword transpose
+    unsigned lo[4][4], hi[4][4];     // [pair i][dword j]: lo = channel 2j of rows (2i,2i+1), hi = channel 2j+1
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const unsigned x[4] = {r[2 * i].x, r[2 * i].y, r[2 * i].z, r[2 * i].w};
+        const unsigned y[4] = {r[2 * i + 1].x, r[2 * i + 1].y, r[2 * i + 1].z, r[2 * i + 1].w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            lo[i][j] = (x[j] & 0xffffu) | (y[j] << 16);
+            hi[i][j] = (x[j] >> 16) | (y[j] & 0xffff0000u);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        o[2 * j] = make_uint4(lo[0][j], lo[1][j], lo[2][j], lo[3][j]);
+        o[2 * j + 1] = make_uint4(hi[0][j], hi[1][j], hi[2][j], hi[3][j]);
+    }
+}
+__device__ __forceinline__ void transpose_unit(const uint4 (&r)[8], uint4 (&o)[8], float) {
+    o[0] = make_uint4(r[0].x, r[1].x, r[2].x, r[3].x);
+    o[1] = make_uint4(r[0].y, r[1].y, r[2].y, r[3].y);
+    o[2] = make_uint4(r[0].z, r[1].z, r[2].z, r[3].z);
+    o[3] = make_uint4(r[0].w, r[1].w, r[2].w, r[3].w);
+}
+
+template <typename T, int TA, int TB>
+__global__ void __launch_bounds__(256) wgrad_mfma_kernel(WgP p) {
+    constexpr int SEG = WT<T>::SEG;
+    constexpr int KS = 4 * SEG;                            // voxels per K-step (one 64-byte LDS row)
+    constexpr int TM = TA / 2 / 16, TN = TB / 2 / 16;      // 2x2 waves
+    constexpr int UA = (TA / SEG) * 4, UB = (TB / SEG) * 4;   // SEGxSEG units per K-step
+    constexpr int NU = (UA + UB + 255) / 256;
+    __shared__ __attribute__((aligned(16))) unsigned char A_s[TA * 64];
+    __shared__ __attribute__((aligned(16))) unsigned char B_s[TB * 64];
+    __shared__ long long a_off_s[KS], b_off_s[KS];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int bTiles = (p.CB + TB - 1) / TB;
+    const int a0 = (blockIdx.x / bTiles) * TA, b0 = (blockIdx.x % bTiles) * TB;
+    const int tap = blockIdx.y;
+    const int kw = tap % p.kw, kh = (tap / p.kw) % p.kh, kd = tap / (p.kw * p.kh);
+    const long long BV = (long long)p.BD * p.BH * p.BW, TV = BV * p.N;
+    const long long vbeg = (long long)blockIdx.z * p.vox_per_split;
+    long long vend = vbeg + p.vox_per_split; if (vend > TV) vend = TV;
+    const T* A = (const T*)p.A; const T* B = (const T*)p.B;
+
+    f32x4_t acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    const int fr = lane & 15, fs = lane >> 4;
+
+    for (long long vs = vbeg; vs < vend; vs += KS) {
+        if (tid < KS) {
+            const long long v = vs + tid;
+            long long ao = -1, bo = -1;
+            if (v < vend) {
+                const int n = (int)(v / BV); long long r = v % BV;
+                const int bw = (int)(r % p.BW); r /= p.BW;
+                const int bh = (int)(r % p.BH); const int bd = (int)(r / p.BH);
+                const int ad = bd * p.sd + kd - p.pd, ah = bh * p.sh + kh - p.ph, aw = bw * p.sw + kw - p.pw;
+                if (ad >= 0 && ad < p.AD && ah >= 0 && ah < p.AH && aw >= 0 && aw < p.AW) {
+                    ao = (((long long)n * p.AD + ad) * p.AH + ah) * p.AW + aw;
+                    bo = v;        // a voxel whose shifted partner is outside the volume contributes nothing
+                }
+            }
+            a_off_s[tid] = ao; b_off_s[tid] = bo;
+        }
+        __syncthreads();           // also fences the previous step's fragment reads before A_s/B_s are rewritten
+#pragma unroll
+        for (int q = 0; q < NU; ++q) {
+            const int u = tid + 256 * q;
+            if (u < UA + UB) {
+                const bool isA = u < UA;
+                const int uu = isA ? u : u - UA;
+                const int ncg = (isA ? TA : TB) / SEG;
+                const int cg = uu % ncg, ks = uu / ncg;                 // channel group, k segment
+                const int C = isA ? p.CA : p.CB, c0 = (isA ? a0 : b0) + cg * SEG;
+                const T* base = isA ? A : B;
+                uint4 r[8], o[8];
+#pragma unroll
+                for (int j = 0; j < SEG; ++j) {
+                    const long long off = isA ? a_off_s[ks * SEG + j] : b_off_s[ks * SEG + j];
+                    r[j] = (off >= 0 && c0 < C) ? *reinterpret_cast<const uint4*>(base + off * C + c0) : make_uint4(0, 0, 0, 0);
+                }
+                transpose_unit(r, o, T());
+                unsigned char* dst = isA ? A_s : B_s;
+#pragma unroll
+                for (int c = 0; c < SEG; ++c) {
+                    const int row = cg * SEG + c;
+                    *reinterpret_cast<uint4*>(dst + row * 64 + wswz(row, ks) * 16) = o[c];
+                }
+            }
+        }
+        __syncthreads();
+        uint4 af[TM], bfr[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int row = wm * (TA / 2) + i * 16 + fr;
+            af[i] = *reinterpret_cast<const uint4*>(A_s + row * 64 + wswz(row, fs) * 16);
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int row = wn * (TB / 2) + j * 16 + fr;
+            bfr[j] = *reinterpret_cast<const uint4*>(B_s + row * 64 + wswz(row, fs) * 16);
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                if constexpr (sizeof(T) == 2) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, af[i]),
+                                                                        __builtin_bit_cast(bf16x8_t, bfr[j]), acc[i][j], 0, 0, 0);
+                } else {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(af[i].x), __uint_as_float(bfr[j].x), acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(af[i].y), __uint_as_float(bfr[j].y), acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(af[i].z), __uint_as_float(bfr[j].z), acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(af[i].w), __uint_as_float(bfr[j].w), acc[i][j], 0, 0, 0);
+                }
+            }
+    }
+    // D[i = a][j = b]: lane holds a = 4*fs + r, b = fr
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int b = b0 + wn * (TB / 2) + j * 16 + fr;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int a = a0 + wm * (TA / 2) + i * 16 + fs * 4 + r;
+                if (a < p.CA && b < p.CB)
+                    atomicAdd(p.R + (long long)tap * p.RT + (long long)(a + p.a_off) * p.RSA + (b + p.b_off), acc[i][j][r]);
+            }
+        }
+}
+
+bool m1_mfma_wgrad_supported(const WgradSpec& g) {
+    const int SEG = g.dtype == M1_BF16 ? 8 : 4;
+    return g.CA % SEG == 0 && g.CB % SEG == 0;
+}
+
+template <typename T, int TA, int TB>
+static int launch_wg(WgP p, hipStream_t st) {
+    constexpr int KS = 4 * WT<T>::SEG;
+    const int aTiles = (p.CA + TA - 1) / TA, bTiles = (p.CB + TB - 1) / TB;
+    const int taps = p.kd * p.kh * p.kw;
+    const long long TV = (long long)p.N * p.BD * p.BH * p.BW;
+    long long splits = cdiv_ll(1536, (long long)aTiles * bTiles * taps);
+    const long long max_splits = cdiv_ll(TV, 8 * KS);
+    if (splits > max_splits) splits = max_splits;
+    if (splits < 1) splits = 1;
+    long long vps = cdiv_ll(cdiv_ll(TV, splits), KS) * KS;
+    splits = cdiv_ll(TV, vps);
+    p.vox_per_split = vps;
+    dim3 grid(aTiles * bTiles, taps, (unsigned)splits);
+    hipLaunchKernelGGL((wgrad_mfma_kernel<T, TA, TB>), grid, dim3(256), 0, st, p);
+    return m1_check_launch();
+}
+
+static inline int pick_t(int c) { return c > 64 ? 128 : (c > 32 ? 64 : 32); }
+
+template <typename T>
+static int run_wg(const WgradSpec& g, hipStream_t st) {
+    WgP p; static_cast<WgradSpec&>(p) = g; p.vox_per_split = 0;
+    const int ta = pick_t(g.CA), tb = pick_t(g.CB);
+#define WG_CASE(A_, B_) if (ta == A_ && tb == B_) return launch_wg<T, A_, B_>(p, st);
+    WG_CASE(128, 128) WG_CASE(128, 64) WG_CASE(128, 32)
+    WG_CASE(64, 128) WG_CASE(64, 64) WG_CASE(64, 32)
+    WG_CASE(32, 128) WG_CASE(32, 64) WG_CASE(32, 32)
+#undef WG_CASE
+    return M1_ERR_UNSUPPORTED;
+}
+
+int m1_mfma_wgrad(const WgradSpec& g, hipStream_t st) {
+    return g.dtype == M1_BF16 ? run_wg<bf16_t>(g, st) : run_wg<float>(g, st);
+}

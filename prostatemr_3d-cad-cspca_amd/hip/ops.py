@@ -68,6 +68,11 @@ def _desc(srcs: Sequence[torch.Tensor], cout: int, k, s) -> L.m1_conv_desc_t:
     return d
 
 
+def _conv_ws(d, transposed: bool, role: int, device) -> torch.Tensor:
+    n = L.load().m1_conv_ws_bytes(C.byref(d), 1 if transposed else 0, role)
+    return torch.empty(max(int(n), 256), dtype=torch.uint8, device=device)
+
+
 def same_out(size: int, s: int) -> int:
     return -(-size // s)
 
@@ -92,7 +97,8 @@ class _Conv3d(torch.autograd.Function):
             osz = (d.N, same_out(d.D, d.sd), same_out(d.H, d.sh), same_out(d.W, d.sw), cout)
         y = torch.empty(osz, dtype=x0.dtype, device=x0.device)
         fn = lib.m1_convT3d_fwd if transposed else lib.m1_conv3d_fwd
-        L.check(fn(C.byref(d), _p(w), _p(b), _p(y), _stream()), "m1_convT3d_fwd" if transposed else "m1_conv3d_fwd")
+        ws = _conv_ws(d, transposed, 0, x0.device)
+        L.check(fn(C.byref(d), _p(w), _p(b), _p(y), _p(ws), _stream()), "m1_convT3d_fwd" if transposed else "m1_conv3d_fwd")
         ctx.save_for_backward(w, *srcs)
         ctx.k, ctx.s, ctx.transposed, ctx.has_bias, ctx.cout = tuple(k), tuple(s), transposed, b is not None, cout
         return y
@@ -110,8 +116,7 @@ class _Conv3d(torch.autograd.Function):
         if ctx.needs_input_grad[0] or (ctx.has_bias and ctx.needs_input_grad[1]):
             dw = torch.empty_like(w)
             db = torch.empty(ctx.cout, dtype=torch.float32, device=w.device) if ctx.has_bias else None
-            V = dy.shape[1] * dy.shape[2] * dy.shape[3]
-            ws = _ws(d.N, V, ctx.cout, 1, w.device) if db is not None else None
+            ws = _conv_ws(d, ctx.transposed, 2, w.device)
             fn = lib.m1_convT3d_wgrad if ctx.transposed else lib.m1_conv3d_wgrad
             L.check(fn(C.byref(d), _p(dy), _p(dw), _p(db), _p(ws), st), f"m1_{name}_wgrad")
         dsrc: List[Optional[torch.Tensor]] = []
@@ -128,7 +133,8 @@ class _Conv3d(torch.autograd.Function):
                 ptrs[i] = None
         if any_d:
             fn = lib.m1_convT3d_dgrad if ctx.transposed else lib.m1_conv3d_dgrad
-            L.check(fn(C.byref(d), _p(w), _p(dy), ptrs, st), f"m1_{name}_dgrad")
+            ws = _conv_ws(d, ctx.transposed, 1, w.device)
+            L.check(fn(C.byref(d), _p(w), _p(dy), ptrs, _p(ws), st), f"m1_{name}_dgrad")
         return (dw, db, None, None, None, *dsrc)
 
 
@@ -459,6 +465,11 @@ def adam_amsgrad_(p, g, m, v, vhat, n_kernel, n_bias, l2_kernel, l2_bias, grad_s
 
 def step_advance(step_dev, rng_dev):
     L.check(L.load().m1_step_advance(_p(step_dev), _p(rng_dev), _stream()), "m1_step_advance")
+
+
+def set_force_direct(on: bool):
+    """Test hook: route every conv through the generic direct kernels instead of the matrix-core kernels."""
+    L.load().m1_set_force_direct(1 if on else 0)
 
 
 def prof_enable(on: bool):

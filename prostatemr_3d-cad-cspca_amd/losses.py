@@ -18,10 +18,14 @@ class Focal:
     def __init__(self, alpha=[0.25, 0.75], gamma=2.00):
         self.alpha = alpha
         self.gamma = gamma
+        self._cw = {}        # device -> class-weight tensor (created once: no H2D copy inside a captured step)
 
     def FL(self, y_true, y_pred):
         """L:32-41: renormalise -> clip [eps, 1-eps] -> -y*log p -> * y(1-p)^gamma -> * alpha -> sum_{DHWC} -> mean_b."""
-        class_weights = torch.as_tensor(self.alpha, dtype=torch.float32, device=y_pred.device)
+        key = (y_pred.device, tuple(float(a) for a in self.alpha))
+        if key not in self._cw:
+            self._cw = {key: torch.as_tensor(self.alpha, dtype=torch.float32, device=y_pred.device)}
+        class_weights = self._cw[key]
         y_true = y_true.to(torch.float32)
         y_pred = y_pred / y_pred.sum(dim=-1, keepdim=True)
         y_pred = torch.clamp(y_pred, K_EPSILON, 1 - K_EPSILON)

@@ -27,6 +27,26 @@ def _ball_target(shape, seed):
     return torch.from_numpy(t)
 
 
+def _check_grads(m, P64):
+    """Every parameter gradient within 1e-3 relative L2 of the fp64 oracle.  Parameters whose true gradient is
+    (numerically) zero -- a conv bias that feeds an InstanceNorm is mean-subtracted away; sersd0/logits of a
+    probabilistic core reach no loss -- are compared on the absolute scale of the largest gradient."""
+    ref = {k.replace("m1_model.", ""): P64[k.replace("m1_model.", "")].grad for k, _ in m.named_parameters()}
+    gmax = max(float(g.norm()) for g in ref.values() if g is not None)
+    worst = ("", 0.0)
+    for k, p in m.named_parameters():
+        name = k.replace("m1_model.", "")
+        go = ref[name] if ref[name] is not None else torch.zeros_like(p.detach().cpu().double())
+        gh = p.grad.detach().double().cpu() if p.grad is not None else torch.zeros_like(go)
+        if float(go.norm()) < 1e-6 * gmax:
+            assert float(gh.norm()) < 1e-4 * gmax, (name, float(gh.norm()), gmax)
+            continue
+        e = float((gh - go).norm() / go.norm())
+        if e > worst[1]:
+            worst = (name, e)
+    assert worst[1] < 1e-3, worst
+
+
 def test_native_library_is_the_loaded_compute_path(dev):
     lib = PKG.hip.lib.load()
     assert lib.m1_abi_version() == 1
@@ -56,13 +76,7 @@ def test_c1_deterministic_forward_and_gradients(dev, deep_sup):
     loss = focal(tgt.to(dev), probs) + m.regularization_loss()
     assert abs(float(loss) - float(loss_o)) < 1e-3 * abs(float(loss_o))
     loss.backward()
-    worst = ("", 0.0)
-    for k, p in m.named_parameters():
-        name = k.replace("m1_model.", "")
-        e = rel_l2(p.grad, P64[name].grad)
-        if e > worst[1]:
-            worst = (name, e)
-    assert worst[1] < 1e-3, worst
+    _check_grads(m, P64)
 
 
 def test_c1_probabilistic_forward_kl_and_gradients(dev):
@@ -89,18 +103,7 @@ def test_c1_probabilistic_forward_kl_and_gradients(dev):
     loss = focal(tgt.to(dev), det) + 10.0 * elbo(None, kl) + m.regularization_loss()
     assert abs(float(loss) - float(loss_o)) < 1e-3 * abs(float(loss_o))
     loss.backward()
-    worst = ("", 0.0)
-    for k, p in m.named_parameters():
-        name = k.replace("m1_model.", "")
-        go = P64[name].grad
-        if go is None or float(go.abs().max()) == 0.0:
-            # sersd0 / logits of each core: no data gradient in the probabilistic graph, L2 only
-            assert p.grad is None or rel_l2(p.grad, torch.zeros_like(p.grad.cpu()) + (go if go is not None else 0)) < 1e-3 or True
-            continue
-        e = rel_l2(p.grad, go)
-        if e > worst[1]:
-            worst = (name, e)
-    assert worst[1] < 1e-3, worst
+    _check_grads(m, P64)
 
 
 def test_golden_fixture_c1_det(dev):
@@ -112,7 +115,7 @@ def test_golden_fixture_c1_det(dev):
     m = build_m1(cfg, dev)
     load_params_into(m, P)
     m(torch.from_numpy(g["x"]).to(dev))
-    logits = m.references.m1_model['logits'].cpu().numpy()
+    logits = m.references.m1_model['logits'].detach().cpu().numpy()
     assert np.abs(logits - g["logits"]).max() < 1e-3
 
 
@@ -126,7 +129,7 @@ def test_golden_fixture_c1_prob(dev):
     load_params_into(m, P)
     eps = [torch.from_numpy(g[f"eps{i}"]).to(dev) for i in range(3)]
     det, kl = m(torch.from_numpy(g["x"]).to(dev), eps_q=eps)
-    tc = m.references.m1_model['prob_train_conv'].cpu().numpy()
+    tc = m.references.m1_model['prob_train_conv'].detach().cpu().numpy()
     assert np.abs(tc - g["train_conv"]).max() < 1e-3
     assert abs(float(kl) - float(g["kl"])) < 1e-3 * max(1.0, abs(float(g["kl"])))
 

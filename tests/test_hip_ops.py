@@ -349,3 +349,61 @@ def test_adam_amsgrad_matches_keras_formula(dev):
         p = p - lr_t * mm / (hh.sqrt() + eps)
     assert int(step) == 4
     assert rel_err(pd[:n], p) < 1e-5
+
+
+# ---- matrix-core (MFMA implicit-GEMM) path: shapes chosen to hit every tile config and edge ----
+MFMA_SHAPES = [([64], 128), ([8], 8), ([16], 40), ([64, 32, 96], 192), ([256], 32), ([3, 64], 64), ([128], 136)]
+MFMA_KS = [((3, 3, 3), (1, 1, 1)), ((1, 3, 3), (1, 2, 2)), ((3, 3, 3), (2, 2, 2)), ((1, 1, 1), (1, 1, 1))]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("transposed", [False, True])
+@pytest.mark.parametrize("k,s", MFMA_KS)
+@pytest.mark.parametrize("chans", MFMA_SHAPES)
+def test_conv_mfma_paths_fwd_bwd(dev, dtype, transposed, k, s, chans):
+    cins, cout = chans
+    N, D, H, W = (2, 3, 10, 9) if not transposed else (2, 3, 5, 6)       # M not a multiple of the 128-row tile
+    xs = [rnd((N, D, H, W, c), 30 + i) for i, c in enumerate(cins)]
+    wshape = (*k, cout, sum(cins)) if transposed else (*k, sum(cins), cout)
+    w = rnd(wshape, 6, 1.0 / (sum(cins) * k[0] * k[1] * k[2]) ** 0.5); b = rnd((cout,), 7)
+    if dtype == torch.bfloat16:
+        xs = [x.bfloat16().float() for x in xs]
+    fo = O.conv3d_transpose_same if transposed else O.conv3d_same
+    yo = fo(torch.cat(xs, -1).double(), w.double(), b.double(), s)
+    dy = rnd(tuple(yo.shape), 8)
+    if dtype == torch.bfloat16:
+        dy = dy.bfloat16().float()
+    yo, (gx, gw, gb) = _oracle_grads(lambda x, w_, b_: fo(x, w_, b_, s), [torch.cat(xs, -1), w, b], dy)
+    fh = ops.conv3d_transpose_same if transposed else ops.conv3d_same
+    res = {}
+    for force in (False, True):
+        ops.set_force_direct(force)
+        try:
+            xd = [x.to(dev, dtype).requires_grad_(True) for x in xs]
+            wd, bd = w.to(dev).requires_grad_(True), b.to(dev).requires_grad_(True)
+            y = fh(xd, wd, bd, k, s)
+            y.backward(dy.to(dev, dtype))
+            res[force] = (y.detach(), wd.grad, bd.grad, [x.grad for x in xd])
+        finally:
+            ops.set_force_direct(False)
+    tol = TOL[dtype]
+    for force in (False, True):
+        y, gwd, gbd, gxd = res[force]
+        assert rel_err(y, yo) < tol, ("y", force)
+        assert rel_err(gwd, gw) < tol, ("dw", force)
+        assert rel_err(gbd, gb) < tol, ("db", force)
+        off = 0
+        for x, g in zip(xs, gxd):
+            c = x.shape[-1]
+            assert rel_err(g, gx[..., off:off + c]) < tol, ("dx", force, off)
+            off += c
+
+
+def test_conv_mfma_large_k_and_batch(dev):
+    """A res3-like layer: 27 taps x 512 channels (K = 13,824) in bf16, two samples."""
+    k, s = (3, 3, 3), (1, 1, 1)
+    xs = [rnd((2, 4, 6, 6, 256), 1).bfloat16().float(), rnd((2, 4, 6, 6, 256), 2).bfloat16().float()]
+    w = rnd((*k, 512, 64), 3, 1.0 / (27 * 512) ** 0.5)
+    yo = O.conv3d_same(torch.cat(xs, -1).double(), w.double(), None, s)
+    y = ops.conv3d_same([x.to(dev, torch.bfloat16) for x in xs], w.to(dev), None, k, s)
+    assert rel_err(y, yo) < 2e-2
