@@ -68,8 +68,12 @@ size_t m1_conv_ws_bytes(const m1_conv_desc_t* d, int transposed, int role);
 int m1_conv3d_fwd(const m1_conv_desc_t* d, const float* w, const float* bias, void* y, void* ws, void* stream);
 /* dx[i]: gradient buffer of concat member i (same shape/dtype as src[i]) or NULL to skip it. */
 int m1_conv3d_dgrad(const m1_conv_desc_t* d, const float* w, const void* dy, void* const* dx, void* ws, void* stream);
-/* dw (kd,kh,kw,Cin,Cout) and db (Cout) are OVERWRITTEN (zeroed inside, then accumulated). */
-int m1_conv3d_wgrad(const m1_conv_desc_t* d, const void* dy, float* dw, float* db, void* ws, void* stream);
+/* dw (kd,kh,kw,Cin,Cout) and db (Cout): accumulate == 0 -> overwritten (zeroed inside first);
+ * accumulate != 0 -> added to what is there (the caller's flat gradient buffer, zeroed once per step: a weight
+ * shared by several passes -- prior / posterior cores run twice per step -- sums without any extra copy). The
+ * same flag has the same meaning on every other parameter-gradient output of this ABI. */
+int m1_conv3d_wgrad(const m1_conv_desc_t* d, const void* dy, float* dw, float* db, void* ws, int accumulate,
+                    void* stream);
 /* test hook: 1 = route every conv through the generic direct kernels (no matrix cores). */
 int m1_set_force_direct(int on);
 
@@ -77,7 +81,8 @@ int m1_set_force_direct(int on);
  * w: Keras layout (kd,kh,kw,Cout,Cin) fp32; y: (N, D*sd, H*sh, W*sw, Cout). */
 int m1_convT3d_fwd(const m1_conv_desc_t* d, const float* w, const float* bias, void* y, void* ws, void* stream);
 int m1_convT3d_dgrad(const m1_conv_desc_t* d, const float* w, const void* dy, void* const* dx, void* ws, void* stream);
-int m1_convT3d_wgrad(const m1_conv_desc_t* d, const void* dy, float* dw, float* db, void* ws, void* stream);
+int m1_convT3d_wgrad(const m1_conv_desc_t* d, const void* dy, float* dw, float* db, void* ws, int accumulate,
+                     void* stream);
 
 /* ---- tfa.layers.InstanceNormalization (eps 1e-3) [+ LeakyReLU(slope)] : B:38,40,42,44,54-60,104,128;
  *      N:473,575-576.  x,y: (N,V,C).  stats: (N,C,2) fp32 = {mean, rstd}.
@@ -87,10 +92,10 @@ int m1_instnorm_stats(const void* x, int N, long long V, int C, int dtype, float
                       void* stream);
 int m1_instnorm_apply(const void* x, const float* stats, const float* gamma, const float* beta, float slope,
                       void* y, int N, long long V, int C, int dtype, void* stream);
-/* dy = grad wrt the (activated) output; writes dx (grad wrt raw x), dgamma, dbeta (C, overwritten). */
+/* dy = grad wrt the (activated) output; writes dx (grad wrt raw x); dgamma, dbeta (C): see `accumulate`. */
 int m1_instnorm_bwd(const void* x, const float* stats, const float* gamma, const float* beta, float slope,
                     const void* dy, void* dx, float* dgamma, float* dbeta, int N, long long V, int C, int dtype,
-                    float* ws, void* stream);
+                    float* ws, int accumulate, void* stream);
 
 /* ---- SE gate + multiplicative residual combine : B:68-78 ----
  * gate: g = sigmoid(W7 . lrelu(W6 . beta3 + b6) + b7)  (GAP(IN3(.)) == beta3 exactly).
@@ -99,7 +104,7 @@ int m1_se_gate_fwd(const float* beta3, const float* W6, const float* b6, const f
                    int F, int Fr, float* hidden, float* g, void* stream);
 int m1_se_gate_bwd(const float* beta3, const float* W6, const float* W7, const float* hidden, const float* g,
                    const float* dg, int F, int Fr, float* dbeta3_add, float* dW6, float* db6, float* dW7,
-                   float* db7, void* stream);
+                   float* db7, int accumulate, void* stream);
 /* out = dropout( lrelu( IN3(y3) * g * IN4(y4) ) ); y3,y4 raw conv outputs (N,V,F); stats3/4 (N,F,2).
  * Dropout state is DEVICE resident so a captured graph can be replayed: rng[0] = seed, rng[1] = step
  * counter (advanced by m1_step_advance); layer_id separates the streams of different layers. The mask is
@@ -108,13 +113,15 @@ int m1_se_combine_fwd(const void* y3, const void* y4, const float* stats3, const
                       const float* gamma3, const float* beta3, const float* gamma4, const float* beta4,
                       const float* g, void* out, int N, long long V, int F, int dtype, float drop_rate,
                       const uint64_t* rng, uint64_t layer_id, void* stream);
-/* writes dy3, dy4 (grads wrt the RAW conv outputs, i.e. through both InstanceNorms), and overwrites
- * dgamma3,dbeta3,dgamma4,dbeta4,dg (F each).  ws: m1_reduce_ws_floats(N,V,F,5). */
+/* writes dy3, dy4 (grads wrt the RAW conv outputs, i.e. through both InstanceNorms); dgamma3,dbeta3,dgamma4,
+ * dbeta4 (F each) per `accumulate`; dg (F) is scratch for m1_se_gate_bwd and always overwritten.
+ * ws: m1_reduce_ws_floats(N,V,F,5). */
 int m1_se_combine_bwd(const void* y3, const void* y4, const float* stats3, const float* stats4,
                       const float* gamma3, const float* beta3, const float* gamma4, const float* beta4,
                       const float* g, const void* dout, void* dy3, void* dy4, float* dgamma3, float* dbeta3,
                       float* dgamma4, float* dbeta4, float* dg, int N, long long V, int F, int dtype,
-                      float drop_rate, const uint64_t* rng, uint64_t layer_id, float* ws, void* stream);
+                      float drop_rate, const uint64_t* rng, uint64_t layer_id, float* ws, int accumulate,
+                      void* stream);
 
 /* ---- grid attention gate pieces : B:113-124 ----
  * theta: (N, Dt,Ht,Wt, C) ; phi: (N, Dp,Hp,Wp, C) nearest-upsampled by (Dt/Dp,...) ;
@@ -125,7 +132,8 @@ int m1_gate_sigma_fwd(const void* theta, const void* phi, const float* wpsi, con
  * ws: m1_reduce_ws_floats(N, Dt*Ht*Wt, C, 2) floats */
 int m1_gate_sigma_bwd(const void* theta, const void* phi, const float* wpsi, const void* sigma,
                       const void* dsigma, void* dtheta, void* dphi, float* dwpsi, float* dbpsi, int N, int Dt,
-                      int Ht, int Wt, int Dp, int Hp, int Wp, int C, int dtype, float* ws, void* stream);
+                      int Ht, int Wt, int Dp, int Hp, int Wp, int C, int dtype, float* ws, int accumulate,
+                      void* stream);
 /* y = sigma_up * x : x (N,D,H,W,C), sigma (N,D/ss0,H/ss1,W/ss2) */
 int m1_mul_sigma_fwd(const void* x, const void* sigma, void* y, int N, int D, int H, int W, int C, int s0,
                      int s1, int s2, int dtype, void* stream);

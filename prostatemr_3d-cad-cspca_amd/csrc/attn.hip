@@ -81,13 +81,13 @@ struct GateWF {
     }
 };
 __global__ void gate_w_finalize_kernel(const float* __restrict__ sums /*[N][C][2]*/, int N, int C,
-                                       float* __restrict__ dwpsi, float* __restrict__ dbpsi) {
+                                       float* __restrict__ dwpsi, float* __restrict__ dbpsi, int acc) {
     int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
     double s = 0.0, b = 0.0;
     for (int n = 0; n < N; ++n) { s += sums[((size_t)n * C + c) * 2]; b += sums[((size_t)n * C + c) * 2 + 1]; }
-    dwpsi[c] = (float)s;
-    if (c == 0) dbpsi[0] = (float)b;
+    dwpsi[c] = (acc ? dwpsi[c] : 0.f) + (float)s;
+    if (c == 0) dbpsi[0] = (acc ? dbpsi[0] : 0.f) + (float)b;
 }
 
 // dphi[n,p,c] = sum_{v in window(p)} dtheta[n,v,c]
@@ -137,7 +137,7 @@ static int gate_fwd_impl(const void* theta, const void* phi, const float* wpsi, 
 
 template <typename T>
 static int gate_bwd_impl(const void* theta, const void* phi, const float* wpsi, const void* sigma, const void* dsigma,
-                         void* dtheta, void* dphi, float* dwpsi, float* dbpsi, const Geo& g, float* ws, hipStream_t st) {
+                         void* dtheta, void* dphi, float* dwpsi, float* dbpsi, const Geo& g, float* ws, hipStream_t st, int acc) {
     constexpr int VW = sizeof(T) == 2 ? 8 : 4;
     const long long Vt = (long long)g.Dt * g.Ht * g.Wt, Vp = (long long)g.Dp * g.Hp * g.Wp;
     if (g.C % VW == 0) {
@@ -157,7 +157,7 @@ static int gate_bwd_impl(const void* theta, const void* phi, const float* wpsi, 
     const int nchunks = m1_red_nchunks(Vt, g.C);
     float* sums = ws + (size_t)g.N * nchunks * g.C * 2;
     rc = m1_reduce_finalize_launch<2>(ws, g.N, g.C, nchunks, sums, 0, 0.f, st); if (rc) return rc;
-    hipLaunchKernelGGL(gate_w_finalize_kernel, dim3((g.C + 255) / 256), dim3(256), 0, st, sums, g.N, g.C, dwpsi, dbpsi);
+    hipLaunchKernelGGL(gate_w_finalize_kernel, dim3((g.C + 255) / 256), dim3(256), 0, st, sums, g.N, g.C, dwpsi, dbpsi, acc);
     return m1_check_launch();
 }
 
@@ -179,13 +179,14 @@ extern "C" int m1_gate_sigma_fwd(const void* theta, const void* phi, const float
 
 extern "C" int m1_gate_sigma_bwd(const void* theta, const void* phi, const float* wpsi, const void* sigma,
                                  const void* dsigma, void* dtheta, void* dphi, float* dwpsi, float* dbpsi, int N, int Dt,
-                                 int Ht, int Wt, int Dp, int Hp, int Wp, int C, int dtype, float* ws, void* stream) {
+                                 int Ht, int Wt, int Dp, int Hp, int Wp, int C, int dtype, float* ws, int accumulate,
+                                 void* stream) {
     if (!theta || !phi || !wpsi || !sigma || !dsigma || !dtheta || !dphi || !dwpsi || !dbpsi || !ws) return M1_ERR_BAD_ARG;
     Geo g; int rc = make_geo(g, N, Dt, Ht, Wt, Dp, Hp, Wp, C); if (rc) return rc;
     M1ProfScope ps("gate_sigma_bwd", 0.0, 4.0 * N * Dt * Ht * Wt * C * (dtype == M1_BF16 ? 2 : 4), (hipStream_t)stream);
     return dtype == M1_BF16
-               ? gate_bwd_impl<bf16_t>(theta, phi, wpsi, sigma, dsigma, dtheta, dphi, dwpsi, dbpsi, g, ws, (hipStream_t)stream)
-               : gate_bwd_impl<float>(theta, phi, wpsi, sigma, dsigma, dtheta, dphi, dwpsi, dbpsi, g, ws, (hipStream_t)stream);
+               ? gate_bwd_impl<bf16_t>(theta, phi, wpsi, sigma, dsigma, dtheta, dphi, dwpsi, dbpsi, g, ws, (hipStream_t)stream, accumulate)
+               : gate_bwd_impl<float>(theta, phi, wpsi, sigma, dsigma, dtheta, dphi, dwpsi, dbpsi, g, ws, (hipStream_t)stream, accumulate);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -169,10 +169,11 @@ extern "C" int m1_convT3d_dgrad(const m1_conv_desc_t* d, const float* w, const v
 }
 
 // ---- weight gradients ------------------------------------------------------------------------------------------
-static int wgrad_common(const m1_conv_desc_t* d, bool T, const void* dy, float* dw, float* db, void* ws, hipStream_t st) {
+static int wgrad_common(const m1_conv_desc_t* d, bool T, const void* dy, float* dw, float* db, void* ws, hipStream_t st,
+                        int accumulate) {
     Geo q = T ? convT_geo(d) : conv_geo(d);
     const size_t nw = (size_t)d->kd * d->kh * d->kw * d->Cin * d->Cout;
-    if (hipMemsetAsync(dw, 0, nw * sizeof(float), st) != hipSuccess) return M1_ERR_LAUNCH;
+    if (!accumulate && hipMemsetAsync(dw, 0, nw * sizeof(float), st) != hipSuccess) return M1_ERR_LAUNCH;
     int off = 0;
     for (int i = 0; i < d->nsrc; ++i) {
         WgradSpec g{};
@@ -193,17 +194,19 @@ static int wgrad_common(const m1_conv_desc_t* d, bool T, const void* dy, float* 
     }
     if (db) {
         if (!ws) return M1_ERR_WORKSPACE;
-        return m1_colsum_internal(dy, d->N, (long long)q.OD * q.OH * q.OW, d->Cout, d->dtype, db, (float*)ws, st);
+        return m1_colsum_internal(dy, d->N, (long long)q.OD * q.OH * q.OW, d->Cout, d->dtype, db, (float*)ws, st, accumulate);
     }
     return M1_OK;
 }
-extern "C" int m1_conv3d_wgrad(const m1_conv_desc_t* d, const void* dy, float* dw, float* db, void* ws, void* stream) {
+extern "C" int m1_conv3d_wgrad(const m1_conv_desc_t* d, const void* dy, float* dw, float* db, void* ws, int accumulate,
+                               void* stream) {
     if (!desc_ok(d) || !dy || !dw) return M1_ERR_BAD_ARG;
     M1ProfScope ps("conv3d_wgrad", 2.0 * conv_macs(d, false), conv_bytes(d, false), (hipStream_t)stream);
-    return wgrad_common(d, false, dy, dw, db, ws, (hipStream_t)stream);
+    return wgrad_common(d, false, dy, dw, db, ws, (hipStream_t)stream, accumulate);
 }
-extern "C" int m1_convT3d_wgrad(const m1_conv_desc_t* d, const void* dy, float* dw, float* db, void* ws, void* stream) {
+extern "C" int m1_convT3d_wgrad(const m1_conv_desc_t* d, const void* dy, float* dw, float* db, void* ws, int accumulate,
+                                void* stream) {
     if (!desc_ok(d) || !dy || !dw) return M1_ERR_BAD_ARG;
     M1ProfScope ps("convT3d_wgrad", 2.0 * conv_macs(d, true), conv_bytes(d, true), (hipStream_t)stream);
-    return wgrad_common(d, true, dy, dw, db, ws, (hipStream_t)stream);
+    return wgrad_common(d, true, dy, dw, db, ws, (hipStream_t)stream, accumulate);
 }

@@ -144,18 +144,18 @@ __global__ void __launch_bounds__(256) in_bwd_apply_kernel(const T* __restrict__
 
 // dgamma[c] = sum_n sums[n][c][1], dbeta[c] = sum_n sums[n][c][0]
 __global__ void in_bwd_param_kernel(const float* __restrict__ sums, int N, int C, float* __restrict__ dgamma,
-                                    float* __restrict__ dbeta) {
+                                    float* __restrict__ dbeta, int accumulate) {
     int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
     double g = 0.0, b = 0.0;
     for (int n = 0; n < N; ++n) { b += sums[((size_t)n * C + c) * 2]; g += sums[((size_t)n * C + c) * 2 + 1]; }
-    dgamma[c] = (float)g; dbeta[c] = (float)b;
+    dgamma[c] = (accumulate ? dgamma[c] : 0.f) + (float)g; dbeta[c] = (accumulate ? dbeta[c] : 0.f) + (float)b;
 }
 
 template <typename T>
 static int bwd_impl(const void* x, const float* stats, const float* gamma, const float* beta, float slope,
                     const void* dy, void* dx, float* dgamma, float* dbeta, int N, long long V, int C, float* ws,
-                    hipStream_t st) {
+                    hipStream_t st, int accumulate) {
     InBwdF<T> f{(const T*)x, (const T*)dy, stats, gamma, beta, slope, V, C};
     int rc = m1_reduce_nc_launch<2>(f, N, V, C, ws, st);
     if (rc) return rc;
@@ -163,7 +163,7 @@ static int bwd_impl(const void* x, const float* stats, const float* gamma, const
     float* sums = ws + (size_t)N * nchunks * C * 2;
     rc = m1_reduce_finalize_launch<2>(ws, N, C, nchunks, sums, 0, 0.f, st);
     if (rc) return rc;
-    hipLaunchKernelGGL(in_bwd_param_kernel, dim3((C + 255) / 256), dim3(256), 0, st, sums, N, C, dgamma, dbeta);
+    hipLaunchKernelGGL(in_bwd_param_kernel, dim3((C + 255) / 256), dim3(256), 0, st, sums, N, C, dgamma, dbeta, accumulate);
     constexpr int VW = sizeof(T) == 2 ? 8 : 4;
     if (C % VW == 0) {
         long long per = V * (C / VW);
@@ -181,12 +181,12 @@ static int bwd_impl(const void* x, const float* stats, const float* gamma, const
 
 extern "C" int m1_instnorm_bwd(const void* x, const float* stats, const float* gamma, const float* beta, float slope,
                                const void* dy, void* dx, float* dgamma, float* dbeta, int N, long long V, int C,
-                               int dtype, float* ws, void* stream) {
+                               int dtype, float* ws, int accumulate, void* stream) {
     if (!x || !stats || !gamma || !beta || !dy || !dx || !dgamma || !dbeta || !ws) return M1_ERR_BAD_ARG;
     M1ProfScope ps("instnorm_bwd", 0.0, 5.0 * N * V * C * (dtype == M1_BF16 ? 2 : 4), (hipStream_t)stream);
     return dtype == M1_BF16
-               ? bwd_impl<bf16_t>(x, stats, gamma, beta, slope, dy, dx, dgamma, dbeta, N, V, C, ws, (hipStream_t)stream)
-               : bwd_impl<float>(x, stats, gamma, beta, slope, dy, dx, dgamma, dbeta, N, V, C, ws, (hipStream_t)stream);
+               ? bwd_impl<bf16_t>(x, stats, gamma, beta, slope, dy, dx, dgamma, dbeta, N, V, C, ws, (hipStream_t)stream, accumulate)
+               : bwd_impl<float>(x, stats, gamma, beta, slope, dy, dx, dgamma, dbeta, N, V, C, ws, (hipStream_t)stream, accumulate);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -200,11 +200,11 @@ struct ColSumF {
     }
 };
 // Internal (used by conv wgrad): ws must hold N*nchunks*C floats.
-int m1_colsum_internal(const void* x, int N, long long V, int C, int dtype, float* out, float* ws, hipStream_t st) {
+int m1_colsum_internal(const void* x, int N, long long V, int C, int dtype, float* out, float* ws, hipStream_t st, int accumulate) {
     int rc;
     if (dtype == M1_BF16) { ColSumF<bf16_t> f{(const bf16_t*)x, V, C}; rc = m1_reduce_nc_launch<1>(f, N, V, C, ws, st); }
     else { ColSumF<float> f{(const float*)x, V, C}; rc = m1_reduce_nc_launch<1>(f, N, V, C, ws, st); }
     if (rc) return rc;
     // partial is [N*nchunks][C][1]: fold all rows as one sample
-    return m1_reduce_finalize_launch<1>(ws, 1, C, N * m1_red_nchunks(V, C), out, 0, 0.f, st);
+    return m1_reduce_finalize_launch<1>(ws, 1, C, N * m1_red_nchunks(V, C), out, 0, 0.f, st, accumulate);
 }

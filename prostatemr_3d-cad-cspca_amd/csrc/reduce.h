@@ -61,7 +61,8 @@ __global__ void __launch_bounds__(M1_RED_THREADS) m1_reduce_nc_kernel(F f, long 
 // stats_V > 0 (NS == 2 only): writes {mean, rstd} computed in fp64 from (sum, sum of squares) instead.
 template <int NS>
 __global__ void __launch_bounds__(256) m1_reduce_finalize_kernel(const float* __restrict__ partial, int N, int C, int nchunks,
-                                                                 float* __restrict__ out, long long stats_V, float eps) {
+                                                                 float* __restrict__ out, long long stats_V, float eps,
+                                                                 int accumulate) {
     const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (i >= N * C) return;
     const int n = i / C, c = i % C;
@@ -82,15 +83,15 @@ __global__ void __launch_bounds__(256) m1_reduce_finalize_kernel(const float* __
             out[(size_t)i * NS + NS - 1] = (float)(1.0 / sqrt(var + (double)eps));
         } else {
 #pragma unroll
-            for (int k = 0; k < NS; ++k) out[(size_t)i * NS + k] = (float)s[k];
+            for (int k = 0; k < NS; ++k) out[(size_t)i * NS + k] = (accumulate ? out[(size_t)i * NS + k] : 0.f) + (float)s[k];
         }
     }
 }
 template <int NS>
 static inline int m1_reduce_finalize_launch(const float* partial, int N, int C, int nchunks, float* out, long long stats_V,
-                                            float eps, hipStream_t st) {
+                                            float eps, hipStream_t st, int accumulate = 0) {
     hipLaunchKernelGGL((m1_reduce_finalize_kernel<NS>), dim3((N * C + 3) / 4), dim3(256), 0, st, partial, N, C, nchunks, out,
-                       stats_V, eps);
+                       stats_V, eps, accumulate);
     return m1_check_launch();
 }
 

@@ -36,12 +36,12 @@ __global__ void __launch_bounds__(256) se_gate_bwd_kernel(const float* __restric
                                                           const float* __restrict__ g, const float* __restrict__ dg, int F,
                                                           int Fr, float* __restrict__ dbeta3_add, float* __restrict__ dW6,
                                                           float* __restrict__ db6, float* __restrict__ dW7,
-                                                          float* __restrict__ db7) {
+                                                          float* __restrict__ db7, int acc) {
     __shared__ float dgp_s[SE_MAX_F];
     __shared__ float dh_s[SE_MAX_FR];
     for (int c = threadIdx.x; c < F; c += blockDim.x) {
         const float t = dg[c] * g[c] * (1.f - g[c]);
-        dgp_s[c] = t; db7[c] = t;
+        dgp_s[c] = t; db7[c] = (acc ? db7[c] : 0.f) + t;
     }
     __syncthreads();
     for (int j = threadIdx.x; j < Fr; j += blockDim.x) {
@@ -49,17 +49,17 @@ __global__ void __launch_bounds__(256) se_gate_bwd_kernel(const float* __restric
         float s = 0.f;
         for (int c = 0; c < F; ++c) {
             s = fmaf(W7[(size_t)j * F + c], dgp_s[c], s);
-            dW7[(size_t)j * F + c] = h * dgp_s[c];
+            dW7[(size_t)j * F + c] = (acc ? dW7[(size_t)j * F + c] : 0.f) + h * dgp_s[c];
         }
         const float dhid = s * lrelu_g(hidden[j], 0.1f);
-        dh_s[j] = dhid; db6[j] = dhid;
+        dh_s[j] = dhid; db6[j] = (acc ? db6[j] : 0.f) + dhid;
     }
     __syncthreads();
     for (int c = threadIdx.x; c < F; c += blockDim.x) {
         float s = 0.f;
         for (int j = 0; j < Fr; ++j) {
             s = fmaf(W6[(size_t)c * Fr + j], dh_s[j], s);
-            dW6[(size_t)c * Fr + j] = beta3[c] * dh_s[j];
+            dW6[(size_t)c * Fr + j] = (acc ? dW6[(size_t)c * Fr + j] : 0.f) + beta3[c] * dh_s[j];
         }
         dbeta3_add[c] += s;
     }
@@ -74,11 +74,11 @@ extern "C" int m1_se_gate_fwd(const float* beta3, const float* W6, const float* 
 }
 extern "C" int m1_se_gate_bwd(const float* beta3, const float* W6, const float* W7, const float* hidden, const float* g,
                               const float* dg, int F, int Fr, float* dbeta3_add, float* dW6, float* db6, float* dW7,
-                              float* db7, void* stream) {
+                              float* db7, int accumulate, void* stream) {
     if (!beta3 || !W6 || !W7 || !hidden || !g || !dg || !dbeta3_add || !dW6 || !db6 || !dW7 || !db7) return M1_ERR_BAD_ARG;
     if (F > SE_MAX_F || Fr > SE_MAX_FR) return M1_ERR_UNSUPPORTED;
     hipLaunchKernelGGL(se_gate_bwd_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, beta3, W6, W7, hidden, g, dg, F, Fr,
-                       dbeta3_add, dW6, db6, dW7, db7);
+                       dbeta3_add, dW6, db6, dW7, db7, accumulate);
     return m1_check_launch();
 }
 
@@ -181,13 +181,15 @@ __global__ void __launch_bounds__(256) se_combine_bwd_apply_kernel(const T* __re
 
 __global__ void se_bwd_param_kernel(const float* __restrict__ sums, int N, int F, float* __restrict__ dgamma3,
                                     float* __restrict__ dbeta3, float* __restrict__ dgamma4, float* __restrict__ dbeta4,
-                                    float* __restrict__ dg) {
+                                    float* __restrict__ dg, int acc) {
     int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= F) return;
     double s[5] = {0, 0, 0, 0, 0};
     for (int n = 0; n < N; ++n)
         for (int k = 0; k < 5; ++k) s[k] += sums[((size_t)n * F + c) * 5 + k];
-    dbeta3[c] = (float)s[0]; dgamma3[c] = (float)s[1]; dbeta4[c] = (float)s[2]; dgamma4[c] = (float)s[3]; dg[c] = (float)s[4];
+    dbeta3[c] = (acc ? dbeta3[c] : 0.f) + (float)s[0]; dgamma3[c] = (acc ? dgamma3[c] : 0.f) + (float)s[1];
+    dbeta4[c] = (acc ? dbeta4[c] : 0.f) + (float)s[2]; dgamma4[c] = (acc ? dgamma4[c] : 0.f) + (float)s[3];
+    dg[c] = (float)s[4];     // dg is scratch for the gate backward: always overwritten
 }
 
 static inline int grid_x(long long per) { long long g = cdiv_ll(per, 256); return (int)(g > 4096 ? 4096 : (g < 1 ? 1 : g)); }
@@ -207,7 +209,7 @@ static int se_fwd_impl(const void* y3, const void* y4, const SeParams& p, void* 
 template <typename T>
 static int se_bwd_impl(const void* y3, const void* y4, const void* dout, const SeParams& p, void* dy3, void* dy4,
                        float* dgamma3, float* dbeta3, float* dgamma4, float* dbeta4, float* dg, int N, float* ws,
-                       hipStream_t st) {
+                       hipStream_t st, int acc) {
     SeBwdF<T> f{(const T*)y3, (const T*)y4, (const T*)dout, p};
     int rc = m1_reduce_nc_launch<5>(f, N, p.V, p.F, ws, st);
     if (rc) return rc;
@@ -216,7 +218,7 @@ static int se_bwd_impl(const void* y3, const void* y4, const void* dout, const S
     rc = m1_reduce_finalize_launch<5>(ws, N, p.F, nchunks, sums, 0, 0.f, st);
     if (rc) return rc;
     hipLaunchKernelGGL(se_bwd_param_kernel, dim3((p.F + 255) / 256), dim3(256), 0, st, sums, N, p.F, dgamma3, dbeta3, dgamma4,
-                       dbeta4, dg);
+                       dbeta4, dg, acc);
     constexpr int VW = sizeof(T) == 2 ? 8 : 4;
     if (p.F % VW == 0)
         hipLaunchKernelGGL((se_combine_bwd_apply_kernel<T, VW>), dim3(grid_x(p.V * (p.F / VW)), N), dim3(256), 0, st,
@@ -244,12 +246,13 @@ extern "C" int m1_se_combine_bwd(const void* y3, const void* y4, const float* st
                                  const float* gamma3, const float* beta3, const float* gamma4, const float* beta4,
                                  const float* g, const void* dout, void* dy3, void* dy4, float* dgamma3, float* dbeta3,
                                  float* dgamma4, float* dbeta4, float* dg, int N, long long V, int F, int dtype,
-                                 float drop_rate, const uint64_t* rng, uint64_t layer_id, float* ws, void* stream) {
+                                 float drop_rate, const uint64_t* rng, uint64_t layer_id, float* ws, int accumulate,
+                                 void* stream) {
     if (!y3 || !y4 || !dout || !dy3 || !dy4 || !dgamma3 || !dbeta3 || !dgamma4 || !dbeta4 || !dg || !ws) return M1_ERR_BAD_ARG;
     if (drop_rate > 0.f && !rng) return M1_ERR_BAD_ARG;
     SeParams p{stats3, stats4, gamma3, beta3, gamma4, beta4, g, V, F, drop_rate, rng, layer_id};
     M1ProfScope ps("se_combine_bwd", 0.0, 8.0 * N * V * F * (dtype == M1_BF16 ? 2 : 4), (hipStream_t)stream);
     return dtype == M1_BF16
-               ? se_bwd_impl<bf16_t>(y3, y4, dout, p, dy3, dy4, dgamma3, dbeta3, dgamma4, dbeta4, dg, N, ws, (hipStream_t)stream)
-               : se_bwd_impl<float>(y3, y4, dout, p, dy3, dy4, dgamma3, dbeta3, dgamma4, dbeta4, dg, N, ws, (hipStream_t)stream);
+               ? se_bwd_impl<bf16_t>(y3, y4, dout, p, dy3, dy4, dgamma3, dbeta3, dgamma4, dbeta4, dg, N, ws, (hipStream_t)stream, accumulate)
+               : se_bwd_impl<float>(y3, y4, dout, p, dy3, dy4, dgamma3, dbeta3, dgamma4, dbeta4, dg, N, ws, (hipStream_t)stream, accumulate);
 }

@@ -68,6 +68,17 @@ def _desc(srcs: Sequence[torch.Tensor], cout: int, k, s) -> L.m1_conv_desc_t:
     return d
 
 
+def _sink(param: torch.Tensor, like: Optional[torch.Tensor] = None):
+    """(buffer, accumulate, autograd_return) for a parameter gradient.  A parameter bound to an optimiser's flat
+    gradient buffer (optim.FlatParams sets ``_m1_gsink``) gets its gradient ACCUMULATED there by the kernel and
+    autograd receives None (no per-parameter tensors, no AccumulateGrad adds, no gather pass)."""
+    g = getattr(param, "_m1_gsink", None)
+    if g is not None:
+        return g, 1, None
+    t = torch.empty_like(param if like is None else like, dtype=torch.float32)
+    return t, 0, t
+
+
 def _conv_ws(d, transposed: bool, role: int, device) -> torch.Tensor:
     n = L.load().m1_conv_ws_bytes(C.byref(d), 1 if transposed else 0, role)
     return torch.empty(max(int(n), 256), dtype=torch.uint8, device=device)
@@ -100,6 +111,7 @@ class _Conv3d(torch.autograd.Function):
         ws = _conv_ws(d, transposed, 0, x0.device)
         L.check(fn(C.byref(d), _p(w), _p(b), _p(y), _p(ws), _stream()), "m1_convT3d_fwd" if transposed else "m1_conv3d_fwd")
         ctx.save_for_backward(w, *srcs)
+        ctx.w_param, ctx.b_param = w, b
         ctx.k, ctx.s, ctx.transposed, ctx.has_bias, ctx.cout = tuple(k), tuple(s), transposed, b is not None, cout
         return y
 
@@ -114,11 +126,17 @@ class _Conv3d(torch.autograd.Function):
         name = "convT3d" if ctx.transposed else "conv3d"
         dw = db = None
         if ctx.needs_input_grad[0] or (ctx.has_bias and ctx.needs_input_grad[1]):
-            dw = torch.empty_like(w)
-            db = torch.empty(ctx.cout, dtype=torch.float32, device=w.device) if ctx.has_bias else None
+            wbuf, acc_w, dw = _sink(ctx.w_param)
+            bbuf = None
+            if ctx.has_bias:
+                bbuf, acc_b, db = _sink(ctx.b_param)
+                if acc_b != acc_w:      # both or neither live in the flat buffer; otherwise fall back to temporaries
+                    wbuf, acc_w, dw = torch.empty_like(w), 0, None
+                    bbuf, db = torch.empty(ctx.cout, dtype=torch.float32, device=w.device), None
+                    dw, db = wbuf, bbuf
             ws = _conv_ws(d, ctx.transposed, 2, w.device)
             fn = lib.m1_convT3d_wgrad if ctx.transposed else lib.m1_conv3d_wgrad
-            L.check(fn(C.byref(d), _p(dy), _p(dw), _p(db), _p(ws), st), f"m1_{name}_wgrad")
+            L.check(fn(C.byref(d), _p(dy), _p(wbuf), _p(bbuf), _p(ws), acc_w, st), f"m1_{name}_wgrad")
         dsrc: List[Optional[torch.Tensor]] = []
         ptrs = (C.c_void_p * len(srcs))()
         any_d = False
@@ -176,6 +194,7 @@ class _InstNormAct(torch.autograd.Function):
         L.check(L.load().m1_instnorm_apply(_p(x), _p(stats), _p(gamma), _p(beta), float(slope), _p(y), N, V, Cn, _dt(x),
                                            _stream()), "m1_instnorm_apply")
         ctx.save_for_backward(x, stats, gamma, beta)
+        ctx.g_param, ctx.b_param = gamma, beta
         ctx.slope = float(slope)
         return y
 
@@ -186,11 +205,14 @@ class _InstNormAct(torch.autograd.Function):
         N, Cn = int(x.shape[0]), int(x.shape[-1])
         V = x.numel() // (N * Cn)
         dx = torch.empty_like(x)
-        dg = torch.empty_like(gamma)
-        db = torch.empty_like(beta)
+        gbuf, acc, dg = _sink(ctx.g_param)
+        bbuf, acc2, db = _sink(ctx.b_param)
+        if acc != acc2:
+            gbuf, bbuf, acc = torch.empty_like(gamma), torch.empty_like(beta), 0
+            dg, db = gbuf, bbuf
         ws = _ws(N, V, Cn, 2, x.device)
-        L.check(L.load().m1_instnorm_bwd(_p(x), _p(stats), _p(gamma), _p(beta), ctx.slope, _p(dy), _p(dx), _p(dg), _p(db),
-                                         N, V, Cn, _dt(x), _p(ws), _stream()), "m1_instnorm_bwd")
+        L.check(L.load().m1_instnorm_bwd(_p(x), _p(stats), _p(gamma), _p(beta), ctx.slope, _p(dy), _p(dx), _p(gbuf), _p(bbuf),
+                                         N, V, Cn, _dt(x), _p(ws), acc, _stream()), "m1_instnorm_bwd")
         return dx, dg, db, None
 
 
@@ -219,6 +241,7 @@ class _SECombine(torch.autograd.Function):
         L.check(lib.m1_se_combine_fwd(_p(y3), _p(y4), _p(s3), _p(s4), _p(g3), _p(b3), _p(g4), _p(b4), _p(g), _p(out), N, V, Fn,
                                       _dt(y3), float(drop_rate), _p(rng), int(layer_id), st), "m1_se_combine_fwd")
         ctx.save_for_backward(y3, y4, s3, s4, g3, b3, g4, b4, W6, W7, hidden, g)
+        ctx.params = (g3, b3, g4, b4, W6, b6, W7, b7)
         ctx.rng, ctx.drop_rate, ctx.layer_id = rng, float(drop_rate), int(layer_id)
         return out
 
@@ -233,17 +256,20 @@ class _SECombine(torch.autograd.Function):
         st = _stream()
         dev = y3.device
         dy3, dy4 = torch.empty_like(y3), torch.empty_like(y4)
-        dg3, db3, dg4, db4, dg = (torch.empty(Fn, dtype=torch.float32, device=dev) for _ in range(5))
+        sinks = [_sink(p) for p in ctx.params]
+        acc = sinks[0][1]
+        if any(sk[1] != acc for sk in sinks):
+            sinks = [(t, 0, t) for t in (torch.empty_like(p, dtype=torch.float32) for p in ctx.params)]
+            acc = 0
+        (bg3, _, rg3), (bb3, _, rb3), (bg4, _, rg4), (bb4, _, rb4), (bW6, _, rW6), (bb6, _, rb6), (bW7, _, rW7), (bb7, _, rb7) = sinks
+        dg = torch.empty(Fn, dtype=torch.float32, device=dev)
         ws = _ws(N, V, Fn, 5, dev)
         L.check(lib.m1_se_combine_bwd(_p(y3), _p(y4), _p(s3), _p(s4), _p(g3), _p(b3), _p(g4), _p(b4), _p(g), _p(dout),
-                                      _p(dy3), _p(dy4), _p(dg3), _p(db3), _p(dg4), _p(db4), _p(dg), N, V, Fn, _dt(y3),
-                                      ctx.drop_rate, _p(ctx.rng), ctx.layer_id, _p(ws), st), "m1_se_combine_bwd")
-        dW6, dW7 = torch.empty_like(W6), torch.empty_like(W7)
-        db6 = torch.empty(Fr, dtype=torch.float32, device=dev)
-        db7 = torch.empty(Fn, dtype=torch.float32, device=dev)
-        L.check(lib.m1_se_gate_bwd(_p(b3), _p(W6), _p(W7), _p(hidden), _p(g), _p(dg), Fn, Fr, _p(db3), _p(dW6), _p(db6),
-                                   _p(dW7), _p(db7), st), "m1_se_gate_bwd")
-        return dy3, dy4, dg3, db3, dg4, db4, dW6, db6, dW7, db7, None, None, None
+                                      _p(dy3), _p(dy4), _p(bg3), _p(bb3), _p(bg4), _p(bb4), _p(dg), N, V, Fn, _dt(y3),
+                                      ctx.drop_rate, _p(ctx.rng), ctx.layer_id, _p(ws), acc, st), "m1_se_combine_bwd")
+        L.check(lib.m1_se_gate_bwd(_p(b3), _p(W6), _p(W7), _p(hidden), _p(g), _p(dg), Fn, Fr, _p(bb3), _p(bW6), _p(bb6),
+                                   _p(bW7), _p(bb7), acc, st), "m1_se_gate_bwd")
+        return dy3, dy4, rg3, rb3, rg4, rb4, rW6, rb6, rW7, rb7, None, None, None
 
 
 def se_combine(y3, y4, g3, b3, g4, b4, W6, b6, W7, b7, drop_rate=0.0, rng=None, layer_id=0):
@@ -264,6 +290,7 @@ class _GateSigma(torch.autograd.Function):
         L.check(L.load().m1_gate_sigma_fwd(_p(theta), _p(phi), _p(wpsi), _p(bpsi), _p(sigma), N, Dt, Ht, Wt, Dp, Hp, Wp, Cn,
                                            _dt(theta), _stream()), "m1_gate_sigma_fwd")
         ctx.save_for_backward(theta, phi, wpsi, sigma)
+        ctx.w_param, ctx.b_param = wpsi, bpsi
         return sigma
 
     @staticmethod
@@ -273,11 +300,14 @@ class _GateSigma(torch.autograd.Function):
         N, Dt, Ht, Wt, Cn = (int(v) for v in theta.shape)
         Dp, Hp, Wp = (int(v) for v in phi.shape[1:4])
         dtheta, dphi = torch.empty_like(theta), torch.empty_like(phi)
-        dw = torch.empty_like(wpsi)
-        db = torch.empty(1, dtype=torch.float32, device=theta.device)
+        wbuf, acc, dw = _sink(ctx.w_param)
+        bbuf, acc2, db = _sink(ctx.b_param)
+        if acc != acc2:
+            wbuf, bbuf, acc = torch.empty_like(wpsi), torch.empty(1, dtype=torch.float32, device=theta.device), 0
+            dw, db = wbuf, bbuf
         ws = _ws(N, Dt * Ht * Wt, Cn, 2, theta.device)
-        L.check(L.load().m1_gate_sigma_bwd(_p(theta), _p(phi), _p(wpsi), _p(sigma), _p(dsigma), _p(dtheta), _p(dphi), _p(dw),
-                                           _p(db), N, Dt, Ht, Wt, Dp, Hp, Wp, Cn, _dt(theta), _p(ws), _stream()),
+        L.check(L.load().m1_gate_sigma_bwd(_p(theta), _p(phi), _p(wpsi), _p(sigma), _p(dsigma), _p(dtheta), _p(dphi), _p(wbuf),
+                                           _p(bbuf), N, Dt, Ht, Wt, Dp, Hp, Wp, Cn, _dt(theta), _p(ws), acc, _stream()),
                 "m1_gate_sigma_bwd")
         return dtheta, dphi, dw, db
 

@@ -60,18 +60,22 @@ class FlatParams:
                 v.copy_(p.data)
                 p.data = v
                 self.views.append(v)
-                self.gviews.append(self.grad[off:off + n].view(p.shape))
+                gv = self.grad[off:off + n].view(p.shape)
+                self.gviews.append(gv)
+                p._m1_gsink = gv          # the HIP backward kernels accumulate this parameter's gradient here
                 off += n
 
-    def gather_grads(self):
-        """Copy the autograd .grad tensors into the flat gradient buffer (zeros where a parameter got none)."""
+    def zero_grad(self):
+        """One memset of the flat gradient buffer (the kernels accumulate into it during backward)."""
         self.grad.zero_()
-        dst, src = [], []
+
+    def gather_grads(self):
+        """Fold in gradients that reached a parameter through autograd's own .grad (a parameter used by a torch op
+        instead of a HIP kernel); the HIP path never takes this branch."""
         for p, gv in zip(self.params, self.gviews):
             if p.grad is not None:
-                dst.append(gv); src.append(p.grad)
-        if dst:
-            torch._foreach_copy_(dst, src)
+                gv.add_(p.grad)
+                p.grad = None
 
 
 class Adam:
@@ -119,6 +123,7 @@ class Adam:
     def zero_grad(self):
         for p in self.flatp.params:
             p.grad = None
+        self.flatp.zero_grad()
 
     def set_lr_device(self):
         self.lr_dev.fill_(self.lr)
