@@ -90,29 +90,46 @@ __global__ void gate_w_finalize_kernel(const float* __restrict__ sums /*[N][C][2
     if (c == 0) dbpsi[0] = (acc ? dbpsi[0] : 0.f) + (float)b;
 }
 
-// dphi[n,p,c] = sum_{v in window(p)} dtheta[n,v,c]
+// dphi[n,p,c] = sum_{v in window(p)} dtheta[n,v,c].  One block per coarse voxel: lanes = channel groups x window
+// lanes (the window is up to 4*16*16 = 1024 fine voxels at res0), folded through LDS.
 template <typename T, int VEC>
 __global__ void __launch_bounds__(256) window_sum_kernel(const T* __restrict__ dtheta, T* __restrict__ dphi, Geo g) {
+    __shared__ float red[256 * VEC];
     const long long Vp = (long long)g.Dp * g.Hp * g.Wp;
     const int cg = g.C / VEC;
-    const long long per = Vp * g.N * cg;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < per; i += (long long)gridDim.x * blockDim.x) {
-        const int c0 = (int)(i % cg) * VEC; const long long gp = i / cg;
+    int CGP = 1; while (CGP < cg && CGP < 256) CGP <<= 1;
+    const int WL = 256 / CGP, cl = threadIdx.x % CGP, wl = threadIdx.x / CGP;
+    const int win = g.ud * g.uh * g.uw;
+    for (long long gp = blockIdx.x; gp < Vp * g.N; gp += gridDim.x) {
         const int n = (int)(gp / Vp); long long r = gp % Vp;
         const int pw = (int)(r % g.Wp); r /= g.Wp; const int ph = (int)(r % g.Hp); const int pd = (int)(r / g.Hp);
-        float s[VEC];
+        for (int cb = 0; cb < cg; cb += CGP) {
+            const int c0 = (cb + cl) * VEC;
+            float s[VEC];
 #pragma unroll
-        for (int k = 0; k < VEC; ++k) s[k] = 0.f;
-        for (int a = 0; a < g.ud; ++a)
-            for (int b = 0; b < g.uh; ++b)
-                for (int e = 0; e < g.uw; ++e) {
+            for (int k = 0; k < VEC; ++k) s[k] = 0.f;
+            if (cb + cl < cg)
+                for (int wi = wl; wi < win; wi += WL) {
+                    const int e = wi % g.uw, b = (wi / g.uw) % g.uh, a = wi / (g.uw * g.uh);
                     const long long v = (((long long)n * g.Dt + pd * g.ud + a) * g.Ht + ph * g.uh + b) * g.Wt + pw * g.uw + e;
                     float t[VEC];
                     VecIO<T, VEC>::ld(dtheta + (size_t)v * g.C + c0, t);
 #pragma unroll
                     for (int k = 0; k < VEC; ++k) s[k] += t[k];
                 }
-        VecIO<T, VEC>::st(dphi + (size_t)gp * g.C + c0, s);
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) red[threadIdx.x * VEC + k] = s[k];
+            __syncthreads();
+            if (wl == 0 && cb + cl < cg) {
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) s[k] = 0.f;
+                for (int q = 0; q < WL; ++q)
+#pragma unroll
+                    for (int k = 0; k < VEC; ++k) s[k] += red[(q * CGP + cl) * VEC + k];
+                VecIO<T, VEC>::st(dphi + (size_t)gp * g.C + c0, s);
+            }
+            __syncthreads();
+        }
     }
 }
 
@@ -143,12 +160,12 @@ static int gate_bwd_impl(const void* theta, const void* phi, const float* wpsi, 
     if (g.C % VW == 0) {
         hipLaunchKernelGGL((gate_dtheta_kernel<T, VW>), dim3(gx_for(Vt * g.N * (g.C / VW))), dim3(256), 0, st, (const T*)theta,
                            (const T*)phi, wpsi, (const T*)sigma, (const T*)dsigma, (T*)dtheta, g);
-        hipLaunchKernelGGL((window_sum_kernel<T, VW>), dim3(gx_for(Vp * g.N * (g.C / VW))), dim3(256), 0, st, (const T*)dtheta,
+        hipLaunchKernelGGL((window_sum_kernel<T, VW>), dim3((unsigned)(Vp * g.N > 4096 ? 4096 : Vp * g.N)), dim3(256), 0, st, (const T*)dtheta,
                            (T*)dphi, g);
     } else {
         hipLaunchKernelGGL((gate_dtheta_kernel<T, 1>), dim3(gx_for(Vt * g.N * g.C)), dim3(256), 0, st, (const T*)theta,
                            (const T*)phi, wpsi, (const T*)sigma, (const T*)dsigma, (T*)dtheta, g);
-        hipLaunchKernelGGL((window_sum_kernel<T, 1>), dim3(gx_for(Vp * g.N * g.C)), dim3(256), 0, st, (const T*)dtheta,
+        hipLaunchKernelGGL((window_sum_kernel<T, 1>), dim3((unsigned)(Vp * g.N > 4096 ? 4096 : Vp * g.N)), dim3(256), 0, st, (const T*)dtheta,
                            (T*)dphi, g);
     }
     int rc = m1_check_launch(); if (rc) return rc;

@@ -130,6 +130,27 @@ __device__ __forceinline__ bool philox_keep(uint64_t seed, uint64_t base, uint64
     return u >= rate;
 }
 
+// VEC consecutive elements starting at idx0 (one Philox call per 4 consecutive stream positions when aligned)
+template <int VEC>
+__device__ __forceinline__ void philox_keep_vec(uint64_t seed, uint64_t base, uint64_t idx0, float rate, bool* keep) {
+    const uint64_t e0 = base + idx0;
+    if constexpr (VEC % 4 == 0) {
+        if ((e0 & 3) == 0) {
+#pragma unroll
+            for (int q = 0; q < VEC / 4; ++q) {
+                const uint4 r = philox4x32_10(seed, (e0 >> 2) + q);
+                keep[4 * q + 0] = (float)(r.x >> 8) * (1.0f / 16777216.0f) >= rate;
+                keep[4 * q + 1] = (float)(r.y >> 8) * (1.0f / 16777216.0f) >= rate;
+                keep[4 * q + 2] = (float)(r.z >> 8) * (1.0f / 16777216.0f) >= rate;
+                keep[4 * q + 3] = (float)(r.w >> 8) * (1.0f / 16777216.0f) >= rate;
+            }
+            return;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) keep[k] = philox_keep(seed, base, idx0 + k, rate);
+}
+
 // ---- host helpers ----
 static inline int m1_check_launch() {
     hipError_t e = hipGetLastError();

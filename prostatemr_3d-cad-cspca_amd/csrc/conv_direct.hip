@@ -292,6 +292,102 @@ int m1_direct_wgrad(const WgradSpec& spec, hipStream_t st) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// skinny weight gradient: one side has only a handful of channels (stem: Cin = 2..3; class logits / latent heads:
+// Cout = 2..6; latent z members).  Lanes run along the WIDE side's channels (coalesced), every thread keeps the
+// NT x SM partial sums of its wide channel in registers, voxel-lanes are folded through LDS, one atomic per output.
+// ------------------------------------------------------------------------------------------------
+template <typename T, int NT, int SM, bool SMALL_A>
+__global__ void __launch_bounds__(256) wgrad_skinny_kernel(WgradP p) {
+    __shared__ float red[256];
+    const int tid = threadIdx.x;
+    const int wide = SMALL_A ? p.CB : p.CA, small = SMALL_A ? p.CA : p.CB;
+    int WP = 1; while (WP < wide) WP <<= 1;
+    const int VL = 256 / WP, wc = tid % WP, vl = tid / WP;
+    const long long BV = (long long)p.BD * p.BH * p.BW, TV = BV * p.N;
+    const long long vbeg = (long long)blockIdx.x * p.vox_per_split;
+    long long vend = vbeg + p.vox_per_split; if (vend > TV) vend = TV;
+    const T* A = (const T*)p.A; const T* B = (const T*)p.B;
+    float acc[NT][SM];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int k = 0; k < SM; ++k) acc[t][k] = 0.f;
+    if (wc < wide) {
+        for (long long v = vbeg + vl; v < vend; v += VL) {
+            const int n = (int)(v / BV); long long r = v % BV;
+            const int bw = (int)(r % p.BW); r /= p.BW;
+            const int bh = (int)(r % p.BH); const int bd = (int)(r / p.BH);
+            float bval[SM];
+            if (SMALL_A) bval[0] = Act<T>::ld(B + v * p.CB + wc);
+            else {
+#pragma unroll
+                for (int k = 0; k < SM; ++k) bval[k] = k < small ? Act<T>::ld(B + v * p.CB + k) : 0.f;
+            }
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const int kw = t % p.kw, kh = (t / p.kw) % p.kh, kd = t / (p.kw * p.kh);
+                const int ad = bd * p.sd + kd - p.pd, ah = bh * p.sh + kh - p.ph, aw = bw * p.sw + kw - p.pw;
+                if (ad < 0 || ad >= p.AD || ah < 0 || ah >= p.AH || aw < 0 || aw >= p.AW) continue;
+                const long long ao = (((long long)n * p.AD + ad) * p.AH + ah) * p.AW + aw;
+                if (SMALL_A) {
+#pragma unroll
+                    for (int k = 0; k < SM; ++k) if (k < small) acc[t][k] = fmaf(Act<T>::ld(A + ao * p.CA + k), bval[0], acc[t][k]);
+                } else {
+                    const float av = Act<T>::ld(A + ao * p.CA + wc);
+#pragma unroll
+                    for (int k = 0; k < SM; ++k) acc[t][k] = fmaf(av, bval[k], acc[t][k]);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int k = 0; k < SM; ++k) {
+            if (k >= small) continue;                   // block-uniform
+            red[tid] = acc[t][k];
+            __syncthreads();
+            if (vl == 0 && wc < wide) {
+                float s = 0.f;
+                for (int q = 0; q < VL; ++q) s += red[q * WP + wc];
+                const int a = SMALL_A ? k : wc, b = SMALL_A ? wc : k;
+                atomicAdd(p.R + (long long)t * p.RT + (long long)(a + p.a_off) * p.RSA + (b + p.b_off), s);
+            }
+            __syncthreads();
+        }
+}
+
+bool m1_skinny_wgrad_supported(const WgradSpec& g) {
+    const int nt = g.kd * g.kh * g.kw;
+    if (nt != 1 && nt != 9 && nt != 27) return false;
+    if (g.CA <= 4 && g.CB <= 256) return true;
+    if (g.CB <= 4 && g.CA <= 256) return true;
+    if (g.CB <= 8 && g.CA <= 256 && nt == 1) return true;
+    return false;
+}
+
+template <typename T>
+static int skinny_launch(WgradP p, hipStream_t st) {
+    const int nt = p.kd * p.kh * p.kw;
+    const long long TV = (long long)p.N * p.BD * p.BH * p.BW;
+    long long blocks = cdiv_ll(TV, 256); if (blocks > 4096) blocks = 4096; if (blocks < 1) blocks = 1;
+    p.vox_per_split = cdiv_ll(TV, blocks);
+    blocks = cdiv_ll(TV, p.vox_per_split);
+    const dim3 grid((unsigned)blocks), blk(256);
+    const bool smallA = p.CA <= 4 && p.CB <= 256;
+#define SK(NT_, SM_, SA_) hipLaunchKernelGGL((wgrad_skinny_kernel<T, NT_, SM_, SA_>), grid, blk, 0, st, p)
+    if (smallA) { if (nt == 1) SK(1, 4, true); else if (nt == 9) SK(9, 4, true); else SK(27, 4, true); }
+    else if (p.CB <= 4) { if (nt == 1) SK(1, 4, false); else if (nt == 9) SK(9, 4, false); else SK(27, 4, false); }
+    else SK(1, 8, false);
+#undef SK
+    return m1_check_launch();
+}
+int m1_skinny_wgrad(const WgradSpec& spec, hipStream_t st) {
+    WgradP p; static_cast<WgradSpec&>(p) = spec; p.vox_per_split = 0;
+    return spec.dtype == M1_BF16 ? skinny_launch<bf16_t>(p, st) : skinny_launch<float>(p, st);
+}
+
+// ------------------------------------------------------------------------------------------------
 // spec-based entry (dispatch.hip builds the specs)
 // ------------------------------------------------------------------------------------------------
 int m1_direct_gather(const GatherSpec& g, hipStream_t st) {

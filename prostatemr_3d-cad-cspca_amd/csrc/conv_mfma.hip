@@ -284,6 +284,17 @@ __global__ void pack_weights_kernel(PackP p, T* __restrict__ out) {
 // ------------------------------------------------------------------------------------------------
 static inline int seg_of(int dtype) { return dtype == M1_BF16 ? 8 : 4; }
 static inline int pick_bn(int ocn) { return ocn > 64 ? 128 : (ocn > 32 ? 64 : (ocn > 16 ? 32 : 16)); }
+// narrower N tiles when the problem is too small to fill the chip with 128-wide ones
+static inline int pick_bn_for(int ocn, long long maxM, int ncls) {
+    int bn = pick_bn(ocn);
+    while (bn > 32 && cdiv_ll(maxM, 64) * ncls * ((ocn + bn - 1) / bn) < 512) bn >>= 1;
+    return bn;
+}
+static inline long long spec_maxM(const GatherSpec& g) {
+    if (g.mode == 0) return (long long)g.N * g.OD * g.OH * g.OW;
+    return (long long)g.N * ((g.OD + g.sd - 1) / g.sd) * ((g.OH + g.sh - 1) / g.sh) * ((g.OW + g.sw - 1) / g.sw);
+}
+static inline int spec_ncls(const GatherSpec& g) { return g.mode == 1 ? g.sd * g.sh * g.sw : 1; }
 
 bool m1_mfma_supported(const GatherSpec& g) {
     const int SEG = seg_of(g.dtype);
@@ -330,7 +341,7 @@ static void build_classes(const GatherSpec& g, int CC, int SEG, int OCpad, MfmaP
 size_t m1_mfma_ws_bytes(const GatherSpec& g) {
     const int SEG = seg_of(g.dtype);
     int CC = 0; for (int i = 0; i < g.nsrc; ++i) CC += g.srcC[i];
-    const int BN = pick_bn(g.OC), OCpad = (g.OC + BN - 1) / BN * BN;
+    const int BN = pick_bn_for(g.OC, spec_maxM(g), spec_ncls(g)), OCpad = (g.OC + BN - 1) / BN * BN;
     long long tot = 0;
     build_classes(g, CC, SEG, OCpad, nullptr, nullptr, &tot);
     return (size_t)tot * (g.dtype == M1_BF16 ? 2 : 4) + 256;
@@ -362,7 +373,7 @@ static int run_mfma(const GatherSpec& g, void* ws, hipStream_t st) {
     mp.nsrc = g.nsrc; mp.CC = CC; mp.ID = g.ID; mp.IH = g.IH; mp.IW = g.IW; mp.out = g.out; mp.OC = g.OC; mp.OCn = g.OC;
     mp.OD = g.OD; mp.OH = g.OH; mp.OW = g.OW; mp.N = g.N; mp.wp = ws; mp.bias = g.bias; mp.mode = g.mode;
     mp.sd = g.sd; mp.sh = g.sh; mp.sw = g.sw; mp.pd = g.pd; mp.ph = g.ph; mp.pw = g.pw; mp.accumulate = g.accumulate;
-    const int BN = pick_bn(g.OC), OCpad = (g.OC + BN - 1) / BN * BN;
+    const int BN = pick_bn_for(g.OC, spec_maxM(g), spec_ncls(g)), OCpad = (g.OC + BN - 1) / BN * BN;
     long long tot = 0;
     build_classes(g, CC, SEG, OCpad, &mp, &pp, &tot);
     pp.w = g.w; pp.wST = g.wST; pp.wSC = g.wSC; pp.wSO = g.wSO; pp.oc_off = g.oc_off; pp.cc_off = g.cc_off; pp.OCn = g.OC; pp.OCpad = OCpad; pp.CC = CC;
@@ -371,14 +382,15 @@ static int run_mfma(const GatherSpec& g, void* ws, hipStream_t st) {
     hipLaunchKernelGGL(pack_weights_kernel<T>, dim3((unsigned)pblocks, pp.nclasses), dim3(256), 0, st, pp, (T*)ws);
     int rc = m1_check_launch(); if (rc) return rc;
 
-    long long maxM;
-    if (g.mode == 0) maxM = (long long)g.N * g.OD * g.OH * g.OW;
-    else maxM = (long long)g.N * ((g.OD + g.sd - 1) / g.sd) * ((g.OH + g.sh - 1) / g.sh) * ((g.OW + g.sw - 1) / g.sw);
+    const long long maxM = spec_maxM(g);
+    // 128-row tiles unless that leaves the 256 CUs short of work (res3/res4 layers: M = 4,000 / 500 voxels)
+    const long long blocks128 = cdiv_ll(maxM, 128) * mp.nclasses * (OCpad / BN);
+    const bool small = blocks128 < 512;
     switch (BN) {
-        case 128: return launch_cfg<T, 128, 128, 2, 2>(mp, maxM, OCpad, st);
-        case 64:  return launch_cfg<T, 128, 64, 4, 1>(mp, maxM, OCpad, st);
-        case 32:  return launch_cfg<T, 128, 32, 4, 1>(mp, maxM, OCpad, st);
-        default:  return launch_cfg<T, 128, 16, 4, 1>(mp, maxM, OCpad, st);
+        case 128: return small ? launch_cfg<T, 64, 128, 1, 4>(mp, maxM, OCpad, st) : launch_cfg<T, 128, 128, 2, 2>(mp, maxM, OCpad, st);
+        case 64:  return small ? launch_cfg<T, 64, 64, 2, 2>(mp, maxM, OCpad, st) : launch_cfg<T, 128, 64, 4, 1>(mp, maxM, OCpad, st);
+        case 32:  return small ? launch_cfg<T, 64, 32, 4, 1>(mp, maxM, OCpad, st) : launch_cfg<T, 128, 32, 4, 1>(mp, maxM, OCpad, st);
+        default:  return small ? launch_cfg<T, 64, 16, 4, 1>(mp, maxM, OCpad, st) : launch_cfg<T, 128, 16, 4, 1>(mp, maxM, OCpad, st);
     }
 }
 

@@ -188,7 +188,10 @@ static int wgrad_common(const m1_conv_desc_t* d, bool T, const void* dy, float* 
             g.B = d->src[i].ptr; g.CB = d->src[i].C; g.BD = d->D; g.BH = d->H; g.BW = d->W;
             g.RT = (long long)d->Cout * d->Cin; g.RSA = d->Cin; g.a_off = 0; g.b_off = off;
         }
-        int rc = (!g_force_direct && m1_mfma_wgrad_supported(g)) ? m1_mfma_wgrad(g, st) : m1_direct_wgrad(g, st);
+        int rc;
+        if (!g_force_direct && m1_skinny_wgrad_supported(g)) rc = m1_skinny_wgrad(g, st);
+        else if (!g_force_direct && m1_mfma_wgrad_supported(g)) rc = m1_mfma_wgrad(g, st);
+        else rc = m1_direct_wgrad(g, st);
         if (rc) return rc;
         off += d->src[i].C;
     }

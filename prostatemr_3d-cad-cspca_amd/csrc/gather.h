@@ -29,6 +29,8 @@ struct WgradSpec {
 
 int m1_direct_gather(const GatherSpec& g, hipStream_t st);
 int m1_direct_wgrad(const WgradSpec& g, hipStream_t st);
+bool m1_skinny_wgrad_supported(const WgradSpec& g);
+int m1_skinny_wgrad(const WgradSpec& g, hipStream_t st);
 bool m1_mfma_supported(const GatherSpec& g);
 size_t m1_mfma_ws_bytes(const GatherSpec& g);
 int m1_mfma_gather(const GatherSpec& g, void* ws, hipStream_t st);

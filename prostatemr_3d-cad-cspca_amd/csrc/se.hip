@@ -11,24 +11,59 @@
 #define SE_MAX_F 1024
 #define SE_MAX_FR 256
 
-// ---------------- gate (one block) ----------------
+// ---------------- gate (one block; every dot product is split over the block and folded through LDS) ----------------
+// out[j] = sum_c v[c] * W[c*ldw + j]   for j < J, c < Cn  (W row-major [Cn][J]); 256 threads = (256/JP) c-slices x JP columns
+__device__ __forceinline__ void block_matvec_cols(const float* __restrict__ v, const float* __restrict__ W, int Cn, int J,
+                                                  float* __restrict__ red /*[256]*/, float* __restrict__ out_s /*[J]*/) {
+    for (int j0 = 0; j0 < J; j0 += 256) {
+        const int jn = J - j0 < 256 ? J - j0 : 256;
+        int JP = 1; while (JP < jn) JP <<= 1;
+        const int parts = 256 / JP, jl = threadIdx.x % JP, part = threadIdx.x / JP;
+        float s = 0.f;
+        if (jl < jn)
+            for (int c = part; c < Cn; c += parts) s = fmaf(v[c], W[(size_t)c * J + j0 + jl], s);
+        red[threadIdx.x] = s;
+        __syncthreads();
+        if (part == 0 && jl < jn) {
+            float t = 0.f;
+            for (int q = 0; q < parts; ++q) t += red[q * JP + jl];
+            out_s[j0 + jl] = t;
+        }
+        __syncthreads();
+    }
+}
+
 __global__ void __launch_bounds__(256) se_gate_fwd_kernel(const float* __restrict__ beta3, const float* __restrict__ W6,
                                                           const float* __restrict__ b6, const float* __restrict__ W7,
                                                           const float* __restrict__ b7, int F, int Fr,
                                                           float* __restrict__ hidden, float* __restrict__ g) {
+    __shared__ float red[256];
+    __shared__ float v_s[SE_MAX_F];
+    __shared__ float o_s[SE_MAX_F];
     __shared__ float h_s[SE_MAX_FR];
-    for (int j = threadIdx.x; j < Fr; j += blockDim.x) {
-        float s = b6[j];
-        for (int c = 0; c < F; ++c) s = fmaf(beta3[c], W6[(size_t)c * Fr + j], s);
-        hidden[j] = s;
-        h_s[j] = lrelu_f(s, 0.1f);
+    for (int c = threadIdx.x; c < F; c += 256) v_s[c] = beta3[c];
+    __syncthreads();
+    block_matvec_cols(v_s, W6, F, Fr, red, o_s);                 // hidden = W6^T beta3
+    for (int j = threadIdx.x; j < Fr; j += 256) {
+        const float s = o_s[j] + b6[j];
+        hidden[j] = s; h_s[j] = lrelu_f(s, 0.1f);
     }
     __syncthreads();
-    for (int c = threadIdx.x; c < F; c += blockDim.x) {
-        float s = b7[c];
-        for (int j = 0; j < Fr; ++j) s = fmaf(h_s[j], W7[(size_t)j * F + c], s);
-        g[c] = 1.f / (1.f + expf(-s));
+    block_matvec_cols(h_s, W7, Fr, F, red, o_s);                 // gpre = W7^T h
+    for (int c = threadIdx.x; c < F; c += 256) g[c] = 1.f / (1.f + expf(-(o_s[c] + b7[c])));
+}
+
+// out[r] = sum_j W[r*J + j] * v[j]  for r < R (rows contiguous): one wave per row, lanes along j
+__device__ __forceinline__ void block_matvec_rows(const float* __restrict__ W, const float* __restrict__ v, int R, int J,
+                                                  float* __restrict__ out_s) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int r = wave; r < R; r += 4) {
+        float s = 0.f;
+        for (int j = lane; j < J; j += 64) s = fmaf(W[(size_t)r * J + j], v[j], s);
+        s = wave_sum(s);
+        if (lane == 0) out_s[r] = s;
     }
+    __syncthreads();
 }
 
 __global__ void __launch_bounds__(256) se_gate_bwd_kernel(const float* __restrict__ beta3, const float* __restrict__ W6,
@@ -38,30 +73,30 @@ __global__ void __launch_bounds__(256) se_gate_bwd_kernel(const float* __restric
                                                           float* __restrict__ db6, float* __restrict__ dW7,
                                                           float* __restrict__ db7, int acc) {
     __shared__ float dgp_s[SE_MAX_F];
+    __shared__ float o_s[SE_MAX_F];
     __shared__ float dh_s[SE_MAX_FR];
-    for (int c = threadIdx.x; c < F; c += blockDim.x) {
+    __shared__ float h_s[SE_MAX_FR];
+    for (int c = threadIdx.x; c < F; c += 256) {
         const float t = dg[c] * g[c] * (1.f - g[c]);
         dgp_s[c] = t; db7[c] = (acc ? db7[c] : 0.f) + t;
     }
+    for (int j = threadIdx.x; j < Fr; j += 256) h_s[j] = lrelu_f(hidden[j], 0.1f);
     __syncthreads();
-    for (int j = threadIdx.x; j < Fr; j += blockDim.x) {
-        const float h = lrelu_f(hidden[j], 0.1f);
-        float s = 0.f;
-        for (int c = 0; c < F; ++c) {
-            s = fmaf(W7[(size_t)j * F + c], dgp_s[c], s);
-            dW7[(size_t)j * F + c] = (acc ? dW7[(size_t)j * F + c] : 0.f) + h * dgp_s[c];
-        }
-        const float dhid = s * lrelu_g(hidden[j], 0.1f);
+    block_matvec_rows(W7, dgp_s, Fr, F, o_s);                     // dh[j] = sum_c W7[j][c] dgpre[c]
+    for (int j = threadIdx.x; j < Fr; j += 256) {
+        const float dhid = o_s[j] * lrelu_g(hidden[j], 0.1f);
         dh_s[j] = dhid; db6[j] = (acc ? db6[j] : 0.f) + dhid;
     }
+    for (int i = threadIdx.x; i < Fr * F; i += 256) {            // dW7[j][c] = h[j] * dgpre[c]
+        const int j = i / F, c = i % F;
+        dW7[i] = (acc ? dW7[i] : 0.f) + h_s[j] * dgp_s[c];
+    }
     __syncthreads();
-    for (int c = threadIdx.x; c < F; c += blockDim.x) {
-        float s = 0.f;
-        for (int j = 0; j < Fr; ++j) {
-            s = fmaf(W6[(size_t)c * Fr + j], dh_s[j], s);
-            dW6[(size_t)c * Fr + j] = (acc ? dW6[(size_t)c * Fr + j] : 0.f) + beta3[c] * dh_s[j];
-        }
-        dbeta3_add[c] += s;
+    block_matvec_rows(W6, dh_s, F, Fr, o_s);                      // dbeta3[c] += sum_j W6[c][j] dhid[j]
+    for (int c = threadIdx.x; c < F; c += 256) dbeta3_add[c] += o_s[c];
+    for (int i = threadIdx.x; i < F * Fr; i += 256) {            // dW6[c][j] = beta3[c] * dhid[j]
+        const int c = i / Fr, j = i % Fr;
+        dW6[i] = (acc ? dW6[i] : 0.f) + beta3[c] * dh_s[j];
     }
 }
 
@@ -112,9 +147,13 @@ __global__ void __launch_bounds__(256) se_combine_fwd_kernel(const T* __restrict
             const int c = c0 + k; const size_t sc = ((size_t)n * F + c) * 2;
             const float x_ = (a[k] - p.stats3[sc]) * p.stats3[sc + 1] * p.gamma3[c] + p.beta3[c];
             const float rho = (b[k] - p.stats4[sc]) * p.stats4[sc + 1] * p.gamma4[c] + p.beta4[c];
-            float o = lrelu_f(x_ * p.g[c] * rho, 0.1f);
-            if (p.drop_rate > 0.f) o = philox_keep(seed, rbase, base + i * VEC + k, p.drop_rate) ? o * keep_scale : 0.f;
-            a[k] = o;
+            a[k] = lrelu_f(x_ * p.g[c] * rho, 0.1f);
+        }
+        if (p.drop_rate > 0.f) {
+            bool keep[VEC];
+            philox_keep_vec<VEC>(seed, rbase, base + i * VEC, p.drop_rate, keep);
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) a[k] = keep[k] ? a[k] * keep_scale : 0.f;
         }
         VecIO<T, VEC>::st(out + base + i * VEC, a);
     }
@@ -159,6 +198,8 @@ __global__ void __launch_bounds__(256) se_combine_bwd_apply_kernel(const T* __re
         VecIO<T, VEC>::ld(y3 + base + i * VEC, a);
         VecIO<T, VEC>::ld(y4 + base + i * VEC, b);
         VecIO<T, VEC>::ld(dout + base + i * VEC, d);
+        bool keep[VEC];
+        if (p.drop_rate > 0.f) philox_keep_vec<VEC>(seed, rbase, base + i * VEC, p.drop_rate, keep);
 #pragma unroll
         for (int k = 0; k < VEC; ++k) {
             const int c = c0 + k; const size_t sc = ((size_t)n * F + c) * 2;
@@ -167,7 +208,7 @@ __global__ void __launch_bounds__(256) se_combine_bwd_apply_kernel(const T* __re
             const float x_ = xh3 * p.gamma3[c] + p.beta3[c], rho = xh4 * p.gamma4[c] + p.beta4[c];
             const float g = p.g[c], u = x_ * g * rho;
             float dd = d[k];
-            if (p.drop_rate > 0.f) dd = philox_keep(seed, rbase, base + i * VEC + k, p.drop_rate) ? dd * keep_scale : 0.f;
+            if (p.drop_rate > 0.f) dd = keep[k] ? dd * keep_scale : 0.f;
             const float du = dd * lrelu_g(u, 0.1f);
             const float dx_ = du * g * rho, drho = du * g * x_;
             const float* s = sums + ((size_t)n * F + c) * 5;

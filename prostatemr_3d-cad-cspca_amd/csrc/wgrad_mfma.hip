@@ -48,15 +48,16 @@ __device__ __forceinline__ void transpose_unit(const uint4 (&r)[8], uint4 (&o)[8
     o[3] = make_uint4(r[0].w, r[1].w, r[2].w, r[3].w);
 }
 
-template <typename T, int TA, int TB>
+template <typename T, int TA, int TB, int KB>
 __global__ void __launch_bounds__(256) wgrad_mfma_kernel(WgP p) {
     constexpr int SEG = WT<T>::SEG;
-    constexpr int KS = 4 * SEG;                            // voxels per K-step (one 64-byte LDS row)
+    constexpr int KS1 = 4 * SEG;                           // voxels per 64-byte LDS row
+    constexpr int KS = KS1 * KB;                           // voxels per K-step (KB row-blocks: keeps all 256 threads loading)
     constexpr int TM = TA / 2 / 16, TN = TB / 2 / 16;      // 2x2 waves
-    constexpr int UA = (TA / SEG) * 4, UB = (TB / SEG) * 4;   // SEGxSEG units per K-step
+    constexpr int UA = (TA / SEG) * 4 * KB, UB = (TB / SEG) * 4 * KB;   // SEGxSEG units per K-step
     constexpr int NU = (UA + UB + 255) / 256;
-    __shared__ __attribute__((aligned(16))) unsigned char A_s[TA * 64];
-    __shared__ __attribute__((aligned(16))) unsigned char B_s[TB * 64];
+    __shared__ __attribute__((aligned(16))) unsigned char A_s[KB * TA * 64];
+    __shared__ __attribute__((aligned(16))) unsigned char B_s[KB * TB * 64];
     __shared__ long long a_off_s[KS], b_off_s[KS];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -78,8 +79,8 @@ __global__ void __launch_bounds__(256) wgrad_mfma_kernel(WgP p) {
     const int fr = lane & 15, fs = lane >> 4;
 
     for (long long vs = vbeg; vs < vend; vs += KS) {
-        if (tid < KS) {
-            const long long v = vs + tid;
+        for (int t = tid; t < KS; t += 256) {
+            const long long v = vs + t;
             long long ao = -1, bo = -1;
             if (v < vend) {
                 const int n = (int)(v / BV); long long r = v % BV;
@@ -91,7 +92,7 @@ __global__ void __launch_bounds__(256) wgrad_mfma_kernel(WgP p) {
                     bo = v;        // a voxel whose shifted partner is outside the volume contributes nothing
                 }
             }
-            a_off_s[tid] = ao; b_off_s[tid] = bo;
+            a_off_s[t] = ao; b_off_s[t] = bo;
         }
         __syncthreads();           // also fences the previous step's fragment reads before A_s/B_s are rewritten
 #pragma unroll
@@ -101,7 +102,7 @@ __global__ void __launch_bounds__(256) wgrad_mfma_kernel(WgP p) {
                 const bool isA = u < UA;
                 const int uu = isA ? u : u - UA;
                 const int ncg = (isA ? TA : TB) / SEG;
-                const int cg = uu % ncg, ks = uu / ncg;                 // channel group, k segment
+                const int cg = uu % ncg, ks = uu / ncg;                 // channel group, k segment (0 .. 4*KB-1)
                 const int C = isA ? p.CA : p.CB, c0 = (isA ? a0 : b0) + cg * SEG;
                 const T* base = isA ? A : B;
                 uint4 r[8], o[8];
@@ -111,25 +112,27 @@ __global__ void __launch_bounds__(256) wgrad_mfma_kernel(WgP p) {
                     r[j] = (off >= 0 && c0 < C) ? *reinterpret_cast<const uint4*>(base + off * C + c0) : make_uint4(0, 0, 0, 0);
                 }
                 transpose_unit(r, o, T());
-                unsigned char* dst = isA ? A_s : B_s;
+                unsigned char* dst = (isA ? A_s : B_s) + (ks >> 2) * ((isA ? TA : TB) * 64);
 #pragma unroll
                 for (int c = 0; c < SEG; ++c) {
                     const int row = cg * SEG + c;
-                    *reinterpret_cast<uint4*>(dst + row * 64 + wswz(row, ks) * 16) = o[c];
+                    *reinterpret_cast<uint4*>(dst + row * 64 + wswz(row, ks & 3) * 16) = o[c];
                 }
             }
         }
         __syncthreads();
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) {
         uint4 af[TM], bfr[TN];
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             const int row = wm * (TA / 2) + i * 16 + fr;
-            af[i] = *reinterpret_cast<const uint4*>(A_s + row * 64 + wswz(row, fs) * 16);
+            af[i] = *reinterpret_cast<const uint4*>(A_s + kb * TA * 64 + row * 64 + wswz(row, fs) * 16);
         }
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int row = wn * (TB / 2) + j * 16 + fr;
-            bfr[j] = *reinterpret_cast<const uint4*>(B_s + row * 64 + wswz(row, fs) * 16);
+            bfr[j] = *reinterpret_cast<const uint4*>(B_s + kb * TB * 64 + row * 64 + wswz(row, fs) * 16);
         }
 #pragma unroll
         for (int i = 0; i < TM; ++i)
@@ -145,6 +148,7 @@ __global__ void __launch_bounds__(256) wgrad_mfma_kernel(WgP p) {
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(af[i].w), __uint_as_float(bfr[j].w), acc[i][j], 0, 0, 0);
                 }
             }
+        }
     }
     // D[i = a][j = b]: lane holds a = 4*fs + r, b = fr
 #pragma unroll
@@ -168,19 +172,20 @@ bool m1_mfma_wgrad_supported(const WgradSpec& g) {
 
 template <typename T, int TA, int TB>
 static int launch_wg(WgP p, hipStream_t st) {
-    constexpr int KS = 4 * WT<T>::SEG;
+    constexpr int KB = (TA + TB) <= 64 ? 8 : ((TA + TB) <= 128 ? 4 : 2);
+    constexpr int KS = 4 * WT<T>::SEG * KB;
     const int aTiles = (p.CA + TA - 1) / TA, bTiles = (p.CB + TB - 1) / TB;
     const int taps = p.kd * p.kh * p.kw;
     const long long TV = (long long)p.N * p.BD * p.BH * p.BW;
     long long splits = cdiv_ll(1536, (long long)aTiles * bTiles * taps);
-    const long long max_splits = cdiv_ll(TV, 8 * KS);
+    const long long max_splits = cdiv_ll(TV, 4 * KS);
     if (splits > max_splits) splits = max_splits;
     if (splits < 1) splits = 1;
     long long vps = cdiv_ll(cdiv_ll(TV, splits), KS) * KS;
     splits = cdiv_ll(TV, vps);
     p.vox_per_split = vps;
     dim3 grid(aTiles * bTiles, taps, (unsigned)splits);
-    hipLaunchKernelGGL((wgrad_mfma_kernel<T, TA, TB>), grid, dim3(256), 0, st, p);
+    hipLaunchKernelGGL((wgrad_mfma_kernel<T, TA, TB, KB>), grid, dim3(256), 0, st, p);
     return m1_check_launch();
 }
 
