@@ -102,6 +102,7 @@ int m1_instnorm_bwd(const void* x, const float* stats, const float* gamma, const
  * W6: (F,Fr) W7: (Fr,F) Keras (1,1,1,Cin,Cout) layout.  hidden: (Fr) pre-activation, saved for bwd. */
 int m1_se_gate_fwd(const float* beta3, const float* W6, const float* b6, const float* W7, const float* b7,
                    int F, int Fr, float* hidden, float* g, void* stream);
+/* dg: the F + Fr float scratch written by m1_se_combine_bwd (contents are consumed and overwritten). */
 int m1_se_gate_bwd(const float* beta3, const float* W6, const float* W7, const float* hidden, const float* g,
                    const float* dg, int F, int Fr, float* dbeta3_add, float* dW6, float* db6, float* dW7,
                    float* db7, int accumulate, void* stream);
@@ -114,7 +115,7 @@ int m1_se_combine_fwd(const void* y3, const void* y4, const float* stats3, const
                       const float* g, void* out, int N, long long V, int F, int dtype, float drop_rate,
                       const uint64_t* rng, uint64_t layer_id, void* stream);
 /* writes dy3, dy4 (grads wrt the RAW conv outputs, i.e. through both InstanceNorms); dgamma3,dbeta3,dgamma4,
- * dbeta4 (F each) per `accumulate`; dg (F) is scratch for m1_se_gate_bwd and always overwritten.
+ * dbeta4 (F each) per `accumulate`; dg is scratch for m1_se_gate_bwd, F + Fr floats, first F always overwritten.
  * ws: m1_reduce_ws_floats(N,V,F,5). */
 int m1_se_combine_bwd(const void* y3, const void* y4, const float* stats3, const float* stats4,
                       const float* gamma3, const float* beta3, const float* gamma4, const float* beta4,

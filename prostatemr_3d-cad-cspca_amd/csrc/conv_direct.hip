@@ -370,7 +370,7 @@ template <typename T>
 static int skinny_launch(WgradP p, hipStream_t st) {
     const int nt = p.kd * p.kh * p.kw;
     const long long TV = (long long)p.N * p.BD * p.BH * p.BW;
-    long long blocks = cdiv_ll(TV, 256); if (blocks > 4096) blocks = 4096; if (blocks < 1) blocks = 1;
+    long long blocks = cdiv_ll(TV, 512); if (blocks > 768) blocks = 768; if (blocks < 1) blocks = 1;   // atomics on few addresses: keep the block count moderate
     p.vox_per_split = cdiv_ll(TV, blocks);
     blocks = cdiv_ll(TV, p.vox_per_split);
     const dim3 grid((unsigned)blocks), blk(256);

@@ -38,6 +38,9 @@ struct MfmaP {
     long long cls_woff[MF_MAX_CLASSES];     // element offset of the class matrix in wp
     signed char tdd[MF_MAX_TAPS], tdh[MF_MAX_TAPS], tdw[MF_MAX_TAPS];   // gather offsets per (class-ordered) tap
     int accumulate;             // out += result (used when another kernel already wrote the other concat members)
+    int ksplit;                 // > 1: blockIdx.y = cls*ksplit + ks; partial sums go to acc32 with fp32 atomics
+    float* acc32;               // [out voxels][OC] fp32, zeroed by the host before the launch (ksplit > 1 only)
+    int aligned;                // every concat member is a multiple of one 64-byte K-chunk: incremental addressing
 };
 
 template <typename T> struct MT;
@@ -68,7 +71,7 @@ __global__ void __launch_bounds__(256) conv_mfma_kernel(MfmaP p) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
-    const int cls = blockIdx.y;
+    const int cls = blockIdx.y / p.ksplit, ksp = blockIdx.y % p.ksplit;
     const int oc0 = blockIdx.z * BN;
 
     int pdc = 0, phc = 0, pwc = 0, QD = p.OD, QH = p.OH, QW = p.OW;
@@ -108,7 +111,10 @@ __global__ void __launch_bounds__(256) conv_mfma_kernel(MfmaP p) {
 
     const int spt = p.CC / SEG;                          // segments per tap
     const int nseg = ntaps * spt;
-    const int nchunks = (nseg + 3) >> 2;
+    const int nchunks_all = (nseg + 3) >> 2;
+    const int cps = (nchunks_all + p.ksplit - 1) / p.ksplit;        // chunks per split
+    const int c_beg = ksp * cps;
+    const int nchunks = (c_beg + cps <= nchunks_all ? cps : nchunks_all - c_beg);   // may be <= 0 for a trailing split
     const int kpad = p.cls_kpad[cls];
     const T* wp = (const T*)p.wp + p.cls_woff[cls];
 
@@ -121,7 +127,52 @@ __global__ void __launch_bounds__(256) conv_mfma_kernel(MfmaP p) {
     uint4 ra[A_LD], rb[B_LD];
     const int lseg = tid & 3, lrow = tid >> 2;           // loader: 4 lanes cover one 64-byte row
 
+    // incremental loader state (aligned case): current tap / concat member / channel offset and per-row bases
+    int st_tap = 0, st_s = 0, st_c = 0;
+    const T* st_ptr[A_LD];
+    auto st_set_tap = [&]() {          // voxel bases of this thread's rows for tap st_tap, member st_s
+        const int tp = s_tap[st_tap];
+        const int dd = (signed char)(tp & 0xff), dh = (signed char)((tp >> 8) & 0xff), dw = (signed char)((tp >> 16) & 0xff);
+#pragma unroll
+        for (int i = 0; i < A_LD; ++i) {
+            const int4 ri = rowinfo[lrow + 64 * i];
+            const int id = ri.y + dd, ih = ri.z + dh, iw = ri.w + dw;
+            st_ptr[i] = nullptr;
+            if (ri.x >= 0 && id >= 0 && id < p.ID && ih >= 0 && ih < p.IH && iw >= 0 && iw < p.IW) {
+                const long long vox = (((long long)ri.x * p.ID + id) * p.IH + ih) * p.IW + iw;
+                st_ptr[i] = s_src[st_s] + vox * s_srcC[st_s] + lseg * SEG;
+            }
+        }
+    };
+    if (p.aligned && nchunks > 0) {
+        const int cpt = spt >> 2;                          // chunks per tap
+        st_tap = c_beg / cpt;
+        int c = (c_beg - st_tap * cpt) * 4 * SEG;
+        while (c >= s_srcC[st_s]) { c -= s_srcC[st_s]; ++st_s; }
+        st_c = c;
+        st_set_tap();
+    }
+    auto prefetch_aligned = [&](int chunk) {
+#pragma unroll
+        for (int i = 0; i < A_LD; ++i)
+            ra[i] = st_ptr[i] ? *reinterpret_cast<const uint4*>(st_ptr[i] + st_c) : make_uint4(0, 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < B_LD; ++i) {
+            const int e = tid + 256 * i;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (e < BN * 4)
+                v = *reinterpret_cast<const uint4*>(wp + (long long)(oc0 + (e >> 2)) * kpad + (long long)(chunk * 4 + (e & 3)) * SEG);
+            rb[i] = v;
+        }
+        st_c += 4 * SEG;
+        if (st_c >= s_srcC[st_s]) {                        // next concat member, or next tap
+            st_c = 0;
+            if (++st_s == p.nsrc) { st_s = 0; ++st_tap; }
+            if (st_tap < ntaps) st_set_tap();
+        }
+    };
     auto prefetch = [&](int chunk) {
+        if (p.aligned) { prefetch_aligned(chunk); return; }
         // ---- A: gathered activations ----
         const int kseg = chunk * 4 + lseg;
         const T* sp = nullptr; int sC = 0, coff = 0, dd = 0, dh = 0, dw = 0;
@@ -173,13 +224,15 @@ __global__ void __launch_bounds__(256) conv_mfma_kernel(MfmaP p) {
         }
     };
 
-    prefetch(0);
-    stage(0);
-    __syncthreads();
     const int fr = lane & 15, fs = lane >> 4;
+    if (nchunks > 0) {
+        prefetch(c_beg);
+        stage(0);
+    }
+    __syncthreads();
     for (int it = 0; it < nchunks; ++it) {
         const int buf = it & 1;
-        if (it + 1 < nchunks) prefetch(it + 1);
+        if (it + 1 < nchunks) prefetch(c_beg + it + 1);
         uint4 af[TM], bfr[TN];
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
@@ -209,6 +262,21 @@ __global__ void __launch_bounds__(256) conv_mfma_kernel(MfmaP p) {
         __syncthreads();
     }
 
+    if (p.ksplit > 1) {            // partial K range: fp32 atomics into the accumulation buffer (finish kernel converts)
+        if (nchunks <= 0) return;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int oc = oc0 + wn * (BN / WN) + j * 16 + fr;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int orow = outrow[wm * (BM / WM) + i * 16 + fs * 4 + r];
+                    if (orow >= 0 && oc < p.OCn) atomicAdd(p.acc32 + (long long)orow * p.OC + oc, acc[i][j][r]);
+                }
+            }
+        return;
+    }
     // ---- epilogue: acc (+bias) -> T -> LDS tile [BM][BN] (row pitch BN+SEG to spread banks) -> 16-B stores ----
     constexpr int CP = BN + SEG;                          // pitch in elements
     T* C_s = reinterpret_cast<T*>(A_s);                   // reuses the A/B buffers (all waves are past the last sync)
@@ -279,16 +347,38 @@ __global__ void pack_weights_kernel(PackP p, T* __restrict__ out) {
     }
 }
 
+// out = T(acc32 + bias) [+ out]   (split-K finish)
+template <typename T>
+__global__ void splitk_finish_kernel(const float* __restrict__ acc32, const float* __restrict__ bias, T* __restrict__ out,
+                                     long long n, int OC, int accumulate) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        float v = acc32[i] + (bias ? bias[i % OC] : 0.f);
+        if (accumulate) v += Act<T>::ld(out + i);
+        Act<T>::st(out + i, v);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
 static inline int seg_of(int dtype) { return dtype == M1_BF16 ? 8 : 4; }
 static inline int pick_bn(int ocn) { return ocn > 64 ? 128 : (ocn > 32 ? 64 : (ocn > 16 ? 32 : 16)); }
-// narrower N tiles when the problem is too small to fill the chip with 128-wide ones
-static inline int pick_bn_for(int ocn, long long maxM, int ncls) {
-    int bn = pick_bn(ocn);
-    while (bn > 32 && cdiv_ll(maxM, 64) * ncls * ((ocn + bn - 1) / bn) < 512) bn >>= 1;
-    return bn;
+struct Plan { int BN, BM, ksplit; };
+// 128-row tiles unless that leaves the 256 CUs short of work (res3/res4: M = 4,000 / 500 voxels) -> 64 rows, and
+// if still short, split K (taps x channels, up to 13,824 deep there) over blockIdx.y.
+static inline Plan make_plan(int ocn, long long maxM, int ncls, int min_nchunks) {
+    Plan pl; pl.BN = pick_bn(ocn);
+    const int ntile = (ocn + pl.BN - 1) / pl.BN;
+    pl.BM = cdiv_ll(maxM, 128) * ncls * ntile >= 256 ? 128 : 64;
+    const long long blocks = cdiv_ll(maxM, pl.BM) * ncls * ntile;
+    pl.ksplit = 1;
+    if (blocks < 256 && min_nchunks >= 16) {
+        long long want = cdiv_ll(512, blocks), cap = min_nchunks / 8;
+        pl.ksplit = (int)(want < cap ? want : cap);
+        if (pl.ksplit < 1) pl.ksplit = 1;
+        if (pl.ksplit > 32) pl.ksplit = 32;
+    }
+    return pl;
 }
 static inline long long spec_maxM(const GatherSpec& g) {
     if (g.mode == 0) return (long long)g.N * g.OD * g.OH * g.OW;
@@ -338,18 +428,31 @@ static void build_classes(const GatherSpec& g, int CC, int SEG, int OCpad, MfmaP
     *total_elems = woff;
 }
 
+static inline int min_class_chunks(const GatherSpec& g, int CC, int SEG) {
+    // smallest K-chunk count over the parity classes (mode 1) -- the split factor must suit every class
+    MfmaP tmp{}; long long tot = 0;
+    build_classes(g, CC, SEG, 16, &tmp, nullptr, &tot);
+    int mn = 1 << 30;
+    for (int c = 0; c < tmp.nclasses; ++c) { int n = tmp.cls_kpad[c] / (4 * SEG); if (n < mn) mn = n; }
+    return mn;
+}
+static inline size_t out_elems(const GatherSpec& g) { return (size_t)g.N * g.OD * g.OH * g.OW * g.OC; }
+
 size_t m1_mfma_ws_bytes(const GatherSpec& g) {
     const int SEG = seg_of(g.dtype);
     int CC = 0; for (int i = 0; i < g.nsrc; ++i) CC += g.srcC[i];
-    const int BN = pick_bn_for(g.OC, spec_maxM(g), spec_ncls(g)), OCpad = (g.OC + BN - 1) / BN * BN;
+    const Plan pl = make_plan(g.OC, spec_maxM(g), spec_ncls(g), min_class_chunks(g, CC, SEG));
+    const int BN = pl.BN, OCpad = (g.OC + BN - 1) / BN * BN;
     long long tot = 0;
     build_classes(g, CC, SEG, OCpad, nullptr, nullptr, &tot);
-    return (size_t)tot * (g.dtype == M1_BF16 ? 2 : 4) + 256;
+    size_t bytes = ((size_t)tot * (g.dtype == M1_BF16 ? 2 : 4) + 255) / 256 * 256;
+    if (pl.ksplit > 1) bytes += out_elems(g) * sizeof(float);
+    return bytes + 256;
 }
 
 template <typename T, int BM, int BN, int WM, int WN>
 static int launch_cfg(const MfmaP& mp, long long maxM, int OCpad, hipStream_t st) {
-    dim3 grid((unsigned)cdiv_ll(maxM, BM), mp.nclasses, OCpad / BN);
+    dim3 grid((unsigned)cdiv_ll(maxM, BM), mp.nclasses * mp.ksplit, OCpad / BN);
     const size_t smem = mfma_smem_bytes<T, BM, BN>();
     auto kern = conv_mfma_kernel<T, BM, BN, WM, WN>;
     static bool attr_set = false;     // per instantiation
@@ -373,9 +476,17 @@ static int run_mfma(const GatherSpec& g, void* ws, hipStream_t st) {
     mp.nsrc = g.nsrc; mp.CC = CC; mp.ID = g.ID; mp.IH = g.IH; mp.IW = g.IW; mp.out = g.out; mp.OC = g.OC; mp.OCn = g.OC;
     mp.OD = g.OD; mp.OH = g.OH; mp.OW = g.OW; mp.N = g.N; mp.wp = ws; mp.bias = g.bias; mp.mode = g.mode;
     mp.sd = g.sd; mp.sh = g.sh; mp.sw = g.sw; mp.pd = g.pd; mp.ph = g.ph; mp.pw = g.pw; mp.accumulate = g.accumulate;
-    const int BN = pick_bn_for(g.OC, spec_maxM(g), spec_ncls(g)), OCpad = (g.OC + BN - 1) / BN * BN;
+    const Plan pl = make_plan(g.OC, spec_maxM(g), spec_ncls(g), min_class_chunks(g, CC, SEG));
+    const int BN = pl.BN, OCpad = (g.OC + BN - 1) / BN * BN;
     long long tot = 0;
     build_classes(g, CC, SEG, OCpad, &mp, &pp, &tot);
+    mp.ksplit = pl.ksplit; mp.acc32 = nullptr; mp.aligned = 1;
+    for (int i = 0; i < g.nsrc; ++i) if (g.srcC[i] % (4 * SEG)) mp.aligned = 0;
+    if (pl.ksplit > 1) {
+        const size_t wbytes = ((size_t)tot * sizeof(T) + 255) / 256 * 256;
+        mp.acc32 = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(ws) + wbytes);
+        if (hipMemsetAsync(mp.acc32, 0, out_elems(g) * sizeof(float), st) != hipSuccess) return M1_ERR_LAUNCH;
+    }
     pp.w = g.w; pp.wST = g.wST; pp.wSC = g.wSC; pp.wSO = g.wSO; pp.oc_off = g.oc_off; pp.cc_off = g.cc_off; pp.OCn = g.OC; pp.OCpad = OCpad; pp.CC = CC;
     int maxk = 0; for (int c = 0; c < pp.nclasses; ++c) maxk = pp.cls_kpad[c] > maxk ? pp.cls_kpad[c] : maxk;
     long long pblocks = cdiv_ll((long long)OCpad * maxk, 256); if (pblocks > 2048) pblocks = 2048; if (pblocks < 1) pblocks = 1;
@@ -383,15 +494,19 @@ static int run_mfma(const GatherSpec& g, void* ws, hipStream_t st) {
     int rc = m1_check_launch(); if (rc) return rc;
 
     const long long maxM = spec_maxM(g);
-    // 128-row tiles unless that leaves the 256 CUs short of work (res3/res4 layers: M = 4,000 / 500 voxels)
-    const long long blocks128 = cdiv_ll(maxM, 128) * mp.nclasses * (OCpad / BN);
-    const bool small = blocks128 < 512;
+    const bool small = pl.BM == 64;
+    int rc2;
     switch (BN) {
-        case 128: return small ? launch_cfg<T, 64, 128, 1, 4>(mp, maxM, OCpad, st) : launch_cfg<T, 128, 128, 2, 2>(mp, maxM, OCpad, st);
-        case 64:  return small ? launch_cfg<T, 64, 64, 2, 2>(mp, maxM, OCpad, st) : launch_cfg<T, 128, 64, 4, 1>(mp, maxM, OCpad, st);
-        case 32:  return small ? launch_cfg<T, 64, 32, 4, 1>(mp, maxM, OCpad, st) : launch_cfg<T, 128, 32, 4, 1>(mp, maxM, OCpad, st);
-        default:  return small ? launch_cfg<T, 64, 16, 4, 1>(mp, maxM, OCpad, st) : launch_cfg<T, 128, 16, 4, 1>(mp, maxM, OCpad, st);
+        case 128: rc2 = small ? launch_cfg<T, 64, 128, 1, 4>(mp, maxM, OCpad, st) : launch_cfg<T, 128, 128, 2, 2>(mp, maxM, OCpad, st); break;
+        case 64:  rc2 = small ? launch_cfg<T, 64, 64, 2, 2>(mp, maxM, OCpad, st) : launch_cfg<T, 128, 64, 4, 1>(mp, maxM, OCpad, st); break;
+        case 32:  rc2 = small ? launch_cfg<T, 64, 32, 4, 1>(mp, maxM, OCpad, st) : launch_cfg<T, 128, 32, 4, 1>(mp, maxM, OCpad, st); break;
+        default:  rc2 = small ? launch_cfg<T, 64, 16, 4, 1>(mp, maxM, OCpad, st) : launch_cfg<T, 128, 16, 4, 1>(mp, maxM, OCpad, st); break;
     }
+    if (rc2 || pl.ksplit <= 1) return rc2;
+    const long long ne = (long long)out_elems(g);
+    long long fb = cdiv_ll(ne, 256); if (fb > 2048) fb = 2048;
+    hipLaunchKernelGGL(splitk_finish_kernel<T>, dim3((unsigned)fb), dim3(256), 0, st, mp.acc32, g.bias, (T*)g.out, ne, g.OC, g.accumulate);
+    return m1_check_launch();
 }
 
 int m1_mfma_gather(const GatherSpec& g, void* ws, hipStream_t st) {

@@ -66,37 +66,44 @@ __device__ __forceinline__ void block_matvec_rows(const float* __restrict__ W, c
     __syncthreads();
 }
 
-__global__ void __launch_bounds__(256) se_gate_bwd_kernel(const float* __restrict__ beta3, const float* __restrict__ W6,
-                                                          const float* __restrict__ W7, const float* __restrict__ hidden,
-                                                          const float* __restrict__ g, const float* __restrict__ dg, int F,
-                                                          int Fr, float* __restrict__ dbeta3_add, float* __restrict__ dW6,
-                                                          float* __restrict__ db6, float* __restrict__ dW7,
-                                                          float* __restrict__ db7, int acc) {
+// backward, phase A (one block): dgpre = dg*g*(1-g) -> db7; dhid = (W7 dgpre) * lrelu'(hidden) -> db6.
+// dgpre overwrites dg (scratch), dhid goes to dg[F .. F+Fr) -- the caller sizes dg as F + Fr floats.
+__global__ void __launch_bounds__(256) se_gate_bwd_a_kernel(const float* __restrict__ W7, const float* __restrict__ hidden,
+                                                            const float* __restrict__ g, float* __restrict__ dg, int F, int Fr,
+                                                            float* __restrict__ db6, float* __restrict__ db7, int acc) {
     __shared__ float dgp_s[SE_MAX_F];
-    __shared__ float o_s[SE_MAX_F];
-    __shared__ float dh_s[SE_MAX_FR];
-    __shared__ float h_s[SE_MAX_FR];
+    __shared__ float o_s[SE_MAX_FR];
     for (int c = threadIdx.x; c < F; c += 256) {
         const float t = dg[c] * g[c] * (1.f - g[c]);
         dgp_s[c] = t; db7[c] = (acc ? db7[c] : 0.f) + t;
     }
-    for (int j = threadIdx.x; j < Fr; j += 256) h_s[j] = lrelu_f(hidden[j], 0.1f);
     __syncthreads();
     block_matvec_rows(W7, dgp_s, Fr, F, o_s);                     // dh[j] = sum_c W7[j][c] dgpre[c]
+    for (int c = threadIdx.x; c < F; c += 256) dg[c] = dgp_s[c];
     for (int j = threadIdx.x; j < Fr; j += 256) {
         const float dhid = o_s[j] * lrelu_g(hidden[j], 0.1f);
-        dh_s[j] = dhid; db6[j] = (acc ? db6[j] : 0.f) + dhid;
+        dg[F + j] = dhid; db6[j] = (acc ? db6[j] : 0.f) + dhid;
     }
-    for (int i = threadIdx.x; i < Fr * F; i += 256) {            // dW7[j][c] = h[j] * dgpre[c]
+}
+// phase B (F*Fr threads): the two outer products and dbeta3 += W6 dhid
+__global__ void __launch_bounds__(256) se_gate_bwd_b_kernel(const float* __restrict__ beta3, const float* __restrict__ W6,
+                                                            const float* __restrict__ hidden, const float* __restrict__ dg,
+                                                            int F, int Fr, float* __restrict__ dbeta3_add,
+                                                            float* __restrict__ dW6, float* __restrict__ dW7, int acc) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= F * Fr) return;
+    {   // dW7[j][c] = h[j] * dgpre[c]
         const int j = i / F, c = i % F;
-        dW7[i] = (acc ? dW7[i] : 0.f) + h_s[j] * dgp_s[c];
+        dW7[i] = (acc ? dW7[i] : 0.f) + lrelu_f(hidden[j], 0.1f) * dg[c];
     }
-    __syncthreads();
-    block_matvec_rows(W6, dh_s, F, Fr, o_s);                      // dbeta3[c] += sum_j W6[c][j] dhid[j]
-    for (int c = threadIdx.x; c < F; c += 256) dbeta3_add[c] += o_s[c];
-    for (int i = threadIdx.x; i < F * Fr; i += 256) {            // dW6[c][j] = beta3[c] * dhid[j]
+    {   // dW6[c][j] = beta3[c] * dhid[j]
         const int c = i / Fr, j = i % Fr;
-        dW6[i] = (acc ? dW6[i] : 0.f) + beta3[c] * dh_s[j];
+        dW6[i] = (acc ? dW6[i] : 0.f) + beta3[c] * dg[F + j];
+    }
+    if (i < F) {
+        float s = 0.f;
+        for (int j = 0; j < Fr; ++j) s = fmaf(W6[(size_t)i * Fr + j], dg[F + j], s);
+        dbeta3_add[i] += s;
     }
 }
 
@@ -112,8 +119,10 @@ extern "C" int m1_se_gate_bwd(const float* beta3, const float* W6, const float* 
                               float* db7, int accumulate, void* stream) {
     if (!beta3 || !W6 || !W7 || !hidden || !g || !dg || !dbeta3_add || !dW6 || !db6 || !dW7 || !db7) return M1_ERR_BAD_ARG;
     if (F > SE_MAX_F || Fr > SE_MAX_FR) return M1_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(se_gate_bwd_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, beta3, W6, W7, hidden, g, dg, F, Fr,
-                       dbeta3_add, dW6, db6, dW7, db7, accumulate);
+    float* dgw = const_cast<float*>(dg);   // dg is scratch of F + Fr floats (see include/m1hip.h)
+    hipLaunchKernelGGL(se_gate_bwd_a_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, W7, hidden, g, dgw, F, Fr, db6, db7, accumulate);
+    hipLaunchKernelGGL(se_gate_bwd_b_kernel, dim3((F * Fr + 255) / 256), dim3(256), 0, (hipStream_t)stream, beta3, W6, hidden, dgw,
+                       F, Fr, dbeta3_add, dW6, dW7, accumulate);
     return m1_check_launch();
 }
 

@@ -262,7 +262,7 @@ class _SECombine(torch.autograd.Function):
             sinks = [(t, 0, t) for t in (torch.empty_like(p, dtype=torch.float32) for p in ctx.params)]
             acc = 0
         (bg3, _, rg3), (bb3, _, rb3), (bg4, _, rg4), (bb4, _, rb4), (bW6, _, rW6), (bb6, _, rb6), (bW7, _, rW7), (bb7, _, rb7) = sinks
-        dg = torch.empty(Fn, dtype=torch.float32, device=dev)
+        dg = torch.empty(Fn + Fr, dtype=torch.float32, device=dev)
         ws = _ws(N, V, Fn, 5, dev)
         L.check(lib.m1_se_combine_bwd(_p(y3), _p(y4), _p(s3), _p(s4), _p(g3), _p(b3), _p(g4), _p(b4), _p(g), _p(dout),
                                       _p(dy3), _p(dy4), _p(bg3), _p(bb3), _p(bg4), _p(bb4), _p(dg), N, V, Fn, _dt(y3),
