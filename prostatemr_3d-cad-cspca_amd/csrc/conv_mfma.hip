@@ -25,7 +25,9 @@ typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 struct MfmaP {
     const void* src[M1_MAX_SRC];
     int srcC[M1_MAX_SRC];
-    int nsrc, CC;               // CC = contraction channels per tap (sum srcC)
+    int srcSeg[M1_MAX_SRC];     // 16-byte K segments per member = ceil(C / SEG): a member that is not a multiple of SEG
+                                // (latent z: 1..3 channels, stem input: 2..3) is zero-padded to whole segments in K space
+    int nsrc, CC, spt;          // CC = contraction channels per tap (sum srcC); spt = segments per tap (sum srcSeg)
     int ID, IH, IW;             // gathered tensor extent
     void* out;
     int OC, OCn;                // out row stride (channels) / channels computed by this launch
@@ -49,6 +51,17 @@ template <> struct MT<float> { static constexpr int SEG = 4; };
 
 __device__ __forceinline__ int swz(int row, int seg) { return seg ^ ((-(row >> 2)) & 3); }
 
+// n (< SEG) elements starting at p, zero padded to one 16-byte segment (element-wise loads: p need not be aligned)
+template <typename T>
+__device__ __forceinline__ uint4 load_partial_seg(const T* p, int n) {
+    constexpr int SEG = MT<T>::SEG;
+    union { uint4 v; T e[SEG]; } u;
+    u.v = make_uint4(0, 0, 0, 0);
+#pragma unroll
+    for (int k = 0; k < SEG; ++k) if (k < n) u.e[k] = p[k];
+    return u.v;
+}
+
 template <typename T, int BM, int BN, int WM, int WN>
 __global__ void __launch_bounds__(256) conv_mfma_kernel(MfmaP p) {
     constexpr int SEG = MT<T>::SEG;
@@ -64,8 +77,9 @@ __global__ void __launch_bounds__(256) conv_mfma_kernel(MfmaP p) {
     int* outrow = reinterpret_cast<int*>(rowinfo + BM);                            // [BM] output voxel index or -1
     const T** s_src = reinterpret_cast<const T**>(outrow + BM);                    // [6]
     int* s_srcC = reinterpret_cast<int*>(s_src + M1_MAX_SRC);                      // [6]
-    int* s_tap = s_srcC + M1_MAX_SRC;                                              // [27] packed dd|dh|dw
-    constexpr int TBL_BYTES = (BM * 20 + M1_MAX_SRC * 12 + MF_MAX_TAPS * 4 + 15) / 16 * 16;
+    int* s_srcSeg = s_srcC + M1_MAX_SRC;                                           // [6]
+    int* s_tap = s_srcSeg + M1_MAX_SRC;                                            // [27] packed dd|dh|dw
+    constexpr int TBL_BYTES = (BM * 20 + M1_MAX_SRC * 16 + MF_MAX_TAPS * 4 + 15) / 16 * 16;
     unsigned char* A_s = smem + TBL_BYTES;               // [2][BM][64]
     unsigned char* B_s = A_s + 2 * A_BYTES;              // [2][BN][64]
 
@@ -101,7 +115,7 @@ __global__ void __launch_bounds__(256) conv_mfma_kernel(MfmaP p) {
         }
         rowinfo[r] = ri; outrow[r] = orow;
     }
-    if (tid < M1_MAX_SRC) { s_src[tid] = (const T*)p.src[tid]; s_srcC[tid] = p.srcC[tid]; }
+    if (tid < M1_MAX_SRC) { s_src[tid] = (const T*)p.src[tid]; s_srcC[tid] = p.srcC[tid]; s_srcSeg[tid] = p.srcSeg[tid]; }
     const int ntaps = p.cls_ntaps[cls], tfirst = p.cls_first[cls];
     if (tid < ntaps) {
         const int t = tfirst + tid;
@@ -109,7 +123,7 @@ __global__ void __launch_bounds__(256) conv_mfma_kernel(MfmaP p) {
     }
     __syncthreads();
 
-    const int spt = p.CC / SEG;                          // segments per tap
+    const int spt = p.spt;                               // segments per tap
     const int nseg = ntaps * spt;
     const int nchunks_all = (nseg + 3) >> 2;
     const int cps = (nchunks_all + p.ksplit - 1) / p.ksplit;        // chunks per split
@@ -179,9 +193,9 @@ __global__ void __launch_bounds__(256) conv_mfma_kernel(MfmaP p) {
         const bool kvalid = kseg < nseg;
         if (kvalid) {
             const int tap_i = kseg / spt;
-            int c = (kseg - tap_i * spt) * SEG, s = 0;
-            while (c >= s_srcC[s]) { c -= s_srcC[s]; ++s; }
-            sp = s_src[s]; sC = s_srcC[s]; coff = c;
+            int cs = kseg - tap_i * spt, s = 0;
+            while (cs >= s_srcSeg[s]) { cs -= s_srcSeg[s]; ++s; }
+            sp = s_src[s]; sC = s_srcC[s]; coff = cs * SEG;
             const int tp = s_tap[tap_i];
             dd = (signed char)(tp & 0xff); dh = (signed char)((tp >> 8) & 0xff); dw = (signed char)((tp >> 16) & 0xff);
         }
@@ -192,7 +206,8 @@ __global__ void __launch_bounds__(256) conv_mfma_kernel(MfmaP p) {
             const int id = ri.y + dd, ih = ri.z + dh, iw = ri.w + dw;
             if (kvalid && ri.x >= 0 && id >= 0 && id < p.ID && ih >= 0 && ih < p.IH && iw >= 0 && iw < p.IW) {
                 const long long vox = (((long long)ri.x * p.ID + id) * p.IH + ih) * p.IW + iw;
-                v = *reinterpret_cast<const uint4*>(sp + vox * sC + coff);
+                if (sC % SEG == 0) v = *reinterpret_cast<const uint4*>(sp + vox * sC + coff);
+                else v = load_partial_seg<T>(sp + vox * sC + coff, sC - coff < SEG ? sC - coff : SEG);
             }
             ra[i] = v;
         }
@@ -302,6 +317,15 @@ __global__ void __launch_bounds__(256) conv_mfma_kernel(MfmaP p) {
         if (orow < 0 || oc >= p.OCn) continue;
         uint4 v = *reinterpret_cast<const uint4*>(C_s + row * CP + cs * SEG);
         T* dst = out + (long long)orow * p.OC + oc;
+        if (p.OC % SEG != 0 || oc + SEG > p.OCn) {       // output row not 16-byte tiled (dz: 1..3 channels; class logits)
+            const T* ve = reinterpret_cast<const T*>(&v);
+            for (int k = 0; k < SEG && oc + k < p.OCn; ++k) {
+                float a = Act<T>::ld(ve + k);
+                if (p.accumulate) a += Act<T>::ld(dst + k);
+                Act<T>::st(dst + k, a);
+            }
+            continue;
+        }
         if (p.accumulate) {
             float a[SEG], b[SEG];
             VecIO<T, SEG>::ld(reinterpret_cast<const T*>(&v), a);
@@ -317,7 +341,7 @@ __global__ void __launch_bounds__(256) conv_mfma_kernel(MfmaP p) {
 
 template <typename T, int BM, int BN>
 static constexpr size_t mfma_smem_bytes() {
-    size_t tbl = (BM * 20 + M1_MAX_SRC * 12 + MF_MAX_TAPS * 4 + 15) / 16 * 16;
+    size_t tbl = (BM * 20 + M1_MAX_SRC * 16 + MF_MAX_TAPS * 4 + 15) / 16 * 16;
     size_t pipe = 2 * BM * 64 + 2 * BN * 64;
     size_t epi = (size_t)BM * (BN + MT<T>::SEG) * sizeof(T);
     return tbl + (pipe > epi ? pipe : epi);
@@ -328,6 +352,7 @@ static constexpr size_t mfma_smem_bytes() {
 // ------------------------------------------------------------------------------------------------
 struct PackP {
     const float* w; long long wST, wSC, wSO; int oc_off, cc_off, OCn, OCpad, CC;
+    int nsrc, spt, SEG; int srcC[M1_MAX_SRC], srcSeg[M1_MAX_SRC];
     int nclasses; int cls_ntaps[MF_MAX_CLASSES], cls_first[MF_MAX_CLASSES], cls_kpad[MF_MAX_CLASSES];
     long long cls_woff[MF_MAX_CLASSES];
     unsigned char wtap[MF_MAX_TAPS];
@@ -339,9 +364,15 @@ __global__ void pack_weights_kernel(PackP p, T* __restrict__ out) {
     const long long tot = (long long)p.OCpad * kpad;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < tot; i += (long long)gridDim.x * blockDim.x) {
         const int oc = (int)(i / kpad), k = (int)(i % kpad);
-        const int tap_i = k / p.CC, c = k % p.CC;
+        const int kpt = p.spt * p.SEG;                      // padded K per tap
+        const int tap_i = k / kpt;
+        int seg = (k % kpt) / p.SEG, c = 0, s = 0;
+        const int lane = k % p.SEG;
+        while (s < p.nsrc && seg >= p.srcSeg[s]) { seg -= p.srcSeg[s]; c += p.srcC[s]; ++s; }
+        const bool cvalid = s < p.nsrc && seg * p.SEG + lane < p.srcC[s];
+        c += seg * p.SEG + lane;                            // channel on the (unpadded) concat axis
         float v = 0.f;
-        if (oc < p.OCn && tap_i < ntaps)
+        if (oc < p.OCn && tap_i < ntaps && cvalid)
             v = p.w[(long long)p.wtap[p.cls_first[cls] + tap_i] * p.wST + (long long)(c + p.cc_off) * p.wSC + (long long)(oc + p.oc_off) * p.wSO];
         Act<T>::st(out + p.cls_woff[cls] + i, v);
     }
@@ -387,14 +418,14 @@ static inline long long spec_maxM(const GatherSpec& g) {
 static inline int spec_ncls(const GatherSpec& g) { return g.mode == 1 ? g.sd * g.sh * g.sw : 1; }
 
 bool m1_mfma_supported(const GatherSpec& g) {
-    const int SEG = seg_of(g.dtype);
-    if (g.OC % SEG) return false;
-    for (int i = 0; i < g.nsrc; ++i) if (g.srcC[i] % SEG) return false;
     if (g.kd * g.kh * g.kw > MF_MAX_TAPS) return false;
     if (g.mode == 1 && g.sd * g.sh * g.sw > MF_MAX_CLASSES) return false;
     return true;
 }
 
+static inline int spec_spt(const GatherSpec& g, int SEG) {
+    int s = 0; for (int i = 0; i < g.nsrc; ++i) s += (g.srcC[i] + SEG - 1) / SEG; return s;
+}
 static void build_classes(const GatherSpec& g, int CC, int SEG, int OCpad, MfmaP* mp, PackP* pp, long long* total_elems) {
     const int ncls = g.mode == 1 ? g.sd * g.sh * g.sw : 1;
     int t = 0; long long woff = 0;
@@ -417,7 +448,7 @@ static void build_classes(const GatherSpec& g, int CC, int SEG, int OCpad, MfmaP
             }
         }
         const int nt = t - first;
-        const int nseg = nt * (CC / SEG);
+        const int nseg = nt * spec_spt(g, SEG);
         const int kpad = ((nseg + 3) / 4) * 4 * SEG;
         if (mp) { mp->cls_ntaps[c] = nt; mp->cls_first[c] = first; mp->cls_kpad[c] = kpad; mp->cls_woff[c] = woff; }
         if (pp) { pp->cls_ntaps[c] = nt; pp->cls_first[c] = first; pp->cls_kpad[c] = kpad; pp->cls_woff[c] = woff; }
@@ -471,9 +502,12 @@ static int run_mfma(const GatherSpec& g, void* ws, hipStream_t st) {
     int CC = 0;
     for (int i = 0; i < M1_MAX_SRC; ++i) {
         mp.src[i] = i < g.nsrc ? g.src[i] : nullptr; mp.srcC[i] = i < g.nsrc ? g.srcC[i] : (1 << 30);
+        mp.srcSeg[i] = i < g.nsrc ? (g.srcC[i] + SEG - 1) / SEG : (1 << 30);
+        pp.srcC[i] = i < g.nsrc ? g.srcC[i] : 0; pp.srcSeg[i] = i < g.nsrc ? (g.srcC[i] + SEG - 1) / SEG : 0;
         if (i < g.nsrc) CC += g.srcC[i];
     }
-    mp.nsrc = g.nsrc; mp.CC = CC; mp.ID = g.ID; mp.IH = g.IH; mp.IW = g.IW; mp.out = g.out; mp.OC = g.OC; mp.OCn = g.OC;
+    mp.nsrc = g.nsrc; mp.CC = CC; mp.spt = spec_spt(g, SEG);
+    pp.nsrc = g.nsrc; pp.spt = mp.spt; pp.SEG = SEG; mp.ID = g.ID; mp.IH = g.IH; mp.IW = g.IW; mp.out = g.out; mp.OC = g.OC; mp.OCn = g.OC;
     mp.OD = g.OD; mp.OH = g.OH; mp.OW = g.OW; mp.N = g.N; mp.wp = ws; mp.bias = g.bias; mp.mode = g.mode;
     mp.sd = g.sd; mp.sh = g.sh; mp.sw = g.sw; mp.pd = g.pd; mp.ph = g.ph; mp.pw = g.pw; mp.accumulate = g.accumulate;
     const Plan pl = make_plan(g.OC, spec_maxM(g), spec_ncls(g), min_class_chunks(g, CC, SEG));

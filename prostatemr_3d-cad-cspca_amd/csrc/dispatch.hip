@@ -86,22 +86,12 @@ static GatherSpec dgrad_spec(const m1_conv_desc_t* d, bool T, const float* w, co
 
 static inline size_t align256(size_t v) { return (v + 255) / 256 * 256; }
 
-// splits a forward-type spec into an MFMA part (aligned members) and a direct part (the rest)
+// Every channel count runs on the matrix-core kernels (unaligned members are zero-padded to whole 16-byte K
+// segments inside the kernel); the generic direct kernels remain as the m1_set_force_direct reference path.
 static void split_members(const GatherSpec& g, GatherSpec* mf, GatherSpec* dr) {
-    const int SEG = g.dtype == M1_BF16 ? 8 : 4;
     *mf = g; *dr = g; mf->nsrc = 0; dr->nsrc = 0;
-    if (g_force_direct || g.OC % SEG) { *dr = g; return; }
-    // members must stay contiguous on the weight's contraction axis: MFMA takes the longest aligned SUFFIX
-    int first_aligned = g.nsrc;
-    for (int i = g.nsrc - 1; i >= 0 && g.srcC[i] % SEG == 0; --i) first_aligned = i;
-    int off = 0;
-    for (int i = 0; i < g.nsrc; ++i) {
-        GatherSpec* t = i >= first_aligned ? mf : dr;
-        if (t->nsrc == 0) t->cc_off = g.cc_off + off;
-        t->src[t->nsrc] = g.src[i]; t->srcC[t->nsrc] = g.srcC[i]; ++t->nsrc;
-        off += g.srcC[i];
-    }
-    if (mf->nsrc && !m1_mfma_supported(*mf)) { *dr = g; mf->nsrc = 0; }
+    if (g_force_direct || !m1_mfma_supported(g)) { *dr = g; return; }
+    *mf = g;
 }
 
 static size_t gather_ws_bytes(const GatherSpec& g) {
@@ -189,7 +179,7 @@ static int wgrad_common(const m1_conv_desc_t* d, bool T, const void* dy, float* 
             g.RT = (long long)d->Cout * d->Cin; g.RSA = d->Cin; g.a_off = 0; g.b_off = off;
         }
         int rc;
-        if (!g_force_direct && m1_skinny_wgrad_supported(g)) rc = m1_skinny_wgrad(g, st);
+        if (g_force_direct == 2 && m1_skinny_wgrad_supported(g)) rc = m1_skinny_wgrad(g, st);   // test hook for that kernel
         else if (!g_force_direct && m1_mfma_wgrad_supported(g)) rc = m1_mfma_wgrad(g, st);
         else rc = m1_direct_wgrad(g, st);
         if (rc) return rc;

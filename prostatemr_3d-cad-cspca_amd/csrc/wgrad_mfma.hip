@@ -109,7 +109,17 @@ __global__ void __launch_bounds__(256) wgrad_mfma_kernel(WgP p) {
 #pragma unroll
                 for (int j = 0; j < SEG; ++j) {
                     const long long off = isA ? a_off_s[ks * SEG + j] : b_off_s[ks * SEG + j];
-                    r[j] = (off >= 0 && c0 < C) ? *reinterpret_cast<const uint4*>(base + off * C + c0) : make_uint4(0, 0, 0, 0);
+                    uint4 v = make_uint4(0, 0, 0, 0);
+                    if (off >= 0 && c0 < C) {
+                        if (C % SEG == 0) v = *reinterpret_cast<const uint4*>(base + off * C + c0);
+                        else {          // member not 16-byte tiled (stem input, latent z, class logits): element loads, zero pad
+                            union { uint4 q; T e[SEG]; } u; u.q = make_uint4(0, 0, 0, 0);
+#pragma unroll
+                            for (int k = 0; k < SEG; ++k) if (c0 + k < C) u.e[k] = base[off * C + c0 + k];
+                            v = u.q;
+                        }
+                    }
+                    r[j] = v;
                 }
                 transpose_unit(r, o, T());
                 unsigned char* dst = (isA ? A_s : B_s) + (ks >> 2) * ((isA ? TA : TB) * 64);
@@ -165,10 +175,7 @@ __global__ void __launch_bounds__(256) wgrad_mfma_kernel(WgP p) {
         }
 }
 
-bool m1_mfma_wgrad_supported(const WgradSpec& g) {
-    const int SEG = g.dtype == M1_BF16 ? 8 : 4;
-    return g.CA % SEG == 0 && g.CB % SEG == 0;
-}
+bool m1_mfma_wgrad_supported(const WgradSpec& g) { (void)g; return true; }
 
 template <typename T, int TA, int TB>
 static int launch_wg(WgP p, hipStream_t st) {
