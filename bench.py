@@ -160,39 +160,61 @@ def main():
     model.train()
     loss_buf = torch.zeros(1, device=dev)
 
-    def step():
+    def fwd_bwd():
+        """forward (all core passes) + loss + backward: gradients land in the flat buffer (kernels accumulate there)."""
+        opt.zero_grad()
         outs = model(x)
         total, _ = model.compute_loss(outs, {"detection": tgt})
-        opt.zero_grad()
         total.backward()
         opt.flatp.gather_grads()
+        loss_buf.copy_(total.detach().reshape(1))
+
+    def update():
+        """gradient exchange (N > 1) + fused Adam-amsgrad/L2 + counters."""
         if opt.reducer is not None:
             opt.reducer.all_reduce(opt.flatp.grad)
         opt.apply_flat()
         ops.step_advance(None, model.rng_state)
-        loss_buf.copy_(total.detach().reshape(1))
+
+    def step():
+        fwd_bwd()
+        update()
 
     # ---- eager warm-up (also primes the allocator), then optional whole-step hipGraph ----
     for _ in range(max(1, min(a.warmup, 2))):
         step()
     torch.cuda.synchronize()
     use_graph, graph, graph_err = (not a.no_graph), None, None
+    # N = 1: the whole step is one hipGraph.  N > 1: forward+backward are captured, the RCCL exchange and the
+    # optimiser kernel are launched eagerly behind the replay (no collective inside a captured graph).
+    captured = step if world == 1 else fwd_bwd
     if use_graph:
         try:
             s = torch.cuda.Stream()
             s.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(s):
-                step()
+                captured()
+                if world > 1:
+                    update()
             torch.cuda.current_stream().wait_stream(s)
             torch.cuda.synchronize()
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
-                step()
+                captured()
             torch.cuda.synchronize()
+            if world > 1:
+                update()
         except Exception as e:  # noqa: BLE001 -- fall back to eager launches, report it
             graph, graph_err = None, f"{type(e).__name__}: {str(e)[:200]}"
             torch.cuda.synchronize()
-    run = (lambda: graph.replay()) if graph is not None else step
+    if graph is None:
+        run = step
+    elif world == 1:
+        run = graph.replay
+    else:
+        def run():
+            graph.replay()
+            update()
 
     for _ in range(a.warmup):
         run()

@@ -65,9 +65,13 @@ int m1_abi_version(void);
 /* ws: caller-owned scratch of m1_conv_ws_bytes(d, transposed, role) bytes, 256-byte aligned (packed bf16/fp32
  * weight panels for the matrix-core kernels; bias-gradient partials for wgrad). role: 0 fwd, 1 dgrad, 2 wgrad. */
 size_t m1_conv_ws_bytes(const m1_conv_desc_t* d, int transposed, int role);
-int m1_conv3d_fwd(const m1_conv_desc_t* d, const float* w, const float* bias, void* y, void* ws, void* stream);
+/* ws_packed != 0: ws still holds the weight panels a previous call with the SAME descriptor geometry, role and
+ * (unchanged) weights left there -- the pack pass is skipped (the prior / posterior cores run twice per step). */
+int m1_conv3d_fwd(const m1_conv_desc_t* d, const float* w, const float* bias, void* y, void* ws, int ws_packed,
+                  void* stream);
 /* dx[i]: gradient buffer of concat member i (same shape/dtype as src[i]) or NULL to skip it. */
-int m1_conv3d_dgrad(const m1_conv_desc_t* d, const float* w, const void* dy, void* const* dx, void* ws, void* stream);
+int m1_conv3d_dgrad(const m1_conv_desc_t* d, const float* w, const void* dy, void* const* dx, void* ws, int ws_packed,
+                    void* stream);
 /* dw (kd,kh,kw,Cin,Cout) and db (Cout): accumulate == 0 -> overwritten (zeroed inside first);
  * accumulate != 0 -> added to what is there (the caller's flat gradient buffer, zeroed once per step: a weight
  * shared by several passes -- prior / posterior cores run twice per step -- sums without any extra copy). The
@@ -79,8 +83,10 @@ int m1_set_force_direct(int on);
 
 /* ---- Conv3DTranspose(padding='same') + bias : N:496-499,505-507,513-514,520,546-553 ----
  * w: Keras layout (kd,kh,kw,Cout,Cin) fp32; y: (N, D*sd, H*sh, W*sw, Cout). */
-int m1_convT3d_fwd(const m1_conv_desc_t* d, const float* w, const float* bias, void* y, void* ws, void* stream);
-int m1_convT3d_dgrad(const m1_conv_desc_t* d, const float* w, const void* dy, void* const* dx, void* ws, void* stream);
+int m1_convT3d_fwd(const m1_conv_desc_t* d, const float* w, const float* bias, void* y, void* ws, int ws_packed,
+                   void* stream);
+int m1_convT3d_dgrad(const m1_conv_desc_t* d, const float* w, const void* dy, void* const* dx, void* ws, int ws_packed,
+                     void* stream);
 int m1_convT3d_wgrad(const m1_conv_desc_t* d, const void* dy, float* dw, float* db, void* ws, int accumulate,
                      void* stream);
 

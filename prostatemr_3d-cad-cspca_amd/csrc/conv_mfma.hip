@@ -496,7 +496,7 @@ static int launch_cfg(const MfmaP& mp, long long maxM, int OCpad, hipStream_t st
 }
 
 template <typename T>
-static int run_mfma(const GatherSpec& g, void* ws, hipStream_t st) {
+static int run_mfma(const GatherSpec& g, void* ws, int ws_packed, hipStream_t st) {
     constexpr int SEG = MT<T>::SEG;
     MfmaP mp{}; PackP pp{};
     int CC = 0;
@@ -524,8 +524,11 @@ static int run_mfma(const GatherSpec& g, void* ws, hipStream_t st) {
     pp.w = g.w; pp.wST = g.wST; pp.wSC = g.wSC; pp.wSO = g.wSO; pp.oc_off = g.oc_off; pp.cc_off = g.cc_off; pp.OCn = g.OC; pp.OCpad = OCpad; pp.CC = CC;
     int maxk = 0; for (int c = 0; c < pp.nclasses; ++c) maxk = pp.cls_kpad[c] > maxk ? pp.cls_kpad[c] : maxk;
     long long pblocks = cdiv_ll((long long)OCpad * maxk, 256); if (pblocks > 2048) pblocks = 2048; if (pblocks < 1) pblocks = 1;
-    hipLaunchKernelGGL(pack_weights_kernel<T>, dim3((unsigned)pblocks, pp.nclasses), dim3(256), 0, st, pp, (T*)ws);
-    int rc = m1_check_launch(); if (rc) return rc;
+    int rc = M1_OK;
+    if (!ws_packed) {          // the caller may keep the panel of an unchanged weight across calls (2+2 core passes per step)
+        hipLaunchKernelGGL(pack_weights_kernel<T>, dim3((unsigned)pblocks, pp.nclasses), dim3(256), 0, st, pp, (T*)ws);
+        rc = m1_check_launch(); if (rc) return rc;
+    }
 
     const long long maxM = spec_maxM(g);
     const bool small = pl.BM == 64;
@@ -543,7 +546,7 @@ static int run_mfma(const GatherSpec& g, void* ws, hipStream_t st) {
     return m1_check_launch();
 }
 
-int m1_mfma_gather(const GatherSpec& g, void* ws, hipStream_t st) {
+int m1_mfma_gather(const GatherSpec& g, void* ws, int ws_packed, hipStream_t st) {
     if (!ws) return M1_ERR_WORKSPACE;
-    return g.dtype == M1_BF16 ? run_mfma<bf16_t>(g, ws, st) : run_mfma<float>(g, ws, st);
+    return g.dtype == M1_BF16 ? run_mfma<bf16_t>(g, ws, ws_packed, st) : run_mfma<float>(g, ws, ws_packed, st);
 }

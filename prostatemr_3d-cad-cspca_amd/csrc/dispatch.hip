@@ -99,12 +99,12 @@ static size_t gather_ws_bytes(const GatherSpec& g) {
     return mf.nsrc ? align256(m1_mfma_ws_bytes(mf)) : 0;
 }
 
-static int run_gather(const GatherSpec& g, void* ws, hipStream_t st) {
+static int run_gather(const GatherSpec& g, void* ws, int ws_packed, hipStream_t st) {
     GatherSpec mf, dr; split_members(g, &mf, &dr);
     int rc = M1_OK;
     if (mf.nsrc) {
         if (!ws) return M1_ERR_WORKSPACE;
-        rc = m1_mfma_gather(mf, ws, st); if (rc) return rc;
+        rc = m1_mfma_gather(mf, ws, ws_packed, st); if (rc) return rc;
         if (dr.nsrc) { dr.accumulate = 1; dr.bias = nullptr; rc = m1_direct_gather(dr, st); }
         return rc;
     }
@@ -119,8 +119,8 @@ extern "C" size_t m1_conv_ws_bytes(const m1_conv_desc_t* d, int transposed, int 
     if (role == 1) {
         size_t m = 0; int off = 0;
         for (int i = 0; i < d->nsrc; ++i) {
-            size_t b = gather_ws_bytes(dgrad_spec(d, T, nullptr, nullptr, nullptr, i, off));
-            m = b > m ? b : m; off += d->src[i].C;
+            m += gather_ws_bytes(dgrad_spec(d, T, nullptr, nullptr, nullptr, i, off));
+            off += d->src[i].C;
         }
         return m + 256;
     }
@@ -129,33 +129,42 @@ extern "C" size_t m1_conv_ws_bytes(const m1_conv_desc_t* d, int transposed, int 
 }
 
 // ---- Conv3D ------------------------------------------------------------------------------------------------------
-extern "C" int m1_conv3d_fwd(const m1_conv_desc_t* d, const float* w, const float* bias, void* y, void* ws, void* stream) {
+extern "C" int m1_conv3d_fwd(const m1_conv_desc_t* d, const float* w, const float* bias, void* y, void* ws, int ws_packed,
+                             void* stream) {
     if (!desc_ok(d) || !w || !y) return M1_ERR_BAD_ARG;
     M1ProfScope ps("conv3d_fwd", 2.0 * conv_macs(d, false), conv_bytes(d, false), (hipStream_t)stream);
-    return run_gather(fwd_spec(d, false, w, bias, y), ws, (hipStream_t)stream);
+    return run_gather(fwd_spec(d, false, w, bias, y), ws, ws_packed, (hipStream_t)stream);
 }
-extern "C" int m1_convT3d_fwd(const m1_conv_desc_t* d, const float* w, const float* bias, void* y, void* ws, void* stream) {
+extern "C" int m1_convT3d_fwd(const m1_conv_desc_t* d, const float* w, const float* bias, void* y, void* ws, int ws_packed,
+                              void* stream) {
     if (!desc_ok(d) || !w || !y) return M1_ERR_BAD_ARG;
     M1ProfScope ps("convT3d_fwd", 2.0 * conv_macs(d, true), conv_bytes(d, true), (hipStream_t)stream);
-    return run_gather(fwd_spec(d, true, w, bias, y), ws, (hipStream_t)stream);
+    return run_gather(fwd_spec(d, true, w, bias, y), ws, ws_packed, (hipStream_t)stream);
 }
-static int dgrad_common(const m1_conv_desc_t* d, bool T, const float* w, const void* dy, void* const* dx, void* ws, hipStream_t st) {
-    int off = 0;
+static int dgrad_common(const m1_conv_desc_t* d, bool T, const float* w, const void* dy, void* const* dx, void* ws, int ws_packed,
+                        hipStream_t st) {
+    int off = 0; size_t woff = 0;                         // member i's panel lives at its own offset of ws (cacheable)
     for (int i = 0; i < d->nsrc; ++i) {
-        if (dx[i]) { int rc = run_gather(dgrad_spec(d, T, w, dy, dx[i], i, off), ws, st); if (rc) return rc; }
+        const GatherSpec g = dgrad_spec(d, T, w, dy, dx[i], i, off);
+        if (dx[i]) {
+            int rc = run_gather(g, ws ? (unsigned char*)ws + woff : nullptr, ws_packed, st); if (rc) return rc;
+        }
+        woff += gather_ws_bytes(g);
         off += d->src[i].C;
     }
     return M1_OK;
 }
-extern "C" int m1_conv3d_dgrad(const m1_conv_desc_t* d, const float* w, const void* dy, void* const* dx, void* ws, void* stream) {
+extern "C" int m1_conv3d_dgrad(const m1_conv_desc_t* d, const float* w, const void* dy, void* const* dx, void* ws, int ws_packed,
+                               void* stream) {
     if (!desc_ok(d) || !w || !dy || !dx) return M1_ERR_BAD_ARG;
     M1ProfScope ps("conv3d_dgrad", 2.0 * conv_macs(d, false), conv_bytes(d, false), (hipStream_t)stream);
-    return dgrad_common(d, false, w, dy, dx, ws, (hipStream_t)stream);
+    return dgrad_common(d, false, w, dy, dx, ws, ws_packed, (hipStream_t)stream);
 }
-extern "C" int m1_convT3d_dgrad(const m1_conv_desc_t* d, const float* w, const void* dy, void* const* dx, void* ws, void* stream) {
+extern "C" int m1_convT3d_dgrad(const m1_conv_desc_t* d, const float* w, const void* dy, void* const* dx, void* ws, int ws_packed,
+                                void* stream) {
     if (!desc_ok(d) || !w || !dy || !dx) return M1_ERR_BAD_ARG;
     M1ProfScope ps("convT3d_dgrad", 2.0 * conv_macs(d, true), conv_bytes(d, true), (hipStream_t)stream);
-    return dgrad_common(d, true, w, dy, dx, ws, (hipStream_t)stream);
+    return dgrad_common(d, true, w, dy, dx, ws, ws_packed, (hipStream_t)stream);
 }
 
 // ---- weight gradients ------------------------------------------------------------------------------------------

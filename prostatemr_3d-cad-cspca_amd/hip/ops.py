@@ -84,6 +84,36 @@ def _conv_ws(d, transposed: bool, role: int, device) -> torch.Tensor:
     return torch.empty(max(int(n), 256), dtype=torch.uint8, device=device)
 
 
+# Packed weight panels are kept ON the weight tensor object, per (version, role, geometry), while the weights are
+# unchanged, so that the second pass of a core within one train step (prior and posterior each run twice,
+# networks.py:348-352) skips the pack.  Living on the tensor object they die with it (no address-reuse aliasing).
+_PANEL_EPOCH = [0]
+
+
+def invalidate_panels() -> None:
+    """Call after anything that changes weights through raw pointers (the fused optimiser kernel does)."""
+    _PANEL_EPOCH[0] += 1
+
+
+def _panel_ws(w: torch.Tensor, d, transposed: bool, role: int, need_mask=None):
+    store = getattr(w, "_m1_panels", None)
+    stamp = (_PANEL_EPOCH[0], w._version, w.data_ptr())
+    if store is None or store[0] != stamp:
+        store = (stamp, {})
+        try:
+            w._m1_panels = store
+        except Exception:  # noqa: BLE001 -- an object that cannot carry attributes: no caching
+            return _conv_ws(d, transposed, role, w.device), 0
+    key = (role, transposed, d.N, d.D, d.H, d.W, d.kd, d.kh, d.kw, d.sd, d.sh, d.sw, d.dtype,
+           tuple(d.src[i].C for i in range(d.nsrc)), need_mask)
+    hit = store[1].get(key)
+    if hit is not None:
+        return hit, 1
+    ws = _conv_ws(d, transposed, role, w.device)
+    store[1][key] = ws
+    return ws, 0
+
+
 def same_out(size: int, s: int) -> int:
     return -(-size // s)
 
@@ -108,8 +138,8 @@ class _Conv3d(torch.autograd.Function):
             osz = (d.N, same_out(d.D, d.sd), same_out(d.H, d.sh), same_out(d.W, d.sw), cout)
         y = torch.empty(osz, dtype=x0.dtype, device=x0.device)
         fn = lib.m1_convT3d_fwd if transposed else lib.m1_conv3d_fwd
-        ws = _conv_ws(d, transposed, 0, x0.device)
-        L.check(fn(C.byref(d), _p(w), _p(b), _p(y), _p(ws), _stream()), "m1_convT3d_fwd" if transposed else "m1_conv3d_fwd")
+        ws, packed = _panel_ws(w, d, transposed, 0)
+        L.check(fn(C.byref(d), _p(w), _p(b), _p(y), _p(ws), packed, _stream()), "m1_convT3d_fwd" if transposed else "m1_conv3d_fwd")
         ctx.save_for_backward(w, *srcs)
         ctx.w_param, ctx.b_param = w, b
         ctx.k, ctx.s, ctx.transposed, ctx.has_bias, ctx.cout = tuple(k), tuple(s), transposed, b is not None, cout
@@ -151,8 +181,8 @@ class _Conv3d(torch.autograd.Function):
                 ptrs[i] = None
         if any_d:
             fn = lib.m1_convT3d_dgrad if ctx.transposed else lib.m1_conv3d_dgrad
-            ws = _conv_ws(d, ctx.transposed, 1, w.device)
-            L.check(fn(C.byref(d), _p(w), _p(dy), ptrs, _p(ws), st), f"m1_{name}_dgrad")
+            ws, packed = _panel_ws(ctx.w_param, d, ctx.transposed, 1, tuple(bool(g is not None) for g in dsrc))
+            L.check(fn(C.byref(d), _p(w), _p(dy), ptrs, _p(ws), packed, st), f"m1_{name}_dgrad")
         return (dw, db, None, None, None, *dsrc)
 
 

@@ -130,6 +130,8 @@ class LoadableModel(nn.Module):
             for k, v in sd.items():
                 if k in own:
                     own[k].copy_(v.to(own[k].device, own[k].dtype))
+        from ..hip import ops
+        ops.invalidate_panels()
 
     @classmethod
     def load(cls, path, by_name=False):
