@@ -67,8 +67,11 @@ int m1_abi_version(void);
 size_t m1_conv_ws_bytes(const m1_conv_desc_t* d, int transposed, int role);
 /* ws_packed != 0: ws still holds the weight panels a previous call with the SAME descriptor geometry, role and
  * (unchanged) weights left there -- the pack pass is skipped (the prior / posterior cores run twice per step). */
-int m1_conv3d_fwd(const m1_conv_desc_t* d, const float* w, const float* bias, void* y, void* ws, int ws_packed,
-                  void* stream);
+/* stats (optional, (N,Cout,2) fp32): {mean, rstd} (eps 1e-3, biased variance) of y per (n, channel) for the
+ * InstanceNormalization that follows (B:54-60, N:575) -- accumulated from the stored (rounded) outputs in the
+ * conv's own epilogue, so the statistics cost no extra pass over y. */
+int m1_conv3d_fwd(const m1_conv_desc_t* d, const float* w, const float* bias, void* y, float* stats, void* ws,
+                  int ws_packed, void* stream);
 /* dx[i]: gradient buffer of concat member i (same shape/dtype as src[i]) or NULL to skip it. */
 int m1_conv3d_dgrad(const m1_conv_desc_t* d, const float* w, const void* dy, void* const* dx, void* ws, int ws_packed,
                     void* stream);

@@ -15,6 +15,7 @@
 // * epilogue: + bias, convert, stage the block tile in LDS, 16-byte coalesced NDHWC stores.
 #include "common.h"
 #include "gather.h"
+#include "reduce.h"
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
@@ -43,6 +44,8 @@ struct MfmaP {
     int ksplit;                 // > 1: blockIdx.y = cls*ksplit + ks; partial sums go to acc32 with fp32 atomics
     float* acc32;               // [out voxels][OC] fp32, zeroed by the host before the launch (ksplit > 1 only)
     int aligned;                // every concat member is a multiple of one 64-byte K-chunk: incremental addressing
+    float* stat_partial;        // fused InstanceNorm statistics: [N][tiles per sample][OC][2] = {sum, sum of squares} of
+    int stat_tiles;             //   the ROUNDED outputs of each 64/128-row tile (mode 0, tiles never straddle samples)
 };
 
 template <typename T> struct MT;
@@ -62,7 +65,7 @@ __device__ __forceinline__ uint4 load_partial_seg(const T* p, int n) {
     return u.v;
 }
 
-template <typename T, int BM, int BN, int WM, int WN>
+template <typename T, int BM, int BN, int WM, int WN, int KC>
 __global__ void __launch_bounds__(256) conv_mfma_kernel(MfmaP p) {
     constexpr int SEG = MT<T>::SEG;
     constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
@@ -80,8 +83,8 @@ __global__ void __launch_bounds__(256) conv_mfma_kernel(MfmaP p) {
     int* s_srcSeg = s_srcC + M1_MAX_SRC;                                           // [6]
     int* s_tap = s_srcSeg + M1_MAX_SRC;                                            // [27] packed dd|dh|dw
     constexpr int TBL_BYTES = (BM * 20 + M1_MAX_SRC * 16 + MF_MAX_TAPS * 4 + 15) / 16 * 16;
-    unsigned char* A_s = smem + TBL_BYTES;               // [2][BM][64]
-    unsigned char* B_s = A_s + 2 * A_BYTES;              // [2][BN][64]
+    unsigned char* A_s = smem + TBL_BYTES;               // [2][KC][BM][64]
+    unsigned char* B_s = A_s + 2 * KC * A_BYTES;         // [2][KC][BN][64]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
@@ -138,7 +141,7 @@ __global__ void __launch_bounds__(256) conv_mfma_kernel(MfmaP p) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
-    uint4 ra[A_LD], rb[B_LD];
+    uint4 ra[KC][A_LD], rb[KC][B_LD];
     const int lseg = tid & 3, lrow = tid >> 2;           // loader: 4 lanes cover one 64-byte row
 
     // incremental loader state (aligned case): current tap / concat member / channel offset and per-row bases
@@ -166,114 +169,122 @@ __global__ void __launch_bounds__(256) conv_mfma_kernel(MfmaP p) {
         st_c = c;
         st_set_tap();
     }
-    auto prefetch_aligned = [&](int chunk) {
+
+    // loads the KC chunks of pipeline stage `sg` into registers (zero beyond this block's K range)
+    auto prefetch_stage = [&](int sg) {
 #pragma unroll
-        for (int i = 0; i < A_LD; ++i)
-            ra[i] = st_ptr[i] ? *reinterpret_cast<const uint4*>(st_ptr[i] + st_c) : make_uint4(0, 0, 0, 0);
+        for (int kc = 0; kc < KC; ++kc) {
+            const int rel = sg * KC + kc;
+            const int chunk = c_beg + rel;
+            const bool live = rel < nchunks;
+            // ---- B: packed weights, rows = output channels ----
 #pragma unroll
-        for (int i = 0; i < B_LD; ++i) {
-            const int e = tid + 256 * i;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (e < BN * 4)
-                v = *reinterpret_cast<const uint4*>(wp + (long long)(oc0 + (e >> 2)) * kpad + (long long)(chunk * 4 + (e & 3)) * SEG);
-            rb[i] = v;
-        }
-        st_c += 4 * SEG;
-        if (st_c >= s_srcC[st_s]) {                        // next concat member, or next tap
-            st_c = 0;
-            if (++st_s == p.nsrc) { st_s = 0; ++st_tap; }
-            if (st_tap < ntaps) st_set_tap();
-        }
-    };
-    auto prefetch = [&](int chunk) {
-        if (p.aligned) { prefetch_aligned(chunk); return; }
-        // ---- A: gathered activations ----
-        const int kseg = chunk * 4 + lseg;
-        const T* sp = nullptr; int sC = 0, coff = 0, dd = 0, dh = 0, dw = 0;
-        const bool kvalid = kseg < nseg;
-        if (kvalid) {
-            const int tap_i = kseg / spt;
-            int cs = kseg - tap_i * spt, s = 0;
-            while (cs >= s_srcSeg[s]) { cs -= s_srcSeg[s]; ++s; }
-            sp = s_src[s]; sC = s_srcC[s]; coff = cs * SEG;
-            const int tp = s_tap[tap_i];
-            dd = (signed char)(tp & 0xff); dh = (signed char)((tp >> 8) & 0xff); dw = (signed char)((tp >> 16) & 0xff);
-        }
-#pragma unroll
-        for (int i = 0; i < A_LD; ++i) {
-            const int4 ri = rowinfo[lrow + 64 * i];
-            uint4 v = make_uint4(0, 0, 0, 0);
-            const int id = ri.y + dd, ih = ri.z + dh, iw = ri.w + dw;
-            if (kvalid && ri.x >= 0 && id >= 0 && id < p.ID && ih >= 0 && ih < p.IH && iw >= 0 && iw < p.IW) {
-                const long long vox = (((long long)ri.x * p.ID + id) * p.IH + ih) * p.IW + iw;
-                if (sC % SEG == 0) v = *reinterpret_cast<const uint4*>(sp + vox * sC + coff);
-                else v = load_partial_seg<T>(sp + vox * sC + coff, sC - coff < SEG ? sC - coff : SEG);
+            for (int i = 0; i < B_LD; ++i) {
+                const int e = tid + 256 * i;                 // (row, seg) = (e>>2, e&3)
+                uint4 v = make_uint4(0, 0, 0, 0);
+                if (live && e < BN * 4)
+                    v = *reinterpret_cast<const uint4*>(wp + (long long)(oc0 + (e >> 2)) * kpad + (long long)(chunk * 4 + (e & 3)) * SEG);
+                rb[kc][i] = v;
             }
-            ra[i] = v;
-        }
-        // ---- B: packed weights, rows = output channels ----
+            // ---- A: gathered activations ----
+            if (!live) {
 #pragma unroll
-        for (int i = 0; i < B_LD; ++i) {
-            const int e = tid + 256 * i;                 // (row, seg) = (e>>2, e&3)
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (e < BN * 4) {
-                const int brow = e >> 2;
-                v = *reinterpret_cast<const uint4*>(wp + (long long)(oc0 + brow) * kpad + (long long)(chunk * 4 + (e & 3)) * SEG);
+                for (int i = 0; i < A_LD; ++i) ra[kc][i] = make_uint4(0, 0, 0, 0);
+            } else if (p.aligned) {
+#pragma unroll
+                for (int i = 0; i < A_LD; ++i)
+                    ra[kc][i] = st_ptr[i] ? *reinterpret_cast<const uint4*>(st_ptr[i] + st_c) : make_uint4(0, 0, 0, 0);
+                st_c += 4 * SEG;
+                if (st_c >= s_srcC[st_s]) {                // next concat member, or next tap
+                    st_c = 0;
+                    if (++st_s == p.nsrc) { st_s = 0; ++st_tap; }
+                    if (st_tap < ntaps) st_set_tap();
+                }
+            } else {
+                const int kseg = chunk * 4 + lseg;
+                const T* sp = nullptr; int sC = 0, coff = 0, dd = 0, dh = 0, dw = 0;
+                const bool kvalid = kseg < nseg;
+                if (kvalid) {
+                    const int tap_i = kseg / spt;
+                    int cs = kseg - tap_i * spt, s = 0;
+                    while (cs >= s_srcSeg[s]) { cs -= s_srcSeg[s]; ++s; }
+                    sp = s_src[s]; sC = s_srcC[s]; coff = cs * SEG;
+                    const int tp = s_tap[tap_i];
+                    dd = (signed char)(tp & 0xff); dh = (signed char)((tp >> 8) & 0xff); dw = (signed char)((tp >> 16) & 0xff);
+                }
+#pragma unroll
+                for (int i = 0; i < A_LD; ++i) {
+                    const int4 ri = rowinfo[lrow + 64 * i];
+                    uint4 v = make_uint4(0, 0, 0, 0);
+                    const int id = ri.y + dd, ih = ri.z + dh, iw = ri.w + dw;
+                    if (kvalid && coff < sC && ri.x >= 0 && id >= 0 && id < p.ID && ih >= 0 && ih < p.IH && iw >= 0 && iw < p.IW) {
+                        const long long vox = (((long long)ri.x * p.ID + id) * p.IH + ih) * p.IW + iw;
+                        if (sC % SEG == 0) v = *reinterpret_cast<const uint4*>(sp + vox * sC + coff);
+                        else v = load_partial_seg<T>(sp + vox * sC + coff, sC - coff < SEG ? sC - coff : SEG);
+                    }
+                    ra[kc][i] = v;
+                }
             }
-            rb[i] = v;
         }
     };
     auto stage = [&](int buf) {
 #pragma unroll
-        for (int i = 0; i < A_LD; ++i) {
-            const int row = lrow + 64 * i;
-            *reinterpret_cast<uint4*>(A_s + buf * A_BYTES + row * 64 + swz(row, lseg) * 16) = ra[i];
-        }
+        for (int kc = 0; kc < KC; ++kc) {
 #pragma unroll
-        for (int i = 0; i < B_LD; ++i) {
-            const int e = tid + 256 * i;
-            if (e < BN * 4) {
-                const int row = e >> 2;
-                *reinterpret_cast<uint4*>(B_s + buf * B_BYTES + row * 64 + swz(row, e & 3) * 16) = rb[i];
+            for (int i = 0; i < A_LD; ++i) {
+                const int row = lrow + 64 * i;
+                *reinterpret_cast<uint4*>(A_s + (buf * KC + kc) * A_BYTES + row * 64 + swz(row, lseg) * 16) = ra[kc][i];
+            }
+#pragma unroll
+            for (int i = 0; i < B_LD; ++i) {
+                const int e = tid + 256 * i;
+                if (e < BN * 4) {
+                    const int row = e >> 2;
+                    *reinterpret_cast<uint4*>(B_s + (buf * KC + kc) * B_BYTES + row * 64 + swz(row, e & 3) * 16) = rb[kc][i];
+                }
             }
         }
     };
 
     const int fr = lane & 15, fs = lane >> 4;
-    if (nchunks > 0) {
-        prefetch(c_beg);
+    const int nstages = (nchunks + KC - 1) / KC;
+    if (nstages > 0) {
+        prefetch_stage(0);
         stage(0);
     }
     __syncthreads();
-    for (int it = 0; it < nchunks; ++it) {
+    for (int it = 0; it < nstages; ++it) {
         const int buf = it & 1;
-        if (it + 1 < nchunks) prefetch(c_beg + it + 1);
-        uint4 af[TM], bfr[TN];
+        if (it + 1 < nstages) prefetch_stage(it + 1);
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            const int row = wm * (BM / WM) + i * 16 + fr;
-            af[i] = *reinterpret_cast<const uint4*>(A_s + buf * A_BYTES + row * 64 + swz(row, fs) * 16);
-        }
+        for (int kc = 0; kc < KC; ++kc) {
+            uint4 af[TM], bfr[TN];
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int row = wn * (BN / WN) + j * 16 + fr;
-            bfr[j] = *reinterpret_cast<const uint4*>(B_s + buf * B_BYTES + row * 64 + swz(row, fs) * 16);
-        }
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
+            for (int i = 0; i < TM; ++i) {
+                const int row = wm * (BM / WM) + i * 16 + fr;
+                af[i] = *reinterpret_cast<const uint4*>(A_s + (buf * KC + kc) * A_BYTES + row * 64 + swz(row, fs) * 16);
+            }
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
-                if constexpr (sizeof(T) == 2) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, af[i]),
-                                                                        __builtin_bit_cast(bf16x8_t, bfr[j]), acc[i][j], 0, 0, 0);
-                } else {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(af[i].x), __uint_as_float(bfr[j].x), acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(af[i].y), __uint_as_float(bfr[j].y), acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(af[i].z), __uint_as_float(bfr[j].z), acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(af[i].w), __uint_as_float(bfr[j].w), acc[i][j], 0, 0, 0);
-                }
+                const int row = wn * (BN / WN) + j * 16 + fr;
+                bfr[j] = *reinterpret_cast<const uint4*>(B_s + (buf * KC + kc) * B_BYTES + row * 64 + swz(row, fs) * 16);
             }
-        if (it + 1 < nchunks) stage(buf ^ 1);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    if constexpr (sizeof(T) == 2) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, af[i]),
+                                                                            __builtin_bit_cast(bf16x8_t, bfr[j]), acc[i][j], 0, 0, 0);
+                    } else {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(af[i].x), __uint_as_float(bfr[j].x), acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(af[i].y), __uint_as_float(bfr[j].y), acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(af[i].z), __uint_as_float(bfr[j].z), acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(af[i].w), __uint_as_float(bfr[j].w), acc[i][j], 0, 0, 0);
+                    }
+                }
+        }
+        if (it + 1 < nstages) stage(buf ^ 1);
         __syncthreads();
     }
 
@@ -308,6 +319,24 @@ __global__ void __launch_bounds__(256) conv_mfma_kernel(MfmaP p) {
             }
         }
     __syncthreads();
+    if (p.stat_partial) {          // per-tile column sums of the stored (rounded) values -> deterministic partials
+        constexpr int EPI_BYTES = (int)((BM * CP * sizeof(T) + 15) / 16 * 16), PIPE_BYTES = 2 * KC * (A_BYTES + B_BYTES);
+        float* red = reinterpret_cast<float*>(A_s + (PIPE_BYTES > EPI_BYTES ? PIPE_BYTES : EPI_BYTES));   // 2 KB scratch behind both
+        constexpr int G = 256 / BN;                       // row groups
+        const int col = tid % BN, rg = tid / BN;
+        float s = 0.f, ss = 0.f;
+        for (int row = rg; row < BM; row += G) {
+            if (outrow[row] >= 0) { const float v = Act<T>::ld(C_s + row * CP + col); s += v; ss += v * v; }
+        }
+        red[tid * 2] = s; red[tid * 2 + 1] = ss;
+        __syncthreads();
+        if (rg == 0 && oc0 + col < p.OCn) {
+            for (int q = 1; q < G; ++q) { s += red[(q * BN + col) * 2]; ss += red[(q * BN + col) * 2 + 1]; }
+            const long long tile = blockIdx.x;            // mode 0: tiles are sample-major, stat_tiles per sample
+            float* dst = p.stat_partial + ((tile * p.OC) + oc0 + col) * 2;
+            dst[0] = s; dst[1] = ss;
+        }
+    }
     constexpr int SPR = BN / SEG;                         // 16-B segments per tile row
     T* out = (T*)p.out;
     for (int e = tid; e < BM * SPR; e += 256) {
@@ -339,12 +368,12 @@ __global__ void __launch_bounds__(256) conv_mfma_kernel(MfmaP p) {
     }
 }
 
-template <typename T, int BM, int BN>
+template <typename T, int BM, int BN, int KC>
 static constexpr size_t mfma_smem_bytes() {
     size_t tbl = (BM * 20 + M1_MAX_SRC * 16 + MF_MAX_TAPS * 4 + 15) / 16 * 16;
-    size_t pipe = 2 * BM * 64 + 2 * BN * 64;
-    size_t epi = (size_t)BM * (BN + MT<T>::SEG) * sizeof(T);
-    return tbl + (pipe > epi ? pipe : epi);
+    size_t pipe = (size_t)KC * (2 * BM * 64 + 2 * BN * 64);
+    size_t epi = ((size_t)BM * (BN + MT<T>::SEG) * sizeof(T) + 15) / 16 * 16;
+    return tbl + (pipe > epi ? pipe : epi) + 256 * 2 * sizeof(float);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -395,8 +424,10 @@ __global__ void splitk_finish_kernel(const float* __restrict__ acc32, const floa
 static inline int seg_of(int dtype) { return dtype == M1_BF16 ? 8 : 4; }
 static inline int pick_bn(int ocn) { return ocn > 64 ? 128 : (ocn > 32 ? 64 : (ocn > 16 ? 32 : 16)); }
 struct Plan { int BN, BM, ksplit; };
-// 128-row tiles unless that leaves the 256 CUs short of work (res3/res4: M = 4,000 / 500 voxels) -> 64 rows, and
-// if still short, split K (taps x channels, up to 13,824 deep there) over blockIdx.y.
+// 128-row tiles unless that leaves the 256 CUs short of work (res2: 250 tiles, res3/res4: M = 4,000 / 500 voxels)
+// -> 64 rows, and if still short, split K (taps x channels, up to 13,824 deep there) over blockIdx.y.
+// (Measured: keeping 128-row tiles and splitting K harder instead is slower -- the fp32 atomics cost more than the
+// saved L2 -> LDS traffic.)
 static inline Plan make_plan(int ocn, long long maxM, int ncls, int min_nchunks) {
     Plan pl; pl.BN = pick_bn(ocn);
     const int ntile = (ocn + pl.BN - 1) / pl.BN;
@@ -481,11 +512,11 @@ size_t m1_mfma_ws_bytes(const GatherSpec& g) {
     return bytes + 256;
 }
 
-template <typename T, int BM, int BN, int WM, int WN>
-static int launch_cfg(const MfmaP& mp, long long maxM, int OCpad, hipStream_t st) {
+template <typename T, int BM, int BN, int WM, int WN, int KC>
+static int launch_cfg_kc(const MfmaP& mp, long long maxM, int OCpad, hipStream_t st) {
     dim3 grid((unsigned)cdiv_ll(maxM, BM), mp.nclasses * mp.ksplit, OCpad / BN);
-    const size_t smem = mfma_smem_bytes<T, BM, BN>();
-    auto kern = conv_mfma_kernel<T, BM, BN, WM, WN>;
+    const size_t smem = mfma_smem_bytes<T, BM, BN, KC>();
+    auto kern = conv_mfma_kernel<T, BM, BN, WM, WN, KC>;
     static bool attr_set = false;     // per instantiation
     if (smem > 48 * 1024 && !attr_set) {
         if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) return M1_ERR_LAUNCH;
@@ -493,6 +524,15 @@ static int launch_cfg(const MfmaP& mp, long long maxM, int OCpad, hipStream_t st
     }
     hipLaunchKernelGGL(kern, grid, dim3(256), smem, st, mp);
     return m1_check_launch();
+}
+
+// two 64-byte K-chunks per pipeline stage (one barrier per 64 bf16 / 32 fp32 of K) once the K loop is long enough
+template <typename T, int BM, int BN, int WM, int WN>
+static int launch_cfg(const MfmaP& mp, long long maxM, int OCpad, hipStream_t st) {
+    int minchunks = 1 << 30;
+    for (int c = 0; c < mp.nclasses; ++c) { const int n = mp.cls_kpad[c] / (4 * MT<T>::SEG) / mp.ksplit; if (n < minchunks) minchunks = n; }
+    return minchunks >= 6 ? launch_cfg_kc<T, BM, BN, WM, WN, 2>(mp, maxM, OCpad, st)
+                          : launch_cfg_kc<T, BM, BN, WM, WN, 1>(mp, maxM, OCpad, st);
 }
 
 template <typename T>
@@ -514,7 +554,10 @@ static int run_mfma(const GatherSpec& g, void* ws, int ws_packed, hipStream_t st
     const int BN = pl.BN, OCpad = (g.OC + BN - 1) / BN * BN;
     long long tot = 0;
     build_classes(g, CC, SEG, OCpad, &mp, &pp, &tot);
-    mp.ksplit = pl.ksplit; mp.acc32 = nullptr; mp.aligned = 1;
+    mp.ksplit = pl.ksplit; mp.acc32 = nullptr; mp.aligned = 1; mp.stat_partial = nullptr; mp.stat_tiles = 0;
+    const long long Vout = (long long)g.OD * g.OH * g.OW;
+    const bool fuse_stats = g.stats_out && g.stats_ws && g.mode == 0 && pl.ksplit == 1 && (g.N == 1 || Vout % pl.BM == 0);
+    if (fuse_stats) { mp.stat_partial = g.stats_ws; mp.stat_tiles = (int)cdiv_ll(Vout, pl.BM); }
     for (int i = 0; i < g.nsrc; ++i) if (g.srcC[i] % (4 * SEG)) mp.aligned = 0;
     if (pl.ksplit > 1) {
         const size_t wbytes = ((size_t)tot * sizeof(T) + 255) / 256 * 256;
@@ -539,11 +582,22 @@ static int run_mfma(const GatherSpec& g, void* ws, int ws_packed, hipStream_t st
         case 32:  rc2 = small ? launch_cfg<T, 64, 32, 4, 1>(mp, maxM, OCpad, st) : launch_cfg<T, 128, 32, 4, 1>(mp, maxM, OCpad, st); break;
         default:  rc2 = small ? launch_cfg<T, 64, 16, 4, 1>(mp, maxM, OCpad, st) : launch_cfg<T, 128, 16, 4, 1>(mp, maxM, OCpad, st); break;
     }
-    if (rc2 || pl.ksplit <= 1) return rc2;
+    if (rc2) return rc2;
+    if (g.stats_out) {
+        if (fuse_stats) {           // partial layout [N][tiles][OC][2] is exactly what the generic finalize folds (fp64, per wave)
+            rc2 = m1_reduce_finalize_launch<2>(g.stats_ws, g.N, g.OC, mp.stat_tiles, g.stats_out, Vout, g.stats_eps, st);
+            if (rc2) return rc2;
+        } else if (pl.ksplit <= 1) {
+            return m1_stats_internal(g.out, g.N, Vout, g.OC, g.dtype, g.stats_eps, g.stats_out, g.stats_ws, st);
+        }
+    }
+    if (pl.ksplit <= 1) return rc2;
     const long long ne = (long long)out_elems(g);
     long long fb = cdiv_ll(ne, 256); if (fb > 2048) fb = 2048;
     hipLaunchKernelGGL(splitk_finish_kernel<T>, dim3((unsigned)fb), dim3(256), 0, st, mp.acc32, g.bias, (T*)g.out, ne, g.OC, g.accumulate);
-    return m1_check_launch();
+    rc2 = m1_check_launch(); if (rc2) return rc2;
+    if (g.stats_out) return m1_stats_internal(g.out, g.N, Vout, g.OC, g.dtype, g.stats_eps, g.stats_out, g.stats_ws, st);
+    return M1_OK;
 }
 
 int m1_mfma_gather(const GatherSpec& g, void* ws, int ws_packed, hipStream_t st) {

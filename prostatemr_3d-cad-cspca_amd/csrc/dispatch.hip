@@ -115,7 +115,11 @@ static int run_gather(const GatherSpec& g, void* ws, int ws_packed, hipStream_t 
 extern "C" size_t m1_conv_ws_bytes(const m1_conv_desc_t* d, int transposed, int role) {
     if (!desc_ok(d)) return 0;
     const bool T = transposed != 0;
-    if (role == 0) return gather_ws_bytes(fwd_spec(d, T, nullptr, nullptr, nullptr)) + 256;
+    if (role == 0) {
+        Geo q0 = T ? convT_geo(d) : conv_geo(d);
+        return gather_ws_bytes(fwd_spec(d, T, nullptr, nullptr, nullptr)) +
+               align256(m1_stats_ws_floats(d->N, (long long)q0.OD * q0.OH * q0.OW, d->Cout) * sizeof(float)) + 256;
+    }
     if (role == 1) {
         size_t m = 0; int off = 0;
         for (int i = 0; i < d->nsrc; ++i) {
@@ -129,11 +133,23 @@ extern "C" size_t m1_conv_ws_bytes(const m1_conv_desc_t* d, int transposed, int 
 }
 
 // ---- Conv3D ------------------------------------------------------------------------------------------------------
-extern "C" int m1_conv3d_fwd(const m1_conv_desc_t* d, const float* w, const float* bias, void* y, void* ws, int ws_packed,
-                             void* stream) {
+extern "C" int m1_conv3d_fwd(const m1_conv_desc_t* d, const float* w, const float* bias, void* y, float* stats, void* ws,
+                             int ws_packed, void* stream) {
     if (!desc_ok(d) || !w || !y) return M1_ERR_BAD_ARG;
     M1ProfScope ps("conv3d_fwd", 2.0 * conv_macs(d, false), conv_bytes(d, false), (hipStream_t)stream);
-    return run_gather(fwd_spec(d, false, w, bias, y), ws, ws_packed, (hipStream_t)stream);
+    GatherSpec g = fwd_spec(d, false, w, bias, y);
+    if (stats) {
+        if (!ws) return M1_ERR_WORKSPACE;
+        g.stats_out = stats; g.stats_eps = 1e-3f;        // tfa InstanceNormalization epsilon
+        g.stats_ws = reinterpret_cast<float*>((unsigned char*)ws + gather_ws_bytes(g));
+        GatherSpec mf, dr; split_members(g, &mf, &dr);
+        if (!mf.nsrc) {                                   // direct path: conv, then the stand-alone reduction
+            int rc = m1_direct_gather(dr, (hipStream_t)stream); if (rc) return rc;
+            Geo q = conv_geo(d);
+            return m1_stats_internal(y, d->N, (long long)q.OD * q.OH * q.OW, d->Cout, d->dtype, 1e-3f, stats, g.stats_ws, (hipStream_t)stream);
+        }
+    }
+    return run_gather(g, ws, ws_packed, (hipStream_t)stream);
 }
 extern "C" int m1_convT3d_fwd(const m1_conv_desc_t* d, const float* w, const float* bias, void* y, void* ws, int ws_packed,
                               void* stream) {
@@ -173,6 +189,10 @@ static int wgrad_common(const m1_conv_desc_t* d, bool T, const void* dy, float* 
     Geo q = T ? convT_geo(d) : conv_geo(d);
     const size_t nw = (size_t)d->kd * d->kh * d->kw * d->Cin * d->Cout;
     if (!accumulate && hipMemsetAsync(dw, 0, nw * sizeof(float), st) != hipSuccess) return M1_ERR_LAUNCH;
+    // Conv3D bias gradient rides on the matrix-core wgrad of the first concat member (all-ones fragment); the
+    // transposed conv (its dOut is the SHIFTED operand) and the direct path keep the separate column-sum pass
+    const bool fuse_db = db && !T && !g_force_direct;
+    if (fuse_db && !accumulate && hipMemsetAsync(db, 0, (size_t)d->Cout * sizeof(float), st) != hipSuccess) return M1_ERR_LAUNCH;
     int off = 0;
     for (int i = 0; i < d->nsrc; ++i) {
         WgradSpec g{};
@@ -182,6 +202,7 @@ static int wgrad_common(const m1_conv_desc_t* d, bool T, const void* dy, float* 
             g.A = d->src[i].ptr; g.CA = d->src[i].C; g.AD = d->D; g.AH = d->H; g.AW = d->W;
             g.B = dy; g.CB = d->Cout; g.BD = q.OD; g.BH = q.OH; g.BW = q.OW;
             g.RT = (long long)d->Cin * d->Cout; g.RSA = d->Cout; g.a_off = off; g.b_off = 0;
+            if (fuse_db && i == 0) { g.bsum = db; g.bsum_tap = (q.pd * d->kh + q.ph) * d->kw + q.pw; }
         } else {    // dw[tap][co][ci] = sum dOut[i*s+tap-pb][co] * In[i][ci]
             g.A = dy; g.CA = d->Cout; g.AD = q.OD; g.AH = q.OH; g.AW = q.OW;
             g.B = d->src[i].ptr; g.CB = d->src[i].C; g.BD = d->D; g.BH = d->H; g.BW = d->W;
@@ -194,7 +215,7 @@ static int wgrad_common(const m1_conv_desc_t* d, bool T, const void* dy, float* 
         if (rc) return rc;
         off += d->src[i].C;
     }
-    if (db) {
+    if (db && !fuse_db) {
         if (!ws) return M1_ERR_WORKSPACE;
         return m1_colsum_internal(dy, d->N, (long long)q.OD * q.OH * q.OW, d->Cout, d->dtype, db, (float*)ws, st, accumulate);
     }

@@ -15,7 +15,13 @@ struct GatherSpec {
     const float* bias;
     int kd, kh, kw, mode, sd, sh, sw, pd, ph, pw;
     int dtype, accumulate;
+    float* stats_out;          // optional (Conv3D forward only): per-(n,oc) {mean, rstd} of the output for the InstanceNorm
+    float* stats_ws;           //   that follows; fused into the epilogue when the tiling allows, else a reduction pass
+    float stats_eps;
 };
+
+int m1_stats_internal(const void* x, int N, long long V, int C, int dtype, float eps, float* stats, float* ws, hipStream_t st);
+size_t m1_stats_ws_floats(int N, long long V, int C);
 
 // R[tap*RT + (a+a_off)*RSA + (b+b_off)] += sum_{n,v} A[n, v*s + tap - p][a] * B[n, v][b]
 struct WgradSpec {
@@ -25,6 +31,8 @@ struct WgradSpec {
     float* R; long long RT, RSA; int a_off, b_off;
     int kd, kh, kw, sd, sh, sw, pd, ph, pw;
     int dtype;
+    float* bsum;      // optional: bsum[b + b_off] += sum_v B[v][b] (bias gradient of a Conv3D, fused into the tap whose
+    int bsum_tap;     // shifted partner is always inside the volume: tap index bsum_tap); NULL = off
 };
 
 int m1_direct_gather(const GatherSpec& g, hipStream_t st);

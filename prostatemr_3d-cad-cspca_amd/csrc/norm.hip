@@ -3,6 +3,7 @@
 // networks.py:473,575-576.  Backward math: SURVEY.md App. F.
 #include "common.h"
 #include "reduce.h"
+#include "gather.h"
 
 extern "C" size_t m1_reduce_ws_floats(int N, long long V, int C, int nsums) {
     return (size_t)N * m1_red_nchunks(V, C) * C * nsums + (size_t)N * C * nsums + 64;
@@ -26,6 +27,16 @@ static int stats_impl(const void* x, int N, long long V, int C, float eps, float
     int rc = m1_reduce_nc_launch<2>(f, N, V, C, ws, st);
     if (rc) return rc;
     return m1_reduce_finalize_launch<2>(ws, N, C, m1_red_nchunks(V, C), stats, V, eps, st);
+}
+
+int m1_stats_internal(const void* x, int N, long long V, int C, int dtype, float eps, float* stats, float* ws, hipStream_t st) {
+    return dtype == M1_BF16 ? stats_impl<bf16_t>(x, N, V, C, eps, stats, ws, st) : stats_impl<float>(x, N, V, C, eps, stats, ws, st);
+}
+// floats needed by either the fused-epilogue partials (one per 64-row tile at worst) or the stand-alone reduction
+size_t m1_stats_ws_floats(int N, long long V, int C) {
+    const size_t fused = (size_t)N * (size_t)((V + 63) / 64) * C * 2;
+    const size_t alone = m1_reduce_ws_floats(N, V, C, 2);
+    return (fused > alone ? fused : alone) + 64;
 }
 
 extern "C" int m1_instnorm_stats(const void* x, int N, long long V, int C, int dtype, float eps, float* stats,

@@ -77,6 +77,15 @@ __global__ void __launch_bounds__(256) wgrad_mfma_kernel(WgP p) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
     const int fr = lane & 15, fs = lane >> 4;
+    // fused bias gradient: column sums of the B tile by one extra MFMA with an all-ones A fragment (only the
+    // blocks of one always-in-bounds tap and the first a-tile do it, only the wm == 0 waves)
+    const bool do_bsum = p.bsum != nullptr && tap == p.bsum_tap && a0 == 0 && wm == 0;
+    f32x4_t accb[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) accb[j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    uint4 ones;
+    if constexpr (sizeof(T) == 2) ones = make_uint4(0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u);
+    else ones = make_uint4(0x3F800000u, 0x3F800000u, 0x3F800000u, 0x3F800000u);
 
     for (long long vs = vbeg; vs < vend; vs += KS) {
         for (int t = tid; t < KS; t += 256) {
@@ -158,6 +167,26 @@ __global__ void __launch_bounds__(256) wgrad_mfma_kernel(WgP p) {
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(af[i].w), __uint_as_float(bfr[j].w), acc[i][j], 0, 0, 0);
                 }
             }
+        if (do_bsum) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                if constexpr (sizeof(T) == 2) {
+                    accb[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, ones), __builtin_bit_cast(bf16x8_t, bfr[j]), accb[j], 0, 0, 0);
+                } else {
+                    accb[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(1.0f, __uint_as_float(bfr[j].x), accb[j], 0, 0, 0);
+                    accb[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(1.0f, __uint_as_float(bfr[j].y), accb[j], 0, 0, 0);
+                    accb[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(1.0f, __uint_as_float(bfr[j].z), accb[j], 0, 0, 0);
+                    accb[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(1.0f, __uint_as_float(bfr[j].w), accb[j], 0, 0, 0);
+                }
+            }
+        }
+        }
+    }
+    if (do_bsum && fs == 0) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int b = b0 + wn * (TB / 2) + j * 16 + fr;
+            if (b < p.CB) atomicAdd(p.bsum + b + p.b_off, accb[j][0]);
         }
     }
     // D[i = a][j = b]: lane holds a = 4*fs + r, b = fr

@@ -123,7 +123,7 @@ def same_out(size: int, s: int) -> int:
 # ---------------------------------------------------------------------------------------------------------
 class _Conv3d(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, w, b, k, s, transposed, *srcs):
+    def forward(ctx, w, b, k, s, transposed, want_stats, *srcs):
         _req(w, b, *srcs)
         lib = L.load()
         x0 = srcs[0]
@@ -137,16 +137,24 @@ class _Conv3d(torch.autograd.Function):
         else:
             osz = (d.N, same_out(d.D, d.sd), same_out(d.H, d.sh), same_out(d.W, d.sw), cout)
         y = torch.empty(osz, dtype=x0.dtype, device=x0.device)
-        fn = lib.m1_convT3d_fwd if transposed else lib.m1_conv3d_fwd
         ws, packed = _panel_ws(w, d, transposed, 0)
-        L.check(fn(C.byref(d), _p(w), _p(b), _p(y), _p(ws), packed, _stream()), "m1_convT3d_fwd" if transposed else "m1_conv3d_fwd")
+        stats = None
+        if transposed:
+            L.check(lib.m1_convT3d_fwd(C.byref(d), _p(w), _p(b), _p(y), _p(ws), packed, _stream()), "m1_convT3d_fwd")
+        else:
+            if want_stats:
+                stats = torch.empty((d.N, cout, 2), dtype=torch.float32, device=x0.device)
+            L.check(lib.m1_conv3d_fwd(C.byref(d), _p(w), _p(b), _p(y), _p(stats), _p(ws), packed, _stream()), "m1_conv3d_fwd")
         ctx.save_for_backward(w, *srcs)
         ctx.w_param, ctx.b_param = w, b
         ctx.k, ctx.s, ctx.transposed, ctx.has_bias, ctx.cout = tuple(k), tuple(s), transposed, b is not None, cout
+        if want_stats:
+            ctx.mark_non_differentiable(stats)
+            return y, stats
         return y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, *_unused):
         lib = L.load()
         w, *srcs = ctx.saved_tensors
         dy = dy.contiguous()
@@ -171,7 +179,7 @@ class _Conv3d(torch.autograd.Function):
         ptrs = (C.c_void_p * len(srcs))()
         any_d = False
         for i, t in enumerate(srcs):
-            if ctx.needs_input_grad[5 + i]:
+            if ctx.needs_input_grad[6 + i]:
                 g = torch.empty_like(t)
                 dsrc.append(g)
                 ptrs[i] = g.data_ptr()
@@ -183,21 +191,23 @@ class _Conv3d(torch.autograd.Function):
             fn = lib.m1_convT3d_dgrad if ctx.transposed else lib.m1_conv3d_dgrad
             ws, packed = _panel_ws(ctx.w_param, d, ctx.transposed, 1, tuple(bool(g is not None) for g in dsrc))
             L.check(fn(C.byref(d), _p(w), _p(dy), ptrs, _p(ws), packed, st), f"m1_{name}_dgrad")
-        return (dw, db, None, None, None, *dsrc)
+        return (dw, db, None, None, None, None, *dsrc)
 
 
-def conv3d_same(srcs, w, b, k, s):
-    """tf.keras.layers.Conv3D(padding='same') on the channel-concat of ``srcs`` (never materialised)."""
+def conv3d_same(srcs, w, b, k, s, stats: bool = False):
+    """tf.keras.layers.Conv3D(padding='same') on the channel-concat of ``srcs`` (never materialised).
+    ``stats=True`` also returns the (N,Cout,2) {mean, rstd} of the output (for the InstanceNorm that follows),
+    accumulated in the conv's epilogue."""
     if isinstance(srcs, torch.Tensor):
         srcs = [srcs]
-    return _Conv3d.apply(w, b, tuple(k), tuple(s), False, *srcs)
+    return _Conv3d.apply(w, b, tuple(k), tuple(s), False, bool(stats), *srcs)
 
 
 def conv3d_transpose_same(srcs, w, b, k, s):
     """tf.keras.layers.Conv3DTranspose(padding='same') on the channel-concat of ``srcs``."""
     if isinstance(srcs, torch.Tensor):
         srcs = [srcs]
-    return _Conv3d.apply(w, b, tuple(k), tuple(s), True, *srcs)
+    return _Conv3d.apply(w, b, tuple(k), tuple(s), True, False, *srcs)
 
 
 # ---------------------------------------------------------------------------------------------------------
@@ -215,11 +225,12 @@ def instnorm_stats(x: torch.Tensor) -> torch.Tensor:
 
 class _InstNormAct(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, gamma, beta, slope):
+    def forward(ctx, x, gamma, beta, slope, stats):
         _req(x, gamma, beta)
         N, Cn = int(x.shape[0]), int(x.shape[-1])
         V = x.numel() // (N * Cn)
-        stats = instnorm_stats(x)
+        if stats is None:
+            stats = instnorm_stats(x)
         y = torch.empty_like(x)
         L.check(L.load().m1_instnorm_apply(_p(x), _p(stats), _p(gamma), _p(beta), float(slope), _p(y), N, V, Cn, _dt(x),
                                            _stream()), "m1_instnorm_apply")
@@ -243,12 +254,13 @@ class _InstNormAct(torch.autograd.Function):
         ws = _ws(N, V, Cn, 2, x.device)
         L.check(L.load().m1_instnorm_bwd(_p(x), _p(stats), _p(gamma), _p(beta), ctx.slope, _p(dy), _p(dx), _p(gbuf), _p(bbuf),
                                          N, V, Cn, _dt(x), _p(ws), acc, _stream()), "m1_instnorm_bwd")
-        return dx, dg, db, None
+        return dx, dg, db, None, None
 
 
-def instnorm_act(x, gamma, beta, slope: float = 1.0):
-    """tfa InstanceNormalization (eps 1e-3) followed by LeakyReLU(slope) (slope=1 -> no activation)."""
-    return _InstNormAct.apply(x, gamma, beta, slope)
+def instnorm_act(x, gamma, beta, slope: float = 1.0, stats=None):
+    """tfa InstanceNormalization (eps 1e-3) followed by LeakyReLU(slope) (slope=1 -> no activation).
+    ``stats``: the (N,C,2) {mean, rstd} already produced by the conv that wrote ``x`` (else computed here)."""
+    return _InstNormAct.apply(x, gamma, beta, slope, stats)
 
 
 # ---------------------------------------------------------------------------------------------------------
@@ -256,14 +268,15 @@ def instnorm_act(x, gamma, beta, slope: float = 1.0):
 # ---------------------------------------------------------------------------------------------------------
 class _SECombine(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, y3, y4, g3, b3, g4, b4, W6, b6, W7, b7, drop_rate, rng, layer_id):
+    def forward(ctx, y3, y4, g3, b3, g4, b4, W6, b6, W7, b7, drop_rate, rng, layer_id, s3, s4):
         _req(y3, y4, g3, b3, g4, b4, W6, b6, W7, b7)
         lib = L.load()
         N, Fn = int(y3.shape[0]), int(y3.shape[-1])
         V = y3.numel() // (N * Fn)
         Fr = int(W6.shape[-1])
         st = _stream()
-        s3, s4 = instnorm_stats(y3), instnorm_stats(y4)
+        s3 = instnorm_stats(y3) if s3 is None else s3
+        s4 = instnorm_stats(y4) if s4 is None else s4
         hidden = torch.empty(Fr, dtype=torch.float32, device=y3.device)
         g = torch.empty(Fn, dtype=torch.float32, device=y3.device)
         L.check(lib.m1_se_gate_fwd(_p(b3), _p(W6), _p(b6), _p(W7), _p(b7), Fn, Fr, _p(hidden), _p(g), st), "m1_se_gate_fwd")
@@ -299,12 +312,12 @@ class _SECombine(torch.autograd.Function):
                                       ctx.drop_rate, _p(ctx.rng), ctx.layer_id, _p(ws), acc, st), "m1_se_combine_bwd")
         L.check(lib.m1_se_gate_bwd(_p(b3), _p(W6), _p(W7), _p(hidden), _p(g), _p(dg), Fn, Fr, _p(bb3), _p(bW6), _p(bb6),
                                    _p(bW7), _p(bb7), acc, st), "m1_se_gate_bwd")
-        return dy3, dy4, rg3, rb3, rg4, rb4, rW6, rb6, rW7, rb7, None, None, None
+        return dy3, dy4, rg3, rb3, rg4, rb4, rW6, rb6, rW7, rb7, None, None, None, None, None
 
 
-def se_combine(y3, y4, g3, b3, g4, b4, W6, b6, W7, b7, drop_rate=0.0, rng=None, layer_id=0):
+def se_combine(y3, y4, g3, b3, g4, b4, W6, b6, W7, b7, drop_rate=0.0, rng=None, layer_id=0, stats3=None, stats4=None):
     """dropout(lrelu(IN3(y3) * sigmoid(W7.lrelu(W6.beta3+b6)+b7) * IN4(y4)))  (network_blocks.py:60-78)."""
-    return _SECombine.apply(y3, y4, g3, b3, g4, b4, W6, b6, W7, b7, drop_rate, rng, layer_id)
+    return _SECombine.apply(y3, y4, g3, b3, g4, b4, W6, b6, W7, b7, drop_rate, rng, layer_id, stats3, stats4)
 
 
 # ---------------------------------------------------------------------------------------------------------

@@ -53,8 +53,9 @@ class Conv3D(nn.Module):
     def _kernel_shape(self):
         return (*self.kernel_size, self.in_channels, self.filters)
 
-    def forward(self, x: Tensors) -> torch.Tensor:
-        return ops.conv3d_same(_as_list(x), self.kernel, self.bias, self.kernel_size, self.strides)
+    def forward(self, x: Tensors, stats: bool = False):
+        """``stats=True`` -> (y, stats): the InstanceNorm statistics of y come out of the conv's epilogue."""
+        return ops.conv3d_same(_as_list(x), self.kernel, self.bias, self.kernel_size, self.strides, stats=stats)
 
 
 class Conv3DTranspose(Conv3D):
@@ -76,8 +77,8 @@ class InstanceNormalization(nn.Module):
         self.gamma = nn.Parameter(torch.ones(channels))
         self.beta = nn.Parameter(torch.zeros(channels))
 
-    def forward(self, x: torch.Tensor, slope: float = 1.0) -> torch.Tensor:
-        return ops.instnorm_act(x, self.gamma, self.beta, slope)
+    def forward(self, x: torch.Tensor, slope: float = 1.0, stats=None) -> torch.Tensor:
+        return ops.instnorm_act(x, self.gamma, self.beta, slope, stats)
 
 
 # ---- dropout ----------------------------------------------------------------------------------------------
@@ -153,15 +154,17 @@ class SEResNetBottleNeck(nn.Module):
 
     def forward(self, input_tensor: Tensors, dropout: Optional[_DropoutBase] = None) -> torch.Tensor:
         srcs = _as_list(input_tensor)
-        a = self.norm1(self.conv1(srcs), 0.1)                                   # B:53-55
-        a = self.norm2(self.conv2(a), 0.1)                                      # B:56-58
-        y3 = self.conv3(a)                                                      # B:59
-        y4 = self.conv4(srcs)                                                   # B:64
+        y1, s1 = self.conv1(srcs, stats=True)
+        a = self.norm1(y1, 0.1, s1)                                             # B:53-55
+        y2, s2 = self.conv2(a, stats=True)
+        a = self.norm2(y2, 0.1, s2)                                             # B:56-58
+        y3, s3 = self.conv3(a, stats=True)                                      # B:59
+        y4, s4 = self.conv4(srcs, stats=True)                                   # B:64
         rate = dropout.effective_rate() if dropout is not None else 0.0
         return ops.se_combine(y3, y4, self.norm3.gamma, self.norm3.beta, self.norm4.gamma, self.norm4.beta,
                               self.conv6.kernel, self.conv6.bias, self.conv7.kernel, self.conv7.bias, rate,
                               dropout.rng if (dropout is not None and rate > 0.0) else None,
-                              dropout.layer_id if dropout is not None else 0)   # B:60-78 (+ following dropout)
+                              dropout.layer_id if dropout is not None else 0, s3, s4)   # B:60-78 (+ following dropout)
 
 
 # ---- grid attention gate (B:88-130) ---------------------------------------------------------------------
@@ -187,7 +190,8 @@ class GridAttentionBlock3D(nn.Module):
         phi_g = self.phi(g)                                                            # B:112
         sigma = ops.gate_sigma(theta_x, phi_g, self.psi.kernel, self.psi.bias)         # B:113-119
         y = ops.mul_sigma(x, sigma, self.sub_samp)                                     # B:120-124
-        W_y = self.normW(self.W(y), 1.0)                                               # B:127-128
+        Wy_raw, sW = self.W(y, stats=True)
+        W_y = self.normW(Wy_raw, 1.0, sW)                                              # B:127-128
         return W_y, sigma
 
 

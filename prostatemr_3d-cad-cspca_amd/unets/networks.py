@@ -182,7 +182,8 @@ class M1Core(nn.Module):
         outputs = {}
         S = self.strides
         # networks.py:574-576
-        x = self.norme0(self.conve0(inputs), 0.1)
+        x_raw, s0 = self.conve0(inputs, stats=True)
+        x = self.norme0(x_raw, 0.1, s0)
         # networks.py:579-582 (dropout fused into the block's last kernel)
         conv1 = self.serse1(x, dropout=self.drope1)
         conv2 = self.serse2(conv1, dropout=self.drope2)

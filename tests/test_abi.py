@@ -49,6 +49,6 @@ def test_workspace_query_is_pure_host():
 def test_bad_arguments_are_rejected_without_a_gpu():
     lib = L.load()
     d = L.m1_conv_desc_t()          # all zeros: invalid
-    assert lib.m1_conv3d_fwd(ctypes.byref(d), None, None, None, None, 0, None) == -1
+    assert lib.m1_conv3d_fwd(ctypes.byref(d), None, None, None, None, None, 0, None) == -1
     assert lib.m1_kl_fwd(None, None, None, 1, 1, 1, 0, None) == -1
     assert lib.m1_se_gate_fwd(None, None, None, None, None, 8, 1, None, None, None) == -1
