@@ -17,7 +17,13 @@ template <typename T> struct WT;
 template <> struct WT<bf16_t> { static constexpr int SEG = 8; };
 template <> struct WT<float> { static constexpr int SEG = 4; };
 
-__device__ __forceinline__ int wswz(int row, int seg) { return seg ^ ((-(row >> 2)) & 3); }
+// LDS image [row][64 B]: byte offset of 16-byte segment `seg` of logical row `row`.  Rows 8..15 of every 16 are
+// pair-swapped and the slot is XOR-ed with row bits 2..5 so that BOTH the ds_read_b128 fragment reads (16 rows x
+// one slot per lane group) and the staging ds_write_b128 (8 lanes = 8 channel groups 8 rows apart, same slot) are
+// bank-conflict free (checked exhaustively against the gfx950 lane groups, tools/lds_swizzle_check.py).
+__device__ __forceinline__ int woff(int row, int seg) {
+    return ((row ^ ((row >> 3) & 1)) << 6) + (((seg ^ (-(row >> 2)) ^ (row >> 4)) & 3) << 4);
+}
 
 struct WgP : WgradSpec { long long vox_per_split; };
 
@@ -66,9 +72,10 @@ __global__ void __launch_bounds__(256) wgrad_mfma_kernel(WgP p) {
     const int a0 = (blockIdx.x / bTiles) * TA, b0 = (blockIdx.x % bTiles) * TB;
     const int tap = blockIdx.y;
     const int kw = tap % p.kw, kh = (tap / p.kw) % p.kh, kd = tap / (p.kw * p.kh);
-    const long long BV = (long long)p.BD * p.BH * p.BW, TV = BV * p.N;
-    const long long vbeg = (long long)blockIdx.z * p.vox_per_split;
-    long long vend = vbeg + p.vox_per_split; if (vend > TV) vend = TV;
+    // voxel indices fit 32 bits (checked on the host): 32-bit divisions only
+    const int BV = p.BD * p.BH * p.BW, TV = BV * p.N;
+    const int vbeg = (int)(blockIdx.z * p.vox_per_split);
+    int vend = vbeg + (int)p.vox_per_split; if (vend > TV) vend = TV;
     const T* A = (const T*)p.A; const T* B = (const T*)p.B;
 
     f32x4_t acc[TM][TN];
@@ -87,14 +94,14 @@ __global__ void __launch_bounds__(256) wgrad_mfma_kernel(WgP p) {
     if constexpr (sizeof(T) == 2) ones = make_uint4(0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u);
     else ones = make_uint4(0x3F800000u, 0x3F800000u, 0x3F800000u, 0x3F800000u);
 
-    for (long long vs = vbeg; vs < vend; vs += KS) {
+    for (int vs = vbeg; vs < vend; vs += KS) {
         for (int t = tid; t < KS; t += 256) {
-            const long long v = vs + t;
+            const int v = vs + t;
             long long ao = -1, bo = -1;
             if (v < vend) {
-                const int n = (int)(v / BV); long long r = v % BV;
-                const int bw = (int)(r % p.BW); r /= p.BW;
-                const int bh = (int)(r % p.BH); const int bd = (int)(r / p.BH);
+                const int n = v / BV; int r = v - n * BV;
+                const int q1 = r / p.BW; const int bw = r - q1 * p.BW;
+                const int bd = q1 / p.BH; const int bh = q1 - bd * p.BH;
                 const int ad = bd * p.sd + kd - p.pd, ah = bh * p.sh + kh - p.ph, aw = bw * p.sw + kw - p.pw;
                 if (ad >= 0 && ad < p.AD && ah >= 0 && ah < p.AH && aw >= 0 && aw < p.AW) {
                     ao = (((long long)n * p.AD + ad) * p.AH + ah) * p.AW + aw;
@@ -135,7 +142,7 @@ __global__ void __launch_bounds__(256) wgrad_mfma_kernel(WgP p) {
 #pragma unroll
                 for (int c = 0; c < SEG; ++c) {
                     const int row = cg * SEG + c;
-                    *reinterpret_cast<uint4*>(dst + row * 64 + wswz(row, ks & 3) * 16) = o[c];
+                    *reinterpret_cast<uint4*>(dst + woff(row, ks & 3)) = o[c];
                 }
             }
         }
@@ -146,12 +153,12 @@ __global__ void __launch_bounds__(256) wgrad_mfma_kernel(WgP p) {
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             const int row = wm * (TA / 2) + i * 16 + fr;
-            af[i] = *reinterpret_cast<const uint4*>(A_s + kb * TA * 64 + row * 64 + wswz(row, fs) * 16);
+            af[i] = *reinterpret_cast<const uint4*>(A_s + kb * TA * 64 + woff(row, fs));
         }
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int row = wn * (TB / 2) + j * 16 + fr;
-            bfr[j] = *reinterpret_cast<const uint4*>(B_s + kb * TB * 64 + row * 64 + wswz(row, fs) * 16);
+            bfr[j] = *reinterpret_cast<const uint4*>(B_s + kb * TB * 64 + woff(row, fs));
         }
 #pragma unroll
         for (int i = 0; i < TM; ++i)
@@ -204,7 +211,9 @@ __global__ void __launch_bounds__(256) wgrad_mfma_kernel(WgP p) {
         }
 }
 
-bool m1_mfma_wgrad_supported(const WgradSpec& g) { (void)g; return true; }
+bool m1_mfma_wgrad_supported(const WgradSpec& g) {
+    return (long long)g.N * g.BD * g.BH * g.BW < (1ll << 31) - 4096;       // 32-bit voxel arithmetic in the kernel
+}
 
 template <typename T, int TA, int TB>
 static int launch_wg(WgP p, hipStream_t st) {
