@@ -65,6 +65,14 @@ int m1_abi_version(void);
 /* ws: caller-owned scratch of m1_conv_ws_bytes(d, transposed, role) bytes, 256-byte aligned (packed bf16/fp32
  * weight panels for the matrix-core kernels; bias-gradient partials for wgrad). role: 0 fwd, 1 dgrad, 2 wgrad. */
 size_t m1_conv_ws_bytes(const m1_conv_desc_t* d, int transposed, int role);
+/* Packed-panel refresh (no reference counterpart: the panels are this library's own copy of the Keras kernels,
+ * train_model.py:231's optimizer step changes them once per step).  The first pack of a panel (ws_packed == 0) leaves
+ * a job record in front of it inside ws; ws must therefore be ZERO-FILLED when it is first handed over.
+ * m1_conv_pack_jobs writes the device addresses of the records of (d, transposed, role in {0,1}) into jobs_out
+ * (room for M1_MAX_SRC entries) and returns their number; m1_pack_batch re-packs, in one launch, every filled record
+ * of the device array jobs_dev[njobs] from the current weight values (records never filled are skipped). */
+int m1_conv_pack_jobs(const m1_conv_desc_t* d, int transposed, int role, void* ws, void** jobs_out);
+int m1_pack_batch(const void* const* jobs_dev, int njobs, void* stream);
 /* ws_packed != 0: ws still holds the weight panels a previous call with the SAME descriptor geometry, role and
  * (unchanged) weights left there -- the pack pass is skipped (the prior / posterior cores run twice per step). */
 /* stats (optional, (N,Cout,2) fp32): {mean, rstd} (eps 1e-3, biased variance) of y per (n, channel) for the

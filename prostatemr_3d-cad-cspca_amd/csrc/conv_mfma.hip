@@ -40,9 +40,11 @@ struct MfmaP {
     int cls_ntaps[MF_MAX_CLASSES], cls_first[MF_MAX_CLASSES], cls_kpad[MF_MAX_CLASSES];
     long long cls_woff[MF_MAX_CLASSES];     // element offset of the class matrix in wp
     signed char tdd[MF_MAX_TAPS], tdh[MF_MAX_TAPS], tdw[MF_MAX_TAPS];   // gather offsets per (class-ordered) tap
+    int tap_pk[MF_MAX_TAPS];    // the same, packed dd | dh<<8 | dw<<16 (scalar loads in the LDS-DMA loader)
     int accumulate;             // out += result (used when another kernel already wrote the other concat members)
     int ksplit;                 // > 1: blockIdx.y = cls*ksplit + ks; partial sums go to acc32 with fp32 atomics
-    float* acc32;               // [out voxels][OC] fp32, zeroed by the host before the launch (ksplit > 1 only)
+    float* acc32;               // [ksplit][out voxels][OC] fp32 slabs (ksplit > 1 only)
+    long long slab_elems;
     int aligned;                // every concat member is a multiple of one 64-byte K-chunk: incremental addressing
     float* stat_partial;        // fused InstanceNorm statistics: [N][tiles per sample][OC][2] = {sum, sum of squares} of
     int stat_tiles;             //   the ROUNDED outputs of each 64/128-row tile (mode 0, tiles never straddle samples)
@@ -65,7 +67,31 @@ __device__ __forceinline__ uint4 load_partial_seg(const T* p, int n) {
     return u.v;
 }
 
-template <typename T, int BM, int BN, int WM, int WN, int KC>
+// 64 zero bytes: the source of every LDS-DMA piece that falls outside the volume / beyond the K range
+__device__ __attribute__((aligned(64))) unsigned int m1_zero_page[16];
+
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+// one wave-instruction: 64 lanes x 16 bytes from per-lane global addresses to lds_wave_base + lane*16
+__device__ __forceinline__ void glds16(const void* g, void* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)lds_wave_base, 16, 0, 0);
+}
+
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ u32x4_t lds_read128(unsigned lds_addr) {
+    u32x4_t v;
+    asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(lds_addr) : "memory");
+    return v;
+}
+// all outstanding LDS reads have landed; tying the fragment makes its consumers wait behind this statement
+__device__ __forceinline__ void lds_wait(u32x4_t& v) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v)); }
+__device__ __forceinline__ unsigned lds_addr_of(const void* p) { return (unsigned)(unsigned long long)(lptr_t)p; }
+
+// GLDS = true (every concat member a multiple of one 64-byte K-chunk): both operands go global -> LDS by LDS-DMA
+// (global_load_lds_dwordx4), no staging registers and no ds_write pass -- the VGPR -> LDS store path (<= 85 B/clk/CU)
+// was the bound of the register-staged loop.  The DMA writes lane-linear, so the XOR swizzle is applied on the SOURCE
+// side: the lane that owns LDS slot (row, s) fetches K-segment s ^ swz(row).
+template <typename T, int BM, int BN, int WM, int WN, int KC, bool GLDS>
 __global__ void __launch_bounds__(256) conv_mfma_kernel(MfmaP p) {
     constexpr int SEG = MT<T>::SEG;
     constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
@@ -99,7 +125,10 @@ __global__ void __launch_bounds__(256) conv_mfma_kernel(MfmaP p) {
         QW = p.OW > pwc ? (p.OW - pwc + p.sw - 1) / p.sw : 0;
     }
     const long long QV = (long long)QD * QH * QW, Mtot = QV * p.N;
-    const long long m0 = (long long)blockIdx.x * BM;
+    // Workgroups go to the 8 XCDs round-robin (block b -> XCD b & 7): hand each XCD one contiguous range of M tiles so
+    // that the halo voxels neighbouring tiles gather are shared through that XCD's L2.  gridDim.x = 8 * ceil(tiles / 8).
+    const long long tile = (long long)(blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    const long long m0 = tile * BM;
     if (m0 >= Mtot) return;
 
     for (int r = tid; r < BM; r += 256) {
@@ -141,8 +170,13 @@ __global__ void __launch_bounds__(256) conv_mfma_kernel(MfmaP p) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
-    uint4 ra[KC][A_LD], rb[KC][B_LD];
-    const int lseg = tid & 3, lrow = tid >> 2;           // loader: 4 lanes cover one 64-byte row
+    uint4 ra[GLDS ? 1 : KC][GLDS ? 1 : A_LD], rb[GLDS ? 1 : KC][GLDS ? 1 : B_LD];
+    const int lrow = tid >> 2;                           // loader: 4 lanes cover one 64-byte row
+    // register staging: logical segment tid&3, swizzled when written; LDS-DMA: slot tid&3, swizzled when fetched
+    // (rows tid>>2 + 64*i and (tid + 256*i)>>2 all share (row>>2)&3 = (tid>>4)&3)
+    const int lseg = GLDS ? ((tid & 3) ^ ((-(tid >> 4)) & 3)) : (tid & 3);
+    const unsigned char* zero_pg = reinterpret_cast<const unsigned char*>(m1_zero_page);
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
 
     // incremental loader state (aligned case): current tap / concat member / channel offset and per-row bases
     int st_tap = 0, st_s = 0, st_c = 0;
@@ -227,6 +261,38 @@ __global__ void __launch_bounds__(256) conv_mfma_kernel(MfmaP p) {
             }
         }
     };
+    // LDS-DMA: issue the KC chunks of stage `sg` straight into pipeline buffer `buf`
+    auto issue = [&](int sg, int buf) {
+#pragma unroll
+        for (int kc = 0; kc < KC; ++kc) {
+            const int rel = sg * KC + kc;
+            const int chunk = c_beg + rel;
+            const bool live = rel < nchunks;
+#pragma unroll
+            for (int i = 0; i < B_LD; ++i) {
+                const int e = tid + 256 * i;                 // LDS slot (row, s) = (e>>2, e&3)
+                if ((wave_u + 4 * i) * 64 < BN * 4) {        // wave-uniform
+                    const unsigned char* src = live
+                        ? reinterpret_cast<const unsigned char*>(wp + (long long)(oc0 + (e >> 2)) * kpad + (long long)(chunk * 4 + lseg) * SEG)
+                        : zero_pg;
+                    glds16(src, B_s + (buf * KC + kc) * B_BYTES + (wave_u + 4 * i) * 1024);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < A_LD; ++i) {
+                const unsigned char* src = (live && st_ptr[i]) ? reinterpret_cast<const unsigned char*>(st_ptr[i] + st_c) : zero_pg;
+                glds16(src, A_s + (buf * KC + kc) * A_BYTES + (wave_u + 4 * i) * 1024);
+            }
+            if (live) {
+                st_c += 4 * SEG;
+                if (st_c >= s_srcC[st_s]) {
+                    st_c = 0;
+                    if (++st_s == p.nsrc) { st_s = 0; ++st_tap; }
+                    if (st_tap < ntaps) st_set_tap();
+                }
+            }
+        }
+    };
     auto stage = [&](int buf) {
 #pragma unroll
         for (int kc = 0; kc < KC; ++kc) {
@@ -247,15 +313,54 @@ __global__ void __launch_bounds__(256) conv_mfma_kernel(MfmaP p) {
     };
 
     const int fr = lane & 15, fs = lane >> 4;
+    // fragment read addresses of tile (i or j) = base + 1024*tile (16 rows x 64 B; the swizzle term is tile-invariant)
+    const unsigned a_rd = lds_addr_of(A_s) + (wm * (BM / WM) + fr) * 64 + swz(fr, fs) * 16;
+    const unsigned b_rd = lds_addr_of(B_s) + (wn * (BN / WN) + fr) * 64 + swz(fr, fs) * 16;
     const int nstages = (nchunks + KC - 1) / KC;
     if (nstages > 0) {
-        prefetch_stage(0);
-        stage(0);
+        if constexpr (GLDS) issue(0, 0);
+        else { prefetch_stage(0); stage(0); }
     }
     __syncthreads();
     for (int it = 0; it < nstages; ++it) {
         const int buf = it & 1;
-        if (it + 1 < nstages) prefetch_stage(it + 1);
+        if (it + 1 < nstages) { if constexpr (GLDS) issue(it + 1, buf ^ 1); else prefetch_stage(it + 1); }
+        if constexpr (GLDS) {
+            // Fragment reads by inline asm: hipcc cannot tell an LDS-DMA in flight from the buffer being read and would
+            // wait vmcnt(0) before the first ds_read of the stage (no load/compute overlap inside a block).  The reads
+            // of chunk kc+1 are issued before the MFMAs of chunk kc.
+            u32x4_t af[KC][TM], bfr[KC][TN];
+            auto rd = [&](int kc) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) af[kc][i] = lds_read128(a_rd + (buf * KC + kc) * A_BYTES + i * 1024);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) bfr[kc][j] = lds_read128(b_rd + (buf * KC + kc) * B_BYTES + j * 1024);
+            };
+            rd(0);
+#pragma unroll
+            for (int kc = 0; kc < KC; ++kc) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) lds_wait(af[kc][i]);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) lds_wait(bfr[kc][j]);
+                if (kc + 1 < KC) rd(kc + 1);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        if constexpr (sizeof(T) == 2) {
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, af[kc][i]),
+                                                                                __builtin_bit_cast(bf16x8_t, bfr[kc][j]), acc[i][j], 0, 0, 0);
+                        } else {
+#pragma unroll
+                            for (int q = 0; q < 4; ++q)
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(af[kc][i][q]), __uint_as_float(bfr[kc][j][q]), acc[i][j], 0, 0, 0);
+                        }
+                    }
+                if (kc + 1 < KC) __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
 #pragma unroll
         for (int kc = 0; kc < KC; ++kc) {
             uint4 af[TM], bfr[TN];
@@ -284,12 +389,15 @@ __global__ void __launch_bounds__(256) conv_mfma_kernel(MfmaP p) {
                     }
                 }
         }
-        if (it + 1 < nstages) stage(buf ^ 1);
-        __syncthreads();
+        }
+        if constexpr (!GLDS) { if (it + 1 < nstages) stage(buf ^ 1); }
+        __syncthreads();          // (GLDS: the barrier's fence also waits for the stage in flight, vmcnt(0))
     }
 
-    if (p.ksplit > 1) {            // partial K range: fp32 atomics into the accumulation buffer (finish kernel converts)
-        if (nchunks <= 0) return;
+    if (p.ksplit > 1) {            // partial K range: plain stores into this split's own fp32 slab; the finish kernel adds the
+                                   // slabs in a fixed order (run-to-run deterministic, unlike fp32 atomics).  A trailing split
+                                   // with no chunks stores its zeros, so the slabs need no memset.
+        float* slab = p.acc32 + (long long)ksp * p.slab_elems;
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -298,7 +406,7 @@ __global__ void __launch_bounds__(256) conv_mfma_kernel(MfmaP p) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int orow = outrow[wm * (BM / WM) + i * 16 + fs * 4 + r];
-                    if (orow >= 0 && oc < p.OCn) atomicAdd(p.acc32 + (long long)orow * p.OC + oc, acc[i][j][r]);
+                    if (orow >= 0 && oc < p.OCn) slab[(long long)orow * p.OC + oc] = acc[i][j][r];
                 }
             }
         return;
@@ -332,7 +440,7 @@ __global__ void __launch_bounds__(256) conv_mfma_kernel(MfmaP p) {
         __syncthreads();
         if (rg == 0 && oc0 + col < p.OCn) {
             for (int q = 1; q < G; ++q) { s += red[(q * BN + col) * 2]; ss += red[(q * BN + col) * 2 + 1]; }
-            const long long tile = blockIdx.x;            // mode 0: tiles are sample-major, stat_tiles per sample
+            // mode 0: tiles are sample-major, stat_tiles per sample
             float* dst = p.stat_partial + ((tile * p.OC) + oc0 + col) * 2;
             dst[0] = s; dst[1] = ss;
         }
@@ -386,33 +494,78 @@ struct PackP {
     long long cls_woff[MF_MAX_CLASSES];
     unsigned char wtap[MF_MAX_TAPS];
 };
+// source offset (without the output-channel term) of the first column of packed K-segment kseg (SEG columns = SEG
+// consecutive channels of one concat member under one tap) of class cls; *nvalid = its real (non-padding) columns
+__device__ __forceinline__ long long pack_seg_offset(const PackP& p, int cls, int kseg, int* nvalid) {
+    const int tap_i = kseg / p.spt;
+    int seg = kseg - tap_i * p.spt, c = 0, s = 0;
+    while (s < p.nsrc && seg >= p.srcSeg[s]) { seg -= p.srcSeg[s]; c += p.srcC[s]; ++s; }
+    if (s >= p.nsrc || tap_i >= p.cls_ntaps[cls]) { *nvalid = 0; return 0; }
+    const int rem = p.srcC[s] - seg * p.SEG;
+    *nvalid = rem < p.SEG ? rem : p.SEG;
+    c += seg * p.SEG;                                       // channel on the (unpadded) concat axis
+    return (long long)p.wtap[p.cls_first[cls] + tap_i] * p.wST + (long long)(c + p.cc_off) * p.wSC;
+}
+// A pack job leaves its own parameters in front of its panel (first M1_PACK_JOB_BYTES of the workspace region), so that
+// m1_pack_batch can refresh every panel of a model in ONE launch after the optimiser step (per-layer pack launches are
+// ~5 us each, ~150 of them per step otherwise).
+#define M1_PACK_JOB_BYTES 512
+#define M1_PACK_MAGIC 0x4d315031u
+struct PackJob { PackP p; void* out; int dtype; unsigned magic; };
+static_assert(sizeof(PackJob) <= M1_PACK_JOB_BYTES, "pack job record");
+
+// one thread per 16-byte panel segment (SEG consecutive K columns of one output channel)
 template <typename T>
-__global__ void pack_weights_kernel(PackP p, T* __restrict__ out) {
-    const int cls = blockIdx.y;
-    const int kpad = p.cls_kpad[cls], ntaps = p.cls_ntaps[cls];
-    const long long tot = (long long)p.OCpad * kpad;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < tot; i += (long long)gridDim.x * blockDim.x) {
-        const int oc = (int)(i / kpad), k = (int)(i % kpad);
-        const int kpt = p.spt * p.SEG;                      // padded K per tap
-        const int tap_i = k / kpt;
-        int seg = (k % kpt) / p.SEG, c = 0, s = 0;
-        const int lane = k % p.SEG;
-        while (s < p.nsrc && seg >= p.srcSeg[s]) { seg -= p.srcSeg[s]; c += p.srcC[s]; ++s; }
-        const bool cvalid = s < p.nsrc && seg * p.SEG + lane < p.srcC[s];
-        c += seg * p.SEG + lane;                            // channel on the (unpadded) concat axis
-        float v = 0.f;
-        if (oc < p.OCn && tap_i < ntaps && cvalid)
-            v = p.w[(long long)p.wtap[p.cls_first[cls] + tap_i] * p.wST + (long long)(c + p.cc_off) * p.wSC + (long long)(oc + p.oc_off) * p.wSO];
-        Act<T>::st(out + p.cls_woff[cls] + i, v);
+__device__ __forceinline__ void pack_class_elems(const PackP& p, int cls, T* __restrict__ out, long long first, long long stride) {
+    constexpr int SEG = MT<T>::SEG;
+    const int kpad = p.cls_kpad[cls], nks = kpad / SEG;
+    const long long tot = (long long)p.OCpad * nks;
+    // consecutive threads follow the contiguous axis of the SOURCE (the fp32 reads coalesce)
+    const bool oc_fast = p.wSO == 1;
+    for (long long u = first; u < tot; u += stride) {
+        const int oc = oc_fast ? (int)(u % p.OCpad) : (int)(u / nks), kseg = oc_fast ? (int)(u / p.OCpad) : (int)(u % nks);
+        int nvalid;
+        const long long so = pack_seg_offset(p, cls, kseg, &nvalid) + (long long)(oc + p.oc_off) * p.wSO;
+        if (oc >= p.OCn) nvalid = 0;
+        float v[SEG];
+#pragma unroll
+        for (int j = 0; j < SEG; ++j) v[j] = j < nvalid ? p.w[so + (long long)j * p.wSC] : 0.f;
+        VecIO<T, SEG>::st(out + p.cls_woff[cls] + (long long)oc * kpad + (long long)kseg * SEG, v);
     }
 }
-
-// out = T(acc32 + bias) [+ out]   (split-K finish)
 template <typename T>
-__global__ void splitk_finish_kernel(const float* __restrict__ acc32, const float* __restrict__ bias, T* __restrict__ out,
+__global__ void pack_weights_kernel(PackP p, T* __restrict__ out, PackJob* __restrict__ job) {
+    if (job && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+        job->p = p; job->out = out; job->dtype = sizeof(T) == 2 ? M1_BF16 : M1_F32; job->magic = M1_PACK_MAGIC;
+    }
+    pack_class_elems<T>(p, blockIdx.y, out, (long long)blockIdx.x * blockDim.x + threadIdx.x, (long long)gridDim.x * blockDim.x);
+}
+// grid (blocks per job, jobs): re-runs recorded jobs from their device-resident records
+__global__ void __launch_bounds__(256) pack_batch_kernel(const PackJob* const* __restrict__ jobs) {
+    __shared__ PackJob j;
+    const unsigned* src = reinterpret_cast<const unsigned*>(jobs[blockIdx.y]);
+    for (int i = threadIdx.x; i < (int)(sizeof(PackJob) / 4); i += blockDim.x) reinterpret_cast<unsigned*>(&j)[i] = src[i];
+    __syncthreads();
+    if (j.magic != M1_PACK_MAGIC) return;
+    const long long first = (long long)blockIdx.x * blockDim.x + threadIdx.x, stride = (long long)gridDim.x * blockDim.x;
+    for (int cls = 0; cls < j.p.nclasses; ++cls) {
+        if (j.dtype == M1_BF16) pack_class_elems<bf16_t>(j.p, cls, (bf16_t*)j.out, first, stride);
+        else pack_class_elems<float>(j.p, cls, (float*)j.out, first, stride);
+    }
+}
+int m1_pack_batch_internal(const void* const* jobs_dev, int njobs, hipStream_t st) {
+    if (njobs <= 0) return M1_OK;
+    hipLaunchKernelGGL(pack_batch_kernel, dim3(48, (unsigned)njobs), dim3(256), 0, st, reinterpret_cast<const PackJob* const*>(jobs_dev));
+    return m1_check_launch();
+}
+
+// out = T(sum_ks slab[ks] + bias) [+ out]   (split-K finish, fixed summation order)
+template <typename T>
+__global__ void splitk_finish_kernel(const float* __restrict__ acc32, int ksplit, const float* __restrict__ bias, T* __restrict__ out,
                                      long long n, int OC, int accumulate) {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
-        float v = acc32[i] + (bias ? bias[i % OC] : 0.f);
+        float v = bias ? bias[i % OC] : 0.f;
+        for (int k = 0; k < ksplit; ++k) v += acc32[(long long)k * n + i];
         if (accumulate) v += Act<T>::ld(out + i);
         Act<T>::st(out + i, v);
     }
@@ -508,18 +661,19 @@ size_t m1_mfma_ws_bytes(const GatherSpec& g) {
     long long tot = 0;
     build_classes(g, CC, SEG, OCpad, nullptr, nullptr, &tot);
     size_t bytes = ((size_t)tot * (g.dtype == M1_BF16 ? 2 : 4) + 255) / 256 * 256;
-    if (pl.ksplit > 1) bytes += out_elems(g) * sizeof(float);
-    return bytes + 256;
+    if (pl.ksplit > 1) bytes += out_elems(g) * sizeof(float) * pl.ksplit;
+    return bytes + 256 + M1_PACK_JOB_BYTES;
 }
 
 template <typename T, int BM, int BN, int WM, int WN, int KC>
 static int launch_cfg_kc(const MfmaP& mp, long long maxM, int OCpad, hipStream_t st) {
-    dim3 grid((unsigned)cdiv_ll(maxM, BM), mp.nclasses * mp.ksplit, OCpad / BN);
+    dim3 grid((unsigned)(cdiv_ll(cdiv_ll(maxM, BM), 8) * 8), mp.nclasses * mp.ksplit, OCpad / BN);
     const size_t smem = mfma_smem_bytes<T, BM, BN, KC>();
-    auto kern = conv_mfma_kernel<T, BM, BN, WM, WN, KC>;
+    auto kern = mp.aligned ? conv_mfma_kernel<T, BM, BN, WM, WN, KC, true> : conv_mfma_kernel<T, BM, BN, WM, WN, KC, false>;
     static bool attr_set = false;     // per instantiation
     if (smem > 48 * 1024 && !attr_set) {
-        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) return M1_ERR_LAUNCH;
+        if (hipFuncSetAttribute((const void*)conv_mfma_kernel<T, BM, BN, WM, WN, KC, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) return M1_ERR_LAUNCH;
+        if (hipFuncSetAttribute((const void*)conv_mfma_kernel<T, BM, BN, WM, WN, KC, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) return M1_ERR_LAUNCH;
         attr_set = true;
     }
     hipLaunchKernelGGL(kern, grid, dim3(256), smem, st, mp);
@@ -548,7 +702,8 @@ static int run_mfma(const GatherSpec& g, void* ws, int ws_packed, hipStream_t st
     }
     mp.nsrc = g.nsrc; mp.CC = CC; mp.spt = spec_spt(g, SEG);
     pp.nsrc = g.nsrc; pp.spt = mp.spt; pp.SEG = SEG; mp.ID = g.ID; mp.IH = g.IH; mp.IW = g.IW; mp.out = g.out; mp.OC = g.OC; mp.OCn = g.OC;
-    mp.OD = g.OD; mp.OH = g.OH; mp.OW = g.OW; mp.N = g.N; mp.wp = ws; mp.bias = g.bias; mp.mode = g.mode;
+    void* panel = reinterpret_cast<unsigned char*>(ws) + M1_PACK_JOB_BYTES;    // [job record][panels][split-K accumulator]
+    mp.OD = g.OD; mp.OH = g.OH; mp.OW = g.OW; mp.N = g.N; mp.wp = panel; mp.bias = g.bias; mp.mode = g.mode;
     mp.sd = g.sd; mp.sh = g.sh; mp.sw = g.sw; mp.pd = g.pd; mp.ph = g.ph; mp.pw = g.pw; mp.accumulate = g.accumulate;
     const Plan pl = make_plan(g.OC, spec_maxM(g), spec_ncls(g), min_class_chunks(g, CC, SEG));
     const int BN = pl.BN, OCpad = (g.OC + BN - 1) / BN * BN;
@@ -561,15 +716,15 @@ static int run_mfma(const GatherSpec& g, void* ws, int ws_packed, hipStream_t st
     for (int i = 0; i < g.nsrc; ++i) if (g.srcC[i] % (4 * SEG)) mp.aligned = 0;
     if (pl.ksplit > 1) {
         const size_t wbytes = ((size_t)tot * sizeof(T) + 255) / 256 * 256;
-        mp.acc32 = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(ws) + wbytes);
-        if (hipMemsetAsync(mp.acc32, 0, out_elems(g) * sizeof(float), st) != hipSuccess) return M1_ERR_LAUNCH;
+        mp.acc32 = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(panel) + wbytes);
+        mp.slab_elems = (long long)out_elems(g);
     }
     pp.w = g.w; pp.wST = g.wST; pp.wSC = g.wSC; pp.wSO = g.wSO; pp.oc_off = g.oc_off; pp.cc_off = g.cc_off; pp.OCn = g.OC; pp.OCpad = OCpad; pp.CC = CC;
     int maxk = 0; for (int c = 0; c < pp.nclasses; ++c) maxk = pp.cls_kpad[c] > maxk ? pp.cls_kpad[c] : maxk;
     long long pblocks = cdiv_ll((long long)OCpad * maxk, 256); if (pblocks > 2048) pblocks = 2048; if (pblocks < 1) pblocks = 1;
     int rc = M1_OK;
     if (!ws_packed) {          // the caller may keep the panel of an unchanged weight across calls (2+2 core passes per step)
-        hipLaunchKernelGGL(pack_weights_kernel<T>, dim3((unsigned)pblocks, pp.nclasses), dim3(256), 0, st, pp, (T*)ws);
+        hipLaunchKernelGGL(pack_weights_kernel<T>, dim3((unsigned)pblocks, pp.nclasses), dim3(256), 0, st, pp, (T*)panel, reinterpret_cast<PackJob*>(ws));
         rc = m1_check_launch(); if (rc) return rc;
     }
 
@@ -594,7 +749,7 @@ static int run_mfma(const GatherSpec& g, void* ws, int ws_packed, hipStream_t st
     if (pl.ksplit <= 1) return rc2;
     const long long ne = (long long)out_elems(g);
     long long fb = cdiv_ll(ne, 256); if (fb > 2048) fb = 2048;
-    hipLaunchKernelGGL(splitk_finish_kernel<T>, dim3((unsigned)fb), dim3(256), 0, st, mp.acc32, g.bias, (T*)g.out, ne, g.OC, g.accumulate);
+    hipLaunchKernelGGL(splitk_finish_kernel<T>, dim3((unsigned)fb), dim3(256), 0, st, mp.acc32, pl.ksplit, g.bias, (T*)g.out, ne, g.OC, g.accumulate);
     rc2 = m1_check_launch(); if (rc2) return rc2;
     if (g.stats_out) return m1_stats_internal(g.out, g.N, Vout, g.OC, g.dtype, g.stats_eps, g.stats_out, g.stats_ws, st);
     return M1_OK;

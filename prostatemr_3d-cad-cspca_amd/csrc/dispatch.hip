@@ -132,6 +132,31 @@ extern "C" size_t m1_conv_ws_bytes(const m1_conv_desc_t* d, int transposed, int 
     return m1_reduce_ws_floats(d->N, (long long)q.OD * q.OH * q.OW, d->Cout, 1) * sizeof(float) + 256;
 }
 
+// ---- packed-weight panel records ----------------------------------------------------------------------------------
+// Device addresses of the pack-job records inside `ws` (one per matrix-core panel: role 0 -> 1, role 1 -> one per
+// concat member).  A record is filled by the first (lazy) pack of its panel; m1_pack_batch re-runs filled records.
+extern "C" int m1_conv_pack_jobs(const m1_conv_desc_t* d, int transposed, int role, void* ws, void** jobs_out) {
+    if (!desc_ok(d) || !ws || !jobs_out) return 0;
+    const bool T = transposed != 0;
+    int n = 0;
+    if (role == 0) {
+        if (gather_ws_bytes(fwd_spec(d, T, nullptr, nullptr, nullptr))) jobs_out[n++] = ws;
+    } else if (role == 1) {
+        int off = 0; size_t woff = 0;
+        for (int i = 0; i < d->nsrc; ++i) {
+            const size_t b = gather_ws_bytes(dgrad_spec(d, T, nullptr, nullptr, nullptr, i, off));
+            if (b) jobs_out[n++] = (unsigned char*)ws + woff;
+            woff += b; off += d->src[i].C;
+        }
+    }
+    return n;
+}
+extern "C" int m1_pack_batch(const void* const* jobs_dev, int njobs, void* stream) {
+    if (njobs < 0 || (njobs > 0 && !jobs_dev)) return M1_ERR_BAD_ARG;
+    M1ProfScope ps("pack_batch", 0.0, 0.0, (hipStream_t)stream);
+    return m1_pack_batch_internal(jobs_dev, njobs, (hipStream_t)stream);
+}
+
 // ---- Conv3D ------------------------------------------------------------------------------------------------------
 extern "C" int m1_conv3d_fwd(const m1_conv_desc_t* d, const float* w, const float* bias, void* y, float* stats, void* ws,
                              int ws_packed, void* stream) {

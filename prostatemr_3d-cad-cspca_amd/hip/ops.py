@@ -7,6 +7,7 @@ path: ops raise RuntimeError on non-GPU tensors.
 from __future__ import annotations
 
 import ctypes as C
+import weakref
 from typing import List, Optional, Sequence, Tuple
 
 import torch
@@ -79,9 +80,9 @@ def _sink(param: torch.Tensor, like: Optional[torch.Tensor] = None):
     return t, 0, t
 
 
-def _conv_ws(d, transposed: bool, role: int, device) -> torch.Tensor:
+def _conv_ws(d, transposed: bool, role: int, device, zero: bool = False) -> torch.Tensor:
     n = L.load().m1_conv_ws_bytes(C.byref(d), 1 if transposed else 0, role)
-    return torch.empty(max(int(n), 256), dtype=torch.uint8, device=device)
+    return (torch.zeros if zero else torch.empty)(max(int(n), 256), dtype=torch.uint8, device=device)
 
 
 # Packed weight panels are kept ON the weight tensor object, per (version, role, geometry), while the weights are
@@ -90,9 +91,36 @@ def _conv_ws(d, transposed: bool, role: int, device) -> torch.Tensor:
 _PANEL_EPOCH = [0]
 
 
+# Every cached panel is also REGISTERED: (id(weight), key) -> (weakref(weight), data_ptr, workspace, [device addresses of
+# its pack-job records]).  repack_all() refreshes all of them with one m1_pack_batch launch after an optimiser step.
+_PACK_REG: dict = {}
+_PACK_TABLE = [None]      # device int64 tensor of job-record addresses (rebuilt when the registry changes)
+
+
 def invalidate_panels() -> None:
-    """Call after anything that changes weights through raw pointers (the fused optimiser kernel does)."""
+    """Call after anything that changes weights through raw pointers without re-packing (e.g. load_weights)."""
     _PANEL_EPOCH[0] += 1
+    _PACK_REG.clear()
+    _PACK_TABLE[0] = None
+
+
+def repack_all() -> None:
+    """Re-pack every registered weight panel from the current weight values (one kernel launch).  The fused optimiser
+    calls this after its update, so the next step's convolutions find their panels already packed."""
+    dead = [k for k, (r, ptr, _, _) in _PACK_REG.items() if r() is None or r().data_ptr() != ptr]
+    for k in dead:
+        del _PACK_REG[k]
+        _PACK_TABLE[0] = None
+    if not _PACK_REG:
+        return
+    if _PACK_TABLE[0] is None:
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("weight-panel registry changed during graph capture: run one eager step first")
+        ws0 = next(iter(_PACK_REG.values()))[2]
+        ptrs = [j for (_, _, _, jobs) in _PACK_REG.values() for j in jobs]
+        _PACK_TABLE[0] = torch.tensor(ptrs, dtype=torch.int64).to(ws0.device)
+    t = _PACK_TABLE[0]
+    L.check(L.load().m1_pack_batch(_p(t), int(t.numel()), _stream()), "m1_pack_batch")
 
 
 def _panel_ws(w: torch.Tensor, d, transposed: bool, role: int, need_mask=None):
@@ -109,8 +137,13 @@ def _panel_ws(w: torch.Tensor, d, transposed: bool, role: int, need_mask=None):
     hit = store[1].get(key)
     if hit is not None:
         return hit, 1
-    ws = _conv_ws(d, transposed, role, w.device)
+    ws = _conv_ws(d, transposed, role, w.device, zero=True)     # zero: unfilled job records must read as empty
     store[1][key] = ws
+    out = (C.c_void_p * L.M1_MAX_SRC)()
+    n = L.load().m1_conv_pack_jobs(C.byref(d), 1 if transposed else 0, role, _p(ws), out)
+    if n > 0:
+        _PACK_REG[(id(w), key)] = (weakref.ref(w), w.data_ptr(), ws, [int(out[i]) for i in range(n)])
+        _PACK_TABLE[0] = None
     return ws, 0
 
 
@@ -150,6 +183,7 @@ class _Conv3d(torch.autograd.Function):
         ctx.k, ctx.s, ctx.transposed, ctx.has_bias, ctx.cout = tuple(k), tuple(s), transposed, b is not None, cout
         if want_stats:
             ctx.mark_non_differentiable(stats)
+            ctx.set_materialize_grads(False)      # no zero-filled "gradient" for the statistics output
             return y, stats
         return y
 
@@ -157,6 +191,8 @@ class _Conv3d(torch.autograd.Function):
     def backward(ctx, dy, *_unused):
         lib = L.load()
         w, *srcs = ctx.saved_tensors
+        if dy is None:
+            return (None,) * (6 + len(srcs))
         dy = dy.contiguous()
         _req(dy)
         d = _desc(srcs, ctx.cout, ctx.k, ctx.s)

@@ -134,7 +134,7 @@ class Adam:
         ops.adam_amsgrad_(f.flat, f.grad, self.m, self.v, self.vhat, f.n_kernel, f.n_bias, self.l2_kernel, self.l2_bias,
                           self.grad_scale, self.lr_dev, self.beta_1, self.beta_2, self.epsilon, self.step_dev)
         ops.step_advance(self.step_dev, None)
-        ops.invalidate_panels()          # weights changed behind torch's back: cached weight panels are stale
+        ops.repack_all()                 # weights changed behind torch's back: refresh every cached weight panel
 
     def step(self):
         self.set_lr_device()

@@ -407,3 +407,38 @@ def test_conv_mfma_large_k_and_batch(dev):
     yo = O.conv3d_same(torch.cat(xs, -1).double(), w.double(), None, s)
     y = ops.conv3d_same([x.to(dev, torch.bfloat16) for x in xs], w.to(dev), None, k, s)
     assert rel_err(y, yo) < 2e-2
+
+
+@pytest.mark.parametrize("transposed", [False, True])
+def test_repack_all_refreshes_cached_panels(dev, transposed):
+    """Weights changed behind torch's back (as the fused optimiser does) + ops.repack_all(): the cached panels of the
+    forward AND of the data gradient must equal freshly packed ones (one batched launch, records left by the lazy pack)."""
+    k, s = (3, 3, 3), ((1, 2, 2) if transposed else (1, 1, 1))
+    cins, cout = [16, 3, 32], 24
+    xs = [rnd((2, 4, 8, 6, c), 20 + i).to(dev).bfloat16().requires_grad_(True) for i, c in enumerate(cins)]
+    wshape = (*k, cout, sum(cins)) if transposed else (*k, sum(cins), cout)
+    w = rnd(wshape, 7, 0.2).to(dev).requires_grad_(True)
+    b = rnd((cout,), 8).to(dev).requires_grad_(True)
+    f = ops.conv3d_transpose_same if transposed else ops.conv3d_same
+
+    def run():
+        for x in xs:
+            x.grad = None
+        y = f(xs, w, b, k, s)
+        y.backward(torch.ones_like(y))
+        return y.detach().float().clone(), [x.grad.float().clone() for x in xs]
+
+    ops.invalidate_panels()
+    run()                                              # lazy pack: fills + registers the job records
+    alias = torch.from_dlpack(torch.utils.dlpack.to_dlpack(w.detach()))     # same memory, own version counter
+    v0 = w._version
+    alias.mul_(-1.5)
+    assert w._version == v0                            # torch did not notice: the cached panels are now stale
+    ops.repack_all()
+    y1, g1 = run()                                     # cache hits on the refreshed panels
+    ops.invalidate_panels()
+    y2, g2 = run()                                     # freshly packed
+    assert torch.equal(y1, y2)
+    for a, c in zip(g1, g2):
+        assert torch.equal(a, c)
+    ops.invalidate_panels()
