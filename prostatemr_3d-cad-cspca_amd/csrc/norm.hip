@@ -153,16 +153,6 @@ __global__ void __launch_bounds__(256) in_bwd_apply_kernel(const T* __restrict__
     }
 }
 
-// dgamma[c] = sum_n sums[n][c][1], dbeta[c] = sum_n sums[n][c][0]
-__global__ void in_bwd_param_kernel(const float* __restrict__ sums, int N, int C, float* __restrict__ dgamma,
-                                    float* __restrict__ dbeta, int accumulate) {
-    int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    double g = 0.0, b = 0.0;
-    for (int n = 0; n < N; ++n) { b += sums[((size_t)n * C + c) * 2]; g += sums[((size_t)n * C + c) * 2 + 1]; }
-    dgamma[c] = (accumulate ? dgamma[c] : 0.f) + (float)g; dbeta[c] = (accumulate ? dbeta[c] : 0.f) + (float)b;
-}
-
 template <typename T>
 static int bwd_impl(const void* x, const float* stats, const float* gamma, const float* beta, float slope,
                     const void* dy, void* dx, float* dgamma, float* dbeta, int N, long long V, int C, float* ws,
@@ -172,9 +162,9 @@ static int bwd_impl(const void* x, const float* stats, const float* gamma, const
     if (rc) return rc;
     const int nchunks = m1_red_nchunks(V, C);
     float* sums = ws + (size_t)N * nchunks * C * 2;
-    rc = m1_reduce_finalize_launch<2>(ws, N, C, nchunks, sums, 0, 0.f, st);
+    M1ParamOut<2> po{{dbeta, dgamma}, {accumulate, accumulate}};      // dbeta = sum_n sums[.][0], dgamma = sum_n sums[.][1]
+    rc = m1_reduce_finalize_params_launch<2>(ws, N, C, nchunks, sums, po, st);
     if (rc) return rc;
-    hipLaunchKernelGGL(in_bwd_param_kernel, dim3((C + 255) / 256), dim3(256), 0, st, sums, N, C, dgamma, dbeta, accumulate);
     constexpr int VW = sizeof(T) == 2 ? 8 : 4;
     if (C % VW == 0) {
         long long per = V * (C / VW);

@@ -95,6 +95,46 @@ static inline int m1_reduce_finalize_launch(const float* partial, int N, int C, 
     return m1_check_launch();
 }
 
+// Same fold, plus the parameter gradients that are sums over the batch of the per-sample sums (gamma/beta of an
+// InstanceNorm, the SE gate input): ONE WAVE per channel walks the samples.  pout[k] (nullable) receives
+// sum_n out[n][c][k], added to its previous value when pacc[k] != 0.
+template <int NS>
+struct M1ParamOut { float* ptr[NS]; int acc[NS]; };
+template <int NS>
+__global__ void __launch_bounds__(256) m1_reduce_finalize_params_kernel(const float* __restrict__ partial, int N, int C, int nchunks,
+                                                                        float* __restrict__ out, M1ParamOut<NS> po) {
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (c >= C) return;
+    double tot[NS];
+#pragma unroll
+    for (int k = 0; k < NS; ++k) tot[k] = 0.0;
+    for (int n = 0; n < N; ++n) {
+        double s[NS];
+#pragma unroll
+        for (int k = 0; k < NS; ++k) s[k] = 0.0;
+        for (int j = lane; j < nchunks; j += 64)
+#pragma unroll
+            for (int k = 0; k < NS; ++k) s[k] += (double)partial[(((size_t)n * nchunks + j) * C + c) * NS + k];
+#pragma unroll
+        for (int k = 0; k < NS; ++k) { s[k] = wave_sum_d(s[k]); tot[k] += (double)(float)s[k]; }
+        if (lane == 0) {
+#pragma unroll
+            for (int k = 0; k < NS; ++k) out[((size_t)n * C + c) * NS + k] = (float)s[k];
+        }
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < NS; ++k)
+            if (po.ptr[k]) po.ptr[k][c] = (po.acc[k] ? po.ptr[k][c] : 0.f) + (float)tot[k];
+    }
+}
+template <int NS>
+static inline int m1_reduce_finalize_params_launch(const float* partial, int N, int C, int nchunks, float* out,
+                                                   const M1ParamOut<NS>& po, hipStream_t st) {
+    hipLaunchKernelGGL((m1_reduce_finalize_params_kernel<NS>), dim3((C + 3) / 4), dim3(256), 0, st, partial, N, C, nchunks, out, po);
+    return m1_check_launch();
+}
+
 template <int NS, typename F>
 static inline int m1_reduce_nc_launch(const F& f, int N, long long V, int C, float* partial, hipStream_t st) {
     const int chunkV = m1_red_chunkV(V, C), nchunks = m1_red_nchunks(V, C);

@@ -20,8 +20,10 @@ __device__ __forceinline__ void block_matvec_cols(const float* __restrict__ v, c
         int JP = 1; while (JP < jn) JP <<= 1;
         const int parts = 256 / JP, jl = threadIdx.x % JP, part = threadIdx.x / JP;
         float s = 0.f;
-        if (jl < jn)
+        if (jl < jn) {          // independent loads: keep 8 in flight (the single block is latency-bound otherwise)
+#pragma unroll 8
             for (int c = part; c < Cn; c += parts) s = fmaf(v[c], W[(size_t)c * J + j0 + jl], s);
+        }
         red[threadIdx.x] = s;
         __syncthreads();
         if (part == 0 && jl < jn) {
@@ -59,6 +61,7 @@ __device__ __forceinline__ void block_matvec_rows(const float* __restrict__ W, c
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     for (int r = wave; r < R; r += 4) {
         float s = 0.f;
+#pragma unroll 8
         for (int j = lane; j < J; j += 64) s = fmaf(W[(size_t)r * J + j], v[j], s);
         s = wave_sum(s);
         if (lane == 0) out_s[r] = s;
@@ -229,19 +232,6 @@ __global__ void __launch_bounds__(256) se_combine_bwd_apply_kernel(const T* __re
     }
 }
 
-__global__ void se_bwd_param_kernel(const float* __restrict__ sums, int N, int F, float* __restrict__ dgamma3,
-                                    float* __restrict__ dbeta3, float* __restrict__ dgamma4, float* __restrict__ dbeta4,
-                                    float* __restrict__ dg, int acc) {
-    int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= F) return;
-    double s[5] = {0, 0, 0, 0, 0};
-    for (int n = 0; n < N; ++n)
-        for (int k = 0; k < 5; ++k) s[k] += sums[((size_t)n * F + c) * 5 + k];
-    dbeta3[c] = (acc ? dbeta3[c] : 0.f) + (float)s[0]; dgamma3[c] = (acc ? dgamma3[c] : 0.f) + (float)s[1];
-    dbeta4[c] = (acc ? dbeta4[c] : 0.f) + (float)s[2]; dgamma4[c] = (acc ? dgamma4[c] : 0.f) + (float)s[3];
-    dg[c] = (float)s[4];     // dg is scratch for the gate backward: always overwritten
-}
-
 static inline int grid_x(long long per) { long long g = cdiv_ll(per, 256); return (int)(g > 4096 ? 4096 : (g < 1 ? 1 : g)); }
 
 template <typename T>
@@ -265,10 +255,10 @@ static int se_bwd_impl(const void* y3, const void* y4, const void* dout, const S
     if (rc) return rc;
     const int nchunks = m1_red_nchunks(p.V, p.F);
     float* sums = ws + (size_t)N * nchunks * p.F * 5;
-    rc = m1_reduce_finalize_launch<5>(ws, N, p.F, nchunks, sums, 0, 0.f, st);
+    // parameter gradients ride on the fold: dg is scratch for the gate backward (always overwritten)
+    M1ParamOut<5> po{{dbeta3, dgamma3, dbeta4, dgamma4, dg}, {acc, acc, acc, acc, 0}};
+    rc = m1_reduce_finalize_params_launch<5>(ws, N, p.F, nchunks, sums, po, st);
     if (rc) return rc;
-    hipLaunchKernelGGL(se_bwd_param_kernel, dim3((p.F + 255) / 256), dim3(256), 0, st, sums, N, p.F, dgamma3, dbeta3, dgamma4,
-                       dbeta4, dg, acc);
     constexpr int VW = sizeof(T) == 2 ? 8 : 4;
     if (p.F % VW == 0)
         hipLaunchKernelGGL((se_combine_bwd_apply_kernel<T, VW>), dim3(grid_x(p.V * (p.F / VW)), N), dim3(256), 0, st,
