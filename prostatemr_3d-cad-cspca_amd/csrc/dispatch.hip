@@ -209,6 +209,12 @@ extern "C" int m1_convT3d_dgrad(const m1_conv_desc_t* d, const float* w, const v
 }
 
 // ---- weight gradients ------------------------------------------------------------------------------------------
+#include <stdlib.h>
+static bool tf_wanted(const WgradSpec& g) {
+    static int maxc = -1;
+    if (maxc < 0) { const char* e = getenv("M1_TF_MAXC"); maxc = e ? atoi(e) : 64; }
+    return g.CA <= maxc && g.CB <= maxc && m1_tf_wgrad_supported(g);
+}
 static int wgrad_common(const m1_conv_desc_t* d, bool T, const void* dy, float* dw, float* db, void* ws, hipStream_t st,
                         int accumulate) {
     Geo q = T ? convT_geo(d) : conv_geo(d);
@@ -219,6 +225,7 @@ static int wgrad_common(const m1_conv_desc_t* d, bool T, const void* dy, float* 
     const bool fuse_db = db && !T && !g_force_direct;
     if (fuse_db && !accumulate && hipMemsetAsync(db, 0, (size_t)d->Cout * sizeof(float), st) != hipSuccess) return M1_ERR_LAUNCH;
     int off = 0;
+    const int nbias = fuse_db ? d->Cout : 0;
     for (int i = 0; i < d->nsrc; ++i) {
         WgradSpec g{};
         g.N = d->N; g.R = dw; g.kd = d->kd; g.kh = d->kh; g.kw = d->kw; g.sd = d->sd; g.sh = d->sh; g.sw = d->sw;
@@ -233,7 +240,10 @@ static int wgrad_common(const m1_conv_desc_t* d, bool T, const void* dy, float* 
             g.B = d->src[i].ptr; g.CB = d->src[i].C; g.BD = d->D; g.BH = d->H; g.BW = d->W;
             g.RT = (long long)d->Cout * d->Cin; g.RSA = d->Cin; g.a_off = 0; g.b_off = off;
         }
-        int rc;
+        int rc = M1_ERR_UNSUPPORTED;
+        if (!g_force_direct && tf_wanted(g)) rc = m1_tf_wgrad(g, (long long)nw, nbias, st);   // may decline (no launch)
+        if (rc == M1_OK) { off += d->src[i].C; continue; }
+        if (rc != M1_ERR_UNSUPPORTED && rc != M1_ERR_WORKSPACE) return rc;
         if (g_force_direct == 2 && m1_skinny_wgrad_supported(g)) rc = m1_skinny_wgrad(g, st);   // test hook for that kernel
         else if (!g_force_direct && m1_mfma_wgrad_supported(g)) rc = m1_mfma_wgrad(g, st);
         else rc = m1_direct_wgrad(g, st);

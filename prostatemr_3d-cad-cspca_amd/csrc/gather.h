@@ -45,4 +45,8 @@ int m1_mfma_gather(const GatherSpec& g, void* ws, int ws_packed, hipStream_t st)
 int m1_pack_batch_internal(const void* const* jobs_dev, int njobs, hipStream_t st);
 bool m1_mfma_wgrad_supported(const WgradSpec& g);
 int m1_mfma_wgrad(const WgradSpec& g, hipStream_t st);
+bool m1_tf_wgrad_supported(const WgradSpec& g);      // tap-fused variant (wgrad_tf.hip)
+// nw / nb: floats of the whole weight / bias gradient the spec's R / bsum point into.  M1_ERR_WORKSPACE / UNSUPPORTED:
+// nothing was launched, the caller takes the per-tap kernel instead.
+int m1_tf_wgrad(const WgradSpec& g, long long nw, int nb, hipStream_t st);
 int m1_colsum_internal(const void* x, int N, long long V, int C, int dtype, float* out, float* ws, hipStream_t st, int accumulate);

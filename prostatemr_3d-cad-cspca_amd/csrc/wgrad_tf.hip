@@ -1,0 +1,379 @@
+// wgrad_tf.hip -- tap-fused weight gradients (bf16) for the wide, shallow layers (res0..res2: many voxels, <= 32
+// channels per tile), where the per-tap kernel of wgrad_mfma.hip re-reads both operands once per tap.
+//
+//   R[tap][a][b] += sum_{n,v} A[n, v*s + tap - p][a] * B[n, v][b]            all taps of a (1,3,3)/(3,3,3) kernel at once
+//
+// * One block owns a 32(a) x 32(b) channel tile and walks K-tiles of 64 output voxels (2 k-steps of 32: KHs rows x
+//   KWs columns, KWs = 32/16/8 dividing the row length).  Per K-tile it stages, by LDS-DMA (global_load_lds_dwordx4,
+//   no staging registers), the 64 B rows and the A rows of the tile INCLUDING the tap halo -- every A voxel is loaded
+//   once for all taps -- in their natural voxel-major layout.
+// * The MFMA wants K(=voxel)-contiguous fragments: ds_read_b64_tr_b16 (gfx950 transpose read) takes a
+//   [4 voxels][16 channels] block per 16-lane group and hands lane i channel i of the 4 voxels, so a tap is just a
+//   different ROW offset into the same A tile (no register transposes, no unaligned LDS reads).
+//   Probe of the instruction's lane mapping: tools/probes/tr_b16_probe.hip.
+// * wave w accumulates the 16x16 tile (w>>1, w&1) of every tap: NT x 4 accumulator registers; the B fragment of a
+//   k-step is read once and reused by all taps.
+// * K-tiles are dealt round-robin to the blocks of a channel tile; partial sums are combined with fp32 atomics.
+#include "common.h"
+#include "gather.h"
+#include <stdlib.h>
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+typedef short s16x4_t __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+__device__ __attribute__((aligned(64))) unsigned int m1_zero_page_w[16];
+
+__device__ __forceinline__ void glds16w(const void* g, void* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)lds_wave_base, 16, 0, 0);
+}
+// 4 voxels x 16 channels block -> this lane's channel, 4 consecutive voxels (see header)
+__device__ __forceinline__ s16x4_t tr_read(const unsigned char* p) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)p);
+}
+
+#define TF_MAX_NKS 2        // k-steps (of 32 voxels) per K-tile (4 measured slower end to end)
+#define TF_MAX_AIT 10       // LDS-DMA pieces per thread for the A tile
+
+struct TfP {
+    const bf16_t* A; const bf16_t* B; float* R; float* bsum;
+    int CA, CB, AD, AH, AW, BD, BH, BW, N;
+    long long RT, RSA; int a_off, b_off;
+    int sd, sh, sw, pd, ph, pw;
+    int KWs, TH;             // k-step = (32/KWs) rows x KWs columns; K-tile = TH = nks*(32/KWs) rows x KWs columns
+    int AHt, AWt;            // A tile extent per kd slice (rows, columns) incl. halo
+    int spra, sprb;          // 16-byte slots per LDS row = min(C, 32)/8
+    int a_slots, b_slots;    // slots of the A / B tile (a_slots rounded up to whole waves)
+    int a_bytes, b_bytes;    // LDS bytes per buffer (with slack for the 32-byte fragment reads of short rows)
+    int tiles_w, tiles_h; long long ntiles;
+    int bTiles, nsplit;
+    int stages;              // LDS pipeline depth (tiles staged ahead of the MFMAs + 1)
+    float* Rx; long long rx_stride;      // per-XCD private copies of R (+ bias sums behind it): see the epilogue
+    long long rx_bias;       // offset of the bias sums inside one copy
+};
+
+typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+// transpose-read by inline asm: hipcc cannot tell an LDS-DMA still in flight from the buffer being read and would wait
+// vmcnt(0) in front of every compiler-visible LDS read (no prefetch depth at all)
+__device__ __forceinline__ u32x2_t tr_read_asm(unsigned lds_addr) {
+    u32x2_t v;
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"(lds_addr) : "memory");
+    return v;
+}
+__device__ __forceinline__ void lds_wait2(u32x2_t& a, u32x2_t& b) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b)); }
+__device__ __forceinline__ bf16x8_t frag8(u32x2_t lo, u32x2_t hi) {
+    return __builtin_bit_cast(bf16x8_t, __builtin_shufflevector(lo, hi, 0, 1, 2, 3));
+}
+// at most n LDS-DMA pieces of this wave still in flight (n wave-uniform)
+__device__ __forceinline__ void wait_vm(int n) {
+    switch (n) {
+#define TF_W(N_) case N_: asm volatile("s_waitcnt vmcnt(" #N_ ")" ::: "memory"); break;
+        TF_W(0) TF_W(1) TF_W(2) TF_W(3) TF_W(4) TF_W(5) TF_W(6) TF_W(7) TF_W(8) TF_W(9) TF_W(10) TF_W(11) TF_W(12)
+        TF_W(13) TF_W(14) TF_W(15) TF_W(16) TF_W(17) TF_W(18) TF_W(19) TF_W(20) TF_W(21) TF_W(22) TF_W(23) TF_W(24)
+        TF_W(25) TF_W(26) TF_W(27) TF_W(28) TF_W(29) TF_W(30) TF_W(31) TF_W(32) TF_W(33) TF_W(34) TF_W(35) TF_W(36)
+        TF_W(37) TF_W(38) TF_W(39) TF_W(40) TF_W(41) TF_W(42) TF_W(43) TF_W(44) TF_W(45) TF_W(46) TF_W(47) TF_W(48)
+#undef TF_W
+        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    }
+}
+
+#define TF_MAX_STAGES 8
+
+template <int KD, int KH, int KW, int KPARTS, int TF_NKS>
+__global__ void __launch_bounds__(256) wgrad_tf_kernel(TfP p) {
+    constexpr int NT = KD * KH * KW, NG = KD * KH;           // taps; tap groups (the KW taps of one (kd,kh) share a row offset)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // waves -> (16x16 output tile, tap part): with <= 16 channels on a side there are only 2 or 1 tiles and the waves that
+    // share a tile split the taps between them (tap t belongs to part t % kparts)
+    constexpr int kparts = KPARTS, ntile = 4 / KPARTS;       // host: ntile = (CA > 16 ? 2 : 1) * (CB > 16 ? 2 : 1)
+    const int ntb = p.CB > 16 ? 2 : 1;
+    const int tile_id = wave % ntile, part = wave / ntile;
+    const int ta = tile_id / ntb, tb = tile_id % ntb;
+    const int a0 = (blockIdx.x / p.bTiles) * 32, b0 = (blockIdx.x % p.bTiles) * 32;
+    const int PA = p.spra * 16, PB = p.sprb * 16;            // LDS row pitch (bytes)
+    const int stage_bytes = p.a_bytes + p.b_bytes;           // [A tile][B tile] per stage
+    const unsigned char* zero_pg = reinterpret_cast<const unsigned char*>(m1_zero_page_w);
+
+    // ---- per-lane description of its LDS-DMA pieces (the same for every K-tile).  Every wave issues nait + 1 pieces
+    //      per stage (tiles padded to whole 256-slot rounds, padding fetches the zero page): static vmcnt arithmetic ----
+    int a_rel[TF_MAX_AIT], a_pk[TF_MAX_AIT], a_sl[TF_MAX_AIT];
+    const int nait = p.a_slots >> 8;
+#pragma unroll
+    for (int it = 0; it < TF_MAX_AIT; ++it) {
+        const int q = it * 256 + tid;
+        const int row = q / p.spra, slp = q - row * p.spra;
+        const int dd = row / (p.AHt * p.AWt); const int r2 = row - dd * (p.AHt * p.AWt);
+        const int hh = r2 / p.AWt, ww = r2 - hh * p.AWt;
+        // 64-byte rows: the two 32-byte halves of a row swap when bit 3 of the tile column is set -- lane groups 0/1 of a
+        // transpose read sit 8 columns apart and would otherwise hit the same banks
+        const int sl = p.spra == 4 ? (slp ^ (((ww >> 3) & 1) << 1)) : slp;
+        a_rel[it] = (dd * p.AH + hh) * p.AW + ww;
+        a_pk[it] = (row < KD * p.AHt * p.AWt) ? (dd | (hh << 8) | (ww << 16)) : -1;
+        a_sl[it] = sl * 8;
+    }
+    constexpr int NBIT = (TF_NKS * 32 * 4 + 255) / 256;      // LDS-DMA pieces per thread for the B tile (max)
+    const int nbit = (p.b_slots + 255) >> 8;
+    int b_th[NBIT], b_tw[NBIT], b_sl[NBIT]; bool b_on[NBIT];
+#pragma unroll
+    for (int it = 0; it < NBIT; ++it) {
+        const int q = it * 256 + tid;
+        const int row = q / p.sprb, slp = q - row * p.sprb;
+        b_on[it] = q < p.b_slots;
+        b_th[it] = row / p.KWs; b_tw[it] = row - b_th[it] * p.KWs;
+        b_sl[it] = (p.sprb == 4 ? (slp ^ (((b_tw[it] >> 3) & 1) << 1)) : slp) * 8;
+    }
+
+    // tile counter of the NEXT tile to issue, decoded incrementally (no divisions in the loop)
+    int q_kt = blockIdx.y, q_tw, q_th, q_bd, q_n;
+    { int r = q_kt; q_tw = r % p.tiles_w; r /= p.tiles_w; q_th = r % p.tiles_h; r /= p.tiles_h; q_bd = r % p.BD; q_n = r / p.BD; }
+    int s_tw, s_th, s_bd, s_n;
+    { int r = p.nsplit; s_tw = r % p.tiles_w; r /= p.tiles_w; s_th = r % p.tiles_h; r /= p.tiles_h; s_bd = r % p.BD; s_n = r / p.BD; }
+    auto issue = [&](int st) {
+        const bool live = q_kt < (int)p.ntiles;
+        const int twi = q_tw, thi = q_th, bd = q_bd, n = q_n;
+        q_kt += p.nsplit;
+        q_tw += s_tw; int c = q_tw >= p.tiles_w; q_tw -= c ? p.tiles_w : 0;
+        q_th += s_th + c; c = q_th >= p.tiles_h; q_th -= c ? p.tiles_h : 0;
+        q_bd += s_bd + c; c = q_bd >= p.BD; q_bd -= c ? p.BD : 0;
+        q_n += s_n + c;
+        const int ad0 = bd * p.sd - p.pd, ah0 = thi * p.TH * p.sh - p.ph, aw0 = twi * p.KWs * p.sw - p.pw;
+        const int lin0 = ((n * p.AD + ad0) * p.AH + ah0) * p.AW + aw0;
+        unsigned char* As = smem + st * stage_bytes;
+        unsigned char* Bs = As + p.a_bytes;
+#pragma unroll
+        for (int it = 0; it < TF_MAX_AIT; ++it) {
+            if (it < nait) {
+                const int pk = a_pk[it];
+                const int dd = pk & 0xff, hh = (pk >> 8) & 0xff, ww = (pk >> 16) & 0xff;
+                const bool ok = live && pk >= 0 && (unsigned)(ad0 + dd) < (unsigned)p.AD && (unsigned)(ah0 + hh) < (unsigned)p.AH &&
+                                (unsigned)(aw0 + ww) < (unsigned)p.AW;
+                const unsigned char* src = ok ? reinterpret_cast<const unsigned char*>(p.A + (long long)(lin0 + a_rel[it]) * p.CA + a0 + a_sl[it])
+                                              : zero_pg;
+                glds16w(src, As + (it * 256 + wave * 64) * 16);
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < NBIT; ++it) {
+            if (it < nbit) {
+                const int bh = thi * p.TH + b_th[it];
+                const bool ok = live && b_on[it] && bh < p.BH;
+                const long long lin = (((long long)n * p.BD + bd) * p.BH + bh) * p.BW + twi * p.KWs + b_tw[it];
+                const unsigned char* src = ok ? reinterpret_cast<const unsigned char*>(p.B + lin * p.CB + b0 + b_sl[it]) : zero_pg;
+                glds16w(src, Bs + (it * 256 + wave * 64) * 16);
+            }
+        }
+    };
+
+    // ---- fragment read addresses: lane (g = lane>>4, i = lane&15) supplies voxel 8g + 4h + (i>>2), 8-byte piece i&3 ----
+    const int g = lane >> 4, i = lane & 15;
+    const unsigned lds0 = (unsigned)(unsigned long long)(lptr_t)smem;
+    unsigned a_ad[TF_NKS][2][KW], b_ad[TF_NKS][2];            // byte addresses inside stage 0 for tap row (kd,kh) = (0,0)
+#pragma unroll
+    for (int ks = 0; ks < TF_NKS; ++ks)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int kk = ks * 32 + 8 * g + 4 * h + (i >> 2);
+            const int th = kk / p.KWs, tw = kk - th * p.KWs;
+#pragma unroll
+            for (int kw = 0; kw < KW; ++kw) {
+                const int ww = tw * p.sw + kw;
+                const int half = p.spra == 4 ? (ta ^ ((ww >> 3) & 1)) : ta;
+                a_ad[ks][h][kw] = lds0 + ((th * p.sh) * p.AWt + ww) * PA + half * 32 + (i & 3) * 8;
+            }
+            const int halfb = p.sprb == 4 ? (tb ^ ((tw >> 3) & 1)) : tb;
+            b_ad[ks][h] = lds0 + p.a_bytes + kk * PB + halfb * 32 + (i & 3) * 8;
+        }
+    const int grp_pitch = p.AWt * PA;                          // bytes between tap rows kh and kh+1 (kd: x AHt)
+
+    f32x4_t acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    const bool do_bsum = p.bsum != nullptr && a0 == 0 && ta == 0 && part == 0;
+    f32x4_t accb = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    const bf16x8_t ones = __builtin_bit_cast(bf16x8_t, make_uint4(0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u));
+
+    // ---- S-deep pipeline: while tile j is on the MFMAs, tiles j+1 .. j+S-1 are in flight ----
+    const int S = p.stages;
+    const int npiece = nait + nbit;                            // LDS-DMA pieces per wave per stage
+    const long long kt0 = blockIdx.y, step = p.nsplit;
+    for (int s = 0; s < S - 1; ++s) issue(s);
+    int st = 0;
+    for (long long kt = kt0; kt < p.ntiles; kt += step) {
+        wait_vm(npiece * (S - 2));                     // this wave's pieces of tile kt have landed ...
+        __builtin_amdgcn_s_barrier();                          // ... and everybody's; everybody is also done with tile kt - step
+        int stn = st + S - 1; if (stn >= S) stn -= S;
+        issue(stn);                                            // refill the buffer tile kt - step was read from
+        const unsigned sb = (unsigned)(st * stage_bytes);
+        // fragment reads run one unit (= the KH*KW taps of one kd slice for one k-step) ahead of the MFMAs
+        constexpr int NU = TF_NKS * KD, CH = KH * KW;
+        u32x2_t bl[2], bh[2], al[2][CH], ah[2][CH];
+        auto rd_unit = [&](int u, int set) {
+            const int ks = u / KD, kd = u % KD;
+            if (kd == 0) { bl[ks & 1] = tr_read_asm(b_ad[ks][0] + sb); bh[ks & 1] = tr_read_asm(b_ad[ks][1] + sb); }
+#pragma unroll
+            for (int kh = 0; kh < KH; ++kh) {
+                const unsigned ro = sb + (unsigned)((kd * p.AHt + kh) * grp_pitch);
+#pragma unroll
+                for (int kw = 0; kw < KW; ++kw) {
+                    if (((kd * CH + kh * KW + kw) % kparts) == part) {
+                        al[set][kh * KW + kw] = tr_read_asm(a_ad[ks][0][kw] + ro);
+                        ah[set][kh * KW + kw] = tr_read_asm(a_ad[ks][1][kw] + ro);
+                    }
+                }
+            }
+        };
+        rd_unit(0, 0);
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            const int ks = u / KD, kd = u % KD, set = u & 1;
+            if (kd == 0) lds_wait2(bl[ks & 1], bh[ks & 1]);
+#pragma unroll
+            for (int c = 0; c < CH; ++c) lds_wait2(al[set][c], ah[set][c]);
+            if (u + 1 < NU) rd_unit(u + 1, set ^ 1);
+            __builtin_amdgcn_sched_barrier(0);
+            const bf16x8_t bfr = frag8(bl[ks & 1], bh[ks & 1]);
+            if (do_bsum && kd == 0) accb = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, bfr, accb, 0, 0, 0);
+#pragma unroll
+            for (int c = 0; c < CH; ++c)
+                if (((kd * CH + c) % kparts) == part)
+                    acc[kd * CH + c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag8(al[set][c], ah[set][c]), bfr, acc[kd * CH + c], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (++st == S) st = 0;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // the padding stages of the tail
+
+    // ---- D[a][b]: lane holds a = 4*(lane>>4) + r, b = lane&15 ----
+    // Float atomics are executed at the memory side on this multi-XCD part (~7 G requests/s in total, measured), which
+    // would cost more than the whole K loop.  Every block instead STORES its partial tile into its own copy of R
+    // (copy = K-split index); tf_finish_kernel adds the copies.
+    float* Rx = p.Rx + (long long)blockIdx.y * p.rx_stride;
+    const int b = b0 + tb * 16 + i;
+    if (do_bsum && g == 0 && b < p.CB) Rx[p.rx_bias + b + p.b_off] = accb[0];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int a = a0 + ta * 16 + g * 4 + r;
+            if ((t % kparts) == part && a < p.CA && b < p.CB) Rx[(long long)t * p.RT + (long long)(a + p.a_off) * p.RSA + (b + p.b_off)] = acc[t][r];
+        }
+}
+
+// R[idx(i)] += sum over the copies of Rx[copy][idx(i)] for the NT x CA x CB block of one concat member (+ its bias sums):
+// blockIdx.y folds every 16th copy in a fixed order, the 16 partial sums meet in R through atomics.
+struct TfFin { float* Rx; long long stride; int ncopies; float* R; int NT, CA, CB; long long RT, RSA; int a_off, b_off;
+               float* bsum; long long rx_bias; int nb; };
+__global__ void __launch_bounds__(256) tf_finish_kernel(TfFin f) {
+    const long long n = (long long)f.NT * f.CA * f.CB;
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n + f.nb) return;
+    long long idx; float* dst;
+    if (i < n) {
+        const int b = (int)(i % f.CB); const long long q = i / f.CB; const int a = (int)(q % f.CA), t = (int)(q / f.CA);
+        idx = (long long)t * f.RT + (long long)(a + f.a_off) * f.RSA + b + f.b_off; dst = f.R + idx;
+    } else { idx = f.rx_bias + (i - n) + f.b_off; dst = f.bsum + (i - n) + f.b_off; }
+    float s = 0.f;
+#pragma unroll 8
+    for (int y = blockIdx.y; y < f.ncopies; y += gridDim.y) s += f.Rx[(long long)y * f.stride + idx];
+    atomicAdd(dst, s);
+}
+
+// One persistent device buffer for the partial copies (grown outside stream capture only).
+static float* g_rx = nullptr; static long long g_rx_floats = 0; static int g_rx_dev = -1;
+static bool tf_rx_ensure(long long floats, hipStream_t st) {
+    int dev = 0; if (hipGetDevice(&dev) != hipSuccess) return false;
+    if (g_rx && dev == g_rx_dev && g_rx_floats >= floats) return true;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return false;
+    if (g_rx && dev == g_rx_dev) { if (hipDeviceSynchronize() != hipSuccess) return false; (void)hipFree(g_rx); }
+    g_rx = nullptr; g_rx_floats = 0;
+    const long long want = floats < (1ll << 22) ? (1ll << 22) : floats;
+    if (hipMalloc(&g_rx, (size_t)want * sizeof(float)) != hipSuccess) { g_rx = nullptr; return false; }
+    g_rx_floats = want; g_rx_dev = dev;
+    return true;
+}
+
+static inline bool tf_chan_ok(int c) { return c == 8 || c == 16 || (c >= 32 && c % 32 == 0); }
+
+// fills the launch geometry; false = shape outside this kernel (the per-tap kernel of wgrad_mfma.hip takes it)
+static bool tf_plan(const WgradSpec& g, TfP& p) {
+    if (g.dtype != M1_BF16) return false;
+    const bool k133 = g.kd == 1 && g.kh == 3 && g.kw == 3, k333 = g.kd == 3 && g.kh == 3 && g.kw == 3;
+    if (!k133 && !k333) return false;
+    if (!tf_chan_ok(g.CA) || !tf_chan_ok(g.CB)) return false;
+    if (g.BW % 8) return false;
+    if ((long long)g.N * g.AD * g.AH * g.AW >= (1ll << 31) - (1 << 20) || (long long)g.N * g.BD * g.BH * g.BW >= (1ll << 31) - (1 << 20)) return false;
+    p = TfP{};
+    p.A = (const bf16_t*)g.A; p.B = (const bf16_t*)g.B; p.R = g.R; p.bsum = g.bsum;
+    p.CA = g.CA; p.CB = g.CB; p.AD = g.AD; p.AH = g.AH; p.AW = g.AW; p.BD = g.BD; p.BH = g.BH; p.BW = g.BW; p.N = g.N;
+    p.RT = g.RT; p.RSA = g.RSA; p.a_off = g.a_off; p.b_off = g.b_off;
+    p.sd = g.sd; p.sh = g.sh; p.sw = g.sw; p.pd = g.pd; p.ph = g.ph; p.pw = g.pw;
+    p.KWs = g.BW % 32 == 0 ? 32 : (g.BW % 16 == 0 ? 16 : 8);
+    const int nks = 2;
+    p.TH = nks * (32 / p.KWs);
+    p.AHt = (p.TH - 1) * g.sh + g.kh; p.AWt = (p.KWs - 1) * g.sw + g.kw;
+    p.spra = (g.CA < 32 ? g.CA : 32) / 8; p.sprb = (g.CB < 32 ? g.CB : 32) / 8;
+    const int a_rows = g.kd * p.AHt * p.AWt;
+    p.a_slots = (a_rows * p.spra + 255) / 256 * 256; p.b_slots = nks * 32 * p.sprb;
+    if (p.a_slots > TF_MAX_AIT * 256 || p.AHt > 255 || p.AWt > 255) return false;
+    p.a_bytes = p.a_slots * 16; p.b_bytes = (p.b_slots + 255) / 256 * 256 * 16 + 64;      // (+64: slack for the 32-byte fragment reads of short rows)
+    p.tiles_w = g.BW / p.KWs; p.tiles_h = (g.BH + p.TH - 1) / p.TH;
+    p.ntiles = (long long)g.N * g.BD * p.tiles_h * p.tiles_w;
+    if (p.ntiles >= (1ll << 30)) return false;
+    // as many stages as fit ~76 KB (two blocks per CU), at least 3, bounded by the vmcnt range
+    const int sb = p.a_bytes + p.b_bytes, npiece = p.a_slots / 256 + (p.b_slots + 255) / 256;
+    int S = (76 * 1024) / sb;
+    if (S < 3) S = 3;
+    if (S > TF_MAX_STAGES) S = TF_MAX_STAGES;
+    while (S > 3 && npiece * (S - 2) > 48) --S;
+    { static int fs = -1; if (fs < 0) { const char* e = getenv("M1_TF_STAGES"); fs = e ? atoi(e) : 0; } if (fs >= 3) S = fs; }
+    p.stages = S;
+    return npiece * (S - 2) <= 48 && (size_t)S * sb <= 160 * 1024;
+}
+bool m1_tf_wgrad_supported(const WgradSpec& g) { TfP p; return tf_plan(g, p); }
+
+#define TF_MAX_COPY_BYTES (96ll << 20)
+// nw / nb: floats of the whole weight / bias gradient that g.R / g.bsum point into
+int m1_tf_wgrad(const WgradSpec& g, long long nw, int nb, hipStream_t st) {
+    TfP p;
+    if (!tf_plan(g, p)) return M1_ERR_UNSUPPORTED;
+    const int aTiles = (g.CA + 31) / 32; p.bTiles = (g.CB + 31) / 32;
+    const int ctiles = aTiles * p.bTiles;
+    static int tgt = -1; if (tgt < 0) { const char* e = getenv("M1_TF_SPLIT"); tgt = e ? atoi(e) : 512; }
+    long long nsplit = (tgt + ctiles - 1) / ctiles;          // ~2 blocks per CU
+    const long long stride = nw + nb;
+    if (nsplit * stride * 4 > TF_MAX_COPY_BYTES) nsplit = TF_MAX_COPY_BYTES / (stride * 4);
+    if (nsplit > p.ntiles) nsplit = p.ntiles;
+    if (nsplit < 1) return M1_ERR_UNSUPPORTED;
+    p.nsplit = (int)nsplit;
+    if (!tf_rx_ensure(nsplit * stride, st)) return M1_ERR_WORKSPACE;
+    p.Rx = g_rx; p.rx_stride = stride; p.rx_bias = nw;
+    const size_t smem = (size_t)p.stages * (p.a_bytes + p.b_bytes);
+    dim3 grid(ctiles, (unsigned)nsplit);
+    const int kparts = 4 / ((g.CA > 16 ? 2 : 1) * (g.CB > 16 ? 2 : 1));
+    void (*kern)(TfP) = nullptr;
+#define TF_PICK(KD_, KP_) if ((g.kd == KD_) && kparts == KP_) kern = wgrad_tf_kernel<KD_, 3, 3, KP_, 2>;
+    TF_PICK(1, 1) TF_PICK(1, 2) TF_PICK(1, 4) TF_PICK(3, 1) TF_PICK(3, 2) TF_PICK(3, 4)
+#undef TF_PICK
+    if (!kern) return M1_ERR_UNSUPPORTED;
+    {   // raise the dynamic-LDS limit once per instantiation
+        static const void* done[8]; static int ndone = 0;
+        bool seen = false;
+        for (int q = 0; q < ndone; ++q) seen |= done[q] == (const void*)kern;
+        if (!seen) {
+            if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return M1_ERR_LAUNCH;
+            if (ndone < 8) done[ndone++] = (const void*)kern;
+        }
+    }
+    hipLaunchKernelGGL(kern, grid, dim3(256), smem, st, p);
+    int rc = m1_check_launch(); if (rc) return rc;
+    TfFin f{g_rx, stride, (int)nsplit, g.R, g.kd * g.kh * g.kw, g.CA, g.CB, g.RT, g.RSA, g.a_off, g.b_off,
+            g.bsum, nw, g.bsum ? g.CB : 0};
+    const long long n = (long long)f.NT * f.CA * f.CB + f.nb;
+    const int gy = nsplit < 64 ? (int)nsplit : 64;
+    hipLaunchKernelGGL(tf_finish_kernel, dim3((unsigned)((n + 255) / 256), gy), dim3(256), 0, st, f);
+    return m1_check_launch();
+}

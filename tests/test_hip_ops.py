@@ -442,3 +442,36 @@ def test_repack_all_refreshes_cached_panels(dev, transposed):
     for a, c in zip(g1, g2):
         assert torch.equal(a, c)
     ops.invalidate_panels()
+
+
+# ---- tap-fused weight gradient (wgrad_tf.hip): bf16, (1,3,3)/(3,3,3) kernels, row length divisible by 8/16/32 ----
+TF_CASES = [  # (N, D, H, W), cins, cout, k, s, transposed
+    ((1, 3, 6, 32), [32], 32, (1, 3, 3), (1, 1, 1), False),
+    ((2, 2, 5, 64), [32, 32], 8, (1, 3, 3), (1, 1, 1), False),
+    ((1, 4, 9, 16), [16], 16, (3, 3, 3), (1, 1, 1), False),
+    ((2, 3, 10, 8), [8], 32, (3, 3, 3), (1, 1, 1), False),
+    ((1, 4, 12, 32), [32], 16, (1, 3, 3), (1, 2, 2), False),
+    ((1, 5, 8, 16), [32], 64, (3, 3, 3), (2, 2, 2), False),
+    ((1, 3, 6, 16), [64], 32, (1, 3, 3), (1, 2, 2), True),
+    ((1, 2, 4, 8), [32], 32, (3, 3, 3), (2, 2, 2), True),
+    ((1, 3, 7, 24), [64, 32], 96, (3, 3, 3), (1, 1, 1), False),
+]
+
+
+@pytest.mark.parametrize("case", TF_CASES)
+def test_tap_fused_wgrad(dev, case, monkeypatch):
+    dims, cins, cout, k, s, transposed = case
+    xs = [rnd((*dims, c), 40 + i).bfloat16().float() for i, c in enumerate(cins)]
+    wshape = (*k, cout, sum(cins)) if transposed else (*k, sum(cins), cout)
+    w = rnd(wshape, 6, 1.0 / (sum(cins) * k[0] * k[1] * k[2]) ** 0.5); b = rnd((cout,), 7)
+    fo = O.conv3d_transpose_same if transposed else O.conv3d_same
+    yo = fo(torch.cat(xs, -1).double(), w.double(), b.double(), s)
+    dy = rnd(tuple(yo.shape), 8).bfloat16().float()
+    yo, (gx, gw, gb) = _oracle_grads(lambda x, w_, b_: fo(x, w_, b_, s), [torch.cat(xs, -1), w, b], dy)
+    fh = ops.conv3d_transpose_same if transposed else ops.conv3d_same
+    xd = [x.to(dev, torch.bfloat16).requires_grad_(True) for x in xs]
+    wd, bd = w.to(dev).requires_grad_(True), b.to(dev).requires_grad_(True)
+    y = fh(xd, wd, bd, k, s)
+    y.backward(dy.to(dev, torch.bfloat16))
+    assert rel_err(wd.grad, gw) < 1e-4, "dw"          # bf16 inputs are exact in both, fp32 accumulation in both
+    assert rel_err(bd.grad, gb) < 1e-4, "db"

@@ -34,5 +34,6 @@ torch.cuda.synchronize = sync
 sys.argv = ["bench.py", "--workload", os.environ.get("WL", "C2"), "--steps", "1", "--warmup", "1", "--no-graph", "--no-cpu-baseline", "--no-roofline"]
 with Spy():
     bench.main()
-for (f, w, s), n in sorted(seen.items(), key=lambda kv: -kv[1])[:60]:
+flt = os.environ.get("FILTER", "")
+for (f, w, s), n in [kv for kv in sorted(seen.items(), key=lambda kv: -kv[1]) if flt in kv[0][0]][:60]:
     print(f"{n:5d}  {f:34s} {str(s):28s} {w}")
