@@ -9,6 +9,7 @@
 // One block = one (tap, a-tile, b-tile, voxel-split); partial results are combined with fp32 atomics in L2.
 #include "common.h"
 #include "gather.h"
+#include <stdlib.h>
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
@@ -222,7 +223,10 @@ static int launch_wg(WgP p, hipStream_t st) {
     const int aTiles = (p.CA + TA - 1) / TA, bTiles = (p.CB + TB - 1) / TB;
     const int taps = p.kd * p.kh * p.kw;
     const long long TV = (long long)p.N * p.BD * p.BH * p.BW;
-    long long splits = cdiv_ll(1536, (long long)aTiles * bTiles * taps);
+    // ~2 blocks per CU: every extra voxel split adds TA*TB float atomics per tap, and those are executed at the memory
+    // side on this part (measured: 1536 -> 512 target blocks = -28 % on the 128x128x27-tap layers).  M1_WG_BLOCKS overrides.
+    static int tgt = -1; if (tgt < 0) { const char* e = getenv("M1_WG_BLOCKS"); tgt = e ? atoi(e) : 512; }
+    long long splits = cdiv_ll(tgt, (long long)aTiles * bTiles * taps);
     const long long max_splits = cdiv_ll(TV, 4 * KS);
     if (splits > max_splits) splits = max_splits;
     if (splits < 1) splits = 1;
