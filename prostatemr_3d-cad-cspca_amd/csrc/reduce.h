@@ -56,25 +56,28 @@ __global__ void __launch_bounds__(M1_RED_THREADS) m1_reduce_nc_kernel(F f, long 
     }
 }
 
-// out[n][c][k] = sum_chunks partial (fp64 accumulate) -> float.  ONE WAVE per (n,c): lanes stride the chunks.
-// Launch with 256 threads (4 waves) per block and ceil(N*C/4) blocks (m1_reduce_finalize_launch).
+// out[n][c][k] = sum_chunks partial (fp64 accumulate) -> float.  One block per (n,c): threads stride the chunks.
 // stats_V > 0 (NS == 2 only): writes {mean, rstd} computed in fp64 from (sum, sum of squares) instead.
 template <int NS>
 __global__ void __launch_bounds__(256) m1_reduce_finalize_kernel(const float* __restrict__ partial, int N, int C, int nchunks,
                                                                  float* __restrict__ out, long long stats_V, float eps,
                                                                  int accumulate) {
-    const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (i >= N * C) return;
+    // one BLOCK per (n,c): the fold is a chain of dependent cache-line loads, 256 lanes keep it 4x shorter than a wave
+    __shared__ double red[4][NS];
+    const int i = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int n = i / C, c = i % C;
     double s[NS];
 #pragma unroll
     for (int k = 0; k < NS; ++k) s[k] = 0.0;
-    for (int j = lane; j < nchunks; j += 64)
+    for (int j = threadIdx.x; j < nchunks; j += 256)
 #pragma unroll
         for (int k = 0; k < NS; ++k) s[k] += (double)partial[(((size_t)n * nchunks + j) * C + c) * NS + k];
 #pragma unroll
-    for (int k = 0; k < NS; ++k) s[k] = wave_sum_d(s[k]);
-    if (lane == 0) {
+    for (int k = 0; k < NS; ++k) { s[k] = wave_sum_d(s[k]); if (lane == 0) red[wave][k] = s[k]; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int k = 0; k < NS; ++k) s[k] = (red[0][k] + red[1][k]) + (red[2][k] + red[3][k]);
         if (stats_V > 0 && NS == 2) {
             const double mean = s[0] / (double)stats_V;
             double var = s[NS - 1] / (double)stats_V - mean * mean;
@@ -90,7 +93,7 @@ __global__ void __launch_bounds__(256) m1_reduce_finalize_kernel(const float* __
 template <int NS>
 static inline int m1_reduce_finalize_launch(const float* partial, int N, int C, int nchunks, float* out, long long stats_V,
                                             float eps, hipStream_t st, int accumulate = 0) {
-    hipLaunchKernelGGL((m1_reduce_finalize_kernel<NS>), dim3((N * C + 3) / 4), dim3(256), 0, st, partial, N, C, nchunks, out,
+    hipLaunchKernelGGL((m1_reduce_finalize_kernel<NS>), dim3(N * C), dim3(256), 0, st, partial, N, C, nchunks, out,
                        stats_V, eps, accumulate);
     return m1_check_launch();
 }
