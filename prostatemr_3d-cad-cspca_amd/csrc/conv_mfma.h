@@ -1,0 +1,47 @@
+// conv_mfma.h -- launch parameters shared by the implicit-GEMM conv kernels (conv_mfma.hip, conv_halo.hip)
+#pragma once
+#include "common.h"
+#include "gather.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+
+#define MF_MAX_TAPS 27
+#define MF_MAX_CLASSES 8
+
+struct MfmaP {
+    const void* src[M1_MAX_SRC];
+    int srcC[M1_MAX_SRC];
+    int srcSeg[M1_MAX_SRC];     // 16-byte K segments per member = ceil(C / SEG): a member that is not a multiple of SEG
+                                // (latent z: 1..3 channels, stem input: 2..3) is zero-padded to whole segments in K space
+    int nsrc, CC, spt;          // CC = contraction channels per tap (sum srcC); spt = segments per tap (sum srcSeg)
+    int ID, IH, IW;             // gathered tensor extent
+    void* out;
+    int OC, OCn;                // out row stride (channels) / channels computed by this launch
+    int OD, OH, OW, N;
+    const void* wp;             // packed weights
+    const float* bias;
+    int mode, sd, sh, sw, pd, ph, pw;
+    int nclasses;
+    int cls_ntaps[MF_MAX_CLASSES], cls_first[MF_MAX_CLASSES], cls_kpad[MF_MAX_CLASSES];
+    long long cls_woff[MF_MAX_CLASSES];     // element offset of the class matrix in wp
+    signed char tdd[MF_MAX_TAPS], tdh[MF_MAX_TAPS], tdw[MF_MAX_TAPS];   // gather offsets per (class-ordered) tap
+    int tap_pk[MF_MAX_TAPS];    // the same, packed dd | dh<<8 | dw<<16 (scalar loads in the LDS-DMA loader)
+    int accumulate;             // out += result (used when another kernel already wrote the other concat members)
+    int ksplit;                 // > 1: blockIdx.y = cls*ksplit + ks; partial sums go to acc32 with fp32 atomics
+    float* acc32;               // [ksplit][out voxels][OC] fp32 slabs (ksplit > 1 only)
+    long long slab_elems;
+    int aligned;                // every concat member is a multiple of one 64-byte K-chunk: incremental addressing
+    float* stat_partial;        // fused InstanceNorm statistics: [N][tiles per sample][OC][2] = {sum, sum of squares} of
+    int stat_tiles;             //   the ROUNDED outputs of each 64/128-row tile (mode 0, tiles never straddle samples)
+};
+
+template <typename T> struct MT;
+template <> struct MT<bf16_t> { static constexpr int SEG = 8; };
+template <> struct MT<float> { static constexpr int SEG = 4; };
+
+
+// halo-tile variant (conv_halo.hip): takes the same parameters and the same packed panel
+bool m1_halo_conv_supported(const MfmaP& mp, int OCpad);
+int m1_halo_conv_tiles_per_sample(const MfmaP& mp);
+int m1_halo_conv(const MfmaP& mp, int OCpad, hipStream_t st);

@@ -17,42 +17,8 @@
 #include "gather.h"
 #include "reduce.h"
 
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
-typedef __attribute__((ext_vector_type(4))) float f32x4_t;
-
-#define MF_MAX_TAPS 27
-#define MF_MAX_CLASSES 8
-
-struct MfmaP {
-    const void* src[M1_MAX_SRC];
-    int srcC[M1_MAX_SRC];
-    int srcSeg[M1_MAX_SRC];     // 16-byte K segments per member = ceil(C / SEG): a member that is not a multiple of SEG
-                                // (latent z: 1..3 channels, stem input: 2..3) is zero-padded to whole segments in K space
-    int nsrc, CC, spt;          // CC = contraction channels per tap (sum srcC); spt = segments per tap (sum srcSeg)
-    int ID, IH, IW;             // gathered tensor extent
-    void* out;
-    int OC, OCn;                // out row stride (channels) / channels computed by this launch
-    int OD, OH, OW, N;
-    const void* wp;             // packed weights
-    const float* bias;
-    int mode, sd, sh, sw, pd, ph, pw;
-    int nclasses;
-    int cls_ntaps[MF_MAX_CLASSES], cls_first[MF_MAX_CLASSES], cls_kpad[MF_MAX_CLASSES];
-    long long cls_woff[MF_MAX_CLASSES];     // element offset of the class matrix in wp
-    signed char tdd[MF_MAX_TAPS], tdh[MF_MAX_TAPS], tdw[MF_MAX_TAPS];   // gather offsets per (class-ordered) tap
-    int tap_pk[MF_MAX_TAPS];    // the same, packed dd | dh<<8 | dw<<16 (scalar loads in the LDS-DMA loader)
-    int accumulate;             // out += result (used when another kernel already wrote the other concat members)
-    int ksplit;                 // > 1: blockIdx.y = cls*ksplit + ks; partial sums go to acc32 with fp32 atomics
-    float* acc32;               // [ksplit][out voxels][OC] fp32 slabs (ksplit > 1 only)
-    long long slab_elems;
-    int aligned;                // every concat member is a multiple of one 64-byte K-chunk: incremental addressing
-    float* stat_partial;        // fused InstanceNorm statistics: [N][tiles per sample][OC][2] = {sum, sum of squares} of
-    int stat_tiles;             //   the ROUNDED outputs of each 64/128-row tile (mode 0, tiles never straddle samples)
-};
-
-template <typename T> struct MT;
-template <> struct MT<bf16_t> { static constexpr int SEG = 8; };
-template <> struct MT<float> { static constexpr int SEG = 4; };
+#include "conv_mfma.h"
+#include <stdlib.h>
 
 __device__ __forceinline__ int swz(int row, int seg) { return seg ^ ((-(row >> 2)) & 3); }
 
@@ -711,7 +677,7 @@ static int run_mfma(const GatherSpec& g, void* ws, int ws_packed, hipStream_t st
     build_classes(g, CC, SEG, OCpad, &mp, &pp, &tot);
     mp.ksplit = pl.ksplit; mp.acc32 = nullptr; mp.aligned = 1; mp.stat_partial = nullptr; mp.stat_tiles = 0;
     const long long Vout = (long long)g.OD * g.OH * g.OW;
-    const bool fuse_stats = g.stats_out && g.stats_ws && g.mode == 0 && pl.ksplit == 1 && (g.N == 1 || Vout % pl.BM == 0);
+    bool fuse_stats = g.stats_out && g.stats_ws && g.mode == 0 && pl.ksplit == 1 && (g.N == 1 || Vout % pl.BM == 0);
     if (fuse_stats) { mp.stat_partial = g.stats_ws; mp.stat_tiles = (int)cdiv_ll(Vout, pl.BM); }
     for (int i = 0; i < g.nsrc; ++i) if (g.srcC[i] % (4 * SEG)) mp.aligned = 0;
     if (pl.ksplit > 1) {
@@ -731,6 +697,20 @@ static int run_mfma(const GatherSpec& g, void* ws, int ws_packed, hipStream_t st
     const long long maxM = spec_maxM(g);
     const bool small = pl.BM == 64;
     int rc2;
+    // wide, shallow bf16 layers: the halo-tile kernel (conv_halo.hip) stages every input voxel once per tile, not per tap
+    bool halo = false;
+    if constexpr (sizeof(T) == 2) {
+        static int hen = -1; if (hen < 0) { const char* e = getenv("M1_HALO"); hen = e ? atoi(e) : 1; }
+        if (hen && (maxM >= 32768 || hen == 2) && m1_halo_conv_supported(mp, OCpad)) {      // (M1_HALO=2: no size floor, tests)
+            const int tps = m1_halo_conv_tiles_per_sample(mp);
+            if (g.stats_out && g.stats_ws && g.mode == 0 && tps > 0 && tps <= (Vout + 63) / 64) {
+                mp.stat_partial = g.stats_ws; mp.stat_tiles = tps; fuse_stats = true;
+            } else { mp.stat_partial = nullptr; mp.stat_tiles = 0; fuse_stats = false; }
+            halo = true;
+        }
+    }
+    if (halo) rc2 = m1_halo_conv(mp, OCpad, st);
+    else
     switch (BN) {
         case 128: rc2 = small ? launch_cfg<T, 64, 128, 1, 4>(mp, maxM, OCpad, st) : launch_cfg<T, 128, 128, 2, 2>(mp, maxM, OCpad, st); break;
         case 64:  rc2 = small ? launch_cfg<T, 64, 64, 2, 2>(mp, maxM, OCpad, st) : launch_cfg<T, 128, 64, 4, 1>(mp, maxM, OCpad, st); break;

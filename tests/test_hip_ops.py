@@ -475,3 +475,16 @@ def test_tap_fused_wgrad(dev, case, monkeypatch):
     y.backward(dy.to(dev, torch.bfloat16))
     assert rel_err(wd.grad, gw) < 1e-4, "dw"          # bf16 inputs are exact in both, fp32 accumulation in both
     assert rel_err(bd.grad, gb) < 1e-4, "db"
+    # the same shapes are the ones the halo-tile conv kernel takes (M1_HALO=2 lifts its size floor): forward, data gradient
+    assert rel_err(y, yo) < TOL[torch.bfloat16], "y"
+    off = 0
+    for x, gxd in zip(xs, xd):
+        c = x.shape[-1]
+        assert rel_err(gxd.grad, gx[..., off:off + c]) < TOL[torch.bfloat16], ("dx", off)
+        off += c
+    # fused InstanceNorm statistics of the (rounded) output
+    if not transposed:
+        y2, st = ops.conv3d_same([x.detach() for x in xd], wd.detach(), bd.detach(), k, s, stats=True)
+        yf = y2.float()
+        mean = yf.mean(dim=(1, 2, 3)); var = yf.var(dim=(1, 2, 3), unbiased=False)
+        assert rel_err(st[..., 0], mean) < 1e-4 and rel_err(st[..., 1], 1.0 / torch.sqrt(var + 1e-3)) < 1e-4
