@@ -79,6 +79,18 @@ struct GateWF {
                                 Act<T>::ld(phi + ((size_t)n * Vp + phi_voxel(g, v)) * g.C + c), 0.1f);
         acc[0] += dpsi * f; acc[1] += dpsi;
     }
+    static constexpr int kVec = sizeof(T) == 2 ? 8 : 4;
+    __device__ void vec(int n, long long v, int c0, float (*acc)[kVec]) const {
+        const long long Vt = (long long)g.Dt * g.Ht * g.Wt, Vp = (long long)g.Dp * g.Hp * g.Wp;
+        const long long gv = (long long)n * Vt + v;
+        const float sg = Act<T>::ld(sigma + gv);
+        const float dpsi = Act<T>::ld(dsigma + gv) * sg * (1.f - sg);
+        float th[kVec], ph[kVec];
+        VecIO<T, kVec>::ld(theta + (size_t)gv * g.C + c0, th);
+        VecIO<T, kVec>::ld(phi + ((size_t)n * Vp + phi_voxel(g, v)) * g.C + c0, ph);
+#pragma unroll
+        for (int e = 0; e < kVec; ++e) { acc[0][e] += dpsi * lrelu_f(th[e] + ph[e], 0.1f); acc[1][e] += dpsi; }
+    }
 };
 __global__ void gate_w_finalize_kernel(const float* __restrict__ sums /*[N][C][2]*/, int N, int C,
                                        float* __restrict__ dwpsi, float* __restrict__ dbpsi, int acc) {

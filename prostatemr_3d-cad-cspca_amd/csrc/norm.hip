@@ -19,6 +19,13 @@ struct StatsF {
         float xv = Act<T>::ld(x + ((size_t)n * V + v) * C + c);
         acc[0] += xv; acc[1] += xv * xv;
     }
+    static constexpr int kVec = sizeof(T) == 2 ? 8 : 4;
+    __device__ void vec(int n, long long v, int c0, float (*acc)[kVec]) const {
+        float xv[kVec];
+        VecIO<T, kVec>::ld(x + ((size_t)n * V + v) * C + c0, xv);
+#pragma unroll
+        for (int e = 0; e < kVec; ++e) { acc[0][e] += xv[e]; acc[1][e] += xv[e] * xv[e]; }
+    }
 };
 
 template <typename T>
@@ -119,6 +126,20 @@ struct InBwdF {
         const float dy = Act<T>::ld(da + idx) * lrelu_g(yv, slope);
         acc[0] += dy; acc[1] += dy * xh;
     }
+    static constexpr int kVec = sizeof(T) == 2 ? 8 : 4;
+    __device__ void vec(int n, long long v, int c0, float (*acc)[kVec]) const {
+        const size_t idx = ((size_t)n * V + v) * C + c0;
+        float xv[kVec], dv[kVec];
+        VecIO<T, kVec>::ld(x + idx, xv); VecIO<T, kVec>::ld(da + idx, dv);
+#pragma unroll
+        for (int e = 0; e < kVec; ++e) {
+            const int c = c0 + e;
+            const float mean = stats[((size_t)n * C + c) * 2], rstd = stats[((size_t)n * C + c) * 2 + 1];
+            const float xh = (xv[e] - mean) * rstd;
+            const float dy = dv[e] * lrelu_g(gamma[c] * xh + beta[c], slope);
+            acc[0][e] += dy; acc[1][e] += dy * xh;
+        }
+    }
 };
 
 template <typename T, int VEC>
@@ -198,6 +219,13 @@ struct ColSumF {
     const T* x; long long V; int C;
     __device__ void operator()(int n, long long v, int c, float* acc) const {
         acc[0] += Act<T>::ld(x + ((size_t)n * V + v) * C + c);
+    }
+    static constexpr int kVec = sizeof(T) == 2 ? 8 : 4;
+    __device__ void vec(int n, long long v, int c0, float (*acc)[kVec]) const {
+        float xv[kVec];
+        VecIO<T, kVec>::ld(x + ((size_t)n * V + v) * C + c0, xv);
+#pragma unroll
+        for (int e = 0; e < kVec; ++e) acc[0][e] += xv[e];
     }
 };
 // Internal (used by conv wgrad): ws must hold N*nchunks*C floats.

@@ -138,10 +138,70 @@ static inline int m1_reduce_finalize_params_launch(const float* partial, int N, 
     return m1_check_launch();
 }
 
+// Vector variant: a lane owns VEC consecutive channels (one 16-byte load per tensor per voxel) instead of one.
+// Functor contract:  static constexpr int kVec;  __device__ void vec(int n, long long v, int c0, float (*acc)[kVec]) const;
+template <int NS, int VEC, typename F>
+__global__ void __launch_bounds__(M1_RED_THREADS) m1_reduce_nc_vec_kernel(F f, long long V, int C, int chunkV,
+                                                                          int nchunks, float* __restrict__ partial) {
+    __shared__ float red[M1_RED_THREADS * VEC];                      // one sum at a time (NS passes)
+    const int n = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
+    const long long v0 = (long long)chunk * chunkV;
+    long long v1 = v0 + chunkV; if (v1 > V) v1 = V;
+    const int cg = C / VEC;
+    int cpad = 1; while (cpad < cg && cpad < M1_RED_THREADS) cpad <<= 1;   // lanes along the channel groups
+    const int vs = tid / cpad, nvs = M1_RED_THREADS / cpad, cl = tid % cpad;
+    for (int gbase = 0; gbase < cg; gbase += cpad) {
+        const int gi = gbase + cl;
+        float acc[NS][VEC];
+#pragma unroll
+        for (int k = 0; k < NS; ++k)
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) acc[k][e] = 0.f;
+        if (gi < cg)
+            for (long long v = v0 + vs; v < v1; v += nvs) f.vec(n, v, gi * VEC, acc);
+        // fold the voxel sub-lanes: xor-shuffles inside a wave (lanes cpad apart share a channel group), then the
+        // 4 waves (or, for >= 64 channel groups, the voxel sub-lane rows) through LDS, one sum at a time
+        const int wcol = cpad < 64 ? cpad : 64;                      // distinct channel groups per wave
+        const int rows = M1_RED_THREADS / (cpad < 64 ? 64 : cpad);
+        const int row = cpad < 64 ? (tid >> 6) : vs;
+        const bool writer = cpad >= 64 || (tid & 63) < cpad;
+#pragma unroll
+        for (int k = 0; k < NS; ++k) {
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                float s = acc[k][e];
+                for (int o = 32; o >= wcol && wcol < 64; o >>= 1) s += __shfl_xor(s, o, 64);
+                if (writer) red[(row * cpad + cl) * VEC + e] = s;
+            }
+            __syncthreads();
+            if (writer && row == 0 && gi < cg) {
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) {
+                    float s = 0.f;
+                    for (int j = 0; j < rows; ++j) s += red[(j * cpad + cl) * VEC + e];
+                    partial[(((size_t)n * nchunks + chunk) * C + gi * VEC + e) * NS + k] = s;
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+template <typename F, typename = void> struct M1RedVec { static constexpr int value = 0; };
+template <typename F> struct M1RedVec<F, decltype((void)F::kVec)> { static constexpr int value = F::kVec; };
+
 template <int NS, typename F>
 static inline int m1_reduce_nc_launch(const F& f, int N, long long V, int C, float* partial, hipStream_t st) {
     const int chunkV = m1_red_chunkV(V, C), nchunks = m1_red_nchunks(V, C);
     dim3 grid(nchunks, N);
+    constexpr int VEC = M1RedVec<F>::value;
+    if constexpr (VEC > 0) {
+        if (C % VEC == 0) {
+            hipLaunchKernelGGL((m1_reduce_nc_vec_kernel<NS, VEC, F>), grid, dim3(M1_RED_THREADS), 0, st, f, V, C, chunkV, nchunks,
+                               partial);
+            return m1_check_launch();
+        }
+    }
     hipLaunchKernelGGL((m1_reduce_nc_kernel<NS, F>), grid, dim3(M1_RED_THREADS), 0, st, f, V, C, chunkV, nchunks,
                        partial);
     return m1_check_launch();

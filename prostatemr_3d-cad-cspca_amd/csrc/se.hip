@@ -191,6 +191,29 @@ struct SeBwdF {
         const float dx_ = du * g * rho, drho = du * g * x_;
         acc[0] += dx_; acc[1] += dx_ * xh3; acc[2] += drho; acc[3] += drho * xh4; acc[4] += du * x_ * rho;
     }
+    static constexpr int kVec = sizeof(T) == 2 ? 8 : 4;
+    __device__ void vec(int n, long long v, int c0, float (*acc)[kVec]) const {
+        const int F = p.F;
+        const size_t idx = ((size_t)n * p.V + v) * F + c0;
+        float a[kVec], b[kVec], d[kVec];
+        VecIO<T, kVec>::ld(y3 + idx, a); VecIO<T, kVec>::ld(y4 + idx, b); VecIO<T, kVec>::ld(dout + idx, d);
+        bool keep[kVec];
+        if (p.drop_rate > 0.f) { uint64_t seed, rbase; se_rng(p, seed, rbase); philox_keep_vec<kVec>(seed, rbase, idx, p.drop_rate, keep); }
+        const float keep_scale = p.drop_rate > 0.f ? 1.f / (1.f - p.drop_rate) : 1.f;
+#pragma unroll
+        for (int e = 0; e < kVec; ++e) {
+            const int c = c0 + e; const size_t sc = ((size_t)n * F + c) * 2;
+            const float xh3 = (a[e] - p.stats3[sc]) * p.stats3[sc + 1];
+            const float xh4 = (b[e] - p.stats4[sc]) * p.stats4[sc + 1];
+            const float x_ = xh3 * p.gamma3[c] + p.beta3[c], rho = xh4 * p.gamma4[c] + p.beta4[c];
+            const float g = p.g[c], u = x_ * g * rho;
+            float dd = d[e];
+            if (p.drop_rate > 0.f) dd = keep[e] ? dd * keep_scale : 0.f;
+            const float du = dd * lrelu_g(u, 0.1f);
+            const float dx_ = du * g * rho, drho = du * g * x_;
+            acc[0][e] += dx_; acc[1][e] += dx_ * xh3; acc[2][e] += drho; acc[3][e] += drho * xh4; acc[4][e] += du * x_ * rho;
+        }
+    }
 };
 
 template <typename T, int VEC>
