@@ -289,8 +289,14 @@ static bool halo_plan(const MfmaP& m, int OCpad, HaloP& p) {
     if (m.mode == 0) { p.sde = m.sd; p.she = m.sh; p.swe = m.sw; p.pde = m.pd; p.phe = m.ph; p.pwe = m.pw; }
     else { p.sde = p.she = p.swe = 1; p.pde = p.phe = p.pwe = 0; }
     { static int nt_ = -1; if (nt_ < 0) { const char* e = getenv("M1_HALO_THREADS"); nt_ = e ? atoi(e) : 512; } p.nthr = nt_ == 512 ? 512 : 256; }
+    p.TW = m.OW % 32 == 0 ? 32 : (m.OW % 16 == 0 ? 16 : 8);
+    if (p.nthr == 512) {      // 256-voxel tiles unless their row padding wastes clearly more than 128-voxel tiles would
+        const int th5 = 256 / p.TW, th2 = 128 / p.TW;
+        const double e5 = (double)m.OH / ((m.OH + th5 - 1) / th5 * th5), e2 = (double)m.OH / ((m.OH + th2 - 1) / th2 * th2);
+        if (e5 < 0.9 * e2) p.nthr = 256;
+    }
     const int BMh = p.nthr / 2;
-    p.TW = m.OW % 32 == 0 ? 32 : (m.OW % 16 == 0 ? 16 : 8); p.TH = BMh / p.TW;
+    p.TH = BMh / p.TW;
     p.tiles_w = m.OW / p.TW; p.tiles_h = (m.OH + p.TH - 1) / p.TH;
     p.tiles_per_sample = m.OD * p.tiles_h * p.tiles_w;
     const long long nt_all = (long long)m.N * p.tiles_per_sample;

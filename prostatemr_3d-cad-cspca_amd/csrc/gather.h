@@ -49,4 +49,9 @@ bool m1_tf_wgrad_supported(const WgradSpec& g);      // tap-fused variant (wgrad
 // nw / nb: floats of the whole weight / bias gradient the spec's R / bsum point into.  M1_ERR_WORKSPACE / UNSUPPORTED:
 // nothing was launched, the caller takes the per-tap kernel instead.
 int m1_tf_wgrad(const WgradSpec& g, long long nw, int nb, hipStream_t st);
+// partial-copy buffer (persistent, grown outside stream capture only; nullptr = unavailable) and the fold of `ncopies`
+// copies of stride `stride` floats into g.R / g.bsum (bias sums sit at offset nw inside a copy)
+float* m1_wg_rx_get(long long floats, hipStream_t st);
+int m1_wg_rx_finish(float* rx, long long stride, int ncopies, const WgradSpec& g, long long nw, hipStream_t st);
+int m1_mfma_wgrad_ex(const WgradSpec& g, long long nw, int nb, hipStream_t st);
 int m1_colsum_internal(const void* x, int N, long long V, int C, int dtype, float* out, float* ws, hipStream_t st, int accumulate);

@@ -26,7 +26,7 @@ __device__ __forceinline__ int woff(int row, int seg) {
     return ((row ^ ((row >> 3) & 1)) << 6) + (((seg ^ (-(row >> 2)) ^ (row >> 4)) & 3) << 4);
 }
 
-struct WgP : WgradSpec { long long vox_per_split; };
+struct WgP : WgradSpec { long long vox_per_split; float* Rx; long long rx_stride, rx_bias; };   // Rx: per-split partial copies
 
 // r[j] = 16 bytes of voxel j (SEG channels); returns o[c] = 16 bytes of channel c (SEG voxels)
 __device__ __forceinline__ void transpose_unit(const uint4 (&r)[8], uint4 (&o)[8], bf16_t) {
@@ -190,11 +190,14 @@ __global__ void __launch_bounds__(256) wgrad_mfma_kernel(WgP p) {
         }
         }
     }
+    // small weight tensors: every split stores into its own copy (m1_wg_rx_finish folds them) -- hundreds of blocks
+    // adding into the same few cache lines serialise at the memory-side atomic unit (~85 ns per request and line)
+    float* const Rx = p.Rx ? p.Rx + (long long)blockIdx.z * p.rx_stride : nullptr;
     if (do_bsum && fs == 0) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int b = b0 + wn * (TB / 2) + j * 16 + fr;
-            if (b < p.CB) atomicAdd(p.bsum + b + p.b_off, accb[j][0]);
+            if (b < p.CB) { if (Rx) Rx[p.rx_bias + b + p.b_off] = accb[j][0]; else atomicAdd(p.bsum + b + p.b_off, accb[j][0]); }
         }
     }
     // D[i = a][j = b]: lane holds a = 4*fs + r, b = fr
@@ -206,8 +209,10 @@ __global__ void __launch_bounds__(256) wgrad_mfma_kernel(WgP p) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int a = a0 + wm * (TA / 2) + i * 16 + fs * 4 + r;
-                if (a < p.CA && b < p.CB)
-                    atomicAdd(p.R + (long long)tap * p.RT + (long long)(a + p.a_off) * p.RSA + (b + p.b_off), acc[i][j][r]);
+                if (a < p.CA && b < p.CB) {
+                    const long long idx = (long long)tap * p.RT + (long long)(a + p.a_off) * p.RSA + (b + p.b_off);
+                    if (Rx) Rx[idx] = acc[i][j][r]; else atomicAdd(p.R + idx, acc[i][j][r]);
+                }
             }
         }
 }
@@ -234,15 +239,25 @@ static int launch_wg(WgP p, hipStream_t st) {
     splits = cdiv_ll(TV, vps);
     p.vox_per_split = vps;
     dim3 grid(aTiles * bTiles, taps, (unsigned)splits);
+    // partial copies instead of atomics when the member's weight block is small and many splits would contend for it
+    bool partial = false;
+    const long long stride = p.rx_stride;                      // = nw + nb (set by the caller) or 0
+    if (stride > 0 && (long long)taps * p.CA * p.CB <= 32768 && splits >= 24 && splits * stride * 4 <= (64ll << 20)) {
+        float* rx = m1_wg_rx_get(splits * stride, st);
+        if (rx) { p.Rx = rx; partial = true; }
+    }
+    if (!partial) { p.Rx = nullptr; }
     hipLaunchKernelGGL((wgrad_mfma_kernel<T, TA, TB, KB>), grid, dim3(256), 0, st, p);
-    return m1_check_launch();
+    int rc = m1_check_launch(); if (rc) return rc;
+    if (partial) return m1_wg_rx_finish(p.Rx, stride, (int)splits, p, p.rx_bias, st);
+    return M1_OK;
 }
 
 static inline int pick_t(int c) { return c > 64 ? 128 : (c > 32 ? 64 : 32); }
 
 template <typename T>
-static int run_wg(const WgradSpec& g, hipStream_t st) {
-    WgP p; static_cast<WgradSpec&>(p) = g; p.vox_per_split = 0;
+static int run_wg(const WgradSpec& g, long long nw, int nb, hipStream_t st) {
+    WgP p; static_cast<WgradSpec&>(p) = g; p.vox_per_split = 0; p.Rx = nullptr; p.rx_stride = nw > 0 ? nw + nb : 0; p.rx_bias = nw;
     const int ta = pick_t(g.CA), tb = pick_t(g.CB);
 #define WG_CASE(A_, B_) if (ta == A_ && tb == B_) return launch_wg<T, A_, B_>(p, st);
     WG_CASE(128, 128) WG_CASE(128, 64) WG_CASE(128, 32)
@@ -253,5 +268,9 @@ static int run_wg(const WgradSpec& g, hipStream_t st) {
 }
 
 int m1_mfma_wgrad(const WgradSpec& g, hipStream_t st) {
-    return g.dtype == M1_BF16 ? run_wg<bf16_t>(g, st) : run_wg<float>(g, st);
+    return g.dtype == M1_BF16 ? run_wg<bf16_t>(g, 0, 0, st) : run_wg<float>(g, 0, 0, st);
+}
+// nw / nb: floats of the whole weight / bias gradient g.R / g.bsum point into (enables the partial-copy epilogue)
+int m1_mfma_wgrad_ex(const WgradSpec& g, long long nw, int nb, hipStream_t st) {
+    return g.dtype == M1_BF16 ? run_wg<bf16_t>(g, nw, nb, st) : run_wg<float>(g, nw, nb, st);
 }

@@ -335,6 +335,16 @@ static bool tf_plan(const WgradSpec& g, TfP& p) {
 }
 bool m1_tf_wgrad_supported(const WgradSpec& g) { TfP p; return tf_plan(g, p); }
 
+// shared with the per-tap kernel (wgrad_mfma.hip), which uses the same partial-copy scheme for small weight tensors
+float* m1_wg_rx_get(long long floats, hipStream_t st) { return tf_rx_ensure(floats, st) ? g_rx : nullptr; }
+int m1_wg_rx_finish(float* rx, long long stride, int ncopies, const WgradSpec& g, long long nw, hipStream_t st) {
+    TfFin f{rx, stride, ncopies, g.R, g.kd * g.kh * g.kw, g.CA, g.CB, g.RT, g.RSA, g.a_off, g.b_off, g.bsum, nw, g.bsum ? g.CB : 0};
+    const long long n = (long long)f.NT * f.CA * f.CB + f.nb;
+    const int gy = ncopies < 64 ? ncopies : 64;
+    hipLaunchKernelGGL(tf_finish_kernel, dim3((unsigned)((n + 255) / 256), gy), dim3(256), 0, st, f);
+    return m1_check_launch();
+}
+
 #define TF_MAX_COPY_BYTES (96ll << 20)
 // nw / nb: floats of the whole weight / bias gradient that g.R / g.bsum point into
 int m1_tf_wgrad(const WgradSpec& g, long long nw, int nb, hipStream_t st) {

@@ -124,6 +124,8 @@ def repack_all() -> None:
 
 
 def _panel_ws(w: torch.Tensor, d, transposed: bool, role: int, need_mask=None):
+    if not w.is_leaf:           # a derived weight (e.g. the zero-padded stem kernel): packed per call, never registered
+        return _conv_ws(d, transposed, role, w.device, zero=True), 0
     store = getattr(w, "_m1_panels", None)
     stamp = (_PANEL_EPOCH[0], w._version, w.data_ptr())
     if store is None or store[0] != stamp:
