@@ -262,23 +262,32 @@ __global__ void __launch_bounds__(256) wgrad_tf_kernel(TfP p) {
         }
 }
 
-// R[idx(i)] += sum over the copies of Rx[copy][idx(i)] for the NT x CA x CB block of one concat member (+ its bias sums):
-// blockIdx.y folds every 16th copy in a fixed order, the 16 partial sums meet in R through atomics.
+// R[idx(i)] += sum over the copies of Rx[copy][idx(i)] for the NT x CA x CB block of one concat member (+ its bias sums).
+// A block owns EL consecutive elements; its 256/EL lane rows stride the copies, fold through LDS, and ONE lane adds the
+// total into R -- fixed order, no atomics: the weight gradient of these layers is run-to-run deterministic.
 struct TfFin { float* Rx; long long stride; int ncopies; float* R; int NT, CA, CB; long long RT, RSA; int a_off, b_off;
-               float* bsum; long long rx_bias; int nb; };
+               float* bsum; long long rx_bias; int nb; int EL; };
 __global__ void __launch_bounds__(256) tf_finish_kernel(TfFin f) {
+    __shared__ float red[256];
     const long long n = (long long)f.NT * f.CA * f.CB;
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n + f.nb) return;
-    long long idx; float* dst;
+    const int e = threadIdx.x % f.EL, y = threadIdx.x / f.EL, YL = 256 / f.EL;
+    const long long i = (long long)blockIdx.x * f.EL + e;
+    long long idx = 0; float* dst = nullptr;
     if (i < n) {
         const int b = (int)(i % f.CB); const long long q = i / f.CB; const int a = (int)(q % f.CA), t = (int)(q / f.CA);
         idx = (long long)t * f.RT + (long long)(a + f.a_off) * f.RSA + b + f.b_off; dst = f.R + idx;
-    } else { idx = f.rx_bias + (i - n) + f.b_off; dst = f.bsum + (i - n) + f.b_off; }
+    } else if (i < n + f.nb) { idx = f.rx_bias + (i - n) + f.b_off; dst = f.bsum + (i - n) + f.b_off; }
     float s = 0.f;
+    if (dst) {
 #pragma unroll 8
-    for (int y = blockIdx.y; y < f.ncopies; y += gridDim.y) s += f.Rx[(long long)y * f.stride + idx];
-    atomicAdd(dst, s);
+        for (int c = y; c < f.ncopies; c += YL) s += f.Rx[(long long)c * f.stride + idx];
+    }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if (y == 0 && dst) {
+        for (int q = 1; q < YL; ++q) s += red[q * f.EL + e];
+        *dst += s;
+    }
 }
 
 // One persistent device buffer for the partial copies (grown outside stream capture only).
@@ -338,10 +347,10 @@ bool m1_tf_wgrad_supported(const WgradSpec& g) { TfP p; return tf_plan(g, p); }
 // shared with the per-tap kernel (wgrad_mfma.hip), which uses the same partial-copy scheme for small weight tensors
 float* m1_wg_rx_get(long long floats, hipStream_t st) { return tf_rx_ensure(floats, st) ? g_rx : nullptr; }
 int m1_wg_rx_finish(float* rx, long long stride, int ncopies, const WgradSpec& g, long long nw, hipStream_t st) {
-    TfFin f{rx, stride, ncopies, g.R, g.kd * g.kh * g.kw, g.CA, g.CB, g.RT, g.RSA, g.a_off, g.b_off, g.bsum, nw, g.bsum ? g.CB : 0};
+    TfFin f{rx, stride, ncopies, g.R, g.kd * g.kh * g.kw, g.CA, g.CB, g.RT, g.RSA, g.a_off, g.b_off, g.bsum, nw, g.bsum ? g.CB : 0, 32};
     const long long n = (long long)f.NT * f.CA * f.CB + f.nb;
-    const int gy = ncopies < 64 ? ncopies : 64;
-    hipLaunchKernelGGL(tf_finish_kernel, dim3((unsigned)((n + 255) / 256), gy), dim3(256), 0, st, f);
+    while (f.EL > 4 && n / f.EL < 128) f.EL >>= 1;           // small blocks of R: more lane rows per element, more blocks
+    hipLaunchKernelGGL(tf_finish_kernel, dim3((unsigned)((n + f.EL - 1) / f.EL)), dim3(256), 0, st, f);
     return m1_check_launch();
 }
 
@@ -380,10 +389,5 @@ int m1_tf_wgrad(const WgradSpec& g, long long nw, int nb, hipStream_t st) {
     }
     hipLaunchKernelGGL(kern, grid, dim3(256), smem, st, p);
     int rc = m1_check_launch(); if (rc) return rc;
-    TfFin f{g_rx, stride, (int)nsplit, g.R, g.kd * g.kh * g.kw, g.CA, g.CB, g.RT, g.RSA, g.a_off, g.b_off,
-            g.bsum, nw, g.bsum ? g.CB : 0};
-    const long long n = (long long)f.NT * f.CA * f.CB + f.nb;
-    const int gy = nsplit < 64 ? (int)nsplit : 64;
-    hipLaunchKernelGGL(tf_finish_kernel, dim3((unsigned)((n + 255) / 256), gy), dim3(256), 0, st, f);
-    return m1_check_launch();
+    return m1_wg_rx_finish(g_rx, stride, (int)nsplit, g, nw, st);
 }
