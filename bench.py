@@ -105,6 +105,36 @@ def cpu_baseline(workload, prob, dense, deep, dims, filters, kl_w, budget_s=20.0
                       f"{t:.2f} s/step on {cores} threads, scaled by voxel ratio"}
 
 
+# kernel names behind each C-ABI entry-point family (the PMC pass sees kernels, the hipEvent timer sees entry points)
+_FAMILY_KERNELS = {
+    "wgrad": (("conv3d_wgrad", "convT3d_wgrad"), ("wgrad_mfma_kernel", "wgrad_tf_kernel", "tf_finish_kernel")),
+    "conv": (("conv3d_fwd", "conv3d_dgrad", "convT3d_fwd", "convT3d_dgrad"),
+             ("conv_mfma_kernel", "conv_halo_kernel", "splitk_finish_kernel")),
+}
+
+
+def hbm_traffic(a, B, recs, family):
+    """HBM bytes per launch of the dominant entry-point family, from the committed rocprofv3 --pmc FETCH_SIZE /
+    WRITE_SIZE passes of this same workload (profiles/r01_c2_bf16_hbm_traffic.json, tools/collect_profiles.sh; FETCH_SIZE
+    doubled as MI355X_MICROARCH.md prescribes for gfx950).  None when no committed measurement matches the run."""
+    if not (a.workload == "C2" and a.dtype == "bf16" and B == 1):
+        return None, "no committed PMC pass for this workload"
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_c2_bf16_hbm_traffic.json")
+    try:
+        with open(path) as f:
+            pm = json.load(f)
+    except OSError:
+        return None, "profiles/r01_c2_bf16_hbm_traffic.json not found"
+    for fams, kernels in _FAMILY_KERNELS.values():
+        if family in fams:
+            gb = sum(pm["kernels"].get(k, {}).get("fetch_GB_per_step", 0.0) + pm["kernels"].get(k, {}).get("write_GB_per_step", 0.0)
+                     for k in kernels)
+            launches = sum(q["launches"] for q in recs if q["name"] in fams) / a.prof_steps
+            return gb * 1e9 / max(launches, 1.0), ("bytes per entry-point launch, kernels " + "+".join(kernels) +
+                                                   " shared by " + "+".join(fams) + "; rocprofv3 --pmc FETCH_SIZE(x2)/WRITE_SIZE")
+    return None, "family not mapped to kernels"
+
+
 def main():
     a = parse()
     import torch
@@ -255,9 +285,12 @@ def main():
             else:
                 roof = {"bound": "hbm", "achieved": gb_ach, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": f_h}
             roof.update({"traffic": None, "kernel": r["name"], "launches_per_step": r["launches"] / a.prof_steps,
+                         "algorithmic_bytes_per_launch": r["bytes"] / r["launches"],
                          "avg_launch_ms": r["total_ms"] / r["launches"],
                          "kernel_ms_per_step": r["total_ms"] / a.prof_steps,
                          "all_kernels_ms_per_step": {q["name"]: round(q["total_ms"] / a.prof_steps, 4) for q in recs}})
+
+            roof["traffic"], roof["traffic_note"] = hbm_traffic(a, B, recs, r["name"])
 
     if world > 1:
         dist.barrier()
