@@ -58,13 +58,14 @@ __device__ __forceinline__ unsigned lds_addr_of(const void* p) { return (unsigne
 // was the bound of the register-staged loop.  The DMA writes lane-linear, so the XOR swizzle is applied on the SOURCE
 // side: the lane that owns LDS slot (row, s) fetches K-segment s ^ swz(row).
 template <typename T, int BM, int BN, int WM, int WN, int KC, bool GLDS>
-__global__ void __launch_bounds__(256) conv_mfma_kernel(MfmaP p) {
+__global__ void __launch_bounds__(WM * WN * 64) conv_mfma_kernel(MfmaP p) {
+    constexpr int NTHR = WM * WN * 64, NW = WM * WN;        // 4 waves, or 8 for the 128x128 tile of the deep layers
     constexpr int SEG = MT<T>::SEG;
     constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
     constexpr int A_BYTES = BM * 64, B_BYTES = BN * 64;
-    constexpr int A_LD = BM / 64;                       // 16-B loads per thread per chunk for A (BM*4/256)
-    constexpr int B_LD = (BN * 4 + 255) / 256;          // for B
-    static_assert(WM * WN == 4 && BM % 64 == 0 && BN % 16 == 0, "tile config");
+    constexpr int A_LD = BM * 4 / NTHR;                 // 16-B loads per thread per chunk for A
+    constexpr int B_LD = (BN * 4 + NTHR - 1) / NTHR;    // for B
+    static_assert((NW == 4 || NW == 8) && (BM * 4) % NTHR == 0 && BN % 16 == 0, "tile config");
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     // tables first (they must survive the epilogue tile, which reuses the pipeline buffers)
@@ -97,7 +98,7 @@ __global__ void __launch_bounds__(256) conv_mfma_kernel(MfmaP p) {
     const long long m0 = tile * BM;
     if (m0 >= Mtot) return;
 
-    for (int r = tid; r < BM; r += 256) {
+    for (int r = tid; r < BM; r += NTHR) {
         const long long m = m0 + r;
         int4 ri = make_int4(-1, 0, 0, 0); int orow = -1;
         if (m < Mtot) {
@@ -139,7 +140,7 @@ __global__ void __launch_bounds__(256) conv_mfma_kernel(MfmaP p) {
     uint4 ra[GLDS ? 1 : KC][GLDS ? 1 : A_LD], rb[GLDS ? 1 : KC][GLDS ? 1 : B_LD];
     const int lrow = tid >> 2;                           // loader: 4 lanes cover one 64-byte row
     // register staging: logical segment tid&3, swizzled when written; LDS-DMA: slot tid&3, swizzled when fetched
-    // (rows tid>>2 + 64*i and (tid + 256*i)>>2 all share (row>>2)&3 = (tid>>4)&3)
+    // (rows tid>>2 + (NTHR/4)*i and (tid + NTHR*i)>>2 all share (row>>2)&3 = (tid>>4)&3)
     const int lseg = GLDS ? ((tid & 3) ^ ((-(tid >> 4)) & 3)) : (tid & 3);
     const unsigned char* zero_pg = reinterpret_cast<const unsigned char*>(m1_zero_page);
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
@@ -152,7 +153,7 @@ __global__ void __launch_bounds__(256) conv_mfma_kernel(MfmaP p) {
         const int dd = (signed char)(tp & 0xff), dh = (signed char)((tp >> 8) & 0xff), dw = (signed char)((tp >> 16) & 0xff);
 #pragma unroll
         for (int i = 0; i < A_LD; ++i) {
-            const int4 ri = rowinfo[lrow + 64 * i];
+            const int4 ri = rowinfo[lrow + (NTHR / 4) * i];
             const int id = ri.y + dd, ih = ri.z + dh, iw = ri.w + dw;
             st_ptr[i] = nullptr;
             if (ri.x >= 0 && id >= 0 && id < p.ID && ih >= 0 && ih < p.IH && iw >= 0 && iw < p.IW) {
@@ -180,7 +181,7 @@ __global__ void __launch_bounds__(256) conv_mfma_kernel(MfmaP p) {
             // ---- B: packed weights, rows = output channels ----
 #pragma unroll
             for (int i = 0; i < B_LD; ++i) {
-                const int e = tid + 256 * i;                 // (row, seg) = (e>>2, e&3)
+                const int e = tid + NTHR * i;                 // (row, seg) = (e>>2, e&3)
                 uint4 v = make_uint4(0, 0, 0, 0);
                 if (live && e < BN * 4)
                     v = *reinterpret_cast<const uint4*>(wp + (long long)(oc0 + (e >> 2)) * kpad + (long long)(chunk * 4 + (e & 3)) * SEG);
@@ -214,7 +215,7 @@ __global__ void __launch_bounds__(256) conv_mfma_kernel(MfmaP p) {
                 }
 #pragma unroll
                 for (int i = 0; i < A_LD; ++i) {
-                    const int4 ri = rowinfo[lrow + 64 * i];
+                    const int4 ri = rowinfo[lrow + (NTHR / 4) * i];
                     uint4 v = make_uint4(0, 0, 0, 0);
                     const int id = ri.y + dd, ih = ri.z + dh, iw = ri.w + dw;
                     if (kvalid && coff < sC && ri.x >= 0 && id >= 0 && id < p.ID && ih >= 0 && ih < p.IH && iw >= 0 && iw < p.IW) {
@@ -236,18 +237,18 @@ __global__ void __launch_bounds__(256) conv_mfma_kernel(MfmaP p) {
             const bool live = rel < nchunks;
 #pragma unroll
             for (int i = 0; i < B_LD; ++i) {
-                const int e = tid + 256 * i;                 // LDS slot (row, s) = (e>>2, e&3)
-                if ((wave_u + 4 * i) * 64 < BN * 4) {        // wave-uniform
+                const int e = tid + NTHR * i;                 // LDS slot (row, s) = (e>>2, e&3)
+                if ((wave_u + NW * i) * 64 < BN * 4) {        // wave-uniform
                     const unsigned char* src = live
                         ? reinterpret_cast<const unsigned char*>(wp + (long long)(oc0 + (e >> 2)) * kpad + (long long)(chunk * 4 + lseg) * SEG)
                         : zero_pg;
-                    glds16(src, B_s + (buf * KC + kc) * B_BYTES + (wave_u + 4 * i) * 1024);
+                    glds16(src, B_s + (buf * KC + kc) * B_BYTES + (wave_u + NW * i) * 1024);
                 }
             }
 #pragma unroll
             for (int i = 0; i < A_LD; ++i) {
                 const unsigned char* src = (live && st_ptr[i]) ? reinterpret_cast<const unsigned char*>(st_ptr[i] + st_c) : zero_pg;
-                glds16(src, A_s + (buf * KC + kc) * A_BYTES + (wave_u + 4 * i) * 1024);
+                glds16(src, A_s + (buf * KC + kc) * A_BYTES + (wave_u + NW * i) * 1024);
             }
             if (live) {
                 st_c += 4 * SEG;
@@ -264,12 +265,12 @@ __global__ void __launch_bounds__(256) conv_mfma_kernel(MfmaP p) {
         for (int kc = 0; kc < KC; ++kc) {
 #pragma unroll
             for (int i = 0; i < A_LD; ++i) {
-                const int row = lrow + 64 * i;
+                const int row = lrow + (NTHR / 4) * i;
                 *reinterpret_cast<uint4*>(A_s + (buf * KC + kc) * A_BYTES + row * 64 + swz(row, lseg) * 16) = ra[kc][i];
             }
 #pragma unroll
             for (int i = 0; i < B_LD; ++i) {
-                const int e = tid + 256 * i;
+                const int e = tid + NTHR * i;
                 if (e < BN * 4) {
                     const int row = e >> 2;
                     *reinterpret_cast<uint4*>(B_s + (buf * KC + kc) * B_BYTES + row * 64 + swz(row, e & 3) * 16) = rb[kc][i];
@@ -396,7 +397,7 @@ __global__ void __launch_bounds__(256) conv_mfma_kernel(MfmaP p) {
     if (p.stat_partial) {          // per-tile column sums of the stored (rounded) values -> deterministic partials
         constexpr int EPI_BYTES = (int)((BM * CP * sizeof(T) + 15) / 16 * 16), PIPE_BYTES = 2 * KC * (A_BYTES + B_BYTES);
         float* red = reinterpret_cast<float*>(A_s + (PIPE_BYTES > EPI_BYTES ? PIPE_BYTES : EPI_BYTES));   // 2 KB scratch behind both
-        constexpr int G = 256 / BN;                       // row groups
+        constexpr int G = NTHR / BN;                      // row groups
         const int col = tid % BN, rg = tid / BN;
         float s = 0.f, ss = 0.f;
         for (int row = rg; row < BM; row += G) {
@@ -413,7 +414,7 @@ __global__ void __launch_bounds__(256) conv_mfma_kernel(MfmaP p) {
     }
     constexpr int SPR = BN / SEG;                         // 16-B segments per tile row
     T* out = (T*)p.out;
-    for (int e = tid; e < BM * SPR; e += 256) {
+    for (int e = tid; e < BM * SPR; e += NTHR) {
         const int row = e / SPR, cs = e % SPR;
         const int orow = outrow[row];
         const int oc = oc0 + cs * SEG;
@@ -442,12 +443,12 @@ __global__ void __launch_bounds__(256) conv_mfma_kernel(MfmaP p) {
     }
 }
 
-template <typename T, int BM, int BN, int KC>
+template <typename T, int BM, int BN, int KC, int NTHR>
 static constexpr size_t mfma_smem_bytes() {
     size_t tbl = (BM * 20 + M1_MAX_SRC * 16 + MF_MAX_TAPS * 4 + 15) / 16 * 16;
     size_t pipe = (size_t)KC * (2 * BM * 64 + 2 * BN * 64);
     size_t epi = ((size_t)BM * (BN + MT<T>::SEG) * sizeof(T) + 15) / 16 * 16;
-    return tbl + (pipe > epi ? pipe : epi) + 256 * 2 * sizeof(float);
+    return tbl + (pipe > epi ? pipe : epi) + NTHR * 2 * sizeof(float);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -634,7 +635,7 @@ size_t m1_mfma_ws_bytes(const GatherSpec& g) {
 template <typename T, int BM, int BN, int WM, int WN, int KC>
 static int launch_cfg_kc(const MfmaP& mp, long long maxM, int OCpad, hipStream_t st) {
     dim3 grid((unsigned)(cdiv_ll(cdiv_ll(maxM, BM), 8) * 8), mp.nclasses * mp.ksplit, OCpad / BN);
-    const size_t smem = mfma_smem_bytes<T, BM, BN, KC>();
+    const size_t smem = mfma_smem_bytes<T, BM, BN, KC, WM * WN * 64>();
     auto kern = mp.aligned ? conv_mfma_kernel<T, BM, BN, WM, WN, KC, true> : conv_mfma_kernel<T, BM, BN, WM, WN, KC, false>;
     static bool attr_set = false;     // per instantiation
     if (smem > 48 * 1024 && !attr_set) {
@@ -642,7 +643,7 @@ static int launch_cfg_kc(const MfmaP& mp, long long maxM, int OCpad, hipStream_t
         if (hipFuncSetAttribute((const void*)conv_mfma_kernel<T, BM, BN, WM, WN, KC, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) return M1_ERR_LAUNCH;
         attr_set = true;
     }
-    hipLaunchKernelGGL(kern, grid, dim3(256), smem, st, mp);
+    hipLaunchKernelGGL(kern, grid, dim3(WM * WN * 64), smem, st, mp);
     return m1_check_launch();
 }
 
@@ -677,8 +678,13 @@ static int run_mfma(const GatherSpec& g, void* ws, int ws_packed, hipStream_t st
     build_classes(g, CC, SEG, OCpad, &mp, &pp, &tot);
     mp.ksplit = pl.ksplit; mp.acc32 = nullptr; mp.aligned = 1; mp.stat_partial = nullptr; mp.stat_tiles = 0;
     const long long Vout = (long long)g.OD * g.OH * g.OW;
-    bool fuse_stats = g.stats_out && g.stats_ws && g.mode == 0 && pl.ksplit == 1 && (g.N == 1 || Vout % pl.BM == 0);
-    if (fuse_stats) { mp.stat_partial = g.stats_ws; mp.stat_tiles = (int)cdiv_ll(Vout, pl.BM); }
+    // M1_CONV8=1 (experiment, off): 128x128 tiles on 8 waves for the deep layers -- halves the weight-tile re-reads of the
+    // 64-row tiles at the same waves per CU; measured -8 % on the 512->128 forward, +4 % on its data gradient, neutral end to end
+    static int c8 = -1; if (c8 < 0) { const char* e = getenv("M1_CONV8"); c8 = e ? atoi(e) : 0; }
+    const bool use8 = c8 && BN == 128 && pl.ksplit == 1 && cdiv_ll(spec_maxM(g), 128) * spec_ncls(g) * (OCpad / 128) >= 160;
+    const int bm_eff = use8 ? 128 : pl.BM;
+    bool fuse_stats = g.stats_out && g.stats_ws && g.mode == 0 && pl.ksplit == 1 && (g.N == 1 || Vout % bm_eff == 0);
+    if (fuse_stats) { mp.stat_partial = g.stats_ws; mp.stat_tiles = (int)cdiv_ll(Vout, bm_eff); }
     for (int i = 0; i < g.nsrc; ++i) if (g.srcC[i] % (4 * SEG)) mp.aligned = 0;
     if (pl.ksplit > 1) {
         const size_t wbytes = ((size_t)tot * sizeof(T) + 255) / 256 * 256;
@@ -712,7 +718,8 @@ static int run_mfma(const GatherSpec& g, void* ws, int ws_packed, hipStream_t st
     if (halo) rc2 = m1_halo_conv(mp, OCpad, st);
     else
     switch (BN) {
-        case 128: rc2 = small ? launch_cfg<T, 64, 128, 1, 4>(mp, maxM, OCpad, st) : launch_cfg<T, 128, 128, 2, 2>(mp, maxM, OCpad, st); break;
+        case 128: rc2 = use8 ? launch_cfg<T, 128, 128, 2, 4>(mp, maxM, OCpad, st)
+                             : (small ? launch_cfg<T, 64, 128, 1, 4>(mp, maxM, OCpad, st) : launch_cfg<T, 128, 128, 2, 2>(mp, maxM, OCpad, st)); break;
         case 64:  rc2 = small ? launch_cfg<T, 64, 64, 2, 2>(mp, maxM, OCpad, st) : launch_cfg<T, 128, 64, 4, 1>(mp, maxM, OCpad, st); break;
         case 32:  rc2 = small ? launch_cfg<T, 64, 32, 4, 1>(mp, maxM, OCpad, st) : launch_cfg<T, 128, 32, 4, 1>(mp, maxM, OCpad, st); break;
         default:  rc2 = small ? launch_cfg<T, 64, 16, 4, 1>(mp, maxM, OCpad, st) : launch_cfg<T, 128, 16, 4, 1>(mp, maxM, OCpad, st); break;
