@@ -86,6 +86,16 @@ template <> struct VecIO<bf16_t, 8> {
     }
 };
 
+// blocks of 256 threads for `per` vector elements whose channel group is (index % cg): at most ~2048 blocks, and
+// gridDim.x*256 a multiple of cg so that a thread keeps its channel group across its grid-stride loop
+static inline int m1_grid_for(long long per, int cg) {
+    long long g = (per + 255) / 256; if (g > 2048) g = 2048; if (g < 1) g = 1;
+    // (g*256) % cg == 0  <=>  g is a multiple of cg / gcd(cg, 256)
+    long long a = cg, b = 256; while (b) { long long t = a % b; a = b; b = t; }
+    const long long need = cg / a;
+    g = (g + need - 1) / need * need;
+    return (int)g;
+}
 __device__ __forceinline__ float lrelu_f(float x, float slope) { return x >= 0.f ? x : slope * x; }
 __device__ __forceinline__ float lrelu_g(float x, float slope) { return x >= 0.f ? 1.f : slope; }
 __device__ __forceinline__ float sigmoid_f(float x) { return 1.f / (1.f + __expf(-x)); }

@@ -138,8 +138,10 @@ __global__ void __launch_bounds__(NTHR) conv_halo_kernel(HaloP p) {
                 const int dd = pk & 0xff, hh = (pk >> 8) & 0xff, ww = (pk >> 16) & 0xff;
                 const bool ok = live && pk >= 0 && (unsigned)(id0 + dd) < (unsigned)m.ID && (unsigned)(ih0 + hh) < (unsigned)m.IH &&
                                 (unsigned)(iw0 + ww) < (unsigned)m.IW;
-                const unsigned char* src = ok ? reinterpret_cast<const unsigned char*>(x_base[it] + (long long)(lin0 + x_rel[it]) * x_C[it] + x_co[it])
-                                              : zero_pg;
+                // branch-free select (the compiler turns the ?: into a branch around the 64-bit address arithmetic)
+                const long long real = (long long)(x_base[it] + (long long)(lin0 + x_rel[it]) * x_C[it] + x_co[it]);
+                const long long zp = (long long)zero_pg;
+                const unsigned char* src = reinterpret_cast<const unsigned char*>(zp + ((real - zp) & -(long long)ok));
                 glds16h(src, Xs + (it * NTHR + wave * 64) * 16);
             }
         }

@@ -67,18 +67,21 @@ __global__ void __launch_bounds__(256) in_apply_kernel(const T* __restrict__ x, 
     const T* xn = x + (size_t)n * V * C;
     T* yn = y + (size_t)n * V * C;
     const int cg = C / VEC;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < per;
-         i += (long long)gridDim.x * blockDim.x) {
-        const int c0 = (int)(i % cg) * VEC;
+    // the launch keeps gridDim.x*blockDim.x a multiple of the channel groups: a thread's channels never change, their
+    // parameters are loaded once (4*VEC scalar loads per 16-byte vector otherwise -- the kernel was L1/issue bound)
+    const long long i0 = (long long)blockIdx.x * blockDim.x + threadIdx.x, stride = (long long)gridDim.x * blockDim.x;
+    const int c0 = (int)(i0 % cg) * VEC;
+    float mean[VEC], rstd[VEC], gm[VEC], bt[VEC];
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) {
+        const int c = c0 + k;
+        mean[k] = stats[((size_t)n * C + c) * 2]; rstd[k] = stats[((size_t)n * C + c) * 2 + 1]; gm[k] = gamma[c]; bt[k] = beta[c];
+    }
+    for (long long i = i0; i < per; i += stride) {
         float v[VEC];
         VecIO<T, VEC>::ld(xn + i * VEC, v);
 #pragma unroll
-        for (int k = 0; k < VEC; ++k) {
-            const int c = c0 + k;
-            const float mean = stats[((size_t)n * C + c) * 2], rstd = stats[((size_t)n * C + c) * 2 + 1];
-            float t = (v[k] - mean) * rstd * gamma[c] + beta[c];
-            v[k] = lrelu_f(t, slope);
-        }
+        for (int k = 0; k < VEC; ++k) v[k] = lrelu_f((v[k] - mean[k]) * rstd[k] * gm[k] + bt[k], slope);
         VecIO<T, VEC>::st(yn + i * VEC, v);
     }
 }
@@ -90,12 +93,12 @@ static int apply_impl(const void* x, const float* stats, const float* gamma, con
     long long per;
     if (C % VW == 0) {
         per = V * (C / VW);
-        int gx = (int)(cdiv_ll(per, 256) > 4096 ? 4096 : cdiv_ll(per, 256));
+        int gx = m1_grid_for(per, C / VW);
         hipLaunchKernelGGL((in_apply_kernel<T, VW>), dim3(gx, N), dim3(256), 0, st, (const T*)x, stats, gamma, beta,
                            slope, (T*)y, V, C);
     } else {
         per = V * C;
-        int gx = (int)(cdiv_ll(per, 256) > 4096 ? 4096 : cdiv_ll(per, 256));
+        int gx = m1_grid_for(per, C);
         hipLaunchKernelGGL((in_apply_kernel<T, 1>), dim3(gx, N), dim3(256), 0, st, (const T*)x, stats, gamma, beta,
                            slope, (T*)y, V, C);
     }
@@ -154,21 +157,24 @@ __global__ void __launch_bounds__(256) in_bwd_apply_kernel(const T* __restrict__
     const long long per = V * cg;
     const size_t base = (size_t)n * V * C;
     const float invV = 1.0f / (float)V;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < per;
-         i += (long long)gridDim.x * blockDim.x) {
-        const int c0 = (int)(i % cg) * VEC;
+    const long long i0 = (long long)blockIdx.x * blockDim.x + threadIdx.x, stride = (long long)gridDim.x * blockDim.x;
+    const int c0 = (int)(i0 % cg) * VEC;                 // invariant per thread (see in_apply_kernel)
+    float mean[VEC], rstd[VEC], gm[VEC], bt[VEC], s0[VEC], s1[VEC];
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) {
+        const int c = c0 + k;
+        mean[k] = stats[((size_t)n * C + c) * 2]; rstd[k] = stats[((size_t)n * C + c) * 2 + 1]; gm[k] = gamma[c]; bt[k] = beta[c];
+        s0[k] = sums[((size_t)n * C + c) * 2] * invV; s1[k] = sums[((size_t)n * C + c) * 2 + 1] * invV;
+    }
+    for (long long i = i0; i < per; i += stride) {
         float xv[VEC], dv[VEC];
         VecIO<T, VEC>::ld(x + base + i * VEC, xv);
         VecIO<T, VEC>::ld(da + base + i * VEC, dv);
 #pragma unroll
         for (int k = 0; k < VEC; ++k) {
-            const int c = c0 + k;
-            const float mean = stats[((size_t)n * C + c) * 2], rstd = stats[((size_t)n * C + c) * 2 + 1];
-            const float xh = (xv[k] - mean) * rstd;
-            const float yv = gamma[c] * xh + beta[c];
-            const float dy = dv[k] * lrelu_g(yv, slope);
-            const float s0 = sums[((size_t)n * C + c) * 2], s1 = sums[((size_t)n * C + c) * 2 + 1];
-            dv[k] = gamma[c] * rstd * (dy - s0 * invV - xh * s1 * invV);
+            const float xh = (xv[k] - mean[k]) * rstd[k];
+            const float dy = dv[k] * lrelu_g(gm[k] * xh + bt[k], slope);
+            dv[k] = gm[k] * rstd[k] * (dy - s0[k] - xh * s1[k]);
         }
         VecIO<T, VEC>::st(dx + base + i * VEC, dv);
     }
@@ -189,12 +195,12 @@ static int bwd_impl(const void* x, const float* stats, const float* gamma, const
     constexpr int VW = sizeof(T) == 2 ? 8 : 4;
     if (C % VW == 0) {
         long long per = V * (C / VW);
-        int gx = (int)(cdiv_ll(per, 256) > 4096 ? 4096 : cdiv_ll(per, 256));
+        int gx = m1_grid_for(per, C / VW);
         hipLaunchKernelGGL((in_bwd_apply_kernel<T, VW>), dim3(gx, N), dim3(256), 0, st, (const T*)x, (const T*)dy,
                            stats, gamma, beta, slope, sums, (T*)dx, V, C);
     } else {
         long long per = V * C;
-        int gx = (int)(cdiv_ll(per, 256) > 4096 ? 4096 : cdiv_ll(per, 256));
+        int gx = m1_grid_for(per, C);
         hipLaunchKernelGGL((in_bwd_apply_kernel<T, 1>), dim3(gx, N), dim3(256), 0, st, (const T*)x, (const T*)dy,
                            stats, gamma, beta, slope, sums, (T*)dx, V, C);
     }

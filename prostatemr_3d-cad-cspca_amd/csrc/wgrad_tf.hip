@@ -150,8 +150,9 @@ __global__ void __launch_bounds__(256) wgrad_tf_kernel(TfP p) {
                 const int dd = pk & 0xff, hh = (pk >> 8) & 0xff, ww = (pk >> 16) & 0xff;
                 const bool ok = live && pk >= 0 && (unsigned)(ad0 + dd) < (unsigned)p.AD && (unsigned)(ah0 + hh) < (unsigned)p.AH &&
                                 (unsigned)(aw0 + ww) < (unsigned)p.AW;
-                const unsigned char* src = ok ? reinterpret_cast<const unsigned char*>(p.A + (long long)(lin0 + a_rel[it]) * p.CA + a0 + a_sl[it])
-                                              : zero_pg;
+                const long long real = (long long)(p.A + (long long)(lin0 + a_rel[it]) * p.CA + a0 + a_sl[it]);
+                const long long zp = (long long)zero_pg;                 // branch-free select
+                const unsigned char* src = reinterpret_cast<const unsigned char*>(zp + ((real - zp) & -(long long)ok));
                 glds16w(src, As + (it * 256 + wave * 64) * 16);
             }
         }
