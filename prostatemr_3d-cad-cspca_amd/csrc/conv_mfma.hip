@@ -554,6 +554,19 @@ static inline Plan make_plan(int ocn, long long maxM, int ncls, int min_nchunks)
     pl.BM = cdiv_ll(maxM, 128) * ncls * ntile >= 256 ? 128 : 64;
     const long long blocks = cdiv_ll(maxM, pl.BM) * ncls * ntile;
     pl.ksplit = 1;
+    {   // very deep contractions (>= 200 chunks: the dense-skip concats of the full model) with a 128-wide oc tile and only
+        // ~250 row tiles: 128x128 tiles (64x64 per wave: fewer fragment reads and weight re-reads per MFMA) and slab
+        // split-K to get the blocks back (-19 % on the 512->128-channel res2 layer).  M1_PLAN128=<target blocks>, 0 = off
+        static int t128 = -1; if (t128 < 0) { const char* e = getenv("M1_PLAN128"); t128 = e ? atoi(e) : 768; }
+        const long long b128 = cdiv_ll(maxM, 128) * ncls * ntile;
+        if (t128 > 0 && pl.BN == 128 && b128 >= 100 && b128 < t128 && min_nchunks >= 200) {
+            pl.BM = 128;
+            long long want = cdiv_ll(t128, b128), cap = min_nchunks / 64;
+            pl.ksplit = (int)(want < cap ? want : cap);
+            if (pl.ksplit < 1) pl.ksplit = 1;
+            return pl;
+        }
+    }
     if (blocks < 256 && min_nchunks >= 16) {
         long long want = cdiv_ll(512, blocks), cap = min_nchunks / 8;
         pl.ksplit = (int)(want < cap ? want : cap);
