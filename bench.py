@@ -135,6 +135,11 @@ def hbm_traffic(a, B, recs, family):
     return None, "family not mapped to kernels"
 
 
+def _dbg(msg):
+    if os.environ.get("M1_BENCH_DEBUG"):
+        print(f"[rank {os.environ.get('RANK', '0')}] {msg}", file=sys.stderr, flush=True)
+
+
 def main():
     a = parse()
     import torch
@@ -147,11 +152,18 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != a.gpus and world > 1:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    # (M1_BENCH_BACKEND=gloo: functional check of the N > 1 code path with every rank on one GPU; never a measurement)
+    backend = os.environ.get("M1_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local = local % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend=backend, rank=rank, world_size=world)
 
     dims, filters, prob, dense, deep = WORKLOADS[a.workload]
     B = a.batch or 1
@@ -211,9 +223,11 @@ def main():
         update()
 
     # ---- eager warm-up (also primes the allocator), then optional whole-step hipGraph ----
+    _dbg("model built; eager warm-up")
     for _ in range(max(1, min(a.warmup, 2))):
         step()
     torch.cuda.synchronize()
+    _dbg("eager warm-up done")
     use_graph, graph, graph_err = (not a.no_graph), None, None
     # N = 1: the whole step is one hipGraph.  N > 1: forward+backward are captured, the RCCL exchange and the
     # optimiser kernel are launched eagerly behind the replay (no collective inside a captured graph).
@@ -246,11 +260,13 @@ def main():
             graph.replay()
             update()
 
+    _dbg(f"graph={'yes' if graph is not None else 'no'} err={graph_err}; timed warm-up")
     for _ in range(a.warmup):
         run()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
+    _dbg("timing")
     t0 = time.perf_counter()
     for _ in range(a.steps):
         run()
@@ -268,8 +284,10 @@ def main():
     roof = None
     if not a.no_roofline and rank == 0:
         ops.prof_reset(); ops.prof_enable(True)
+        saved_reducer, opt.reducer = opt.reducer, None     # rank 0 alone: no collective in the profiled steps (timing is over)
         for _ in range(a.prof_steps):
             step()
+        opt.reducer = saved_reducer
         torch.cuda.synchronize()
         recs = ops.prof_read()
         ops.prof_enable(False)
