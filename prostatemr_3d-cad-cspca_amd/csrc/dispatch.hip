@@ -213,6 +213,7 @@ extern "C" int m1_convT3d_dgrad(const m1_conv_desc_t* d, const float* w, const v
 static bool tf_wanted(const WgradSpec& g) {
     static int maxc = -1;
     if (maxc < 0) { const char* e = getenv("M1_TF_MAXC"); maxc = e ? atoi(e) : 64; }
+    if (m1_tf64_wgrad_supported(g)) return true;
     return g.CA <= maxc && g.CB <= maxc && m1_tf_wgrad_supported(g);
 }
 static int wgrad_common(const m1_conv_desc_t* d, bool T, const void* dy, float* dw, float* db, void* ws, hipStream_t st,

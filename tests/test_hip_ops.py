@@ -455,11 +455,18 @@ TF_CASES = [  # (N, D, H, W), cins, cout, k, s, transposed
     ((1, 3, 6, 16), [64], 32, (1, 3, 3), (1, 2, 2), True),
     ((1, 2, 4, 8), [32], 32, (3, 3, 3), (2, 2, 2), True),
     ((1, 3, 7, 24), [64, 32], 96, (3, 3, 3), (1, 1, 1), False),
+    # both sides multiples of 64 channels: the 64x64-tile kernel (one kd slice per blockIdx.z)
+    ((1, 3, 6, 16), [64], 64, (3, 3, 3), (1, 1, 1), False),
+    ((2, 2, 5, 32), [128], 64, (1, 3, 3), (1, 1, 1), False),
+    ((1, 3, 8, 16), [64], 128, (3, 3, 3), (2, 2, 2), False),
+    ((1, 2, 4, 8), [64], 64, (3, 3, 3), (2, 2, 2), True),
+    ((1, 2, 6, 8), [64, 128], 64, (1, 3, 3), (1, 1, 1), False),
 ]
 
 
 @pytest.mark.parametrize("case", TF_CASES)
 def test_tap_fused_wgrad(dev, case, monkeypatch):
+    # (run the suite once more with M1_TF64=1 / M1_HALO=2 / M1_TF_MAXC=512 to force the optional kernels onto these shapes)
     dims, cins, cout, k, s, transposed = case
     xs = [rnd((*dims, c), 40 + i).bfloat16().float() for i, c in enumerate(cins)]
     wshape = (*k, cout, sum(cins)) if transposed else (*k, sum(cins), cout)
