@@ -246,6 +246,7 @@ static int wgrad_common(const m1_conv_desc_t* d, bool T, const void* dy, float* 
         if (rc == M1_OK) { off += d->src[i].C; continue; }
         if (rc != M1_ERR_UNSUPPORTED && rc != M1_ERR_WORKSPACE) return rc;
         if (g_force_direct == 2 && m1_skinny_wgrad_supported(g)) rc = m1_skinny_wgrad(g, st);   // test hook for that kernel
+        else if (!g_force_direct && m1_tap_wgrad_supported(g)) rc = m1_tap_wgrad(g, (long long)nw, nbias, st);
         else if (!g_force_direct && m1_mfma_wgrad_supported(g)) rc = m1_mfma_wgrad_ex(g, (long long)nw, nbias, st);
         else rc = m1_direct_wgrad(g, st);
         if (rc) return rc;
