@@ -33,6 +33,7 @@ __device__ __forceinline__ u32x4_t lds_read128h(unsigned lds_addr) {
     return v;
 }
 __device__ __forceinline__ void lds_waith(u32x4_t& v) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v)); }
+__device__ __forceinline__ void lds_tieh(u32x4_t& v) { asm volatile("" : "+v"(v)); }     // no instruction: ordering only
 __device__ __forceinline__ void wait_vmh(int n) {
     switch (n) {
 #define HW(N_) case N_: asm volatile("s_waitcnt vmcnt(" #N_ ")" ::: "memory"); break;
@@ -194,10 +195,11 @@ __global__ void __launch_bounds__(NTHR) conv_halo_kernel(HaloP p) {
         for (int q = 0; q < HL_MAX_CH; ++q) {
             if (q < p.nchunks) {
                 const int cur = q & 1;
+                lds_waith(af[cur][0]);
 #pragma unroll
-                for (int i = 0; i < TM; ++i) lds_waith(af[cur][i]);
+                for (int i = 1; i < TM; ++i) lds_tieh(af[cur][i]);
 #pragma unroll
-                for (int j = 0; j < TN; ++j) lds_waith(bf[cur][j]);
+                for (int j = 0; j < TN; ++j) lds_tieh(bf[cur][j]);
                 if (q + 1 < HL_MAX_CH && q + 1 < p.nchunks) {
 #pragma unroll
                     for (int i = 0; i < TM; ++i) af[cur ^ 1][i] = lds_read128h(a_off[q + 1 < HL_MAX_CH ? q + 1 : q][i] + sb);

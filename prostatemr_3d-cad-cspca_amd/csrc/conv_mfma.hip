@@ -51,6 +51,8 @@ __device__ __forceinline__ u32x4_t lds_read128(unsigned lds_addr) {
 }
 // all outstanding LDS reads have landed; tying the fragment makes its consumers wait behind this statement
 __device__ __forceinline__ void lds_wait(u32x4_t& v) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v)); }
+// no instruction: only orders the consumers of v behind the preceding (volatile) wait
+__device__ __forceinline__ void lds_tie(u32x4_t& v) { asm volatile("" : "+v"(v)); }
 __device__ __forceinline__ unsigned lds_addr_of(const void* p) { return (unsigned)(unsigned long long)(lptr_t)p; }
 
 // GLDS = true (every concat member a multiple of one 64-byte K-chunk): both operands go global -> LDS by LDS-DMA
@@ -59,6 +61,7 @@ __device__ __forceinline__ unsigned lds_addr_of(const void* p) { return (unsigne
 // side: the lane that owns LDS slot (row, s) fetches K-segment s ^ swz(row).
 template <typename T, int BM, int BN, int WM, int WN, int KC, bool GLDS>
 __global__ void __launch_bounds__(WM * WN * 64) conv_mfma_kernel(MfmaP p) {
+#if defined(__HIP_DEVICE_COMPILE__)      // (buffer-resource builtins do not exist in the host pass)
     constexpr int NTHR = WM * WN * 64, NW = WM * WN;        // 4 waves, or 8 for the 128x128 tile of the deep layers
     constexpr int SEG = MT<T>::SEG;
     constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
@@ -162,13 +165,40 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_mfma_kernel(MfmaP p) {
             }
         }
     };
+    // LDS-DMA variant: buffer loads -- the member tensor / weight panel is the resource, a lane keeps a 32-bit byte offset
+    // (2^31 = out of range: the hardware range check returns the zeros of the padding), the chunk offset is the scalar
+    // offset: no per-lane 64-bit address arithmetic in the loop
+    constexpr unsigned OOB = 0x80000000u;
+    unsigned st_vo[A_LD], b_vo[B_LD];
+    __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc((void*)p.src[0], 0, 0, 0x00020000);
+    auto st_set_tap_vo = [&]() {
+        const int tp = s_tap[st_tap];
+        const int dd = (signed char)(tp & 0xff), dh = (signed char)((tp >> 8) & 0xff), dw = (signed char)((tp >> 16) & 0xff);
+        const int sC = __builtin_amdgcn_readfirstlane(s_srcC[st_s]);
+#pragma unroll
+        for (int i = 0; i < A_LD; ++i) {
+            const int4 ri = rowinfo[lrow + (NTHR / 4) * i];
+            const int id = ri.y + dd, ih = ri.z + dh, iw = ri.w + dw;
+            const bool ok = ri.x >= 0 && (unsigned)id < (unsigned)p.ID && (unsigned)ih < (unsigned)p.IH && (unsigned)iw < (unsigned)p.IW;
+            const int vox = ((ri.x * p.ID + id) * p.IH + ih) * p.IW + iw;
+            st_vo[i] = ok ? (unsigned)((vox * sC + lseg * SEG) * (int)sizeof(T)) : OOB;
+        }
+        rs_a = __builtin_amdgcn_make_buffer_rsrc((void*)p.src[__builtin_amdgcn_readfirstlane(st_s)], 0, 0x7fffffff, 0x00020000);
+    };
+    if constexpr (GLDS) {
+#pragma unroll
+        for (int i = 0; i < B_LD; ++i) {
+            const int e = tid + NTHR * i;
+            b_vo[i] = (unsigned)(((oc0 + (e >> 2)) * kpad + lseg * SEG) * (int)sizeof(T));
+        }
+    }
     if (p.aligned && nchunks > 0) {
         const int cpt = spt >> 2;                          // chunks per tap
         st_tap = c_beg / cpt;
         int c = (c_beg - st_tap * cpt) * 4 * SEG;
         while (c >= s_srcC[st_s]) { c -= s_srcC[st_s]; ++st_s; }
         st_c = c;
-        st_set_tap();
+        if constexpr (GLDS) st_set_tap_vo(); else st_set_tap();
     }
 
     // loads the KC chunks of pipeline stage `sg` into registers (zero beyond this block's K range)
@@ -230,32 +260,29 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_mfma_kernel(MfmaP p) {
     };
     // LDS-DMA: issue the KC chunks of stage `sg` straight into pipeline buffer `buf`
     auto issue = [&](int sg, int buf) {
+        const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc((void*)wp, 0, 0x7fffffff, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_0 = __builtin_amdgcn_make_buffer_rsrc((void*)wp, 0, 0, 0x00020000);     // all lanes out of range
 #pragma unroll
         for (int kc = 0; kc < KC; ++kc) {
             const int rel = sg * KC + kc;
             const int chunk = c_beg + rel;
             const bool live = rel < nchunks;
+            const __amdgpu_buffer_rsrc_t rb = live ? rs_b : rs_0, ra = live ? rs_a : rs_0;
 #pragma unroll
-            for (int i = 0; i < B_LD; ++i) {
-                const int e = tid + NTHR * i;                 // LDS slot (row, s) = (e>>2, e&3)
-                if ((wave_u + NW * i) * 64 < BN * 4) {        // wave-uniform
-                    const unsigned char* src = live
-                        ? reinterpret_cast<const unsigned char*>(wp + (long long)(oc0 + (e >> 2)) * kpad + (long long)(chunk * 4 + lseg) * SEG)
-                        : zero_pg;
-                    glds16(src, B_s + (buf * KC + kc) * B_BYTES + (wave_u + NW * i) * 1024);
-                }
-            }
+            for (int i = 0; i < B_LD; ++i)
+                if ((wave_u + NW * i) * 64 < BN * 4)          // wave-uniform
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lptr_t)(B_s + (buf * KC + kc) * B_BYTES + (wave_u + NW * i) * 1024), 16,
+                                                             b_vo[i], chunk * 64, 0, 0);
 #pragma unroll
-            for (int i = 0; i < A_LD; ++i) {
-                const unsigned char* src = (live && st_ptr[i]) ? reinterpret_cast<const unsigned char*>(st_ptr[i] + st_c) : zero_pg;
-                glds16(src, A_s + (buf * KC + kc) * A_BYTES + (wave_u + NW * i) * 1024);
-            }
+            for (int i = 0; i < A_LD; ++i)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lptr_t)(A_s + (buf * KC + kc) * A_BYTES + (wave_u + NW * i) * 1024), 16,
+                                                         st_vo[i], st_c * (int)sizeof(T), 0, 0);
             if (live) {
                 st_c += 4 * SEG;
                 if (st_c >= s_srcC[st_s]) {
                     st_c = 0;
                     if (++st_s == p.nsrc) { st_s = 0; ++st_tap; }
-                    if (st_tap < ntaps) st_set_tap();
+                    if (st_tap < ntaps) st_set_tap_vo();
                 }
             }
         }
@@ -306,10 +333,11 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_mfma_kernel(MfmaP p) {
             rd(0);
 #pragma unroll
             for (int kc = 0; kc < KC; ++kc) {
+                lds_wait(af[kc][0]);                       // one s_waitcnt for the whole chunk, the other fragments are tied to it
 #pragma unroll
-                for (int i = 0; i < TM; ++i) lds_wait(af[kc][i]);
+                for (int i = 1; i < TM; ++i) lds_tie(af[kc][i]);
 #pragma unroll
-                for (int j = 0; j < TN; ++j) lds_wait(bfr[kc][j]);
+                for (int j = 0; j < TN; ++j) lds_tie(bfr[kc][j]);
                 if (kc + 1 < KC) rd(kc + 1);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -441,6 +469,7 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_mfma_kernel(MfmaP p) {
             *reinterpret_cast<uint4*>(dst) = v;
         }
     }
+#endif
 }
 
 template <typename T, int BM, int BN, int KC, int NTHR>
@@ -699,6 +728,9 @@ static int run_mfma(const GatherSpec& g, void* ws, int ws_packed, hipStream_t st
     bool fuse_stats = g.stats_out && g.stats_ws && g.mode == 0 && pl.ksplit == 1 && (g.N == 1 || Vout % bm_eff == 0);
     if (fuse_stats) { mp.stat_partial = g.stats_ws; mp.stat_tiles = (int)cdiv_ll(Vout, bm_eff); }
     for (int i = 0; i < g.nsrc; ++i) if (g.srcC[i] % (4 * SEG)) mp.aligned = 0;
+    for (int i = 0; i < g.nsrc; ++i)          // the LDS-DMA loader addresses a member with 31-bit byte offsets
+        if ((long long)g.N * g.ID * g.IH * g.IW * g.srcC[i] * (long long)sizeof(T) >= (1ll << 31) - 4096) mp.aligned = 0;
+    if (tot * (long long)sizeof(T) >= (1ll << 31) - 4096) mp.aligned = 0;
     if (pl.ksplit > 1) {
         const size_t wbytes = ((size_t)tot * sizeof(T) + 255) / 256 * 256;
         mp.acc32 = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(panel) + wbytes);
