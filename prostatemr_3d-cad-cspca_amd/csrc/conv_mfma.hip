@@ -259,31 +259,38 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_mfma_kernel(MfmaP p) {
         }
     };
     // LDS-DMA: issue the KC chunks of stage `sg` straight into pipeline buffer `buf`
+    const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc((void*)wp, 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_0 = __builtin_amdgcn_make_buffer_rsrc((void*)wp, 0, 0, 0x00020000);     // all lanes out of range
+    auto issue_chunk = [&](int kc, int buf, int chunk, const __amdgpu_buffer_rsrc_t ra, const __amdgpu_buffer_rsrc_t rb) {
+#pragma unroll
+        for (int i = 0; i < B_LD; ++i)
+            if ((NW * (i + 1)) * 64 <= BN * 4 || (wave_u + NW * i) * 64 < BN * 4)      // compile-time true for full rounds, else wave-uniform
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lptr_t)(B_s + (buf * KC + kc) * B_BYTES + (wave_u + NW * i) * 1024), 16,
+                                                         b_vo[i], chunk * 64, 0, 0);
+#pragma unroll
+        for (int i = 0; i < A_LD; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lptr_t)(A_s + (buf * KC + kc) * A_BYTES + (wave_u + NW * i) * 1024), 16,
+                                                     st_vo[i], st_c * (int)sizeof(T), 0, 0);
+    };
+    auto advance_chunk = [&]() {
+        st_c += 4 * SEG;
+        if (st_c >= s_srcC[st_s]) {
+            st_c = 0;
+            if (++st_s == p.nsrc) { st_s = 0; ++st_tap; }
+            if (st_tap < ntaps) st_set_tap_vo();
+        }
+    };
     auto issue = [&](int sg, int buf) {
-        const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc((void*)wp, 0, 0x7fffffff, 0x00020000);
-        const __amdgpu_buffer_rsrc_t rs_0 = __builtin_amdgcn_make_buffer_rsrc((void*)wp, 0, 0, 0x00020000);     // all lanes out of range
+        const int rel0 = sg * KC;
+        if (rel0 + KC <= nchunks) {                        // every chunk of the stage is inside the K range (all but the last stage)
 #pragma unroll
-        for (int kc = 0; kc < KC; ++kc) {
-            const int rel = sg * KC + kc;
-            const int chunk = c_beg + rel;
-            const bool live = rel < nchunks;
-            const __amdgpu_buffer_rsrc_t rb = live ? rs_b : rs_0, ra = live ? rs_a : rs_0;
+            for (int kc = 0; kc < KC; ++kc) { issue_chunk(kc, buf, c_beg + rel0 + kc, rs_a, rs_b); advance_chunk(); }
+        } else {
 #pragma unroll
-            for (int i = 0; i < B_LD; ++i)
-                if ((wave_u + NW * i) * 64 < BN * 4)          // wave-uniform
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lptr_t)(B_s + (buf * KC + kc) * B_BYTES + (wave_u + NW * i) * 1024), 16,
-                                                             b_vo[i], chunk * 64, 0, 0);
-#pragma unroll
-            for (int i = 0; i < A_LD; ++i)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lptr_t)(A_s + (buf * KC + kc) * A_BYTES + (wave_u + NW * i) * 1024), 16,
-                                                         st_vo[i], st_c * (int)sizeof(T), 0, 0);
-            if (live) {
-                st_c += 4 * SEG;
-                if (st_c >= s_srcC[st_s]) {
-                    st_c = 0;
-                    if (++st_s == p.nsrc) { st_s = 0; ++st_tap; }
-                    if (st_tap < ntaps) st_set_tap_vo();
-                }
+            for (int kc = 0; kc < KC; ++kc) {
+                const bool live = rel0 + kc < nchunks;
+                issue_chunk(kc, buf, c_beg + rel0 + kc, live ? rs_a : rs_0, live ? rs_b : rs_0);
+                if (live) advance_chunk();
             }
         }
     };
