@@ -83,6 +83,7 @@ __device__ __forceinline__ void wait_vm(int n) {
 
 template <int KD, int KH, int KW, int KPARTS, int TF_NKS>
 __global__ void __launch_bounds__(256) wgrad_tf_kernel(TfP p) {
+#if defined(__HIP_DEVICE_COMPILE__)      // (buffer-resource builtins do not exist in the host pass)
     constexpr int NT = KD * KH * KW, NG = KD * KH;           // taps; tap groups (the KW taps of one (kd,kh) share a row offset)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -99,7 +100,9 @@ __global__ void __launch_bounds__(256) wgrad_tf_kernel(TfP p) {
 
     // ---- per-lane description of its LDS-DMA pieces (the same for every K-tile).  Every wave issues nait + 1 pieces
     //      per stage (tiles padded to whole 256-slot rounds, padding fetches the zero page): static vmcnt arithmetic ----
-    int a_rel[TF_MAX_AIT], a_pk[TF_MAX_AIT], a_sl[TF_MAX_AIT];
+    // (buffer loads: tile origin in the resource base, constant 32-bit lane offsets, 2^31 = out of range -> zeros)
+    constexpr unsigned OOB = 0x80000000u;
+    unsigned a_vo[TF_MAX_AIT]; int a_pk[TF_MAX_AIT];
     const int nait = p.a_slots >> 8;
 #pragma unroll
     for (int it = 0; it < TF_MAX_AIT; ++it) {
@@ -110,20 +113,20 @@ __global__ void __launch_bounds__(256) wgrad_tf_kernel(TfP p) {
         // 64-byte rows: the two 32-byte halves of a row swap when bit 3 of the tile column is set -- lane groups 0/1 of a
         // transpose read sit 8 columns apart and would otherwise hit the same banks
         const int sl = p.spra == 4 ? (slp ^ (((ww >> 3) & 1) << 1)) : slp;
-        a_rel[it] = (dd * p.AH + hh) * p.AW + ww;
-        a_pk[it] = (row < KD * p.AHt * p.AWt) ? (dd | (hh << 8) | (ww << 16)) : -1;
-        a_sl[it] = sl * 8;
+        a_pk[it] = dd | (hh << 8) | (ww << 16);
+        a_vo[it] = (row < KD * p.AHt * p.AWt) ? (unsigned)((((dd * p.AH + hh) * p.AW + ww) * p.CA + a0 + sl * 8) * 2) : OOB;
     }
     constexpr int NBIT = (TF_NKS * 32 * 4 + 255) / 256;      // LDS-DMA pieces per thread for the B tile (max)
     const int nbit = (p.b_slots + 255) >> 8;
-    int b_th[NBIT], b_tw[NBIT], b_sl[NBIT]; bool b_on[NBIT];
+    unsigned b_vo[NBIT]; int b_th[NBIT];
 #pragma unroll
     for (int it = 0; it < NBIT; ++it) {
         const int q = it * 256 + tid;
         const int row = q / p.sprb, slp = q - row * p.sprb;
-        b_on[it] = q < p.b_slots;
-        b_th[it] = row / p.KWs; b_tw[it] = row - b_th[it] * p.KWs;
-        b_sl[it] = (p.sprb == 4 ? (slp ^ (((b_tw[it] >> 3) & 1) << 1)) : slp) * 8;
+        const int th = row / p.KWs, tw = row - th * p.KWs;
+        const int sl = p.sprb == 4 ? (slp ^ (((tw >> 3) & 1) << 1)) : slp;
+        b_th[it] = th;
+        b_vo[it] = q < p.b_slots ? (unsigned)(((th * p.BW + tw) * p.CB + b0 + sl * 8) * 2) : OOB;
     }
 
     // tile counter of the NEXT tile to issue, decoded incrementally (no divisions in the loop)
@@ -140,32 +143,35 @@ __global__ void __launch_bounds__(256) wgrad_tf_kernel(TfP p) {
         q_bd += s_bd + c; c = q_bd >= p.BD; q_bd -= c ? p.BD : 0;
         q_n += s_n + c;
         const int ad0 = bd * p.sd - p.pd, ah0 = thi * p.TH * p.sh - p.ph, aw0 = twi * p.KWs * p.sw - p.pw;
-        const int lin0 = ((n * p.AD + ad0) * p.AH + ah0) * p.AW + aw0;
+        const long long lin0 = (((long long)n * p.AD + ad0) * p.AH + ah0) * p.AW + aw0;
+        const int bh0 = thi * p.TH;
+        const long long blin0 = (((long long)n * p.BD + bd) * p.BH + bh0) * p.BW + twi * p.KWs;
         unsigned char* As = smem + st * stage_bytes;
         unsigned char* Bs = As + p.a_bytes;
+        const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)(p.A + lin0 * p.CA), 0, live ? 0x7fffffff : 0, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)(p.B + blin0 * p.CB), 0, live ? 0x7fffffff : 0, 0x00020000);
+        const bool a_inner = ad0 >= 0 && ad0 + KD - 1 < p.AD && ah0 >= 0 && ah0 + p.AHt - 1 < p.AH && aw0 >= 0 && aw0 + p.AWt - 1 < p.AW;
+        if (a_inner) {                                     // uniform: no per-lane work
 #pragma unroll
-        for (int it = 0; it < TF_MAX_AIT; ++it) {
-            if (it < nait) {
-                const int pk = a_pk[it];
-                const int dd = pk & 0xff, hh = (pk >> 8) & 0xff, ww = (pk >> 16) & 0xff;
-                const bool ok = live && pk >= 0 && (unsigned)(ad0 + dd) < (unsigned)p.AD && (unsigned)(ah0 + hh) < (unsigned)p.AH &&
-                                (unsigned)(aw0 + ww) < (unsigned)p.AW;
-                const long long real = (long long)(p.A + (long long)(lin0 + a_rel[it]) * p.CA + a0 + a_sl[it]);
-                const long long zp = (long long)zero_pg;                 // branch-free select
-                const unsigned char* src = reinterpret_cast<const unsigned char*>(zp + ((real - zp) & -(long long)ok));
-                glds16w(src, As + (it * 256 + wave * 64) * 16);
+            for (int it = 0; it < TF_MAX_AIT; ++it)
+                if (it < nait) __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lptr_t)(As + (it * 256 + wave * 64) * 16), 16, a_vo[it], 0, 0, 0);
+        } else {
+#pragma unroll
+            for (int it = 0; it < TF_MAX_AIT; ++it) {
+                if (it < nait) {
+                    const int pk = a_pk[it];
+                    const int dd = pk & 0xff, hh = (pk >> 8) & 0xff, ww = (pk >> 16) & 0xff;
+                    const bool ok = (unsigned)(ad0 + dd) < (unsigned)p.AD && (unsigned)(ah0 + hh) < (unsigned)p.AH && (unsigned)(aw0 + ww) < (unsigned)p.AW;
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lptr_t)(As + (it * 256 + wave * 64) * 16), 16, ok ? a_vo[it] : OOB, 0, 0, 0);
+                }
             }
         }
+        const bool b_inner = bh0 + p.TH <= p.BH;
 #pragma unroll
-        for (int it = 0; it < NBIT; ++it) {
-            if (it < nbit) {
-                const int bh = thi * p.TH + b_th[it];
-                const bool ok = live && b_on[it] && bh < p.BH;
-                const long long lin = (((long long)n * p.BD + bd) * p.BH + bh) * p.BW + twi * p.KWs + b_tw[it];
-                const unsigned char* src = ok ? reinterpret_cast<const unsigned char*>(p.B + lin * p.CB + b0 + b_sl[it]) : zero_pg;
-                glds16w(src, Bs + (it * 256 + wave * 64) * 16);
-            }
-        }
+        for (int it = 0; it < NBIT; ++it)
+            if (it < nbit)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lptr_t)(Bs + (it * 256 + wave * 64) * 16), 16,
+                                                         (b_inner || bh0 + b_th[it] < p.BH) ? b_vo[it] : OOB, 0, 0, 0);
     };
 
     // ---- fragment read addresses: lane (g = lane>>4, i = lane&15) supplies voxel 8g + 4h + (i>>2), 8-byte piece i&3 ----
@@ -261,6 +267,7 @@ __global__ void __launch_bounds__(256) wgrad_tf_kernel(TfP p) {
             const int a = a0 + ta * 16 + g * 4 + r;
             if ((t % kparts) == part && a < p.CA && b < p.CB) Rx[(long long)t * p.RT + (long long)(a + p.a_off) * p.RSA + (b + p.b_off)] = acc[t][r];
         }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------
