@@ -280,7 +280,7 @@ __global__ void __launch_bounds__(256) wgrad_tf_kernel(TfP p) {
 #define TF64_MAX_AIT 6
 __device__ __forceinline__ int tf64_f(int col) { return ((col >> 1) & 1) | (((col >> 3) & 1) << 1); }   // 32-byte piece XOR (bank spread)
 
-__global__ void __launch_bounds__(256) wgrad_tf64_kernel(TfP p) {
+__global__ void __launch_bounds__(256, 2) wgrad_tf64_kernel(TfP p) {
     constexpr int NKS = 2, KH = 3, KW = 3, NT9 = 9;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
