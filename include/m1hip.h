@@ -123,6 +123,18 @@ int m1_se_gate_fwd(const float* beta3, const float* W6, const float* b6, const f
 int m1_se_gate_bwd(const float* beta3, const float* W6, const float* W7, const float* hidden, const float* g,
                    const float* dg, int F, int Fr, float* dbeta3_add, float* dW6, float* db6, float* dW7,
                    float* db7, int accumulate, void* stream);
+/* The gate backward yields parameter gradients only (nothing on the data-gradient chain waits for it): a caller may
+ * collect the jobs of a whole backward pass and run them in two launches.  Same arguments as m1_se_gate_bwd.  Jobs
+ * that name the same destination buffers (one SE block evaluated by several passes of the cores) must have
+ * accumulate = 1; they are applied one after the other in array order, so the sums are run-to-run identical. */
+#define M1_SE_GATE_BATCH 16
+typedef struct {
+    const float* beta3; const float* W6; const float* W7; const float* hidden; const float* g;
+    float* dg;                 /* the F + Fr scratch of m1_se_combine_bwd (must stay alive until the batch has run) */
+    float* dbeta3_add; float* dW6; float* db6; float* dW7; float* db7;
+    int F, Fr, accumulate, _pad;
+} m1_se_gate_job_t;
+int m1_se_gate_bwd_batch(const m1_se_gate_job_t* jobs /* host array */, int njobs, void* stream);
 /* out = dropout( lrelu( IN3(y3) * g * IN4(y4) ) ); y3,y4 raw conv outputs (N,V,F); stats3/4 (N,F,2).
  * Dropout state is DEVICE resident so a captured graph can be replayed: rng[0] = seed, rng[1] = step
  * counter (advanced by m1_step_advance); layer_id separates the streams of different layers. The mask is

@@ -71,7 +71,7 @@ __device__ __forceinline__ void block_matvec_rows(const float* __restrict__ W, c
 
 // backward, phase A (one block): dgpre = dg*g*(1-g) -> db7; dhid = (W7 dgpre) * lrelu'(hidden) -> db6.
 // dgpre overwrites dg (scratch), dhid goes to dg[F .. F+Fr) -- the caller sizes dg as F + Fr floats.
-__global__ void __launch_bounds__(256) se_gate_bwd_a_kernel(const float* __restrict__ W7, const float* __restrict__ hidden,
+__device__ __forceinline__ void se_gate_bwd_a_body(const float* __restrict__ W7, const float* __restrict__ hidden,
                                                             const float* __restrict__ g, float* __restrict__ dg, int F, int Fr,
                                                             float* __restrict__ db6, float* __restrict__ db7, int acc) {
     __shared__ float dgp_s[SE_MAX_F];
@@ -88,12 +88,16 @@ __global__ void __launch_bounds__(256) se_gate_bwd_a_kernel(const float* __restr
         dg[F + j] = dhid; db6[j] = (acc ? db6[j] : 0.f) + dhid;
     }
 }
+__global__ void __launch_bounds__(256) se_gate_bwd_a_kernel(const float* __restrict__ W7, const float* __restrict__ hidden,
+                                                            const float* __restrict__ g, float* __restrict__ dg, int F, int Fr,
+                                                            float* __restrict__ db6, float* __restrict__ db7, int acc) {
+    se_gate_bwd_a_body(W7, hidden, g, dg, F, Fr, db6, db7, acc);
+}
 // phase B (F*Fr threads): the two outer products and dbeta3 += W6 dhid
-__global__ void __launch_bounds__(256) se_gate_bwd_b_kernel(const float* __restrict__ beta3, const float* __restrict__ W6,
-                                                            const float* __restrict__ hidden, const float* __restrict__ dg,
-                                                            int F, int Fr, float* __restrict__ dbeta3_add,
-                                                            float* __restrict__ dW6, float* __restrict__ dW7, int acc) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
+__device__ __forceinline__ void se_gate_bwd_b_body(int i, const float* __restrict__ beta3, const float* __restrict__ W6,
+                                                   const float* __restrict__ hidden, const float* __restrict__ dg,
+                                                   int F, int Fr, float* __restrict__ dbeta3_add,
+                                                   float* __restrict__ dW6, float* __restrict__ dW7, int acc) {
     if (i >= F * Fr) return;
     {   // dW7[j][c] = h[j] * dgpre[c]
         const int j = i / F, c = i % F;
@@ -108,6 +112,56 @@ __global__ void __launch_bounds__(256) se_gate_bwd_b_kernel(const float* __restr
         for (int j = 0; j < Fr; ++j) s = fmaf(W6[(size_t)i * Fr + j], dg[F + j], s);
         dbeta3_add[i] += s;
     }
+}
+
+__global__ void __launch_bounds__(256) se_gate_bwd_b_kernel(const float* __restrict__ beta3, const float* __restrict__ W6,
+                                                            const float* __restrict__ hidden, const float* __restrict__ dg,
+                                                            int F, int Fr, float* __restrict__ dbeta3_add,
+                                                            float* __restrict__ dW6, float* __restrict__ dW7, int acc) {
+    se_gate_bwd_b_body(blockIdx.x * 256 + threadIdx.x, beta3, W6, hidden, dg, F, Fr, dbeta3_add, dW6, dW7, acc);
+}
+// batched variants: blockIdx.y = job (the gate backward produces parameter gradients only, so the caller may collect the
+// jobs of a whole backward pass and run them with two launches instead of two per SE block).  Jobs that accumulate into
+// the same destination (one SE block used by several passes of the cores) form a chain that ONE block column walks in
+// order: no two blocks read-modify-write the same gradient, and the sum order is fixed.
+struct SeGateBatch { m1_se_gate_job_t job[M1_SE_GATE_BATCH]; signed char next[M1_SE_GATE_BATCH]; unsigned char head[M1_SE_GATE_BATCH]; };
+__global__ void __launch_bounds__(256) se_gate_bwd_a_batch_kernel(SeGateBatch b) {
+    if (!b.head[blockIdx.y]) return;
+    for (int q = blockIdx.y; q >= 0; q = b.next[q]) {
+        const m1_se_gate_job_t& j = b.job[q];
+        se_gate_bwd_a_body(j.W7, j.hidden, j.g, j.dg, j.F, j.Fr, j.db6, j.db7, j.accumulate);
+        __syncthreads();
+    }
+}
+__global__ void __launch_bounds__(256) se_gate_bwd_b_batch_kernel(SeGateBatch b) {
+    if (!b.head[blockIdx.y]) return;
+    for (int q = blockIdx.y; q >= 0; q = b.next[q]) {
+        const m1_se_gate_job_t& j = b.job[q];
+        se_gate_bwd_b_body(blockIdx.x * 256 + threadIdx.x, j.beta3, j.W6, j.hidden, j.dg, j.F, j.Fr, j.dbeta3_add, j.dW6, j.dW7, j.accumulate);
+    }
+}
+extern "C" int m1_se_gate_bwd_batch(const m1_se_gate_job_t* jobs, int njobs, void* stream) {
+    if (njobs < 0 || (njobs > 0 && !jobs)) return M1_ERR_BAD_ARG;
+    for (int j0 = 0; j0 < njobs; j0 += M1_SE_GATE_BATCH) {
+        SeGateBatch b{}; int n = njobs - j0 < M1_SE_GATE_BATCH ? njobs - j0 : M1_SE_GATE_BATCH, maxffr = 0;
+        for (int q = 0; q < n; ++q) {
+            const m1_se_gate_job_t& j = jobs[j0 + q];
+            if (!j.beta3 || !j.W6 || !j.W7 || !j.hidden || !j.g || !j.dg || !j.dbeta3_add || !j.dW6 || !j.db6 || !j.dW7 || !j.db7) return M1_ERR_BAD_ARG;
+            if (j.F <= 0 || j.Fr <= 0 || j.F > SE_MAX_F || j.Fr > SE_MAX_FR) return M1_ERR_UNSUPPORTED;
+            b.job[q] = j; b.next[q] = -1; b.head[q] = 1;
+            if (j.F * j.Fr > maxffr) maxffr = j.F * j.Fr;
+            for (int r = q - 1; r >= 0; --r) {           // same destination as an earlier job: append to its chain
+                const m1_se_gate_job_t& e = b.job[r];
+                if (e.dW6 == j.dW6 || e.dW7 == j.dW7 || e.db6 == j.db6 || e.db7 == j.db7 || e.dbeta3_add == j.dbeta3_add) {
+                    if (e.F != j.F || e.Fr != j.Fr || !j.accumulate) return M1_ERR_BAD_ARG;
+                    b.next[r] = (signed char)q; b.head[q] = 0; break;
+                }
+            }
+        }
+        hipLaunchKernelGGL(se_gate_bwd_a_batch_kernel, dim3(1, n), dim3(256), 0, (hipStream_t)stream, b);
+        hipLaunchKernelGGL(se_gate_bwd_b_batch_kernel, dim3((maxffr + 255) / 256, n), dim3(256), 0, (hipStream_t)stream, b);
+    }
+    return m1_check_launch();
 }
 
 extern "C" int m1_se_gate_fwd(const float* beta3, const float* W6, const float* b6, const float* W7, const float* b7,

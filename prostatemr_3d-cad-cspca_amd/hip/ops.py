@@ -304,6 +304,26 @@ def instnorm_act(x, gamma, beta, slope: float = 1.0, stats=None):
 # ---------------------------------------------------------------------------------------------------------
 # SE gate + multiplicative combine (+ fused dropout)
 # ---------------------------------------------------------------------------------------------------------
+_SE_DEFER: list = []      # (m1_se_gate_job_t, tensors kept alive) queued by _SECombine.backward in gradient-sink mode
+
+
+def flush_deferred() -> None:
+    """Run the queued SE gate backwards (m1_se_gate_bwd_batch).  optim.FlatParams.gather_grads calls this before anything
+    reads the flat gradient buffer; the tensors the jobs point at are held until the launch is enqueued."""
+    if not _SE_DEFER:
+        return
+    jobs = (L.SeGateJob * len(_SE_DEFER))(*[j for j, _ in _SE_DEFER])
+    try:
+        L.check(L.load().m1_se_gate_bwd_batch(jobs, len(_SE_DEFER), _stream()), "m1_se_gate_bwd_batch")
+    finally:
+        _SE_DEFER.clear()
+
+
+def drop_deferred() -> None:
+    """Forget queued jobs of a backward pass whose gradients are being discarded (optimiser zero_grad)."""
+    _SE_DEFER.clear()
+
+
 class _SECombine(torch.autograd.Function):
     @staticmethod
     def forward(ctx, y3, y4, g3, b3, g4, b4, W6, b6, W7, b7, drop_rate, rng, layer_id, s3, s4):
@@ -348,8 +368,15 @@ class _SECombine(torch.autograd.Function):
         L.check(lib.m1_se_combine_bwd(_p(y3), _p(y4), _p(s3), _p(s4), _p(g3), _p(b3), _p(g4), _p(b4), _p(g), _p(dout),
                                       _p(dy3), _p(dy4), _p(bg3), _p(bb3), _p(bg4), _p(bb4), _p(dg), N, V, Fn, _dt(y3),
                                       ctx.drop_rate, _p(ctx.rng), ctx.layer_id, _p(ws), acc, st), "m1_se_combine_bwd")
-        L.check(lib.m1_se_gate_bwd(_p(b3), _p(W6), _p(W7), _p(hidden), _p(g), _p(dg), Fn, Fr, _p(bb3), _p(bW6), _p(bb6),
-                                   _p(bW7), _p(bb7), acc, st), "m1_se_gate_bwd")
+        if acc == 1:
+            # parameter gradients only, accumulated into the optimiser's flat buffer: nothing downstream in this backward
+            # reads them, so the job is queued and all SE blocks' gate backwards run as one batch (flush_deferred)
+            job = L.SeGateJob(_p(b3), _p(W6), _p(W7), _p(hidden), _p(g), _p(dg), _p(bb3), _p(bW6), _p(bb6), _p(bW7), _p(bb7),
+                              Fn, Fr, 1, 0)
+            _SE_DEFER.append((job, (b3, W6, W7, hidden, g, dg)))
+        else:
+            L.check(lib.m1_se_gate_bwd(_p(b3), _p(W6), _p(W7), _p(hidden), _p(g), _p(dg), Fn, Fr, _p(bb3), _p(bW6), _p(bb6),
+                                       _p(bW7), _p(bb7), acc, st), "m1_se_gate_bwd")
         return dy3, dy4, rg3, rb3, rg4, rb4, rW6, rb6, rW7, rb7, None, None, None, None, None
 
 

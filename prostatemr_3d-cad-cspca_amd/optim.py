@@ -67,11 +67,14 @@ class FlatParams:
 
     def zero_grad(self):
         """One memset of the flat gradient buffer (the kernels accumulate into it during backward)."""
+        ops.drop_deferred()
         self.grad.zero_()
 
     def gather_grads(self):
-        """Fold in gradients that reached a parameter through autograd's own .grad (a parameter used by a torch op
-        instead of a HIP kernel); the HIP path never takes this branch."""
+        """Complete the flat gradient buffer: run the parameter-gradient jobs the backward queued (ops.flush_deferred),
+        then fold in gradients that reached a parameter through autograd's own .grad (a parameter used by a torch op
+        instead of a HIP kernel); the HIP path never takes that second branch."""
+        ops.flush_deferred()
         for p, gv in zip(self.params, self.gviews):
             if p.grad is not None:
                 gv.add_(p.grad)

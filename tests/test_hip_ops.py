@@ -171,6 +171,43 @@ def test_se_combine_fwd_bwd(dev, dtype, F_, red, V):
         assert rel_err(a.grad, b) < tol * 3, n
 
 
+def test_se_gate_backward_deferred_batch_matches_direct(dev):
+    """Gradient-sink mode queues the SE gate backwards and runs them as one m1_se_gate_bwd_batch at flush_deferred();
+    the sums in the sinks must equal the immediate per-block path (two passes accumulate, like prior+posterior)."""
+    cfgs = [(16, 8, (3, 6, 5)), (32, 4, (2, 8, 8)), (64, 8, (2, 4, 4))]
+
+    def make(F_, red, V, seed):
+        shp = (2, *V, F_)
+        ts = [rnd(shp, seed + 1), rnd(shp, seed + 2) * 1.5 + 0.2, 1 + 0.2 * rnd((F_,), seed + 3), 0.5 * rnd((F_,), seed + 4),
+              1 + 0.2 * rnd((F_,), seed + 5), 0.5 * rnd((F_,), seed + 6), rnd((1, 1, 1, F_, F_ // red), seed + 7, 0.5),
+              0.1 * rnd((F_ // red,), seed + 8), rnd((1, 1, 1, F_ // red, F_), seed + 9, 0.5), 0.1 * rnd((F_,), seed + 10)]
+        return [t.to(dev).requires_grad_(True) for t in ts], rnd(shp, seed + 11).to(dev)
+
+    direct, sinks = [], []
+    for k, (F_, red, V) in enumerate(cfgs):
+        ins, dout = make(F_, red, V, 100 * k)
+        for _ in range(2):
+            ops.se_combine(*ins).backward(dout)
+        direct.append([t.grad.clone() for t in ins[2:]])
+    assert not ops._SE_DEFER
+    for k, (F_, red, V) in enumerate(cfgs):
+        ins, dout = make(F_, red, V, 100 * k)
+        bufs = []
+        for t in ins[2:]:
+            t._m1_gsink = torch.zeros_like(t, dtype=torch.float32)
+            bufs.append(t._m1_gsink)
+        for _ in range(2):
+            ops.se_combine(*ins).backward(dout)
+        assert all(t.grad is None for t in ins[2:])
+        sinks.append(bufs)
+    assert len(ops._SE_DEFER) == 2 * len(cfgs)
+    ops.flush_deferred()
+    assert not ops._SE_DEFER
+    for d, s_ in zip(direct, sinks):
+        for a, b in zip(d, s_):
+            assert rel_err(b, a) < 1e-5
+
+
 def test_se_gate_is_half_at_zero_bias_init(dev):
     """KAT-3: GAP(IN(x)) = beta => with beta=0 and zero FC biases the gate is exactly 0.5."""
     F_ = 16
