@@ -196,6 +196,17 @@ int m1_softmax_heads_fwd(const m1_head_t* heads, int nheads, float* probs, int N
 int m1_softmax_heads_bwd(const m1_head_t* heads, int nheads, const float* probs, const float* dprobs, int N,
                          int D, int H, int W, int nc, int dtype, void* stream);
 
+/* ---- Focal loss on the softmax heads : losses.py:32-49 (FL: renormalise, clip [1e-7, 1-1e-7], -y log p, * y (1-p)^gamma,
+ * * alpha, sum over D,H,W,C, mean over the batch; loss(): mean over the y_pred.shape[-1] / nc heads) ----
+ * probs (N,V,nheads*nc) fp32 as written by m1_softmax_heads_fwd; y_true (N,V,nc) fp32 or bf16; alpha: nc HOST floats.
+ * fwd: ws of m1_focal_ws_floats floats (per-block partials, folded in a fixed order); loss: 1 device float.
+ * bwd: dprobs = dloss[0] * dLoss/dprobs (dloss: 1 device float, e.g. autograd's incoming gradient). */
+size_t m1_focal_ws_floats(int N, long long V, int nheads);
+int m1_focal_fwd(const float* probs, const void* y_true, int y_dtype, const float* alpha, float gamma, int N, long long V,
+                 int nheads, int nc, float* ws, float* loss, void* stream);
+int m1_focal_bwd(const float* probs, const void* y_true, int y_dtype, const float* alpha, float gamma, int N, long long V,
+                 int nheads, int nc, const float* dloss, float* dprobs, void* stream);
+
 /* ---- MonteCarloDropout / Dropout : B:142-143 ; N:462-463 (Philox4x32-10, mask regenerated in bwd) ---- */
 int m1_dropout(const void* x, void* y, long long n, float rate, const uint64_t* rng, uint64_t layer_id, int dtype,
                void* stream);

@@ -107,6 +107,132 @@ __global__ void dropout_kernel(const T* __restrict__ x, T* __restrict__ y, long 
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
         Act<T>::st(y + i, philox_keep(seed, base, (uint64_t)i, rate) ? Act<T>::ld(x + i) * sc : 0.f);
 }
+// ---------------------------------------------------------------------------------------------------------
+// Focal loss on the softmax heads (losses.py:32-49): per head h of nc classes at each voxel
+//   s = sum_c p_c ; q_c = clip(p_c / s, eps, 1-eps) ; fl = sum_c alpha_c * y_c^2 * (1-q_c)^gamma * (-log q_c)
+//   loss = mean_h mean_n sum_voxels fl
+// forward: per-(block, head) partial sums, folded in a fixed order by one block (run-to-run identical);
+// backward: dL/dp_k = go/(N*heads) * ( g_k/s - sum_c g_c p_c / s^2 ), g_c = alpha_c y_c^2 f'(q_c) inside the clip range,
+//   f'(q) = gamma (1-q)^(gamma-1) log q - (1-q)^gamma / q.
+// ---------------------------------------------------------------------------------------------------------
+#define FOCAL_EPS 1e-7f
+struct FocalP {
+    const float* probs; const void* y; float alpha[MAX_NC];
+    long long NV, V; int nheads, nc, N, ydt; float gamma;
+};
+template <typename TY> __device__ __forceinline__ float focal_ld_y(const void* y, long long i);
+template <> __device__ __forceinline__ float focal_ld_y<float>(const void* y, long long i) { return ((const float*)y)[i]; }
+template <> __device__ __forceinline__ float focal_ld_y<unsigned short>(const void* y, long long i) {
+    return __uint_as_float((unsigned)((const unsigned short*)y)[i] << 16);
+}
+__device__ __forceinline__ float focal_pow(float b, float e) { return e == 2.f ? b * b : (e == 1.f ? b : (e == 0.f ? 1.f : powf(b, e))); }
+
+template <typename TY>
+__global__ void __launch_bounds__(256) focal_fwd_kernel(FocalP p, float* __restrict__ partial) {
+    float acc[MAX_HEADS];
+    for (int h = 0; h < MAX_HEADS; ++h) acc[h] = 0.f;
+    const int n = blockIdx.y;
+    for (long long v = (long long)blockIdx.x * 256 + threadIdx.x; v < p.V; v += (long long)gridDim.x * 256) {
+        const long long gv = (long long)n * p.V + v;
+        float y[MAX_NC];
+        for (int c = 0; c < p.nc; ++c) y[c] = focal_ld_y<TY>(p.y, gv * p.nc + c);
+        const float* pp = p.probs + gv * (p.nheads * p.nc);
+        for (int h = 0; h < p.nheads; ++h) {
+            float s = 0.f;
+            for (int c = 0; c < p.nc; ++c) s += pp[h * p.nc + c];
+            float fl = 0.f;
+            for (int c = 0; c < p.nc; ++c) {
+                const float q = fminf(fmaxf(pp[h * p.nc + c] / s, FOCAL_EPS), 1.f - FOCAL_EPS);
+                fl += p.alpha[c] * ((y[c] * focal_pow(1.f - q, p.gamma)) * (y[c] * -logf(q)));
+            }
+            acc[h] += fl;
+        }
+    }
+    __shared__ float red[4][MAX_HEADS];
+    for (int h = 0; h < p.nheads; ++h) {
+        float a = acc[h];
+        for (int o = 32; o > 0; o >>= 1) a += __shfl_down(a, o, 64);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][h] = a;
+    }
+    __syncthreads();
+    if (threadIdx.x < p.nheads)
+        partial[((long long)n * p.nheads + threadIdx.x) * gridDim.x + blockIdx.x] =
+            (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+// one block: loss = (1/(N*heads)) sum_{n,h} sum_blocks partial  (fixed order)
+__global__ void __launch_bounds__(256) focal_finish_kernel(const float* __restrict__ partial, int rows, int per, float scale,
+                                                            float* __restrict__ loss) {
+    __shared__ float red[256];
+    float a = 0.f;
+    for (int r = 0; r < rows; ++r)
+        for (int i = threadIdx.x; i < per; i += 256) a += partial[(long long)r * per + i];
+    red[threadIdx.x] = a;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
+    if (threadIdx.x == 0) loss[0] = red[0] * scale;
+}
+template <typename TY>
+__global__ void __launch_bounds__(256) focal_bwd_kernel(FocalP p, const float* __restrict__ go, float* __restrict__ dprobs) {
+    const float sc = go[0] / (float)((long long)p.N * p.nheads);
+    for (long long gv = (long long)blockIdx.x * 256 + threadIdx.x; gv < p.NV; gv += (long long)gridDim.x * 256) {
+        float y[MAX_NC];
+        for (int c = 0; c < p.nc; ++c) y[c] = focal_ld_y<TY>(p.y, gv * p.nc + c);
+        const float* pp = p.probs + gv * (p.nheads * p.nc);
+        float* dp = dprobs + gv * (p.nheads * p.nc);
+        for (int h = 0; h < p.nheads; ++h) {
+            float s = 0.f, pc[MAX_NC], g[MAX_NC], gp = 0.f;
+            for (int c = 0; c < p.nc; ++c) { pc[c] = pp[h * p.nc + c]; s += pc[c]; }
+            const float inv = 1.f / s;
+            for (int c = 0; c < p.nc; ++c) {
+                const float r = pc[c] / s;
+                float gc = 0.f;
+                if (r >= FOCAL_EPS && r <= 1.f - FOCAL_EPS && y[c] != 0.f) {
+                    const float om = 1.f - r;
+                    const float d = p.gamma == 0.f ? 0.f : p.gamma * focal_pow(om, p.gamma - 1.f) * logf(r);
+                    gc = p.alpha[c] * y[c] * y[c] * (d - focal_pow(om, p.gamma) / r);
+                }
+                g[c] = gc; gp += gc * pc[c];
+            }
+            for (int c = 0; c < p.nc; ++c) dp[h * p.nc + c] = sc * (g[c] - gp * inv) * inv;
+        }
+    }
+}
+static int focal_fill(FocalP& p, const float* probs, const void* y, int y_dtype, const float* alpha, float gamma, int N,
+                      long long V, int nheads, int nc) {
+    if (!probs || !y || !alpha || N <= 0 || V <= 0) return M1_ERR_BAD_ARG;
+    if (nheads <= 0 || nheads > MAX_HEADS || nc <= 0 || nc > MAX_NC || (y_dtype != M1_F32 && y_dtype != M1_BF16)) return M1_ERR_UNSUPPORTED;
+    p.probs = probs; p.y = y; p.V = V; p.NV = (long long)N * V; p.nheads = nheads; p.nc = nc; p.N = N; p.ydt = y_dtype; p.gamma = gamma;
+    for (int c = 0; c < MAX_NC; ++c) p.alpha[c] = c < nc ? alpha[c] : 0.f;
+    return M1_OK;
+}
+extern "C" size_t m1_focal_ws_floats(int N, long long V, int nheads) {
+    if (N <= 0 || V <= 0 || nheads <= 0) return 0;
+    long long blocks = (V + 1023) / 1024; if (blocks > 256) blocks = 256; if (blocks < 1) blocks = 1;
+    return (size_t)N * nheads * blocks;
+}
+extern "C" int m1_focal_fwd(const float* probs, const void* y_true, int y_dtype, const float* alpha, float gamma, int N,
+                            long long V, int nheads, int nc, float* ws, float* loss, void* stream) {
+    FocalP p; int rc = focal_fill(p, probs, y_true, y_dtype, alpha, gamma, N, V, nheads, nc);
+    if (rc != M1_OK) return rc;
+    if (!ws || !loss || N > 65535) return M1_ERR_BAD_ARG;
+    const int blocks = (int)(m1_focal_ws_floats(N, V, nheads) / ((size_t)N * nheads));
+    if (y_dtype == M1_F32) hipLaunchKernelGGL(focal_fwd_kernel<float>, dim3(blocks, N), dim3(256), 0, (hipStream_t)stream, p, ws);
+    else hipLaunchKernelGGL(focal_fwd_kernel<unsigned short>, dim3(blocks, N), dim3(256), 0, (hipStream_t)stream, p, ws);
+    hipLaunchKernelGGL(focal_finish_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, ws, N * nheads, blocks,
+                       1.f / (float)((long long)N * nheads), loss);
+    return m1_check_launch();
+}
+extern "C" int m1_focal_bwd(const float* probs, const void* y_true, int y_dtype, const float* alpha, float gamma, int N,
+                            long long V, int nheads, int nc, const float* dloss, float* dprobs, void* stream) {
+    FocalP p; int rc = focal_fill(p, probs, y_true, y_dtype, alpha, gamma, N, V, nheads, nc);
+    if (rc != M1_OK) return rc;
+    if (!dloss || !dprobs) return M1_ERR_BAD_ARG;
+    long long blocks = (p.NV + 255) / 256; if (blocks > 4096) blocks = 4096;
+    if (y_dtype == M1_F32) hipLaunchKernelGGL(focal_bwd_kernel<float>, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, p, dloss, dprobs);
+    else hipLaunchKernelGGL(focal_bwd_kernel<unsigned short>, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, p, dloss, dprobs);
+    return m1_check_launch();
+}
+
 extern "C" int m1_dropout(const void* x, void* y, long long n, float rate, const uint64_t* rng, uint64_t layer_id, int dtype,
                           void* stream) {
     if (!x || !y || n <= 0 || rate <= 0.f || rate >= 1.f || !rng) return M1_ERR_BAD_ARG;

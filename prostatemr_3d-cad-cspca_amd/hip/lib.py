@@ -86,6 +86,9 @@ SIGNATURES = {
     "m1_kl_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _ll, _i, _i, _vp]),
     "m1_softmax_heads_fwd": (_i, [C.POINTER(m1_head_t), _i, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "m1_softmax_heads_bwd": (_i, [C.POINTER(m1_head_t), _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "m1_focal_ws_floats": (_sz, [_i, _ll, _i]),
+    "m1_focal_fwd": (_i, [_vp, _vp, _i, C.POINTER(_f), _f, _i, _ll, _i, _i, _vp, _vp, _vp]),
+    "m1_focal_bwd": (_i, [_vp, _vp, _i, C.POINTER(_f), _f, _i, _ll, _i, _i, _vp, _vp, _vp]),
     "m1_dropout": (_i, [_vp, _vp, _ll, _f, _vp, _u64, _i, _vp]),
     "m1_cast": (_i, [_vp, _i, _vp, _i, _ll, _vp]),
     "m1_adam_amsgrad": (_i, [_vp] * 5 + [_ll, _ll, _ll, _f, _f, _f, _vp, _f, _f, _f, _vp, _vp]),

@@ -555,6 +555,49 @@ def softmax_heads(logits: Sequence[torch.Tensor], ups: Sequence[Tuple[int, int, 
 
 
 # ---------------------------------------------------------------------------------------------------------
+# Focal loss on the softmax heads (losses.py:32-49)
+# ---------------------------------------------------------------------------------------------------------
+class _Focal(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, y_true, y_pred, alpha, gamma):
+        _req(y_true, y_pred)
+        if y_pred.dtype != torch.float32:
+            raise RuntimeError("focal_loss: y_pred must be the fp32 probabilities of softmax_heads")
+        nc = int(y_true.shape[-1])
+        nheads = int(y_pred.shape[-1]) // nc
+        if nheads * nc != int(y_pred.shape[-1]) or len(alpha) != nc or y_true.shape[:-1] != y_pred.shape[:-1]:
+            raise RuntimeError("focal_loss: y_pred must hold nheads*nc channels over the voxels of y_true, alpha nc weights")
+        if y_true.dtype not in (torch.float32, torch.bfloat16):
+            y_true = y_true.to(torch.float32)
+        N = int(y_pred.shape[0])
+        V = y_true.numel() // (N * nc)
+        lib = L.load()
+        al = (C.c_float * nc)(*[float(a) for a in alpha])
+        ws = torch.empty(max(int(lib.m1_focal_ws_floats(N, V, nheads)), 1), dtype=torch.float32, device=y_pred.device)
+        loss = torch.empty((), dtype=torch.float32, device=y_pred.device)
+        L.check(lib.m1_focal_fwd(_p(y_pred), _p(y_true), _dt(y_true), al, float(gamma), N, V, nheads, nc, _p(ws), _p(loss),
+                                 _stream()), "m1_focal_fwd")
+        ctx.save_for_backward(y_true, y_pred)
+        ctx.cfg = (al, float(gamma), N, V, nheads, nc)
+        return loss
+
+    @staticmethod
+    def backward(ctx, dloss):
+        y_true, y_pred = ctx.saved_tensors
+        al, gamma, N, V, nheads, nc = ctx.cfg
+        dloss = dloss.contiguous().float()
+        dp = torch.empty_like(y_pred)
+        L.check(L.load().m1_focal_bwd(_p(y_pred), _p(y_true), _dt(y_true), al, gamma, N, V, nheads, nc, _p(dloss), _p(dp),
+                                      _stream()), "m1_focal_bwd")
+        return None, dp, None, None
+
+
+def focal_loss(y_true: torch.Tensor, y_pred: torch.Tensor, alpha: Sequence[float], gamma: float) -> torch.Tensor:
+    """Focal.loss (losses.py:43-49) over all heads of ``y_pred`` in one pass; gradient w.r.t. ``y_pred`` only."""
+    return _Focal.apply(y_true.contiguous(), y_pred.contiguous(), tuple(float(a) for a in alpha), float(gamma))
+
+
+# ---------------------------------------------------------------------------------------------------------
 # dropout (standalone), cast
 # ---------------------------------------------------------------------------------------------------------
 class _Dropout(torch.autograd.Function):

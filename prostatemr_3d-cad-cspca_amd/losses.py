@@ -1,6 +1,7 @@
 """Loss functions with the class surface of the reference's losses.py (tf2.5/scripts/model/losses.py):
-``Focal`` (L:20-49) and ``EvidenceLowerBound`` (L:52-63).  Host-side PyTorch plumbing on the device the
-predictions live on (north_star: autograd / Adam / Focal-loss plumbing stays on PyTorch-ROCm).
+``Focal`` (L:20-49) and ``EvidenceLowerBound`` (L:52-63).  On the GPU ``Focal.loss`` is one fused HIP pass over the softmax
+heads (hip.ops.focal_loss: m1_focal_fwd / m1_focal_bwd); host tensors (unit tests of the host logic) take the
+plain expression ``FL`` below, which is also what the fused kernel is tested against.
 ``SoftDicePlusBoundarySurface`` (L:66-130) needs a CPU scipy distance transform per batch and is not on the
 train-step metric path: out of scope.
 """
@@ -36,6 +37,9 @@ class Focal:
 
     def loss(self, y_true, y_pred):
         """L:43-49: mean over the y_pred.shape[-1]//y_true.shape[-1] prediction heads (deep supervision)."""
+        if y_pred.is_cuda:
+            from .hip import ops
+            return ops.focal_loss(y_true, y_pred, self.alpha, self.gamma)
         c = int(y_true.shape[-1])
         n = int(y_pred.shape[-1]) // c
         elems = [self.FL(y_true, y_pred[..., c * i:c * (i + 1)]) for i in range(n)]

@@ -7,7 +7,7 @@ import pytest
 import torch
 
 from oracle import m1_oracle as O
-from util import ops, rel_err, rnd
+from util import PKG, ops, rel_err, rnd
 
 pytestmark = pytest.mark.gpu
 
@@ -331,6 +331,31 @@ def test_softmax_heads_fwd_bwd(dev, dtype, nc):
     assert rel_err(p, po) < 1e-5
     for a, b in zip(ld, grads):
         assert rel_err(a.grad, b) < tol
+
+
+@pytest.mark.parametrize("nheads,nc,gamma,ydt", [(1, 2, 2.0, torch.float32), (4, 2, 2.0, torch.bfloat16), (2, 3, 1.5, torch.float32),
+                                                  (1, 2, 0.0, torch.float32), (3, 2, 1.0, torch.float32)])
+def test_focal_loss_fused_matches_oracle(dev, nheads, nc, gamma, ydt):
+    """m1_focal_fwd / m1_focal_bwd vs the oracle's Focal (losses.py:32-49), incl. saturated probabilities (clip range)."""
+    N, D, H, W = 2, 3, 9, 7
+    g = torch.Generator().manual_seed(5)
+    p = torch.softmax(3.0 * torch.randn((N, D, H, W, nheads, nc), generator=g), dim=-1)
+    p[0, 0, 0, 0, 0] = torch.tensor([1.0] + [0.0] * (nc - 1))            # saturated: outside the clip range
+    p[1, 1, 2, 3, -1] = torch.tensor([0.0] * (nc - 1) + [1.0])
+    p = p.reshape(N, D, H, W, nheads * nc)
+    cls = torch.randint(0, nc, (N, D, H, W), generator=g)
+    y = torch.nn.functional.one_hot(cls, nc).float()
+    alpha = [0.75, 0.25, 0.5][:nc]
+    po = p.clone().requires_grad_(True)
+    lo = O.focal_loss(y, po, alpha, gamma)
+    (3.0 * lo).backward()
+    pd = p.to(dev).requires_grad_(True)
+    ld = PKG.losses.Focal(alpha=alpha, gamma=gamma).loss(y.to(dev, ydt), pd)
+    (3.0 * ld).backward()
+    assert abs(float(ld.detach()) - float(lo.detach())) < 1e-5 * max(1.0, abs(float(lo.detach())))
+    assert rel_err(pd.grad, po.grad) < 1e-5
+    l2 = PKG.losses.Focal(alpha=alpha, gamma=gamma).loss(y.to(dev, ydt), pd.detach())
+    assert float(l2) == float(ld)                                          # fixed-order fold: bit-identical
 
 
 def test_dropout_mask_is_reproducible_and_unbiased(dev):
