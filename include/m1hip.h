@@ -80,9 +80,12 @@ int m1_pack_batch(const void* const* jobs_dev, int njobs, void* stream);
  * conv's own epilogue, so the statistics cost no extra pass over y. */
 int m1_conv3d_fwd(const m1_conv_desc_t* d, const float* w, const float* bias, void* y, float* stats, void* ws,
                   int ws_packed, void* stream);
-/* dx[i]: gradient buffer of concat member i (same shape/dtype as src[i]) or NULL to skip it. */
-int m1_conv3d_dgrad(const m1_conv_desc_t* d, const float* w, const void* dy, void* const* dx, void* ws, int ws_packed,
-                    void* stream);
+/* dx[i]: gradient buffer of concat member i (same shape/dtype as src[i]) or NULL to skip it.
+ * accumulate (NULL = all 0): accumulate[i] != 0 -> dx[i] += instead of dx[i] = : a tensor read by several layers
+ * (an SE block's input feeds conv1 and conv4, B:53,64; an encoder output also feeds its attention gate, N:584-590)
+ * gets its gradient summed by the kernels' own epilogues, in call order, instead of by separate add passes. */
+int m1_conv3d_dgrad(const m1_conv_desc_t* d, const float* w, const void* dy, void* const* dx, const int* accumulate,
+                    void* ws, int ws_packed, void* stream);
 /* dw (kd,kh,kw,Cin,Cout) and db (Cout): accumulate == 0 -> overwritten (zeroed inside first);
  * accumulate != 0 -> added to what is there (the caller's flat gradient buffer, zeroed once per step: a weight
  * shared by several passes -- prior / posterior cores run twice per step -- sums without any extra copy). The
@@ -96,8 +99,8 @@ int m1_set_force_direct(int on);
  * w: Keras layout (kd,kh,kw,Cout,Cin) fp32; y: (N, D*sd, H*sh, W*sw, Cout). */
 int m1_convT3d_fwd(const m1_conv_desc_t* d, const float* w, const float* bias, void* y, void* ws, int ws_packed,
                    void* stream);
-int m1_convT3d_dgrad(const m1_conv_desc_t* d, const float* w, const void* dy, void* const* dx, void* ws, int ws_packed,
-                     void* stream);
+int m1_convT3d_dgrad(const m1_conv_desc_t* d, const float* w, const void* dy, void* const* dx, const int* accumulate,
+                     void* ws, int ws_packed, void* stream);
 int m1_convT3d_wgrad(const m1_conv_desc_t* d, const void* dy, float* dw, float* db, void* ws, int accumulate,
                      void* stream);
 
@@ -167,8 +170,9 @@ int m1_gate_sigma_bwd(const void* theta, const void* phi, const float* wpsi, con
 /* y = sigma_up * x : x (N,D,H,W,C), sigma (N,D/ss0,H/ss1,W/ss2) */
 int m1_mul_sigma_fwd(const void* x, const void* sigma, void* y, int N, int D, int H, int W, int C, int s0,
                      int s1, int s2, int dtype, void* stream);
+/* accumulate_dx != 0: dx += sigma_up * dy (x also feeds other layers, see m1_conv3d_dgrad); dsigma is always overwritten */
 int m1_mul_sigma_bwd(const void* x, const void* sigma, const void* dy, void* dx, void* dsigma, int N, int D,
-                     int H, int W, int C, int s0, int s1, int s2, int dtype, void* stream);
+                     int H, int W, int C, int s0, int s1, int s2, int dtype, int accumulate_dx, void* stream);
 
 /* ---- latent head : N:640-647 (x4 levels) and KL N:373-385 ----
  * ml: (N,V,2L) = [mu | logsigma]; z = mu + exp(clip(logsigma,+-0.1))*eps  (mode 0) or mu (mode 1). */

@@ -230,7 +230,7 @@ __device__ __forceinline__ long long sig_index(const MulGeo& g, long long gv) {
     return (((long long)n * g.Ds + d / g.s0) * g.Hs + h / g.s1) * g.Ws + w / g.s2;
 }
 
-template <typename T, int VEC>
+template <typename T, int VEC, bool ACC = false>
 __global__ void __launch_bounds__(256) mul_sigma_kernel(const T* __restrict__ x, const T* __restrict__ sigma,
                                                         T* __restrict__ y, MulGeo g) {
     const int cg = g.C / VEC;
@@ -242,6 +242,12 @@ __global__ void __launch_bounds__(256) mul_sigma_kernel(const T* __restrict__ x,
         VecIO<T, VEC>::ld(x + i * VEC, a);
 #pragma unroll
         for (int k = 0; k < VEC; ++k) a[k] *= s;
+        if (ACC) {                                        // y += (gradient of a tensor with several consumers)
+            float b[VEC];
+            VecIO<T, VEC>::ld(y + i * VEC, b);
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) a[k] += b[k];
+        }
         VecIO<T, VEC>::st(y + i * VEC, a);
     }
 }
@@ -282,14 +288,14 @@ static int make_mulgeo(MulGeo& g, int N, int D, int H, int W, int C, int s0, int
     return M1_OK;
 }
 
-template <typename T>
+template <typename T, bool ACC = false>
 static int mul_fwd_impl(const void* x, const void* sigma, void* y, const MulGeo& g, hipStream_t st) {
     constexpr int VW = sizeof(T) == 2 ? 8 : 4;
     const long long V = (long long)g.N * g.D * g.H * g.W;
     if (g.C % VW == 0)
-        hipLaunchKernelGGL((mul_sigma_kernel<T, VW>), dim3(gx_for(V * (g.C / VW))), dim3(256), 0, st, (const T*)x, (const T*)sigma, (T*)y, g);
+        hipLaunchKernelGGL((mul_sigma_kernel<T, VW, ACC>), dim3(gx_for(V * (g.C / VW))), dim3(256), 0, st, (const T*)x, (const T*)sigma, (T*)y, g);
     else
-        hipLaunchKernelGGL((mul_sigma_kernel<T, 1>), dim3(gx_for(V * g.C)), dim3(256), 0, st, (const T*)x, (const T*)sigma, (T*)y, g);
+        hipLaunchKernelGGL((mul_sigma_kernel<T, 1, ACC>), dim3(gx_for(V * g.C)), dim3(256), 0, st, (const T*)x, (const T*)sigma, (T*)y, g);
     return m1_check_launch();
 }
 
@@ -303,8 +309,9 @@ extern "C" int m1_mul_sigma_fwd(const void* x, const void* sigma, void* y, int N
 }
 
 template <typename T>
-static int mul_bwd_impl(const void* x, const void* sigma, const void* dy, void* dx, void* dsigma, const MulGeo& g, hipStream_t st) {
-    int rc = mul_fwd_impl<T>(dy, sigma, dx, g, st);   // dx = sigma_up * dy
+static int mul_bwd_impl(const void* x, const void* sigma, const void* dy, void* dx, void* dsigma, const MulGeo& g, int accumulate,
+                        hipStream_t st) {
+    int rc = accumulate ? mul_fwd_impl<T, true>(dy, sigma, dx, g, st) : mul_fwd_impl<T>(dy, sigma, dx, g, st);   // dx (+)= sigma_up * dy
     if (rc) return rc;
     constexpr int VW = sizeof(T) == 2 ? 8 : 4;
     const long long total = (long long)g.N * g.Ds * g.Hs * g.Ws;
@@ -319,10 +326,10 @@ static int mul_bwd_impl(const void* x, const void* sigma, const void* dy, void* 
 }
 
 extern "C" int m1_mul_sigma_bwd(const void* x, const void* sigma, const void* dy, void* dx, void* dsigma, int N, int D, int H,
-                                int W, int C, int s0, int s1, int s2, int dtype, void* stream) {
+                                int W, int C, int s0, int s1, int s2, int dtype, int accumulate_dx, void* stream) {
     if (!x || !sigma || !dy || !dx || !dsigma) return M1_ERR_BAD_ARG;
     MulGeo g; int rc = make_mulgeo(g, N, D, H, W, C, s0, s1, s2); if (rc) return rc;
     M1ProfScope ps("mul_sigma_bwd", 0.0, 4.0 * N * D * H * W * C * (dtype == M1_BF16 ? 2 : 4), (hipStream_t)stream);
-    return dtype == M1_BF16 ? mul_bwd_impl<bf16_t>(x, sigma, dy, dx, dsigma, g, (hipStream_t)stream)
-                            : mul_bwd_impl<float>(x, sigma, dy, dx, dsigma, g, (hipStream_t)stream);
+    return dtype == M1_BF16 ? mul_bwd_impl<bf16_t>(x, sigma, dy, dx, dsigma, g, accumulate_dx, (hipStream_t)stream)
+                            : mul_bwd_impl<float>(x, sigma, dy, dx, dsigma, g, accumulate_dx, (hipStream_t)stream);
 }

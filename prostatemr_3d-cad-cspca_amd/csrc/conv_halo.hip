@@ -261,7 +261,17 @@ __global__ void __launch_bounds__(NTHR) conv_halo_kernel(HaloP p) {
             bf16_t* dst = out + orow * m.OC + oc;
             if (m.OC % SEG != 0 || oc + SEG > m.OCn) {
                 const bf16_t* ve = reinterpret_cast<const bf16_t*>(&v);
-                for (int k = 0; k < SEG && oc + k < m.OCn; ++k) dst[k] = ve[k];
+                for (int k = 0; k < SEG && oc + k < m.OCn; ++k) {
+                    if (m.accumulate) Act<bf16_t>::st(dst + k, Act<bf16_t>::ld(ve + k) + Act<bf16_t>::ld(dst + k));
+                    else dst[k] = ve[k];
+                }
+            } else if (m.accumulate) {                    // dx += (a gradient with several consumers sums in place)
+                float a[SEG], b[SEG];
+                VecIO<bf16_t, SEG>::ld(reinterpret_cast<const bf16_t*>(&v), a);
+                VecIO<bf16_t, SEG>::ld(dst, b);
+#pragma unroll
+                for (int k = 0; k < SEG; ++k) a[k] += b[k];
+                VecIO<bf16_t, SEG>::st(dst, a);
             } else {
                 *reinterpret_cast<uint4*>(dst) = v;
             }
@@ -273,7 +283,7 @@ __global__ void __launch_bounds__(NTHR) conv_halo_kernel(HaloP p) {
 
 // ------------------------------------------------------------------------------------------------
 static bool halo_plan(const MfmaP& m, int OCpad, HaloP& p) {
-    if (m.nclasses != 1 || m.ksplit != 1 || m.accumulate) return false;
+    if (m.nclasses != 1 || m.ksplit != 1) return false;
     if (!(m.mode == 0 || (m.mode == 1 && m.sd == 1 && m.sh == 1 && m.sw == 1))) return false;
     int CC = 0;
     for (int i = 0; i < m.nsrc; ++i) { if (m.srcC[i] % 8) return false; CC += m.srcC[i]; }

@@ -182,11 +182,12 @@ extern "C" int m1_convT3d_fwd(const m1_conv_desc_t* d, const float* w, const flo
     M1ProfScope ps("convT3d_fwd", 2.0 * conv_macs(d, true), conv_bytes(d, true), (hipStream_t)stream);
     return run_gather(fwd_spec(d, true, w, bias, y), ws, ws_packed, (hipStream_t)stream);
 }
-static int dgrad_common(const m1_conv_desc_t* d, bool T, const float* w, const void* dy, void* const* dx, void* ws, int ws_packed,
-                        hipStream_t st) {
+static int dgrad_common(const m1_conv_desc_t* d, bool T, const float* w, const void* dy, void* const* dx, const int* accumulate,
+                        void* ws, int ws_packed, hipStream_t st) {
     int off = 0; size_t woff = 0;                         // member i's panel lives at its own offset of ws (cacheable)
     for (int i = 0; i < d->nsrc; ++i) {
-        const GatherSpec g = dgrad_spec(d, T, w, dy, dx[i], i, off);
+        GatherSpec g = dgrad_spec(d, T, w, dy, dx[i], i, off);
+        g.accumulate = accumulate && accumulate[i] ? 1 : 0;
         if (dx[i]) {
             int rc = run_gather(g, ws ? (unsigned char*)ws + woff : nullptr, ws_packed, st); if (rc) return rc;
         }
@@ -195,17 +196,17 @@ static int dgrad_common(const m1_conv_desc_t* d, bool T, const float* w, const v
     }
     return M1_OK;
 }
-extern "C" int m1_conv3d_dgrad(const m1_conv_desc_t* d, const float* w, const void* dy, void* const* dx, void* ws, int ws_packed,
-                               void* stream) {
+extern "C" int m1_conv3d_dgrad(const m1_conv_desc_t* d, const float* w, const void* dy, void* const* dx, const int* accumulate,
+                               void* ws, int ws_packed, void* stream) {
     if (!desc_ok(d) || !w || !dy || !dx) return M1_ERR_BAD_ARG;
     M1ProfScope ps("conv3d_dgrad", 2.0 * conv_macs(d, false), conv_bytes(d, false), (hipStream_t)stream);
-    return dgrad_common(d, false, w, dy, dx, ws, ws_packed, (hipStream_t)stream);
+    return dgrad_common(d, false, w, dy, dx, accumulate, ws, ws_packed, (hipStream_t)stream);
 }
-extern "C" int m1_convT3d_dgrad(const m1_conv_desc_t* d, const float* w, const void* dy, void* const* dx, void* ws, int ws_packed,
-                                void* stream) {
+extern "C" int m1_convT3d_dgrad(const m1_conv_desc_t* d, const float* w, const void* dy, void* const* dx, const int* accumulate,
+                                void* ws, int ws_packed, void* stream) {
     if (!desc_ok(d) || !w || !dy || !dx) return M1_ERR_BAD_ARG;
     M1ProfScope ps("convT3d_dgrad", 2.0 * conv_macs(d, true), conv_bytes(d, true), (hipStream_t)stream);
-    return dgrad_common(d, true, w, dy, dx, ws, ws_packed, (hipStream_t)stream);
+    return dgrad_common(d, true, w, dy, dx, accumulate, ws, ws_packed, (hipStream_t)stream);
 }
 
 // ---- weight gradients ------------------------------------------------------------------------------------------

@@ -62,10 +62,10 @@ SIGNATURES = {
     "m1_pack_batch": (_i, [_vp, _i, _vp]),
     "m1_set_force_direct": (_i, [_i]),
     "m1_conv3d_fwd": (_i, [_desc_p, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
-    "m1_conv3d_dgrad": (_i, [_desc_p, _vp, _vp, C.POINTER(_vp), _vp, _i, _vp]),
+    "m1_conv3d_dgrad": (_i, [_desc_p, _vp, _vp, C.POINTER(_vp), C.POINTER(_i), _vp, _i, _vp]),
     "m1_conv3d_wgrad": (_i, [_desc_p, _vp, _vp, _vp, _vp, _i, _vp]),
     "m1_convT3d_fwd": (_i, [_desc_p, _vp, _vp, _vp, _vp, _i, _vp]),
-    "m1_convT3d_dgrad": (_i, [_desc_p, _vp, _vp, C.POINTER(_vp), _vp, _i, _vp]),
+    "m1_convT3d_dgrad": (_i, [_desc_p, _vp, _vp, C.POINTER(_vp), C.POINTER(_i), _vp, _i, _vp]),
     "m1_convT3d_wgrad": (_i, [_desc_p, _vp, _vp, _vp, _vp, _i, _vp]),
     "m1_reduce_ws_floats": (_sz, [_i, _ll, _i, _i]),
     "m1_instnorm_stats": (_i, [_vp, _i, _ll, _i, _i, _f, _vp, _vp, _vp]),
@@ -79,7 +79,7 @@ SIGNATURES = {
     "m1_gate_sigma_fwd": (_i, [_vp] * 5 + [_i] * 9 + [_vp]),
     "m1_gate_sigma_bwd": (_i, [_vp] * 9 + [_i] * 9 + [_vp, _i, _vp]),
     "m1_mul_sigma_fwd": (_i, [_vp] * 3 + [_i] * 9 + [_vp]),
-    "m1_mul_sigma_bwd": (_i, [_vp] * 5 + [_i] * 9 + [_vp]),
+    "m1_mul_sigma_bwd": (_i, [_vp] * 5 + [_i] * 10 + [_vp]),
     "m1_latent_sample_fwd": (_i, [_vp, _vp, _vp, _i, _ll, _i, _i, _i, _vp]),
     "m1_latent_sample_bwd": (_i, [_vp, _vp, _vp, _vp, _i, _ll, _i, _i, _i, _vp]),
     "m1_kl_fwd": (_i, [_vp, _vp, _vp, _i, _ll, _i, _i, _vp]),

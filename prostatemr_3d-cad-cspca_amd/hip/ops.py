@@ -80,6 +80,74 @@ def _sink(param: torch.Tensor, like: Optional[torch.Tensor] = None):
     return t, 0, t
 
 
+# ---------------------------------------------------------------------------------------------------------
+# data gradients of tensors with several consumers
+# ---------------------------------------------------------------------------------------------------------
+class _GradSlot:
+    """The one gradient buffer of a tensor that feeds several layers (an SE block's input feeds conv1 and conv4,
+    network_blocks.py:53,64; an encoder output also feeds its attention gate, networks.py:584-590).  The first backward
+    kernel to produce a gradient for the tensor allocates the buffer, the following ones ACCUMULATE into it in their own
+    epilogue (m1_conv3d_dgrad / m1_convT3d_dgrad ``accumulate``, m1_mul_sigma_bwd ``accumulate_dx``): the per-consumer
+    gradient tensors and autograd's add passes over them disappear."""
+    __slots__ = ("buf",)
+
+    def __init__(self):
+        self.buf = None
+
+
+def _slot_target(slot: Optional[_GradSlot], like: torch.Tensor):
+    """(gradient tensor, accumulate flag) for a data gradient shaped like ``like``."""
+    if slot is None:
+        return torch.empty_like(like), 0
+    b = slot.buf
+    if b is not None and b.shape == like.shape and b.dtype == like.dtype and b.is_contiguous():
+        return b, 1
+    g = torch.empty_like(like)
+    if b is None:
+        slot.buf = g
+    return g, 0
+
+
+class _Fanout(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, k, slot, owner):
+        ctx.slot, ctx.owner = slot, owner
+        ctx.set_materialize_grads(False)
+        return tuple(x.view_as(x) for _ in range(k))
+
+    @staticmethod
+    def backward(ctx, *gs):
+        slot = ctx.slot
+        buf = slot.buf
+        if ctx.owner:
+            slot.buf = None
+        rest = None
+        for g in gs:
+            if g is None or (buf is not None and g.data_ptr() == buf.data_ptr() and g.shape == buf.shape):
+                continue                      # nothing, or the slot buffer itself (already holds that consumer's share)
+            if buf is not None:
+                buf.add_(g)                   # a consumer that does not accumulate in its kernel: fold it into the slot
+            else:
+                rest = g if rest is None else rest + g
+        return (buf if buf is not None else rest), None, None, None
+
+
+def fanout(x: torch.Tensor, k: int):
+    """``k`` aliases of ``x``, one per consumer.  Their backward kernels sum the gradient of ``x`` in one shared buffer (see
+    _GradSlot); consumers without an accumulating kernel still work (their gradient is added here).  Each alias must be
+    used by exactly one consumer.  Nested use (a module forks an alias it was handed) shares the outer buffer."""
+    if k <= 1 or not torch.is_grad_enabled() or not x.requires_grad:
+        return (x,) * k
+    slot = getattr(x, "_m1_gslot", None)
+    owner = slot is None
+    if owner:
+        slot = _GradSlot()
+    outs = _Fanout.apply(x, k, slot, owner)
+    for o in outs:
+        o._m1_gslot = slot
+    return outs
+
+
 def _conv_ws(d, transposed: bool, role: int, device, zero: bool = False) -> torch.Tensor:
     n = L.load().m1_conv_ws_bytes(C.byref(d), 1 if transposed else 0, role)
     return (torch.zeros if zero else torch.empty)(max(int(n), 256), dtype=torch.uint8, device=device)
@@ -182,6 +250,7 @@ class _Conv3d(torch.autograd.Function):
             L.check(lib.m1_conv3d_fwd(C.byref(d), _p(w), _p(b), _p(y), _p(stats), _p(ws), packed, _stream()), "m1_conv3d_fwd")
         ctx.save_for_backward(w, *srcs)
         ctx.w_param, ctx.b_param = w, b
+        ctx.gslots = [getattr(t, "_m1_gslot", None) for t in srcs]
         ctx.k, ctx.s, ctx.transposed, ctx.has_bias, ctx.cout = tuple(k), tuple(s), transposed, b is not None, cout
         if want_stats:
             ctx.mark_non_differentiable(stats)
@@ -215,10 +284,11 @@ class _Conv3d(torch.autograd.Function):
             L.check(fn(C.byref(d), _p(dy), _p(wbuf), _p(bbuf), _p(ws), acc_w, st), f"m1_{name}_wgrad")
         dsrc: List[Optional[torch.Tensor]] = []
         ptrs = (C.c_void_p * len(srcs))()
+        accs = (C.c_int * len(srcs))()
         any_d = False
         for i, t in enumerate(srcs):
             if ctx.needs_input_grad[6 + i]:
-                g = torch.empty_like(t)
+                g, accs[i] = _slot_target(ctx.gslots[i], t)
                 dsrc.append(g)
                 ptrs[i] = g.data_ptr()
                 any_d = True
@@ -228,7 +298,7 @@ class _Conv3d(torch.autograd.Function):
         if any_d:
             fn = lib.m1_convT3d_dgrad if ctx.transposed else lib.m1_conv3d_dgrad
             ws, packed = _panel_ws(ctx.w_param, d, ctx.transposed, 1, tuple(bool(g is not None) for g in dsrc))
-            L.check(fn(C.byref(d), _p(w), _p(dy), ptrs, _p(ws), packed, st), f"m1_{name}_dgrad")
+            L.check(fn(C.byref(d), _p(w), _p(dy), ptrs, accs, _p(ws), packed, st), f"m1_{name}_dgrad")
         return (dw, db, None, None, None, None, *dsrc)
 
 
@@ -434,6 +504,7 @@ class _MulSigma(torch.autograd.Function):
                                           _stream()), "m1_mul_sigma_fwd")
         ctx.save_for_backward(x, sigma)
         ctx.ss = tuple(int(v) for v in ss)
+        ctx.gslot = getattr(x, "_m1_gslot", None)
         return y
 
     @staticmethod
@@ -441,8 +512,9 @@ class _MulSigma(torch.autograd.Function):
         x, sigma = ctx.saved_tensors
         dy = dy.contiguous()
         N, D, H, W, Cn = (int(v) for v in x.shape)
-        dx, dsig = torch.empty_like(x), torch.empty_like(sigma)
-        L.check(L.load().m1_mul_sigma_bwd(_p(x), _p(sigma), _p(dy), _p(dx), _p(dsig), N, D, H, W, Cn, *ctx.ss, _dt(x),
+        dsig = torch.empty_like(sigma)
+        dx, acc = _slot_target(ctx.gslot, x)
+        L.check(L.load().m1_mul_sigma_bwd(_p(x), _p(sigma), _p(dy), _p(dx), _p(dsig), N, D, H, W, Cn, *ctx.ss, _dt(x), acc,
                                           _stream()), "m1_mul_sigma_bwd")
         return dx, dsig, None
 

@@ -153,13 +153,14 @@ class SEResNetBottleNeck(nn.Module):
         self.conv7 = Conv3D(self.filters // self.reduction, self.filters, (1, 1, 1), (1, 1, 1), padding="valid")
 
     def forward(self, input_tensor: Tensors, dropout: Optional[_DropoutBase] = None) -> torch.Tensor:
-        srcs = _as_list(input_tensor)
+        pairs = [ops.fanout(t, 2) for t in _as_list(input_tensor)]          # every member feeds conv1 and conv4
+        srcs, srcs4 = [a for a, _ in pairs], [b for _, b in pairs]
         y1, s1 = self.conv1(srcs, stats=True)
         a = self.norm1(y1, 0.1, s1)                                             # B:53-55
         y2, s2 = self.conv2(a, stats=True)
         a = self.norm2(y2, 0.1, s2)                                             # B:56-58
         y3, s3 = self.conv3(a, stats=True)                                      # B:59
-        y4, s4 = self.conv4(srcs, stats=True)                                   # B:64
+        y4, s4 = self.conv4(srcs4, stats=True)                                  # B:64
         rate = dropout.effective_rate() if dropout is not None else 0.0
         return ops.se_combine(y3, y4, self.norm3.gamma, self.norm3.beta, self.norm4.gamma, self.norm4.beta,
                               self.conv6.kernel, self.conv6.bias, self.conv7.kernel, self.conv7.bias, rate,
@@ -185,8 +186,9 @@ class GridAttentionBlock3D(nn.Module):
         self.normW = InstanceNormalization(ic)                                         # norm4, B:104
 
     def forward(self, conv_tensor: torch.Tensor, gating_tensor: torch.Tensor):
-        x, g = conv_tensor, gating_tensor
-        theta_x = self.theta(x)                                                        # B:111
+        g = gating_tensor
+        x_t, x = ops.fanout(conv_tensor, 2)                                            # theta conv and the sigma product
+        theta_x = self.theta(x_t)                                                      # B:111
         phi_g = self.phi(g)                                                            # B:112
         sigma = ops.gate_sigma(theta_x, phi_g, self.psi.kernel, self.psi.bias)         # B:113-119
         y = ops.mul_sigma(x, sigma, self.sub_samp)                                     # B:120-124

@@ -184,44 +184,66 @@ class M1Core(nn.Module):
         # networks.py:574-576
         x_raw, s0 = self.conve0(inputs, stats=True)
         x = self.norme0(x_raw, 0.1, s0)
+        # A tensor read by several layers is handed out as one alias per reader (ops.fanout): the readers' backward kernels
+        # then sum its gradient in one buffer instead of autograd adding per-reader gradient tensors.
+        fo = ops.fanout
+        prob, dense = self.probabilistic, self.dense_skip
         # networks.py:579-582 (dropout fused into the block's last kernel)
-        conv1 = self.serse1(x, dropout=self.drope1)
-        conv2 = self.serse2(conv1, dropout=self.drope2)
-        conv3 = self.serse3(conv2, dropout=self.drope3)
-        convm = self.serse4(conv3, dropout=self.drope4)
+        x_e, x_a = fo(x, 2)
+        conv1 = self.serse1(x_e, dropout=self.drope1)
+        c1_e, c1_a = fo(conv1, 2)
+        conv2 = self.serse2(c1_e, dropout=self.drope2)
+        c2_e, c2_a = fo(conv2, 2)
+        conv3 = self.serse3(c2_e, dropout=self.drope3)
+        c3_e, c3_a = fo(conv3, 2)
+        convm = self.serse4(c3_e, dropout=self.drope4)
+        m_use = list(fo(convm, 7 if prob else 5))          # 4 gates, convtd3 (+ latent head and latent decoder of level 3)
         # networks.py:585-588
-        att_conv0, _ = self.att0(x, convm)
-        att_conv1, _ = self.att1(conv1, convm)
-        att_conv2, _ = self.att2(conv2, convm)
-        att_conv3, _ = self.att3(conv3, convm)
+        att_conv0, _ = self.att0(x_a, m_use.pop())
+        att_conv1, _ = self.att1(c1_a, m_use.pop())
+        att_conv2, _ = self.att2(c2_a, m_use.pop())
+        att_conv3, _ = self.att3(c3_a, m_use.pop())
         # networks.py:591-597
-        deconv3 = self.convtd3(convm)
-        if self.dense_skip:
-            deconv3_up1 = self.convtd3_up1(deconv3)
-            deconv3_up2 = self.convtd3_up2(deconv3_up1)
-            deconv3_up3 = self.convtd3_up3(deconv3_up2)
+        deconv3 = self.convtd3(m_use.pop())
+        if dense:
+            deconv3, d3 = fo(deconv3, 2)
+            deconv3_up1, d3u1 = fo(self.convtd3_up1(d3), 2)
+            deconv3_up2, d3u2 = fo(self.convtd3_up2(d3u1), 2)
+            deconv3_up3 = self.convtd3_up3(d3u2)
         uconv3_ = [deconv3, att_conv3]
+        if prob:
+            uconv3_, uconv3_p = (list(v) for v in zip(*[fo(t, 2) for t in uconv3_]))
         uconv3 = self.sersd3(uconv3_, dropout=self.dropd3)
+        heads_on = self.deep_supervision and not prob
+        u3_up, u3_h = fo(uconv3, 2) if heads_on else (uconv3, uconv3)
         # networks.py:600-607
-        deconv2 = self.convtd2(uconv3)
-        if self.dense_skip:
-            deconv2_up1 = self.convtd2_up1(deconv2)
-            deconv2_up2 = self.convtd2_up2(deconv2_up1)
+        deconv2 = self.convtd2(u3_up)
+        if dense:
+            deconv2, d2 = fo(deconv2, 2)
+            deconv2_up1, d2u1 = fo(self.convtd2_up1(d2), 2)
+            deconv2_up2 = self.convtd2_up2(d2u1)
             uconv2_ = [deconv2, deconv3_up1, att_conv2]
         else:
             uconv2_ = [deconv2, att_conv2]
+        if prob:
+            uconv2_, uconv2_p = (list(v) for v in zip(*[fo(t, 2) for t in uconv2_]))
         uconv2 = self.sersd2(uconv2_, dropout=self.dropd2)
+        u2_up, u2_h = fo(uconv2, 2) if heads_on else (uconv2, uconv2)
         # networks.py:610-616
-        deconv1 = self.convtd1(uconv2)
-        if self.dense_skip:
-            deconv1_up1 = self.convtd1_up1(deconv1)
+        deconv1 = self.convtd1(u2_up)
+        if dense:
+            deconv1, d1 = fo(deconv1, 2)
+            deconv1_up1 = self.convtd1_up1(d1)
             uconv1_ = [deconv1, deconv2_up1, deconv3_up2, att_conv1]
         else:
             uconv1_ = [deconv1, att_conv1]
+        if prob:
+            uconv1_, uconv1_p = (list(v) for v in zip(*[fo(t, 2) for t in uconv1_]))
         uconv1 = self.sersd1(uconv1_, dropout=self.dropd1)
+        u1_up, u1_h = fo(uconv1, 2) if heads_on else (uconv1, uconv1)
         # networks.py:619-624
-        deconv0 = self.convtd0(uconv1)
-        if self.dense_skip:
+        deconv0 = self.convtd0(u1_up)
+        if dense:
             uconv0_ = [deconv0, deconv1_up1, deconv2_up2, deconv3_up3, att_conv0]
         else:
             uconv0_ = [deconv0, att_conv0]
@@ -247,14 +269,20 @@ class M1Core(nn.Module):
         ds_ops = []
         if self.probabilistic:                                                     # networks.py:633-734
             distributions, used_latents = [], []
-            skips = [uconv3_, uconv2_, uconv1_, uconv0_]
+            skips = [uconv3_p, uconv2_p, uconv1_p, uconv0_]
             feats = convm
             zi = 0
             for lvl in range(4):
                 sfx = str(3 - lvl)
                 Ld = self.prob_latent_dims[lvl]
+                if lvl == 0:
+                    f_ml, f_up = m_use.pop(), m_use.pop()
+                elif Ld != 0:
+                    f_ml, f_up = fo(feats, 2)
+                else:
+                    f_ml = f_up = feats
                 if Ld != 0:
-                    ml = getattr(self, "mu_logsig" + sfx)(feats)                   # networks.py:639 (mu | logsigma)
+                    ml = getattr(self, "mu_logsig" + sfx)(f_ml)                    # networks.py:639 (mu | logsigma)
                     if prob_z_q is not None:                                       # networks.py:645
                         z = prob_z_q[lvl]
                     elif prob_mean:                                                # networks.py:646
@@ -266,9 +294,9 @@ class M1Core(nn.Module):
                     zi += 1
                     distributions.append(ml)
                     used_latents.append(z)
-                    up = getattr(self, "dec_hi" + sfx)([z, feats])                 # networks.py:652-653
+                    up = getattr(self, "dec_hi" + sfx)([z, f_up])                  # networks.py:652-653
                 else:
-                    up = getattr(self, "dec_hi" + sfx)(feats)                      # networks.py:655-656
+                    up = getattr(self, "dec_hi" + sfx)(f_up)                       # networks.py:655-656
                 feats = getattr(self, "sersp" + sfx)([up, *skips[lvl]], dropout=getattr(self, "dropp" + sfx))
                 if lvl < 3:
                     ds_ops.append(feats)                                           # networks.py:657,681,705
@@ -283,7 +311,7 @@ class M1Core(nn.Module):
                 s1 = S[1]
                 s12 = tuple(a * b for a, b in zip(S[1], S[2]))
                 s123 = tuple(a * b * c for a, b, c in zip(S[1], S[2], S[3]))
-                heads += [self.dsy1_logits(uconv1), self.dsy2_logits(uconv2), self.dsy3_logits(uconv3)]
+                heads += [self.dsy1_logits(u1_h), self.dsy2_logits(u2_h), self.dsy3_logits(u3_h)]
                 ups += [s1, s12, s123]
             outputs['y_softmax'] = ops.softmax_heads(heads, ups)
             outputs['logits'] = y__

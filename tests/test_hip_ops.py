@@ -333,6 +333,45 @@ def test_softmax_heads_fwd_bwd(dev, dtype, nc):
         assert rel_err(a.grad, b) < tol
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("C_,V,k", [(32, (4, 16, 16), (1, 3, 3)), (16, (3, 8, 8), (3, 3, 3)), (64, (2, 8, 16), (1, 1, 1)), (12, (3, 6, 5), (3, 3, 3))])
+def test_fanout_sums_data_gradients_in_the_kernels(dev, dtype, C_, V, k):
+    """ops.fanout: conv dgrads (matrix-core, halo and strided paths), a transposed conv, the sigma product and one
+    consumer without an accumulating kernel (nested fork) all land in ONE buffer == the plain sum of the separate gradients."""
+    N = 2
+    x0 = rnd((N, *V, C_), 1)
+    if dtype == torch.bfloat16:
+        x0 = x0.bfloat16().float()
+    w1, w4 = rnd((*k, C_, 16), 2, 0.2), rnd((*k, C_, 24), 3, 0.2)
+    w5 = rnd((*k, C_, 8), 4, 0.2)
+    wt = rnd((1, 3, 3, 8, C_), 5, 0.2)
+    sig = torch.sigmoid(rnd((N, *V), 6))
+
+    def run(use_fanout):
+        x = x0.to(dev, dtype).requires_grad_(True)
+        ws = [t.to(dev).requires_grad_(True) for t in (w1, w4, w5, wt)]
+        z = x * 1.0 if dtype == torch.float32 else (x.float() * 1.0).to(dtype)       # non-leaf producer
+        if use_fanout:
+            a, b, c, d, e = ops.fanout(z, 5)
+            d1, d2 = ops.fanout(d, 2)                                                 # nested: shares the outer buffer
+        else:
+            a = b = c = d1 = d2 = e = z
+        outs = [ops.conv3d_same([a], ws[0], None, k, (1, 1, 1)), ops.conv3d_same([b], ws[1], None, k, (1, 1, 1)),
+                ops.conv3d_same([c], ws[2], None, k, (1, 2, 2) if V[1] % 2 == 0 and V[2] % 2 == 0 else (1, 1, 1)),
+                ops.conv3d_transpose_same([d1], ws[3], None, (1, 3, 3), (1, 2, 2)),
+                ops.mul_sigma(d2, sig.to(dev, dtype)), torch.tanh(e.float())]
+        loss = sum((o.float() * rnd(tuple(o.shape), 20 + i).to(dev)).sum() for i, o in enumerate(outs))
+        loss.backward()
+        return x.grad.float().clone(), [w.grad.clone() for w in ws]
+    gx_ref, gw_ref = run(False)
+    gx, gw = run(True)
+    gx2, _ = run(True)
+    assert torch.equal(gx, gx2)                                                       # fixed accumulation order
+    assert rel_err(gx, gx_ref) < (1e-5 if dtype == torch.float32 else 8e-3)
+    for a, b in zip(gw, gw_ref):
+        assert rel_err(a, b) < 1e-5
+
+
 @pytest.mark.parametrize("nheads,nc,gamma,ydt", [(1, 2, 2.0, torch.float32), (4, 2, 2.0, torch.bfloat16), (2, 3, 1.5, torch.float32),
                                                   (1, 2, 0.0, torch.float32), (3, 2, 1.0, torch.float32)])
 def test_focal_loss_fused_matches_oracle(dev, nheads, nc, gamma, ydt):
