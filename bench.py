@@ -33,6 +33,11 @@ PEAK_HBM_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 PEAK_MFMA_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}
 
 
+# volumes per GPU when --batch is not given: the reference trainer's default batch (train_model.py:83, --BATCH_SIZE 2), which is
+# also the per-GPU batch BASELINE.json names for C4; C1 is the reference's batch-1 plumbing case, C5 the single-volume stress case
+DEFAULT_BATCH = {"C1": 1, "C2": 2, "C3": 2, "C5": 1}
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -40,7 +45,9 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default=os.environ.get("M1_BENCH_WORKLOAD", "C2"), choices=sorted(WORKLOADS))
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
-    ap.add_argument("--batch", type=int, default=None, help="volumes per GPU (default 1; C4 = C3 with --batch 2)")
+    ap.add_argument("--batch", type=int, default=None,
+                    help="volumes per GPU (default: 2 for C2/C3 = train_model.py:83's --BATCH_SIZE default and C4's per-GPU batch; "
+                         "1 for C1/C5).  C4 = C3 at its default batch on 8 GPUs")
     ap.add_argument("--dropout", type=float, default=0.5)
     ap.add_argument("--no-graph", action="store_true", help="do not capture the step in a hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -117,7 +124,7 @@ def hbm_traffic(a, B, recs, family):
     """HBM bytes per launch of the dominant entry-point family, from the committed rocprofv3 --pmc FETCH_SIZE /
     WRITE_SIZE passes of this same workload (profiles/r01_c2_bf16_hbm_traffic.json, tools/collect_profiles.sh; FETCH_SIZE
     doubled as MI355X_MICROARCH.md prescribes for gfx950).  None when no committed measurement matches the run."""
-    if not (a.workload == "C2" and a.dtype == "bf16" and B == 1):
+    if not (a.workload == "C2" and a.dtype == "bf16"):
         return None, "no committed PMC pass for this workload"
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_c2_bf16_hbm_traffic.json")
     try:
@@ -125,6 +132,8 @@ def hbm_traffic(a, B, recs, family):
             pm = json.load(f)
     except OSError:
         return None, "profiles/r01_c2_bf16_hbm_traffic.json not found"
+    if int(pm.get("batch", 1)) != B:
+        return None, f"the committed PMC pass was taken at batch {pm.get('batch', 1)} per GPU"
     for fams, kernels in _FAMILY_KERNELS.values():
         if family in fams:
             gb = sum(pm["kernels"].get(k, {}).get("fetch_GB_per_step", 0.0) + pm["kernels"].get(k, {}).get("write_GB_per_step", 0.0)
@@ -166,7 +175,7 @@ def main():
             dist.init_process_group(backend=backend, rank=rank, world_size=world)
 
     dims, filters, prob, dense, deep = WORKLOADS[a.workload]
-    B = a.batch or 1
+    B = a.batch or DEFAULT_BATCH[a.workload]
     act_dtype = torch.bfloat16 if a.dtype == "bf16" else torch.float32
     kl_w = 10.0
 
@@ -330,7 +339,8 @@ def main():
                                     "C2": "C2 M1 deterministic Attention-U-Net (20,160,160,3) filters (32..512)",
                                     "C3": "C3 M1 full hierarchical-probabilistic dense_skip+deep_supervision latents (3,2,1,0) (20,160,160,3)",
                                     "C5": "C5 M1 deterministic high-res (32,256,256,3)"}[a.workload],
-                       "batch_per_gpu": B, "global_batch": B * world, "params": nparams, "dropout": a.dropout,
+                       "batch_per_gpu": B, "global_batch": B * world,
+                       "batch_note": "train_model.py:83 default (--BATCH_SIZE 2)" if a.batch is None and B == 2 else "--batch", "params": nparams, "dropout": a.dropout,
                        "parallelism": f"dp{world}", "hip_graph": graph is not None, "graph_error": graph_err,
                        "loss": final_loss},
             "roofline": roof, "cpu_baseline": cpu,

@@ -12,7 +12,7 @@ done
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -- python3 $R/bench.py --workload C2 --steps 5 --warmup 2 --no-cpu-baseline --no-roofline --no-graph > $O/pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -- python3 $R/bench.py --workload C2 --steps 5 --warmup 2 --no-cpu-baseline --no-roofline --no-graph > $O/pmc_write.log 2>&1
 cd $R
-python3 tools/pmc_traffic.py $(ls $O/pmc_fetch/*/*counter_collection.csv | head -1) $(ls $O/pmc_write/*/*counter_collection.csv | head -1) 7 $O/${TAG}_c2_bf16_hbm_traffic.json > $O/${TAG}_c2_bf16_hbm_traffic.txt
+python3 tools/pmc_traffic.py $(ls $O/pmc_fetch/*/*counter_collection.csv | head -1) $(ls $O/pmc_write/*/*counter_collection.csv | head -1) 7 $O/${TAG}_c2_bf16_hbm_traffic.json 2 > $O/${TAG}_c2_bf16_hbm_traffic.txt
 grep "^{" $O/bench_C2.log > $O/${TAG}_c2_bench_under_rocprof.json; grep "^{" $O/bench_C3.log > $O/${TAG}_c3_bench_under_rocprof.json
 rm -rf $O/kt_C2 $O/kt_C3 $O/pmc_fetch $O/pmc_write
 ls -la $O
