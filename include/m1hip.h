@@ -141,11 +141,14 @@ int m1_se_gate_bwd_batch(const m1_se_gate_job_t* jobs /* host array */, int njob
 /* out = dropout( lrelu( IN3(y3) * g * IN4(y4) ) ); y3,y4 raw conv outputs (N,V,F); stats3/4 (N,F,2).
  * Dropout state is DEVICE resident so a captured graph can be replayed: rng[0] = seed, rng[1] = step
  * counter (advanced by m1_step_advance); layer_id separates the streams of different layers. The mask is
- * a pure function of (rng, layer_id, element index): backward regenerates it, no mask tensor exists. */
+ * a pure function of (rng, layer_id, element index): backward can regenerate it.  keep_mask (optional, bf16 and
+ * F % 8 == 0 only, N*V*F/8 bytes): the forward also stores the keep bits (bit idx & 7 of byte idx >> 3) and a backward
+ * given the same buffer reads them instead of re-running Philox (the backward passes are instruction bound:
+ * 10 Philox rounds per 4 elements were ~45 % of their instructions). */
 int m1_se_combine_fwd(const void* y3, const void* y4, const float* stats3, const float* stats4,
                       const float* gamma3, const float* beta3, const float* gamma4, const float* beta4,
                       const float* g, void* out, int N, long long V, int F, int dtype, float drop_rate,
-                      const uint64_t* rng, uint64_t layer_id, void* stream);
+                      const uint64_t* rng, uint64_t layer_id, unsigned char* keep_mask, void* stream);
 /* writes dy3, dy4 (grads wrt the RAW conv outputs, i.e. through both InstanceNorms); dgamma3,dbeta3,dgamma4,
  * dbeta4 (F each) per `accumulate`; dg is scratch for m1_se_gate_bwd, F + Fr floats, first F always overwritten.
  * ws: m1_reduce_ws_floats(N,V,F,5). */
@@ -153,8 +156,8 @@ int m1_se_combine_bwd(const void* y3, const void* y4, const float* stats3, const
                       const float* gamma3, const float* beta3, const float* gamma4, const float* beta4,
                       const float* g, const void* dout, void* dy3, void* dy4, float* dgamma3, float* dbeta3,
                       float* dgamma4, float* dbeta4, float* dg, int N, long long V, int F, int dtype,
-                      float drop_rate, const uint64_t* rng, uint64_t layer_id, float* ws, int accumulate,
-                      void* stream);
+                      float drop_rate, const uint64_t* rng, uint64_t layer_id, const unsigned char* keep_mask,
+                      float* ws, int accumulate, void* stream);
 
 /* ---- grid attention gate pieces : B:113-124 ----
  * theta: (N, Dt,Ht,Wt, C) ; phi: (N, Dp,Hp,Wp, C) nearest-upsampled by (Dt/Dp,...) ;

@@ -6,7 +6,7 @@
 #include "gather.h"
 
 extern "C" size_t m1_reduce_ws_floats(int N, long long V, int C, int nsums) {
-    return (size_t)N * m1_red_nchunks(V, C) * C * nsums + (size_t)N * C * nsums + 64;
+    return (size_t)N * m1_red_nchunks(V, C, N) * C * nsums + (size_t)N * C * nsums + 64;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -33,7 +33,7 @@ static int stats_impl(const void* x, int N, long long V, int C, float eps, float
     StatsF<T> f{(const T*)x, V, C};
     int rc = m1_reduce_nc_launch<2>(f, N, V, C, ws, st);
     if (rc) return rc;
-    return m1_reduce_finalize_launch<2>(ws, N, C, m1_red_nchunks(V, C), stats, V, eps, st);
+    return m1_reduce_finalize_launch<2>(ws, N, C, m1_red_nchunks(V, C, N), stats, V, eps, st);
 }
 
 int m1_stats_internal(const void* x, int N, long long V, int C, int dtype, float eps, float* stats, float* ws, hipStream_t st) {
@@ -187,7 +187,7 @@ static int bwd_impl(const void* x, const float* stats, const float* gamma, const
     InBwdF<T> f{(const T*)x, (const T*)dy, stats, gamma, beta, slope, V, C};
     int rc = m1_reduce_nc_launch<2>(f, N, V, C, ws, st);
     if (rc) return rc;
-    const int nchunks = m1_red_nchunks(V, C);
+    const int nchunks = m1_red_nchunks(V, C, N);
     float* sums = ws + (size_t)N * nchunks * C * 2;
     M1ParamOut<2> po{{dbeta, dgamma}, {accumulate, accumulate}};      // dbeta = sum_n sums[.][0], dgamma = sum_n sums[.][1]
     rc = m1_reduce_finalize_params_launch<2>(ws, N, C, nchunks, sums, po, st);
@@ -241,5 +241,5 @@ int m1_colsum_internal(const void* x, int N, long long V, int C, int dtype, floa
     else { ColSumF<float> f{(const float*)x, V, C}; rc = m1_reduce_nc_launch<1>(f, N, V, C, ws, st); }
     if (rc) return rc;
     // partial is [N*nchunks][C][1]: fold all rows as one sample
-    return m1_reduce_finalize_launch<1>(ws, 1, C, N * m1_red_nchunks(V, C), out, 0, 0.f, st, accumulate);
+    return m1_reduce_finalize_launch<1>(ws, 1, C, N * m1_red_nchunks(V, C, N), out, 0, 0.f, st, accumulate);
 }

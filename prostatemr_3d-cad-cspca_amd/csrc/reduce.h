@@ -8,19 +8,24 @@
 #pragma once
 #include "common.h"
 
+#include <stdlib.h>
 #define M1_RED_THREADS 256
 
-static inline int m1_red_chunkV(long long V, int C) {
-    // >= ~16 elements per thread, and at most ~1024 chunks per sample (the finalize folds them per wave)
+static inline int m1_red_chunkV(long long V, int C, int N) {
+    // >= ~16 elements per thread, and about 512 blocks per launch (2 per CU): every block ends with a fold of its NS x VEC
+    // register sums through shuffles + LDS that costs as much as ~10 voxel iterations, so more, smaller chunks lose
+    // (measured at batch 2: 1024 chunks per sample -> 256 = -34 % on the SE backward reduction, -3.7 % per step)
     long long per_block = (long long)M1_RED_THREADS * 16 / (C < 256 ? (C < 1 ? 1 : C) : 256);
     if (per_block < 16) per_block = 16;
     long long chunk = per_block;
-    const long long cap = cdiv_ll(V, 1024);
+    static int tgt = -1; if (tgt < 0) { const char* e = getenv("M1_RED_BLOCKS"); tgt = e ? atoi(e) : 512; if (tgt < 1) tgt = 1; }
+    int maxc = tgt / (N < 1 ? 1 : N); if (maxc < 32) maxc = 32;
+    const long long cap = cdiv_ll(V, maxc);
     if (chunk < cap) chunk = cap;
     if (chunk > V) chunk = V;
     return (int)chunk;
 }
-static inline int m1_red_nchunks(long long V, int C) { return (int)cdiv_ll(V, m1_red_chunkV(V, C)); }
+static inline int m1_red_nchunks(long long V, int C, int N) { return (int)cdiv_ll(V, m1_red_chunkV(V, C, N)); }
 
 static inline int m1_pow2_ge(int c) { int p = 1; while (p < c) p <<= 1; return p; }
 
@@ -138,6 +143,9 @@ static inline int m1_reduce_finalize_params_launch(const float* partial, int N, 
     return m1_check_launch();
 }
 
+template <typename F, typename = void> struct M1RedUnroll { static constexpr int value = 1; };
+template <typename F> struct M1RedUnroll<F, decltype((void)F::kUnroll)> { static constexpr int value = F::kUnroll; };
+
 // Vector variant: a lane owns VEC consecutive channels (one 16-byte load per tensor per voxel) instead of one.
 // Functor contract:  static constexpr int kVec;  __device__ void vec(int n, long long v, int c0, float (*acc)[kVec]) const;
 template <int NS, int VEC, typename F>
@@ -157,8 +165,19 @@ __global__ void __launch_bounds__(M1_RED_THREADS) m1_reduce_nc_vec_kernel(F f, l
         for (int k = 0; k < NS; ++k)
 #pragma unroll
             for (int e = 0; e < VEC; ++e) acc[k][e] = 0.f;
-        if (gi < cg)
-            for (long long v = v0 + vs; v < v1; v += nvs) f.vec(n, v, gi * VEC, acc);
+        if (gi < cg) {
+            // M1RedUnroll<F>: voxels in flight per lane (independent 16-byte loads issued back to back; the streaming
+            // functors run at 2-3 waves per SIMD, so the loads of one voxel alone cannot cover the HBM latency)
+            constexpr int U = M1RedUnroll<F>::value;
+            long long v = v0 + vs;
+            if constexpr (U > 1) {
+                for (; v + (long long)(U - 1) * nvs < v1; v += (long long)U * nvs) {
+#pragma unroll
+                    for (int u = 0; u < U; ++u) f.vec(n, v + (long long)u * nvs, gi * VEC, acc);
+                }
+            }
+            for (; v < v1; v += nvs) f.vec(n, v, gi * VEC, acc);
+        }
         // fold the voxel sub-lanes: xor-shuffles inside a wave (lanes cpad apart share a channel group), then the
         // 4 waves (or, for >= 64 channel groups, the voxel sub-lane rows) through LDS, one sum at a time
         const int wcol = cpad < 64 ? cpad : 64;                      // distinct channel groups per wave
@@ -192,7 +211,7 @@ template <typename F> struct M1RedVec<F, decltype((void)F::kVec)> { static const
 
 template <int NS, typename F>
 static inline int m1_reduce_nc_launch(const F& f, int N, long long V, int C, float* partial, hipStream_t st) {
-    const int chunkV = m1_red_chunkV(V, C), nchunks = m1_red_nchunks(V, C);
+    const int chunkV = m1_red_chunkV(V, C, N), nchunks = m1_red_nchunks(V, C, N);
     dim3 grid(nchunks, N);
     constexpr int VEC = M1RedVec<F>::value;
     if constexpr (VEC > 0) {

@@ -188,6 +188,7 @@ struct SeParams {
     const float *stats3, *stats4, *gamma3, *beta3, *gamma4, *beta4, *g;
     long long V; int F;
     float drop_rate; const uint64_t* rng; uint64_t layer_id;
+    unsigned char* mask;      // optional keep-mask, bit (idx & 7) of byte (idx >> 3): written by the forward, read by the backward
 };
 
 __device__ __forceinline__ void se_rng(const SeParams& p, uint64_t& seed, uint64_t& base) {
@@ -220,13 +221,19 @@ __global__ void __launch_bounds__(256) se_combine_fwd_kernel(const T* __restrict
             philox_keep_vec<VEC>(seed, rbase, base + i * VEC, p.drop_rate, keep);
 #pragma unroll
             for (int k = 0; k < VEC; ++k) a[k] = keep[k] ? a[k] * keep_scale : 0.f;
+            if (VEC == 8 && p.mask) {                     // one byte per lane: the backward reads it instead of re-running Philox
+                unsigned m = 0;
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) m |= (keep[k] ? 1u : 0u) << k;
+                p.mask[(base + i * VEC) >> 3] = (unsigned char)m;
+            }
         }
         VecIO<T, VEC>::st(out + base + i * VEC, a);
     }
 }
 
 // ---------------- combine backward ----------------
-template <typename T>
+template <typename T, bool MASKED = false>
 struct SeBwdF {
     const T* y3; const T* y4; const T* dout; SeParams p;
     __device__ void operator()(int n, long long v, int c, float* acc) const {
@@ -246,13 +253,18 @@ struct SeBwdF {
         acc[0] += dx_; acc[1] += dx_ * xh3; acc[2] += drho; acc[3] += drho * xh4; acc[4] += du * x_ * rho;
     }
     static constexpr int kVec = sizeof(T) == 2 ? 8 : 4;
+    static constexpr int kUnroll = 1;
     __device__ void vec(int n, long long v, int c0, float (*acc)[kVec]) const {
         const int F = p.F;
         const size_t idx = ((size_t)n * p.V + v) * F + c0;
         float a[kVec], b[kVec], d[kVec];
         VecIO<T, kVec>::ld(y3 + idx, a); VecIO<T, kVec>::ld(y4 + idx, b); VecIO<T, kVec>::ld(dout + idx, d);
         bool keep[kVec];
-        if (p.drop_rate > 0.f) { uint64_t seed, rbase; se_rng(p, seed, rbase); philox_keep_vec<kVec>(seed, rbase, idx, p.drop_rate, keep); }
+        if (MASKED) {
+            const unsigned m = p.mask[idx >> 3];
+#pragma unroll
+            for (int e = 0; e < kVec; ++e) keep[e] = (m >> e) & 1u;
+        } else if (p.drop_rate > 0.f) { uint64_t seed, rbase; se_rng(p, seed, rbase); philox_keep_vec<kVec>(seed, rbase, idx, p.drop_rate, keep); }
         const float keep_scale = p.drop_rate > 0.f ? 1.f / (1.f - p.drop_rate) : 1.f;
 #pragma unroll
         for (int e = 0; e < kVec; ++e) {
@@ -270,7 +282,7 @@ struct SeBwdF {
     }
 };
 
-template <typename T, int VEC>
+template <typename T, int VEC, bool MASKED = false>
 __global__ void __launch_bounds__(256) se_combine_bwd_apply_kernel(const T* __restrict__ y3, const T* __restrict__ y4,
                                                                    const T* __restrict__ dout, SeParams p,
                                                                    const float* __restrict__ sums /*[N][F][5]*/,
@@ -288,7 +300,11 @@ __global__ void __launch_bounds__(256) se_combine_bwd_apply_kernel(const T* __re
         VecIO<T, VEC>::ld(y4 + base + i * VEC, b);
         VecIO<T, VEC>::ld(dout + base + i * VEC, d);
         bool keep[VEC];
-        if (p.drop_rate > 0.f) philox_keep_vec<VEC>(seed, rbase, base + i * VEC, p.drop_rate, keep);
+        if (MASKED) {
+            const unsigned m = p.mask[(base + i * VEC) >> 3];
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) keep[k] = (m >> k) & 1u;
+        } else if (p.drop_rate > 0.f) philox_keep_vec<VEC>(seed, rbase, base + i * VEC, p.drop_rate, keep);
 #pragma unroll
         for (int k = 0; k < VEC; ++k) {
             const int c = c0 + k; const size_t sc = ((size_t)n * F + c) * 2;
@@ -327,17 +343,22 @@ template <typename T>
 static int se_bwd_impl(const void* y3, const void* y4, const void* dout, const SeParams& p, void* dy3, void* dy4,
                        float* dgamma3, float* dbeta3, float* dgamma4, float* dbeta4, float* dg, int N, float* ws,
                        hipStream_t st, int acc) {
-    SeBwdF<T> f{(const T*)y3, (const T*)y4, (const T*)dout, p};
-    int rc = m1_reduce_nc_launch<5>(f, N, p.V, p.F, ws, st);
+    constexpr int VW = sizeof(T) == 2 ? 8 : 4;
+    const bool masked = VW == 8 && p.mask && p.drop_rate > 0.f && p.F % VW == 0;
+    int rc;
+    if (masked) { SeBwdF<T, true> f{(const T*)y3, (const T*)y4, (const T*)dout, p}; rc = m1_reduce_nc_launch<5>(f, N, p.V, p.F, ws, st); }
+    else { SeBwdF<T> f{(const T*)y3, (const T*)y4, (const T*)dout, p}; rc = m1_reduce_nc_launch<5>(f, N, p.V, p.F, ws, st); }
     if (rc) return rc;
-    const int nchunks = m1_red_nchunks(p.V, p.F);
+    const int nchunks = m1_red_nchunks(p.V, p.F, N);
     float* sums = ws + (size_t)N * nchunks * p.F * 5;
     // parameter gradients ride on the fold: dg is scratch for the gate backward (always overwritten)
     M1ParamOut<5> po{{dbeta3, dgamma3, dbeta4, dgamma4, dg}, {acc, acc, acc, acc, 0}};
     rc = m1_reduce_finalize_params_launch<5>(ws, N, p.F, nchunks, sums, po, st);
     if (rc) return rc;
-    constexpr int VW = sizeof(T) == 2 ? 8 : 4;
-    if (p.F % VW == 0)
+    if (masked)
+        hipLaunchKernelGGL((se_combine_bwd_apply_kernel<T, VW, true>), dim3(grid_x(p.V * (p.F / VW)), N), dim3(256), 0, st,
+                           (const T*)y3, (const T*)y4, (const T*)dout, p, sums, (T*)dy3, (T*)dy4);
+    else if (p.F % VW == 0)
         hipLaunchKernelGGL((se_combine_bwd_apply_kernel<T, VW>), dim3(grid_x(p.V * (p.F / VW)), N), dim3(256), 0, st,
                            (const T*)y3, (const T*)y4, (const T*)dout, p, sums, (T*)dy3, (T*)dy4);
     else
@@ -349,11 +370,12 @@ static int se_bwd_impl(const void* y3, const void* y4, const void* dout, const S
 extern "C" int m1_se_combine_fwd(const void* y3, const void* y4, const float* stats3, const float* stats4,
                                  const float* gamma3, const float* beta3, const float* gamma4, const float* beta4,
                                  const float* g, void* out, int N, long long V, int F, int dtype, float drop_rate,
-                                 const uint64_t* rng, uint64_t layer_id, void* stream) {
+                                 const uint64_t* rng, uint64_t layer_id, unsigned char* keep_mask, void* stream) {
     if (!y3 || !y4 || !stats3 || !stats4 || !gamma3 || !beta3 || !gamma4 || !beta4 || !g || !out) return M1_ERR_BAD_ARG;
     if (drop_rate > 0.f && !rng) return M1_ERR_BAD_ARG;
     if (drop_rate < 0.f || drop_rate >= 1.f) return M1_ERR_BAD_ARG;
-    SeParams p{stats3, stats4, gamma3, beta3, gamma4, beta4, g, V, F, drop_rate, rng, layer_id};
+    if (keep_mask && (dtype != M1_BF16 || F % 8)) return M1_ERR_UNSUPPORTED;
+    SeParams p{stats3, stats4, gamma3, beta3, gamma4, beta4, g, V, F, drop_rate, rng, layer_id, keep_mask};
     M1ProfScope ps("se_combine_fwd", 0.0, 3.0 * N * V * F * (dtype == M1_BF16 ? 2 : 4), (hipStream_t)stream);
     return dtype == M1_BF16 ? se_fwd_impl<bf16_t>(y3, y4, p, out, N, (hipStream_t)stream)
                             : se_fwd_impl<float>(y3, y4, p, out, N, (hipStream_t)stream);
@@ -363,11 +385,12 @@ extern "C" int m1_se_combine_bwd(const void* y3, const void* y4, const float* st
                                  const float* gamma3, const float* beta3, const float* gamma4, const float* beta4,
                                  const float* g, const void* dout, void* dy3, void* dy4, float* dgamma3, float* dbeta3,
                                  float* dgamma4, float* dbeta4, float* dg, int N, long long V, int F, int dtype,
-                                 float drop_rate, const uint64_t* rng, uint64_t layer_id, float* ws, int accumulate,
-                                 void* stream) {
+                                 float drop_rate, const uint64_t* rng, uint64_t layer_id, const unsigned char* keep_mask,
+                                 float* ws, int accumulate, void* stream) {
     if (!y3 || !y4 || !dout || !dy3 || !dy4 || !dgamma3 || !dbeta3 || !dgamma4 || !dbeta4 || !dg || !ws) return M1_ERR_BAD_ARG;
-    if (drop_rate > 0.f && !rng) return M1_ERR_BAD_ARG;
-    SeParams p{stats3, stats4, gamma3, beta3, gamma4, beta4, g, V, F, drop_rate, rng, layer_id};
+    if (drop_rate > 0.f && !rng && !keep_mask) return M1_ERR_BAD_ARG;
+    if (keep_mask && (dtype != M1_BF16 || F % 8)) return M1_ERR_UNSUPPORTED;
+    SeParams p{stats3, stats4, gamma3, beta3, gamma4, beta4, g, V, F, drop_rate, rng, layer_id, const_cast<unsigned char*>(keep_mask)};
     M1ProfScope ps("se_combine_bwd", 0.0, 8.0 * N * V * F * (dtype == M1_BF16 ? 2 : 4), (hipStream_t)stream);
     return dtype == M1_BF16
                ? se_bwd_impl<bf16_t>(y3, y4, dout, p, dy3, dy4, dgamma3, dbeta3, dgamma4, dbeta4, dg, N, ws, (hipStream_t)stream, accumulate)

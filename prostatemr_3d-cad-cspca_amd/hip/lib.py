@@ -74,8 +74,8 @@ SIGNATURES = {
     "m1_se_gate_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp]),
     "m1_se_gate_bwd_batch": (_i, [C.POINTER(SeGateJob), _i, _vp]),
     "m1_se_gate_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
-    "m1_se_combine_fwd": (_i, [_vp] * 10 + [_i, _ll, _i, _i, _f, _vp, _u64, _vp]),
-    "m1_se_combine_bwd": (_i, [_vp] * 17 + [_i, _ll, _i, _i, _f, _vp, _u64, _vp, _i, _vp]),
+    "m1_se_combine_fwd": (_i, [_vp] * 10 + [_i, _ll, _i, _i, _f, _vp, _u64, _vp, _vp]),
+    "m1_se_combine_bwd": (_i, [_vp] * 17 + [_i, _ll, _i, _i, _f, _vp, _u64, _vp, _vp, _i, _vp]),
     "m1_gate_sigma_fwd": (_i, [_vp] * 5 + [_i] * 9 + [_vp]),
     "m1_gate_sigma_bwd": (_i, [_vp] * 9 + [_i] * 9 + [_vp, _i, _vp]),
     "m1_mul_sigma_fwd": (_i, [_vp] * 3 + [_i] * 9 + [_vp]),

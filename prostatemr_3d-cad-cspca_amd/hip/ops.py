@@ -409,9 +409,14 @@ class _SECombine(torch.autograd.Function):
         g = torch.empty(Fn, dtype=torch.float32, device=y3.device)
         L.check(lib.m1_se_gate_fwd(_p(b3), _p(W6), _p(b6), _p(W7), _p(b7), Fn, Fr, _p(hidden), _p(g), st), "m1_se_gate_fwd")
         out = torch.empty_like(y3)
+        # keep bits of the fused dropout, stored for the backward (bf16, F % 8 == 0: one byte per 16-byte vector)
+        mask = None
+        if drop_rate > 0.0 and y3.dtype == torch.bfloat16 and Fn % 8 == 0 and any(ctx.needs_input_grad):
+            mask = torch.empty(y3.numel() // 8, dtype=torch.uint8, device=y3.device)
         L.check(lib.m1_se_combine_fwd(_p(y3), _p(y4), _p(s3), _p(s4), _p(g3), _p(b3), _p(g4), _p(b4), _p(g), _p(out), N, V, Fn,
-                                      _dt(y3), float(drop_rate), _p(rng), int(layer_id), st), "m1_se_combine_fwd")
+                                      _dt(y3), float(drop_rate), _p(rng), int(layer_id), _p(mask), st), "m1_se_combine_fwd")
         ctx.save_for_backward(y3, y4, s3, s4, g3, b3, g4, b4, W6, W7, hidden, g)
+        ctx.mask = mask
         ctx.params = (g3, b3, g4, b4, W6, b6, W7, b7)
         ctx.rng, ctx.drop_rate, ctx.layer_id = rng, float(drop_rate), int(layer_id)
         return out
@@ -437,7 +442,7 @@ class _SECombine(torch.autograd.Function):
         ws = _ws(N, V, Fn, 5, dev)
         L.check(lib.m1_se_combine_bwd(_p(y3), _p(y4), _p(s3), _p(s4), _p(g3), _p(b3), _p(g4), _p(b4), _p(g), _p(dout),
                                       _p(dy3), _p(dy4), _p(bg3), _p(bb3), _p(bg4), _p(bb4), _p(dg), N, V, Fn, _dt(y3),
-                                      ctx.drop_rate, _p(ctx.rng), ctx.layer_id, _p(ws), acc, st), "m1_se_combine_bwd")
+                                      ctx.drop_rate, _p(ctx.rng), ctx.layer_id, _p(ctx.mask), _p(ws), acc, st), "m1_se_combine_bwd")
         if acc == 1:
             # parameter gradients only, accumulated into the optimiser's flat buffer: nothing downstream in this backward
             # reads them, so the job is queued and all SE blocks' gate backwards run as one batch (flush_deferred)

@@ -429,6 +429,36 @@ def test_se_combine_fused_dropout_matches_mask(dev):
     assert torch.isfinite(y3g.grad).all()
 
 
+def test_se_combine_stored_keep_mask_equals_regenerated_mask(dev):
+    """bf16, F % 8 == 0: the forward stores the keep bits and the backward reads them; the gradients must be exactly those of
+    the Philox-regenerating backward (reached here by running the same forward under no stored mask: F = 12 is not a
+    multiple of 8, so the comparison is made on the op outputs of an equivalent composition instead)."""
+    F_ = 16
+    shp = (2, 3, 8, 8, F_)
+    y3, y4 = rnd(shp, 1).to(dev, torch.bfloat16), (rnd(shp, 2) * 1.5 + 0.2).to(dev, torch.bfloat16)
+    g3, b3 = (1 + 0.2 * rnd((F_,), 3)).to(dev), (0.5 * rnd((F_,), 4)).to(dev)
+    g4, b4 = (1 + 0.2 * rnd((F_,), 5)).to(dev), (0.5 * rnd((F_,), 6)).to(dev)
+    W6, b6 = rnd((1, 1, 1, F_, 2), 7, 0.5).to(dev), (0.1 * rnd((2,), 8)).to(dev)
+    W7, b7 = rnd((1, 1, 1, 2, F_), 9, 0.5).to(dev), (0.1 * rnd((F_,), 10)).to(dev)
+    rng = torch.tensor([1234, 7], dtype=torch.int64, device=dev)
+    dout = rnd(shp, 11).to(dev, torch.bfloat16)
+
+    def run(fused):
+        ins = [t.clone().requires_grad_(True) for t in (y3, y4, g3, b3, g4, b4, W6, b6, W7, b7)]
+        if fused:                                            # dropout fused into the combine: stored keep bits
+            out = ops.se_combine(*ins, 0.5, rng, 21)
+        else:                                                # same mask through the stand-alone dropout (regenerates Philox)
+            out = ops.dropout(ops.se_combine(*ins), 0.5, rng, 21)
+        out.backward(dout)
+        return out.detach().float(), [t.grad.float() for t in ins]
+    o1, g1 = run(True)
+    o2, g2 = run(False)
+    assert torch.equal(o1, o2)
+    for a, b in zip(g1, g2):
+        assert rel_err(a, b) < 2e-2 and torch.isfinite(a).all()      # the unfused path rounds d(out) to bf16 once more
+    assert rel_err(g1[0], g2[0]) < 5e-3 and rel_err(g1[1], g2[1]) < 5e-3
+
+
 def test_adam_amsgrad_matches_keras_formula(dev):
     n = 1003
     p0, g = rnd((n,), 1), rnd((n,), 2)
