@@ -126,11 +126,18 @@ int m1_se_gate_fwd(const float* beta3, const float* W6, const float* b6, const f
 int m1_se_gate_bwd(const float* beta3, const float* W6, const float* W7, const float* hidden, const float* g,
                    const float* dg, int F, int Fr, float* dbeta3_add, float* dW6, float* db6, float* dW7,
                    float* db7, int accumulate, void* stream);
+#define M1_SE_GATE_BATCH 16
+/* All gates of a core pass in one launch (they depend on parameters only): same arguments as m1_se_gate_fwd per job. */
+typedef struct {
+    const float* beta3; const float* W6; const float* b6; const float* W7; const float* b7;
+    float* hidden; float* g;
+    int F, Fr;
+} m1_se_gate_fwd_job_t;
+int m1_se_gate_fwd_batch(const m1_se_gate_fwd_job_t* jobs /* host array */, int njobs, void* stream);
 /* The gate backward yields parameter gradients only (nothing on the data-gradient chain waits for it): a caller may
  * collect the jobs of a whole backward pass and run them in two launches.  Same arguments as m1_se_gate_bwd.  Jobs
  * that name the same destination buffers (one SE block evaluated by several passes of the cores) must have
  * accumulate = 1; they are applied one after the other in array order, so the sums are run-to-run identical. */
-#define M1_SE_GATE_BATCH 16
 typedef struct {
     const float* beta3; const float* W6; const float* W7; const float* hidden; const float* g;
     float* dg;                 /* the F + Fr scratch of m1_se_combine_bwd (must stay alive until the batch has run) */

@@ -35,10 +35,10 @@ __device__ __forceinline__ void block_matvec_cols(const float* __restrict__ v, c
     }
 }
 
-__global__ void __launch_bounds__(256) se_gate_fwd_kernel(const float* __restrict__ beta3, const float* __restrict__ W6,
-                                                          const float* __restrict__ b6, const float* __restrict__ W7,
-                                                          const float* __restrict__ b7, int F, int Fr,
-                                                          float* __restrict__ hidden, float* __restrict__ g) {
+__device__ __forceinline__ void se_gate_fwd_body(const float* __restrict__ beta3, const float* __restrict__ W6,
+                                                 const float* __restrict__ b6, const float* __restrict__ W7,
+                                                 const float* __restrict__ b7, int F, int Fr,
+                                                 float* __restrict__ hidden, float* __restrict__ g) {
     __shared__ float red[256];
     __shared__ float v_s[SE_MAX_F];
     __shared__ float o_s[SE_MAX_F];
@@ -53,6 +53,19 @@ __global__ void __launch_bounds__(256) se_gate_fwd_kernel(const float* __restric
     __syncthreads();
     block_matvec_cols(h_s, W7, Fr, F, red, o_s);                 // gpre = W7^T h
     for (int c = threadIdx.x; c < F; c += 256) g[c] = 1.f / (1.f + expf(-(o_s[c] + b7[c])));
+}
+__global__ void __launch_bounds__(256) se_gate_fwd_kernel(const float* __restrict__ beta3, const float* __restrict__ W6,
+                                                          const float* __restrict__ b6, const float* __restrict__ W7,
+                                                          const float* __restrict__ b7, int F, int Fr,
+                                                          float* __restrict__ hidden, float* __restrict__ g) {
+    se_gate_fwd_body(beta3, W6, b6, W7, b7, F, Fr, hidden, g);
+}
+// one block per SE block of a core pass: the gates are functions of the parameters only, so a caller can evaluate all of
+// them up front in one launch (m1_se_gate_fwd_batch)
+struct SeGateFwdBatch { m1_se_gate_fwd_job_t job[M1_SE_GATE_BATCH]; };
+__global__ void __launch_bounds__(256) se_gate_fwd_batch_kernel(SeGateFwdBatch b) {
+    const m1_se_gate_fwd_job_t& j = b.job[blockIdx.x];
+    se_gate_fwd_body(j.beta3, j.W6, j.b6, j.W7, j.b7, j.F, j.Fr, j.hidden, j.g);
 }
 
 // out[r] = sum_j W[r*J + j] * v[j]  for r < R (rows contiguous): one wave per row, lanes along j
@@ -169,6 +182,20 @@ extern "C" int m1_se_gate_fwd(const float* beta3, const float* W6, const float* 
     if (!beta3 || !W6 || !b6 || !W7 || !b7 || !hidden || !g || F <= 0 || Fr <= 0) return M1_ERR_BAD_ARG;
     if (F > SE_MAX_F || Fr > SE_MAX_FR) return M1_ERR_UNSUPPORTED;
     hipLaunchKernelGGL(se_gate_fwd_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, beta3, W6, b6, W7, b7, F, Fr, hidden, g);
+    return m1_check_launch();
+}
+extern "C" int m1_se_gate_fwd_batch(const m1_se_gate_fwd_job_t* jobs, int njobs, void* stream) {
+    if (njobs < 0 || (njobs > 0 && !jobs)) return M1_ERR_BAD_ARG;
+    for (int j0 = 0; j0 < njobs; j0 += M1_SE_GATE_BATCH) {
+        SeGateFwdBatch b{}; const int n = njobs - j0 < M1_SE_GATE_BATCH ? njobs - j0 : M1_SE_GATE_BATCH;
+        for (int q = 0; q < n; ++q) {
+            const m1_se_gate_fwd_job_t& j = jobs[j0 + q];
+            if (!j.beta3 || !j.W6 || !j.b6 || !j.W7 || !j.b7 || !j.hidden || !j.g || j.F <= 0 || j.Fr <= 0) return M1_ERR_BAD_ARG;
+            if (j.F > SE_MAX_F || j.Fr > SE_MAX_FR) return M1_ERR_UNSUPPORTED;
+            b.job[q] = j;
+        }
+        hipLaunchKernelGGL(se_gate_fwd_batch_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, b);
+    }
     return m1_check_launch();
 }
 extern "C" int m1_se_gate_bwd(const float* beta3, const float* W6, const float* W7, const float* hidden, const float* g,

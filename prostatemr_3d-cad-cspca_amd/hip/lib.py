@@ -39,6 +39,11 @@ class m1_head_t(C.Structure):
                 ("u0", C.c_int), ("u1", C.c_int), ("u2", C.c_int), ("_pad", C.c_int)]
 
 
+class SeGateFwdJob(C.Structure):
+    """m1_se_gate_fwd_job_t"""
+    _fields_ = [(n, C.c_void_p) for n in ("beta3", "W6", "b6", "W7", "b7", "hidden", "g")] + [("F", C.c_int), ("Fr", C.c_int)]
+
+
 class SeGateJob(C.Structure):
     """m1_se_gate_job_t"""
     _fields_ = [(n, C.c_void_p) for n in ("beta3", "W6", "W7", "hidden", "g", "dg", "dbeta3_add", "dW6", "db6", "dW7", "db7")] \
@@ -72,6 +77,7 @@ SIGNATURES = {
     "m1_instnorm_apply": (_i, [_vp, _vp, _vp, _vp, _f, _vp, _i, _ll, _i, _i, _vp]),
     "m1_instnorm_bwd": (_i, [_vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _i, _ll, _i, _i, _vp, _i, _vp]),
     "m1_se_gate_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp]),
+    "m1_se_gate_fwd_batch": (_i, [C.POINTER(SeGateFwdJob), _i, _vp]),
     "m1_se_gate_bwd_batch": (_i, [C.POINTER(SeGateJob), _i, _vp]),
     "m1_se_gate_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
     "m1_se_combine_fwd": (_i, [_vp] * 10 + [_i, _ll, _i, _i, _f, _vp, _u64, _vp, _vp]),

@@ -396,7 +396,7 @@ def drop_deferred() -> None:
 
 class _SECombine(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, y3, y4, g3, b3, g4, b4, W6, b6, W7, b7, drop_rate, rng, layer_id, s3, s4):
+    def forward(ctx, y3, y4, g3, b3, g4, b4, W6, b6, W7, b7, drop_rate, rng, layer_id, s3, s4, gate):
         _req(y3, y4, g3, b3, g4, b4, W6, b6, W7, b7)
         lib = L.load()
         N, Fn = int(y3.shape[0]), int(y3.shape[-1])
@@ -405,9 +405,14 @@ class _SECombine(torch.autograd.Function):
         st = _stream()
         s3 = instnorm_stats(y3) if s3 is None else s3
         s4 = instnorm_stats(y4) if s4 is None else s4
-        hidden = torch.empty(Fr, dtype=torch.float32, device=y3.device)
-        g = torch.empty(Fn, dtype=torch.float32, device=y3.device)
-        L.check(lib.m1_se_gate_fwd(_p(b3), _p(W6), _p(b6), _p(W7), _p(b7), Fn, Fr, _p(hidden), _p(g), st), "m1_se_gate_fwd")
+        if gate is not None:                      # evaluated up front with the other gates of the pass (se_gate_batch)
+            hidden, g = gate
+            if hidden.numel() != Fr or g.numel() != Fn:
+                raise RuntimeError("se_combine: precomputed gate does not match this block")
+        else:
+            hidden = torch.empty(Fr, dtype=torch.float32, device=y3.device)
+            g = torch.empty(Fn, dtype=torch.float32, device=y3.device)
+            L.check(lib.m1_se_gate_fwd(_p(b3), _p(W6), _p(b6), _p(W7), _p(b7), Fn, Fr, _p(hidden), _p(g), st), "m1_se_gate_fwd")
         out = torch.empty_like(y3)
         # keep bits of the fused dropout, stored for the backward (bf16, F % 8 == 0: one byte per 16-byte vector)
         mask = None
@@ -452,12 +457,34 @@ class _SECombine(torch.autograd.Function):
         else:
             L.check(lib.m1_se_gate_bwd(_p(b3), _p(W6), _p(W7), _p(hidden), _p(g), _p(dg), Fn, Fr, _p(bb3), _p(bW6), _p(bb6),
                                        _p(bW7), _p(bb7), acc, st), "m1_se_gate_bwd")
-        return dy3, dy4, rg3, rb3, rg4, rb4, rW6, rb6, rW7, rb7, None, None, None, None, None
+        return dy3, dy4, rg3, rb3, rg4, rb4, rW6, rb6, rW7, rb7, None, None, None, None, None, None
 
 
-def se_combine(y3, y4, g3, b3, g4, b4, W6, b6, W7, b7, drop_rate=0.0, rng=None, layer_id=0, stats3=None, stats4=None):
-    """dropout(lrelu(IN3(y3) * sigmoid(W7.lrelu(W6.beta3+b6)+b7) * IN4(y4)))  (network_blocks.py:60-78)."""
-    return _SECombine.apply(y3, y4, g3, b3, g4, b4, W6, b6, W7, b7, drop_rate, rng, layer_id, stats3, stats4)
+def se_combine(y3, y4, g3, b3, g4, b4, W6, b6, W7, b7, drop_rate=0.0, rng=None, layer_id=0, stats3=None, stats4=None,
+               gate=None):
+    """dropout(lrelu(IN3(y3) * sigmoid(W7.lrelu(W6.beta3+b6)+b7) * IN4(y4)))  (network_blocks.py:60-78).
+    ``gate``: the (hidden, g) pair se_gate_batch computed for this block from the same parameters, else evaluated here."""
+    return _SECombine.apply(y3, y4, g3, b3, g4, b4, W6, b6, W7, b7, drop_rate, rng, layer_id, stats3, stats4, gate)
+
+
+def se_gate_batch(params):
+    """[(hidden, g)] for a list of SE blocks' (beta3, W6, b6, W7, b7): the gates depend on parameters only (GAP of an
+    InstanceNorm output is its beta), so one launch evaluates all gates of a core pass (m1_se_gate_fwd_batch)."""
+    if not params:
+        return []
+    _req(*[t for ps in params for t in ps])
+    dev = params[0][0].device
+    sizes = [(int(W6.shape[-1]), int(W6.shape[-2])) for _, W6, _, _, _ in params]          # (Fr, F)
+    buf = torch.empty(sum(a + b for a, b in sizes), dtype=torch.float32, device=dev)
+    jobs = (L.SeGateFwdJob * len(params))()
+    out, off = [], 0
+    for j, ((b3, W6, b6, W7, b7), (Fr, Fn)) in enumerate(zip(params, sizes)):
+        hidden, g = buf[off:off + Fr], buf[off + Fr:off + Fr + Fn]
+        off += Fr + Fn
+        jobs[j] = L.SeGateFwdJob(_p(b3), _p(W6), _p(b6), _p(W7), _p(b7), hidden.data_ptr(), g.data_ptr(), Fn, Fr)
+        out.append((hidden, g))
+    L.check(L.load().m1_se_gate_fwd_batch(jobs, len(params), _stream()), "m1_se_gate_fwd_batch")
+    return out
 
 
 # ---------------------------------------------------------------------------------------------------------

@@ -151,6 +151,17 @@ class SEResNetBottleNeck(nn.Module):
         # Keras defaults: glorot_uniform / zeros, no regulariser (B:45-46)
         self.conv6 = Conv3D(self.filters, self.filters // self.reduction, (1, 1, 1), (1, 1, 1), padding="valid")
         self.conv7 = Conv3D(self.filters // self.reduction, self.filters, (1, 1, 1), (1, 1, 1), padding="valid")
+        self._gate = None
+
+    def gate_params(self):
+        return (self.norm3.beta, self.conv6.kernel, self.conv6.bias, self.conv7.kernel, self.conv7.bias)
+
+    @staticmethod
+    def precompute_gates(blocks):
+        """One launch for the SE gates of all ``blocks`` (functions of parameters only); each block consumes its pair in
+        its next forward."""
+        for blk, pair in zip(blocks, ops.se_gate_batch([b.gate_params() for b in blocks])):
+            blk._gate = pair
 
     def forward(self, input_tensor: Tensors, dropout: Optional[_DropoutBase] = None) -> torch.Tensor:
         pairs = [ops.fanout(t, 2) for t in _as_list(input_tensor)]          # every member feeds conv1 and conv4
@@ -162,10 +173,11 @@ class SEResNetBottleNeck(nn.Module):
         y3, s3 = self.conv3(a, stats=True)                                      # B:59
         y4, s4 = self.conv4(srcs4, stats=True)                                  # B:64
         rate = dropout.effective_rate() if dropout is not None else 0.0
+        gate, self._gate = self._gate, None              # evaluated up front by the owning core (precompute_gates), once per pass
         return ops.se_combine(y3, y4, self.norm3.gamma, self.norm3.beta, self.norm4.gamma, self.norm4.beta,
                               self.conv6.kernel, self.conv6.bias, self.conv7.kernel, self.conv7.bias, rate,
                               dropout.rng if (dropout is not None and rate > 0.0) else None,
-                              dropout.layer_id if dropout is not None else 0, s3, s4)   # B:60-78 (+ following dropout)
+                              dropout.layer_id if dropout is not None else 0, s3, s4, gate)   # B:60-78 (+ following dropout)
 
 
 # ---- grid attention gate (B:88-130) ---------------------------------------------------------------------

@@ -182,6 +182,8 @@ class M1Core(nn.Module):
         outputs = {}
         S = self.strides
         # networks.py:574-576
+        SEResNetBottleNeck.precompute_gates([m for m in self.children() if isinstance(m, SEResNetBottleNeck)
+                                             and not (self.probabilistic and m is self.sersd0)])
         x_raw, s0 = self.conve0(inputs, stats=True)
         x = self.norme0(x_raw, 0.1, s0)
         # A tensor read by several layers is handed out as one alias per reader (ops.fanout): the readers' backward kernels

@@ -208,6 +208,27 @@ def test_se_gate_backward_deferred_batch_matches_direct(dev):
             assert rel_err(b, a) < 1e-5
 
 
+def test_se_gate_batch_equals_per_block_gates(dev):
+    """m1_se_gate_fwd_batch (all gates of a core pass in one launch) == m1_se_gate_fwd per block, and se_combine accepts it."""
+    cfgs = [(16, 8), (32, 4), (64, 8), (512, 8)]
+    params = []
+    for k, (F_, red) in enumerate(cfgs):
+        params.append(tuple(t.to(dev) for t in (0.5 * rnd((F_,), 10 * k + 1), rnd((1, 1, 1, F_, F_ // red), 10 * k + 2, 0.5),
+                                                 0.1 * rnd((F_ // red,), 10 * k + 3), rnd((1, 1, 1, F_ // red, F_), 10 * k + 4, 0.5),
+                                                 0.1 * rnd((F_,), 10 * k + 5))))
+    pairs = ops.se_gate_batch(params)
+    for (b3, W6, b6, W7, b7), (hidden, g) in zip(params, pairs):
+        h_ref = torch.nn.functional.leaky_relu(b3.double() @ W6.double().reshape(W6.shape[-2], -1) + b6.double(), 0.1)
+        g_ref = torch.sigmoid(h_ref @ W7.double().reshape(W7.shape[-2], -1) + b7.double())
+        assert rel_err(g, g_ref.float()) < 1e-5
+        F_ = b3.numel()
+        y3, y4 = rnd((1, 2, 4, 4, F_), 7).to(dev), rnd((1, 2, 4, 4, F_), 8).to(dev)
+        one = torch.ones(F_, device=dev)
+        a = ops.se_combine(y3, y4, one, b3, one, b3, W6, b6, W7, b7)
+        b = ops.se_combine(y3, y4, one, b3, one, b3, W6, b6, W7, b7, gate=(hidden, g))
+        assert torch.equal(a, b)
+
+
 def test_se_gate_is_half_at_zero_bias_init(dev):
     """KAT-3: GAP(IN(x)) = beta => with beta=0 and zero FC biases the gate is exactly 0.5."""
     F_ = 16
