@@ -111,6 +111,38 @@ static int run_gather(const GatherSpec& g, void* ws, int ws_packed, hipStream_t 
     return m1_direct_gather(dr, st);
 }
 
+// ---- stem weight gradient (Cin < 8: the image channels, networks.py:472) -----------------------------------------------
+// 3 (or 2) input channels are 6 (4) bytes per voxel: no 16-byte segments for the LDS-DMA loaders, so this layer used to run
+// on the generic per-tap kernel, re-reading dY once per tap (157 us at batch 2 = the slowest weight gradient of the step for
+// 0.2 % of its flops).  Instead: X -> X8 (zero-padded to 8 channels, one 16-byte segment per voxel) in the workspace, the
+// tap-fused kernel on (X8, dY) into a scratch gradient with 8 input rows per tap, and a fold of its first Cin rows.
+static bool stem_wanted(const m1_conv_desc_t* d, bool T) {
+    static int en = -1; if (en < 0) { const char* e = getenv("M1_STEM_TF"); en = e ? atoi(e) : 1; }
+    return en && !T && !g_force_direct && d->dtype == M1_BF16 && d->nsrc == 1 && d->src[0].C < 8 && d->Cin == d->src[0].C;
+}
+static size_t stem_ws_bytes(const m1_conv_desc_t* d, bool T) {
+    if (!stem_wanted(d, T)) return 0;
+    return align256((size_t)d->N * d->D * d->H * d->W * 8 * 2) + align256((size_t)d->kd * d->kh * d->kw * 8 * d->Cout * sizeof(float));
+}
+__global__ void __launch_bounds__(256) stem_pad8_kernel(const unsigned short* __restrict__ x, uint4* __restrict__ x8, long long nvox, int C) {
+    for (long long v = (long long)blockIdx.x * 256 + threadIdx.x; v < nvox; v += (long long)gridDim.x * 256) {
+        unsigned short e[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int c = 0; c < C; ++c) e[c] = x[v * C + c];
+        uint4 o;
+        o.x = e[0] | ((unsigned)e[1] << 16); o.y = e[2] | ((unsigned)e[3] << 16);
+        o.z = e[4] | ((unsigned)e[5] << 16); o.w = e[6] | ((unsigned)e[7] << 16);
+        x8[v] = o;
+    }
+}
+// dw[t][ci][co] += r8[t][ci][co], ci < Cin   (dw was zeroed above when accumulate == 0)
+__global__ void __launch_bounds__(256) stem_fold_kernel(const float* __restrict__ r8, float* __restrict__ dw, int taps, int Cin, int Cout) {
+    const int n = taps * Cin * Cout;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        const int co = i % Cout, ci = (i / Cout) % Cin, t = i / (Cout * Cin);
+        dw[i] += r8[((size_t)t * 8 + ci) * Cout + co];
+    }
+}
+
 // ---- workspace query ---------------------------------------------------------------------------------------------
 extern "C" size_t m1_conv_ws_bytes(const m1_conv_desc_t* d, int transposed, int role) {
     if (!desc_ok(d)) return 0;
@@ -129,7 +161,7 @@ extern "C" size_t m1_conv_ws_bytes(const m1_conv_desc_t* d, int transposed, int 
         return m + 256;
     }
     Geo q = T ? convT_geo(d) : conv_geo(d);
-    return m1_reduce_ws_floats(d->N, (long long)q.OD * q.OH * q.OW, d->Cout, 1) * sizeof(float) + 256;
+    return align256(m1_reduce_ws_floats(d->N, (long long)q.OD * q.OH * q.OW, d->Cout, 1) * sizeof(float)) + 256 + stem_ws_bytes(d, T);
 }
 
 // ---- packed-weight panel records ----------------------------------------------------------------------------------
@@ -217,6 +249,14 @@ static bool tf_wanted(const WgradSpec& g) {
     if (m1_tf64_wgrad_supported(g)) return true;
     return g.CA <= maxc && g.CB <= maxc && m1_tf_wgrad_supported(g);
 }
+static bool m1_tf_wgrad_supported_stem(const m1_conv_desc_t* d, const Geo& q) {
+    WgradSpec g{};
+    g.N = d->N; g.kd = d->kd; g.kh = d->kh; g.kw = d->kw; g.sd = d->sd; g.sh = d->sh; g.sw = d->sw;
+    g.pd = q.pd; g.ph = q.ph; g.pw = q.pw; g.dtype = d->dtype;
+    g.CA = 8; g.AD = d->D; g.AH = d->H; g.AW = d->W; g.CB = d->Cout; g.BD = q.OD; g.BH = q.OH; g.BW = q.OW;
+    g.RT = (long long)8 * d->Cout; g.RSA = d->Cout;
+    return m1_tf_wgrad_supported(g);
+}
 static int wgrad_common(const m1_conv_desc_t* d, bool T, const void* dy, float* dw, float* db, void* ws, hipStream_t st,
                         int accumulate) {
     Geo q = T ? convT_geo(d) : conv_geo(d);
@@ -228,6 +268,30 @@ static int wgrad_common(const m1_conv_desc_t* d, bool T, const void* dy, float* 
     if (fuse_db && !accumulate && hipMemsetAsync(db, 0, (size_t)d->Cout * sizeof(float), st) != hipSuccess) return M1_ERR_LAUNCH;
     int off = 0;
     const int nbias = fuse_db ? d->Cout : 0;
+    if (stem_wanted(d, T) && ws && m1_tf_wgrad_supported_stem(d, q)) {
+        const int taps = d->kd * d->kh * d->kw, Cin = d->Cin;
+        const long long nvox = (long long)d->N * d->D * d->H * d->W;
+        unsigned char* base = (unsigned char*)ws + align256(m1_reduce_ws_floats(d->N, (long long)q.OD * q.OH * q.OW, d->Cout, 1) * sizeof(float)) + 256;
+        uint4* x8 = reinterpret_cast<uint4*>(base);
+        float* r8 = reinterpret_cast<float*>(base + align256((size_t)nvox * 16));
+        const size_t nw8 = (size_t)taps * 8 * d->Cout;
+        if (hipMemsetAsync(r8, 0, nw8 * sizeof(float), st) != hipSuccess) return M1_ERR_LAUNCH;
+        long long pb = (nvox + 255) / 256; if (pb > 8192) pb = 8192;
+        hipLaunchKernelGGL(stem_pad8_kernel, dim3((unsigned)pb), dim3(256), 0, st, (const unsigned short*)d->src[0].ptr, x8, nvox, Cin);
+        WgradSpec g{};
+        g.N = d->N; g.R = r8; g.kd = d->kd; g.kh = d->kh; g.kw = d->kw; g.sd = d->sd; g.sh = d->sh; g.sw = d->sw;
+        g.pd = q.pd; g.ph = q.ph; g.pw = q.pw; g.dtype = d->dtype;
+        g.A = x8; g.CA = 8; g.AD = d->D; g.AH = d->H; g.AW = d->W;
+        g.B = dy; g.CB = d->Cout; g.BD = q.OD; g.BH = q.OH; g.BW = q.OW;
+        g.RT = (long long)8 * d->Cout; g.RSA = d->Cout; g.a_off = 0; g.b_off = 0;
+        if (fuse_db) { g.bsum = db; g.bsum_tap = (q.pd * d->kh + q.ph) * d->kw + q.pw; }
+        int rc = m1_tf_wgrad(g, (long long)nw8, nbias, st);
+        if (rc == M1_OK) {
+            hipLaunchKernelGGL(stem_fold_kernel, dim3((taps * Cin * d->Cout + 255) / 256), dim3(256), 0, st, r8, dw, taps, Cin, d->Cout);
+            return m1_check_launch();
+        }
+        if (rc != M1_ERR_UNSUPPORTED && rc != M1_ERR_WORKSPACE) return rc;      // declined: nothing launched, take the generic path
+    }
     for (int i = 0; i < d->nsrc; ++i) {
         WgradSpec g{};
         g.N = d->N; g.R = dw; g.kd = d->kd; g.kh = d->kh; g.kw = d->kw; g.sd = d->sd; g.sh = d->sh; g.sw = d->sw;

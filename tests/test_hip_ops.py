@@ -607,6 +607,10 @@ TF_CASES = [  # (N, D, H, W), cins, cout, k, s, transposed
     ((1, 3, 6, 16), [64], 32, (1, 3, 3), (1, 2, 2), True),
     ((1, 2, 4, 8), [32], 32, (3, 3, 3), (2, 2, 2), True),
     ((1, 3, 7, 24), [64, 32], 96, (3, 3, 3), (1, 1, 1), False),
+    # stem (image channels < 8): zero-padded to one 16-byte segment per voxel in the workspace, then the tap-fused kernel
+    ((2, 3, 10, 32), [3], 32, (1, 3, 3), (1, 1, 1), False),
+    ((1, 4, 9, 16), [2], 16, (1, 3, 3), (1, 1, 1), False),
+    ((1, 3, 8, 16), [3], 8, (3, 3, 3), (1, 1, 1), False),
     # both sides multiples of 64 channels: the 64x64-tile kernel (one kd slice per blockIdx.z)
     ((1, 3, 6, 16), [64], 64, (3, 3, 3), (1, 1, 1), False),
     ((2, 2, 5, 32), [128], 64, (1, 3, 3), (1, 1, 1), False),
