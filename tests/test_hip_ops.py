@@ -607,6 +607,9 @@ TF_CASES = [  # (N, D, H, W), cins, cout, k, s, transposed
     ((1, 3, 6, 16), [64], 32, (1, 3, 3), (1, 2, 2), True),
     ((1, 2, 4, 8), [32], 32, (3, 3, 3), (2, 2, 2), True),
     ((1, 3, 7, 24), [64, 32], 96, (3, 3, 3), (1, 1, 1), False),
+    # 1x1x1 with 8 / 16 channels in (register-staged loader; the halo-tile kernel was measured slower on these)
+    ((2, 3, 10, 32), [8], 32, (1, 1, 1), (1, 1, 1), False),
+    ((1, 4, 9, 16), [16], 64, (1, 1, 1), (1, 1, 1), False),
     # stem (image channels < 8): zero-padded to one 16-byte segment per voxel in the workspace, then the tap-fused kernel
     ((2, 3, 10, 32), [3], 32, (1, 3, 3), (1, 1, 1), False),
     ((1, 4, 9, 16), [2], 16, (1, 3, 3), (1, 1, 1), False),
