@@ -26,7 +26,8 @@ __device__ __forceinline__ int woff(int row, int seg) {
     return ((row ^ ((row >> 3) & 1)) << 6) + (((seg ^ (-(row >> 2)) ^ (row >> 4)) & 3) << 4);
 }
 
-struct WgP : WgradSpec { long long vox_per_split; float* Rx; long long rx_stride, rx_bias; };   // Rx: per-split partial copies
+struct WgP : WgradSpec { long long vox_per_split; float* Rx; long long rx_stride, rx_bias;       // Rx: per-split partial copies
+             int xcd_total, xcd_gx, xcd_gy, xcd_gz; };                                             // XCD-aware 1-D launch (see the kernel)
 
 // r[j] = 16 bytes of voxel j (SEG channels); returns o[c] = 16 bytes of channel c (SEG voxels)
 __device__ __forceinline__ void transpose_unit(const uint4 (&r)[8], uint4 (&o)[8], bf16_t) {
@@ -70,12 +71,19 @@ __global__ void __launch_bounds__(256) wgrad_mfma_kernel(WgP p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int bTiles = (p.CB + TB - 1) / TB;
-    const int a0 = (blockIdx.x / bTiles) * TA, b0 = (blockIdx.x % bTiles) * TB;
-    const int tap = blockIdx.y;
+    // XCD-aware block order (p.xcd_total != 0, see wgrad_tap.hip): the ab-tiles and taps of one voxel split share one XCD's L2
+    int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    if (p.xcd_total) {
+        const unsigned L = (blockIdx.x & 7u) * (p.xcd_total >> 3) + (blockIdx.x >> 3);
+        if (L >= (unsigned)(p.xcd_gx * p.xcd_gy * p.xcd_gz)) return;
+        bx = L % p.xcd_gx; by = (L / p.xcd_gx) % p.xcd_gy; bz = L / (p.xcd_gx * p.xcd_gy);
+    }
+    const int a0 = (bx / bTiles) * TA, b0 = (bx % bTiles) * TB;
+    const int tap = by;
     const int kw = tap % p.kw, kh = (tap / p.kw) % p.kh, kd = tap / (p.kw * p.kh);
     // voxel indices fit 32 bits (checked on the host): 32-bit divisions only
     const int BV = p.BD * p.BH * p.BW, TV = BV * p.N;
-    const int vbeg = (int)(blockIdx.z * p.vox_per_split);
+    const int vbeg = (int)(bz * p.vox_per_split);
     int vend = vbeg + (int)p.vox_per_split; if (vend > TV) vend = TV;
     const T* A = (const T*)p.A; const T* B = (const T*)p.B;
 
@@ -192,7 +200,7 @@ __global__ void __launch_bounds__(256) wgrad_mfma_kernel(WgP p) {
     }
     // small weight tensors: every split stores into its own copy (m1_wg_rx_finish folds them) -- hundreds of blocks
     // adding into the same few cache lines serialise at the memory-side atomic unit (~85 ns per request and line)
-    float* const Rx = p.Rx ? p.Rx + (long long)blockIdx.z * p.rx_stride : nullptr;
+    float* const Rx = p.Rx ? p.Rx + (long long)bz * p.rx_stride : nullptr;
     if (do_bsum && fs == 0) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
@@ -233,7 +241,8 @@ static int launch_wg(WgP p, hipStream_t st) {
     // volumes per launch the atomics amortise over twice the voxels: 1024 (-1.5 % per step at batch 2).  M1_WG_BLOCKS overrides.
     static int tgt_env = -1; if (tgt_env < 0) { const char* e = getenv("M1_WG_BLOCKS"); tgt_env = e ? atoi(e) : 0; }
     const int tgt = tgt_env > 0 ? tgt_env : (p.N >= 2 ? 1024 : 512);
-    long long splits = cdiv_ll(tgt, (long long)aTiles * bTiles * taps);
+    static int rdn = -1; if (rdn < 0) { const char* e = getenv("M1_WG_FLOOR"); rdn = e ? atoi(e) : 1; }
+    long long splits = rdn ? tgt / ((long long)aTiles * bTiles * taps) : cdiv_ll(tgt, (long long)aTiles * bTiles * taps);
     const long long max_splits = cdiv_ll(TV, 4 * KS);
     if (splits > max_splits) splits = max_splits;
     if (splits < 1) splits = 1;
@@ -249,7 +258,14 @@ static int launch_wg(WgP p, hipStream_t st) {
         if (rx) { p.Rx = rx; partial = true; }
     }
     if (!partial) { p.Rx = nullptr; }
-    hipLaunchKernelGGL((wgrad_mfma_kernel<T, TA, TB, KB>), grid, dim3(256), 0, st, p);
+    static int xr = -1; if (xr < 0) { const char* e = getenv("M1_WG_XCD"); xr = e ? atoi(e) : 1; }
+    p.xcd_total = 0; p.xcd_gx = (int)grid.x; p.xcd_gy = (int)grid.y; p.xcd_gz = (int)grid.z;
+    if (xr && (long long)grid.x * grid.y > 1 && splits > 1) {
+        p.xcd_total = (int)(((long long)grid.x * grid.y * grid.z + 7) / 8 * 8);
+        hipLaunchKernelGGL((wgrad_mfma_kernel<T, TA, TB, KB>), dim3((unsigned)p.xcd_total), dim3(256), 0, st, p);
+    } else {
+        hipLaunchKernelGGL((wgrad_mfma_kernel<T, TA, TB, KB>), grid, dim3(256), 0, st, p);
+    }
     int rc = m1_check_launch(); if (rc) return rc;
     if (partial) return m1_wg_rx_finish(p.Rx, stride, (int)splits, p, p.rx_bias, st);
     return M1_OK;

@@ -59,6 +59,7 @@ struct TapP {
     int KWs, TH;                 // K-tile = TH rows x KWs columns = 64 voxels (2 k-steps of 32)
     int tiles_w, tiles_h, ntiles, nsplit, bTiles, stages;
     float* Rx; long long rx_stride, rx_bias;     // per-split partial copies of R (+ bias sums), folded by m1_wg_rx_finish
+    int ctiles, taps, xcd_total;                 // xcd_total != 0: 1-D grid of that many blocks, XCD-aware order (see the kernel)
 };
 
 template <int SUBA, int SUBB>     // wave tile = SUBA*16 x SUBB*16 channels, block = 2x2 waves
@@ -71,8 +72,18 @@ __global__ void __launch_bounds__(256) wgrad_tap_kernel(TapP p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wa = wave >> 1, wb = wave & 1;
-    const int a0 = (blockIdx.x / p.bTiles) * TA, b0 = (blockIdx.x % p.bTiles) * TB;
-    const int tap = blockIdx.z;
+    // XCD-aware block order (p.xcd_total != 0: 1-D grid padded to a multiple of 8): consecutive block ids go round-robin
+    // over the 8 XCDs, each with its own L2.  All taps of one voxel split read the same dY tiles and X tiles one row / plane
+    // apart; numbered tap-fastest inside a contiguous per-XCD range they run side by side on ONE XCD and share its L2 instead
+    // of every XCD fetching every tile (measured HBM fetch of this kernel: 6.7x its operands without the remap).
+    int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    if (p.xcd_total) {
+        const unsigned L = (blockIdx.x & 7u) * (p.xcd_total >> 3) + (blockIdx.x >> 3);
+        if (L >= (unsigned)(p.ctiles * p.nsplit * p.taps)) return;
+        bz = L % p.taps; by = (L / p.taps) % p.nsplit; bx = L / (p.taps * p.nsplit);
+    }
+    const int a0 = (bx / p.bTiles) * TA, b0 = (bx % p.bTiles) * TB;
+    const int tap = bz;
     const int tkw = tap % p.kw, tkh = (tap / p.kw) % p.kh, tkd = tap / (p.kw * p.kh);
     const unsigned char* zero_pg = reinterpret_cast<const unsigned char*>(m1_zero_page_t);
 
@@ -98,7 +109,7 @@ __global__ void __launch_bounds__(256) wgrad_tap_kernel(TapP p) {
         b_vo[it] = (b0 + sl * 8 < p.CB) ? (unsigned)(((th * p.BW + tw) * p.CB + b0 + sl * 8) * 2) : OOB;
     }
 
-    int q_kt = blockIdx.y, q_tw, q_th, q_bd, q_n;
+    int q_kt = by, q_tw, q_th, q_bd, q_n;
     { int r = q_kt; q_tw = r % p.tiles_w; r /= p.tiles_w; q_th = r % p.tiles_h; r /= p.tiles_h; q_bd = r % p.BD; q_n = r / p.BD; }
     int s_tw, s_th, s_bd, s_n;
     { int r = p.nsplit; s_tw = r % p.tiles_w; r /= p.tiles_w; s_th = r % p.tiles_h; r /= p.tiles_h; s_bd = r % p.BD; s_n = r / p.BD; }
@@ -173,7 +184,7 @@ __global__ void __launch_bounds__(256) wgrad_tap_kernel(TapP p) {
     constexpr int npiece = AIT + BIT;
     for (int s = 0; s < S - 1; ++s) issue(s);
     int st = 0;
-    for (int kt = blockIdx.y; kt < p.ntiles; kt += p.nsplit) {
+    for (int kt = by; kt < p.ntiles; kt += p.nsplit) {
         wait_vmt(npiece * (S - 2));
         __builtin_amdgcn_s_barrier();
         int stn = st + S - 1; if (stn >= S) stn -= S;
@@ -216,7 +227,7 @@ __global__ void __launch_bounds__(256) wgrad_tap_kernel(TapP p) {
 
     // ---- D[a][b]: lane holds a = 4*(lane>>4) + r, b = lane&15.  Plain stores into this split's copy when there is one
     //      (the memory-side float atomics of ~500 blocks drain for tens of microseconds after the last wave has finished) ----
-    float* const Rx = p.Rx ? p.Rx + (long long)blockIdx.y * p.rx_stride : nullptr;
+    float* const Rx = p.Rx ? p.Rx + (long long)by * p.rx_stride : nullptr;
 #pragma unroll
     for (int y = 0; y < SUBB; ++y) {
         const int b = b0 + (wb * SUBB + y) * 16 + i;
@@ -266,7 +277,9 @@ int m1_tap_wgrad(const WgradSpec& g, long long nw, int nb, hipStream_t st) {
     const int aTiles = (g.CA + TA - 1) / TA; p.bTiles = (g.CB + TB - 1) / TB;
     const int taps = g.kd * g.kh * g.kw, ctiles = aTiles * p.bTiles;
     static int tgt = -1; if (tgt < 0) { const char* e = getenv("M1_WG_TAP_BLOCKS"); tgt = e ? atoi(e) : 512; }
-    long long nsplit = (tgt + (long long)ctiles * taps - 1) / ((long long)ctiles * taps);
+    // round DOWN: 2 blocks per CU x 256 CUs = 512 slots; one block more than that is a second round for its whole XCD
+    static int rdn = -1; if (rdn < 0) { const char* e = getenv("M1_WG_FLOOR"); rdn = e ? atoi(e) : 1; }
+    long long nsplit = rdn ? tgt / ((long long)ctiles * taps) : (tgt + (long long)ctiles * taps - 1) / ((long long)ctiles * taps);
     if (nsplit > p.ntiles / 4) nsplit = p.ntiles / 4;
     if (nsplit < 1) nsplit = 1;
     p.nsplit = (int)nsplit;
@@ -294,7 +307,14 @@ int m1_tap_wgrad(const WgradSpec& g, long long nw, int nb, hipStream_t st) {
     const long long stride = nw + nb;
     p.Rx = nullptr; p.rx_stride = stride; p.rx_bias = nw;
     if (cp && nw > 0 && nsplit >= 2 && nsplit * stride * 4 <= (256ll << 20)) p.Rx = m1_wg_rx_get(nsplit * stride, st);
-    hipLaunchKernelGGL(kern, dim3(ctiles, (unsigned)nsplit, taps), dim3(256), smem, st, p);
+    static int xr = -1; if (xr < 0) { const char* e = getenv("M1_WG_XCD"); xr = e ? atoi(e) : 1; }
+    p.ctiles = ctiles; p.taps = taps; p.xcd_total = 0;
+    if (xr && taps > 1) {
+        p.xcd_total = (int)(((long long)ctiles * nsplit * taps + 7) / 8 * 8);
+        hipLaunchKernelGGL(kern, dim3((unsigned)p.xcd_total), dim3(256), smem, st, p);
+    } else {
+        hipLaunchKernelGGL(kern, dim3(ctiles, (unsigned)nsplit, taps), dim3(256), smem, st, p);
+    }
     int rc = m1_check_launch(); if (rc) return rc;
     if (p.Rx) return m1_wg_rx_finish(p.Rx, stride, (int)nsplit, g, nw, st);
     return M1_OK;
