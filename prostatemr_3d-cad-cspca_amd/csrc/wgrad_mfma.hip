@@ -237,10 +237,9 @@ static int launch_wg(WgP p, hipStream_t st) {
     const int taps = p.kd * p.kh * p.kw;
     const long long TV = (long long)p.N * p.BD * p.BH * p.BW;
     // ~2 blocks per CU: every extra voxel split adds TA*TB float atomics per tap, and those are executed at the memory
-    // side on this part (measured: 1536 -> 512 target blocks = -28 % on the 128x128x27-tap layers).  With two or more
-    // volumes per launch the atomics amortise over twice the voxels: 1024 (-1.5 % per step at batch 2).  M1_WG_BLOCKS overrides.
-    static int tgt_env = -1; if (tgt_env < 0) { const char* e = getenv("M1_WG_BLOCKS"); tgt_env = e ? atoi(e) : 0; }
-    const int tgt = tgt_env > 0 ? tgt_env : (p.N >= 2 ? 1024 : 512);
+    // side on this part (measured: 1536 -> 512 target blocks = -28 % on the 128x128x27-tap layers).  Rounded DOWN: 512 = 2 per
+    // CU; one block more is a second round for its whole XCD (-8 % on the wgrad family).  M1_WG_BLOCKS overrides.
+    static int tgt = -1; if (tgt < 0) { const char* e = getenv("M1_WG_BLOCKS"); tgt = e ? atoi(e) : 512; }
     static int rdn = -1; if (rdn < 0) { const char* e = getenv("M1_WG_FLOOR"); rdn = e ? atoi(e) : 1; }
     long long splits = rdn ? tgt / ((long long)aTiles * bTiles * taps) : cdiv_ll(tgt, (long long)aTiles * bTiles * taps);
     const long long max_splits = cdiv_ll(TV, 4 * KS);
