@@ -1,5 +1,6 @@
 // common.h -- shared device/host helpers for libm1hip (gfx950 / CDNA4 only, wave = 64).
 #pragma once
+#include <stdlib.h>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "../../include/m1hip.h"
@@ -89,7 +90,8 @@ template <> struct VecIO<bf16_t, 8> {
 // blocks of 256 threads for `per` vector elements whose channel group is (index % cg): at most ~2048 blocks, and
 // gridDim.x*256 a multiple of cg so that a thread keeps its channel group across its grid-stride loop
 static inline int m1_grid_for(long long per, int cg) {
-    long long g = (per + 255) / 256; if (g > 2048) g = 2048; if (g < 1) g = 1;
+    static int cap = -1; if (cap < 0) { const char* e = getenv("M1_EW_BLOCKS"); cap = e ? atoi(e) : 2048; if (cap < 1) cap = 1; }
+    long long g = (per + 255) / 256; if (g > cap) g = cap; if (g < 1) g = 1;
     // (g*256) % cg == 0  <=>  g is a multiple of cg / gcd(cg, 256)
     long long a = cg, b = 256; while (b) { long long t = a % b; a = b; b = t; }
     const long long need = cg / a;
