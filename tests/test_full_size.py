@@ -1,0 +1,150 @@
+"""Parity at BASELINE.json's FULL sizes through size-independent properties (the oracle cannot run a whole (20,160,160)
+layer in seconds, and the big-grid kernels -- halo-tile conv, tap-fused / per-tap wgrad at hundreds of blocks, XCD-aware
+orders, slab split-K -- are only reached at these sizes):
+
+* locality: a conv output / data gradient inside a window depends only on the inputs around it, so the HIP result on the
+  full volume, cropped, must equal the oracle run on the cropped inputs (interior voxels);
+* adjointness (KAT-2 at full size): <dW, W'> = <dy, conv(x; W')> and <db, b'> = <dy, 1 b'> pin the weight / bias
+  gradients, which are global sums, to the forward that the crop check pins;
+* the full C2 model: output simplex, parameter count (KAT-9), finite loss and gradients, run-to-run identical logits.
+"""
+import pytest
+import torch
+
+from oracle import m1_oracle as O
+from util import PKG, ops, rel_err, rnd
+
+pytestmark = pytest.mark.gpu
+
+# name, (N, D, H, W), cins, cout, k, s, transposed, crop window (d0, d1, h0, h1, w0, w1) in INPUT voxels (multiples of s)
+FULL = [
+    ("res0 conv4 64->32 (halo tile, 2 members)", (1, 20, 160, 160), [32, 32], 32, (1, 3, 3), (1, 1, 1), False, (7, 10, 40, 64, 96, 136)),
+    ("res0 conv2 8->8 3x3x3", (1, 20, 160, 160), [8], 8, (3, 3, 3), (1, 1, 1), False, (0, 6, 0, 24, 120, 160)),
+    ("res0->res1 32->64 stride (1,2,2)", (1, 20, 160, 160), [32], 64, (1, 3, 3), (1, 2, 2), False, (18, 20, 100, 160, 0, 40)),
+    ("res1 dense concat 4x64->64", (1, 20, 80, 80), [64, 64, 64, 64], 64, (1, 3, 3), (1, 1, 1), False, (3, 5, 20, 44, 30, 62)),
+    ("res2 256->128 3x3x3, batch 2", (2, 20, 40, 40), [128, 128], 128, (3, 3, 3), (1, 1, 1), False, (8, 14, 10, 26, 16, 40)),
+    ("res2->res3 128->256 stride 2", (1, 20, 40, 40), [128], 256, (3, 3, 3), (2, 2, 2), False, (4, 14, 0, 20, 20, 40)),
+    ("convT res1->res0 64->32", (1, 20, 80, 80), [64], 32, (1, 3, 3), (1, 2, 2), True, (5, 8, 30, 50, 0, 24)),
+]
+
+
+def _crop(t, win):
+    d0, d1, h0, h1, w0, w1 = win
+    return t[:, d0:d1, h0:h1, w0:w1]
+
+
+def _interior(t, k, margin=2):
+    sl = [slice(None)]
+    for kk, n in zip(k, t.shape[1:4]):
+        sl.append(slice(margin, n - margin) if kk > 1 else slice(None))
+    return t[tuple(sl)]
+
+
+@pytest.mark.parametrize("case", FULL, ids=[c[0] for c in FULL])
+def test_full_size_conv_locality_and_adjointness(dev, case):
+    name, dims, cins, cout, k, s, transposed, win = case
+    cin = sum(cins)
+    bf = torch.bfloat16
+    xs = [rnd((*dims, c), 10 + i).to(bf) for i, c in enumerate(cins)]
+    wshape = (*k, cout, cin) if transposed else (*k, cin, cout)
+    w = rnd(wshape, 3, 1.0 / (cin * k[0] * k[1] * k[2]) ** 0.5)
+    b = rnd((cout,), 4, 0.1)
+    fh = ops.conv3d_transpose_same if transposed else ops.conv3d_same
+    fo = O.conv3d_transpose_same if transposed else O.conv3d_same
+    xd = [x.to(dev).requires_grad_(True) for x in xs]
+    wd, bd = w.to(dev).requires_grad_(True), b.to(dev).requires_grad_(True)
+    y = fh(xd, wd, bd, k, s)
+    dy = rnd(tuple(y.shape), 5).to(bf)
+    y.backward(dy.to(dev))
+
+    # ---- locality: oracle on the cropped inputs, interior voxels ----
+    xc = torch.cat([_crop(x, win) for x in xs], dim=-1).double().requires_grad_(True)
+    yc = fo(xc, w.double(), b.double(), s)
+    if transposed:
+        owin = tuple(v * st for v, st in zip(win, (s[0], s[0], s[1], s[1], s[2], s[2])))
+    else:
+        owin = tuple(v // st for v, st in zip(win, (s[0], s[0], s[1], s[1], s[2], s[2])))
+    assert tuple(yc.shape[1:4]) == (owin[1] - owin[0], owin[3] - owin[2], owin[5] - owin[4])
+    dyc = _crop(dy, owin).double()
+    # zero the gradient of the crop's rim so that only interior outputs (exact on the crop) feed the crop's dx
+    mask = torch.zeros_like(dyc)
+    _interior(mask, k)[...] = 1.0
+    yc.backward(dyc * mask)
+    got_y = _interior(_crop(y.detach().float().cpu(), owin), k)
+    assert rel_err(got_y, _interior(yc.detach(), k)) < 2e-2, f"{name}: forward"
+    # dx: the full-volume dx sees ALL of dy, the crop only its interior outputs -> compare where both agree: inputs whose
+    # every reader lies in the crop interior, i.e. 2 more voxels in (4 for the rim mask + stride)
+    dy_full_masked = torch.zeros_like(dy.float())
+    _interior(_crop(dy_full_masked, owin), k)[...] = _interior(_crop(dy.float(), owin), k)
+    for t in xd:
+        t.grad = None
+    y2 = fh(xd, wd.detach(), bd.detach(), k, s)
+    y2.backward(dy_full_masked.to(dev, bf))
+    off = 0
+    for x, xg in zip(xs, xd):
+        c = x.shape[-1]
+        got = _crop(xg.grad.float().cpu(), win)
+        want = xc.grad[..., off:off + c]
+        assert rel_err(got, want) < 2e-2, f"{name}: dx member at channel {off}"
+        outside = xg.grad.float().clone()
+        _crop(outside, win)[...] = 0
+        assert float(outside.abs().max()) == 0.0, f"{name}: dx outside the window of a windowed dy must be exactly zero"
+        off += c
+
+    # ---- adjointness at full size: <dW, W'> = <dy, conv(x; W', 0)>,  <db, b'> = <dy, b'> ----
+    # two probes: a random W' (both sides are small sums of +- terms: tolerance = 5x the bf16 rounding noise of the right side)
+    # and W'' along dW itself (left side = |dW|^2 * c, far above the noise: a relative check)
+    dW = wd.grad.double().cpu()
+    probes = [rnd(wshape, 6, 1.0 / (cin * k[0] * k[1] * k[2]) ** 0.5).double(),
+              dW * float(w.double().pow(2).mean().sqrt() / dW.pow(2).mean().sqrt())]
+    dyd = dy.to(dev).double()
+    for pi, w2 in enumerate(probes):
+        with torch.no_grad():
+            y_w2 = fh([t.detach() for t in xd], w2.float().to(dev), None, k, s).double()
+        lhs = float((dW * w2).sum())
+        terms = dyd * y_w2
+        rhs, noise = float(terms.sum()), float(terms.pow(2).sum().sqrt()) * 2.0 ** -9
+        if pi == 0:
+            assert abs(lhs - rhs) < 5.0 * noise + 1e-6 * abs(rhs), f"{name}: <dW,W'> {lhs} vs <dy,conv(x;W')> {rhs} (noise {noise})"
+        else:
+            assert abs(lhs - rhs) < 1e-2 * abs(lhs), f"{name}: <dW,dW c> {lhs} vs <dy,conv(x;dW c)> {rhs}"
+    b2 = rnd((cout,), 7)
+    lhs_b = float((bd.grad.double().cpu() * b2.double()).sum())
+    rhs_b = float((dy.double().sum(dim=(0, 1, 2, 3)) * b2.double()).sum())
+    assert abs(lhs_b - rhs_b) < 1e-3 * float(bd.grad.double().norm().cpu() * b2.double().norm()), f"{name}: bias gradient"
+
+
+def test_full_size_c2_model_properties(dev):
+    """C2 (BASELINE.json configs[1]) at full size, bf16: KAT-9 parameter count, output simplex, finite step, determinism."""
+    init = PKG.initializers
+    PKG.unets.network_blocks.set_init_seed(0)
+    m = PKG.unets.networks.M1(
+        input_spatial_dims=(20, 160, 160), input_channels=3, num_classes=2, filters=(32, 64, 128, 256, 512),
+        strides=((1, 1, 1), (1, 2, 2), (1, 2, 2), (2, 2, 2), (2, 2, 2)),
+        kernel_sizes=((1, 3, 3), (1, 3, 3), (3, 3, 3), (3, 3, 3), (3, 3, 3)), se_reduction=(8, 8, 8, 8, 8),
+        att_sub_samp=((1, 1, 1),) * 4, dropout_rate=0.0, dropout_mode='monte-carlo',
+        kernel_initializer=init.Orthogonal(1.0), bias_initializer=init.TruncatedNormal(0.0, 1e-3),
+        kernel_regularizer=init.l2(1e-4), bias_regularizer=init.l2(1e-4), cascaded=False, dense_skip=False,
+        deep_supervision=False, probabilistic=False, summary=False).to(dev)
+    m.set_compute_dtype(torch.bfloat16)
+    assert sum(p.numel() for p in m.parameters()) == 17525866
+    x = rnd((1, 20, 160, 160, 3), 1).to(dev)
+    tgt = torch.zeros((1, 20, 160, 160, 2)); tgt[..., 0] = 1.0
+    tgt[0, 8:12, 70:90, 70:90, 0] = 0.0; tgt[0, 8:12, 70:90, 70:90, 1] = 1.0
+    focal = PKG.losses.Focal(alpha=[0.75, 0.25], gamma=2.0).loss
+
+    def step():
+        for p in m.parameters():
+            p.grad = None
+        probs = m(x)
+        probs = probs[0] if isinstance(probs, (list, tuple)) else probs
+        loss = focal(tgt.to(dev), probs)
+        loss.backward()
+        return probs.detach(), float(loss.detach()), [p.grad.detach().clone() for p in m.parameters() if p.grad is not None]
+    p1, l1, g1 = step()
+    p2, l2, g2 = step()
+    assert tuple(p1.shape) == (1, 20, 160, 160, 2) and p1.dtype == torch.float32
+    assert float((p1.sum(dim=-1) - 1.0).abs().max()) < 1e-5 and float(p1.min()) >= 0.0
+    assert torch.isfinite(torch.tensor(l1)) and l1 > 0.0
+    assert len(g1) > 200 and all(torch.isfinite(g).all() for g in g1)
+    assert torch.equal(p1, p2) and l1 == l2                                  # forward + loss: bit-identical run to run
