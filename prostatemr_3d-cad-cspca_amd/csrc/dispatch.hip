@@ -143,6 +143,17 @@ __global__ void __launch_bounds__(256) stem_fold_kernel(const float* __restrict_
     }
 }
 
+// Scratch for per-split partial copies of a SMALL weight gradient (+ bias sums): up to 512 copies, at most 96 MB.  It lives in
+// the caller's wgrad workspace -- one region per call, so weight gradients that run concurrently on different streams never
+// share it (the library keeps no device memory of its own).  Large weight tensors use the atomic path: no scratch.
+static size_t wgrad_rx_bytes(const m1_conv_desc_t* d) {
+    const size_t nw = (size_t)d->kd * d->kh * d->kw * d->Cin * d->Cout, stride = (nw > (size_t)8 * d->Cout * d->kd * d->kh * d->kw ? nw : (size_t)8 * d->Cout * d->kd * d->kh * d->kw) + d->Cout;
+    if (nw > ((size_t)1 << 18)) return 0;
+    size_t b = 512 * stride * sizeof(float);
+    if (b > ((size_t)96 << 20)) b = (size_t)96 << 20;
+    return align256(b);
+}
+
 // ---- workspace query ---------------------------------------------------------------------------------------------
 extern "C" size_t m1_conv_ws_bytes(const m1_conv_desc_t* d, int transposed, int role) {
     if (!desc_ok(d)) return 0;
@@ -161,7 +172,8 @@ extern "C" size_t m1_conv_ws_bytes(const m1_conv_desc_t* d, int transposed, int 
         return m + 256;
     }
     Geo q = T ? convT_geo(d) : conv_geo(d);
-    return align256(m1_reduce_ws_floats(d->N, (long long)q.OD * q.OH * q.OW, d->Cout, 1) * sizeof(float)) + 256 + stem_ws_bytes(d, T);
+    return align256(m1_reduce_ws_floats(d->N, (long long)q.OD * q.OH * q.OW, d->Cout, 1) * sizeof(float)) + 256 + stem_ws_bytes(d, T) +
+           wgrad_rx_bytes(d);
 }
 
 // ---- packed-weight panel records ----------------------------------------------------------------------------------
@@ -268,6 +280,12 @@ static int wgrad_common(const m1_conv_desc_t* d, bool T, const void* dy, float* 
     if (fuse_db && !accumulate && hipMemsetAsync(db, 0, (size_t)d->Cout * sizeof(float), st) != hipSuccess) return M1_ERR_LAUNCH;
     int off = 0;
     const int nbias = fuse_db ? d->Cout : 0;
+    float* rx = nullptr; long long rx_floats = 0;              // partial-copy scratch: the tail of the caller's workspace
+    if (ws && wgrad_rx_bytes(d)) {
+        rx = reinterpret_cast<float*>((unsigned char*)ws + align256(m1_reduce_ws_floats(d->N, (long long)q.OD * q.OH * q.OW, d->Cout, 1) * sizeof(float)) +
+                                      256 + stem_ws_bytes(d, T));
+        rx_floats = (long long)(wgrad_rx_bytes(d) / sizeof(float));
+    }
     if (stem_wanted(d, T) && ws && m1_tf_wgrad_supported_stem(d, q)) {
         const int taps = d->kd * d->kh * d->kw, Cin = d->Cin;
         const long long nvox = (long long)d->N * d->D * d->H * d->W;
@@ -284,6 +302,7 @@ static int wgrad_common(const m1_conv_desc_t* d, bool T, const void* dy, float* 
         g.A = x8; g.CA = 8; g.AD = d->D; g.AH = d->H; g.AW = d->W;
         g.B = dy; g.CB = d->Cout; g.BD = q.OD; g.BH = q.OH; g.BW = q.OW;
         g.RT = (long long)8 * d->Cout; g.RSA = d->Cout; g.a_off = 0; g.b_off = 0;
+        g.rx = rx; g.rx_floats = rx_floats;
         if (fuse_db) { g.bsum = db; g.bsum_tap = (q.pd * d->kh + q.ph) * d->kw + q.pw; }
         int rc = m1_tf_wgrad(g, (long long)nw8, nbias, st);
         if (rc == M1_OK) {
@@ -296,6 +315,7 @@ static int wgrad_common(const m1_conv_desc_t* d, bool T, const void* dy, float* 
         WgradSpec g{};
         g.N = d->N; g.R = dw; g.kd = d->kd; g.kh = d->kh; g.kw = d->kw; g.sd = d->sd; g.sh = d->sh; g.sw = d->sw;
         g.pd = q.pd; g.ph = q.ph; g.pw = q.pw; g.dtype = d->dtype;
+        g.rx = rx; g.rx_floats = rx_floats;
         if (!T) {   // dw[tap][ci][co] = sum X[v*s+tap-p][ci] * dY[v][co]
             g.A = d->src[i].ptr; g.CA = d->src[i].C; g.AD = d->D; g.AH = d->H; g.AW = d->W;
             g.B = dy; g.CB = d->Cout; g.BD = q.OD; g.BH = q.OH; g.BW = q.OW;

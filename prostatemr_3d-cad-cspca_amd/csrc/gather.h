@@ -31,6 +31,7 @@ struct WgradSpec {
     float* R; long long RT, RSA; int a_off, b_off;
     int kd, kh, kw, sd, sh, sw, pd, ph, pw;
     int dtype;
+    float* rx; long long rx_floats;   // caller-owned scratch for per-split partial copies of the gradient (inside the wgrad `ws`)
     float* bsum;      // optional: bsum[b + b_off] += sum_v B[v][b] (bias gradient of a Conv3D, fused into the tap whose
     int bsum_tap;     // shifted partner is always inside the volume: tap index bsum_tap); NULL = off
 };
@@ -50,9 +51,9 @@ bool m1_tf64_wgrad_supported(const WgradSpec& g);    // its 64x64-tile kernel (b
 // nw / nb: floats of the whole weight / bias gradient the spec's R / bsum point into.  M1_ERR_WORKSPACE / UNSUPPORTED:
 // nothing was launched, the caller takes the per-tap kernel instead.
 int m1_tf_wgrad(const WgradSpec& g, long long nw, int nb, hipStream_t st);
-// partial-copy buffer (persistent, grown outside stream capture only; nullptr = unavailable) and the fold of `ncopies`
-// copies of stride `stride` floats into g.R / g.bsum (bias sums sit at offset nw inside a copy)
-float* m1_wg_rx_get(long long floats, hipStream_t st);
+// partial-copy scratch (the spec's rx region when it holds `floats`, else nullptr = take the atomic path) and the fold of
+// `ncopies` copies of stride `stride` floats into g.R / g.bsum (bias sums sit at offset nw inside a copy)
+static inline float* m1_wg_rx_get(const WgradSpec& g, long long floats) { return (g.rx && g.rx_floats >= floats) ? g.rx : nullptr; }
 int m1_wg_rx_finish(float* rx, long long stride, int ncopies, const WgradSpec& g, long long nw, hipStream_t st);
 int m1_mfma_wgrad_ex(const WgradSpec& g, long long nw, int nb, hipStream_t st);
 bool m1_tap_wgrad_supported(const WgradSpec& g);     // per-tap kernel on the transpose read (wgrad_tap.hip), >= 64 channels

@@ -253,7 +253,7 @@ static int launch_wg(WgP p, hipStream_t st) {
     bool partial = false;
     const long long stride = p.rx_stride;                      // = nw + nb (set by the caller) or 0
     if (stride > 0 && (long long)taps * p.CA * p.CB <= 32768 && splits >= 24 && splits * stride * 4 <= (64ll << 20)) {
-        float* rx = m1_wg_rx_get(splits * stride, st);
+        float* rx = m1_wg_rx_get(p, splits * stride);
         if (rx) { p.Rx = rx; partial = true; }
     }
     if (!partial) { p.Rx = nullptr; }

@@ -306,7 +306,7 @@ int m1_tap_wgrad(const WgradSpec& g, long long nw, int nb, hipStream_t st) {
     static int cp = -1; if (cp < 0) { const char* e = getenv("M1_WG_TAP_COPIES"); cp = e ? atoi(e) : 0; }
     const long long stride = nw + nb;
     p.Rx = nullptr; p.rx_stride = stride; p.rx_bias = nw;
-    if (cp && nw > 0 && nsplit >= 2 && nsplit * stride * 4 <= (256ll << 20)) p.Rx = m1_wg_rx_get(nsplit * stride, st);
+    if (cp && nw > 0 && nsplit >= 2 && nsplit * stride * 4 <= (256ll << 20)) p.Rx = m1_wg_rx_get(g, nsplit * stride);
     static int xr = -1; if (xr < 0) { const char* e = getenv("M1_WG_XCD"); xr = e ? atoi(e) : 1; }
     p.ctiles = ctiles; p.taps = taps; p.xcd_total = 0;
     if (xr && taps > 1) {

@@ -481,21 +481,6 @@ __global__ void __launch_bounds__(256) tf_finish_kernel(TfFin f) {
     }
 }
 
-// One persistent device buffer for the partial copies (grown outside stream capture only).
-static float* g_rx = nullptr; static long long g_rx_floats = 0; static int g_rx_dev = -1;
-static bool tf_rx_ensure(long long floats, hipStream_t st) {
-    int dev = 0; if (hipGetDevice(&dev) != hipSuccess) return false;
-    if (g_rx && dev == g_rx_dev && g_rx_floats >= floats) return true;
-    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return false;
-    if (g_rx && dev == g_rx_dev) { if (hipDeviceSynchronize() != hipSuccess) return false; (void)hipFree(g_rx); }
-    g_rx = nullptr; g_rx_floats = 0;
-    const long long want = floats < (1ll << 22) ? (1ll << 22) : floats;
-    if (hipMalloc(&g_rx, (size_t)want * sizeof(float)) != hipSuccess) { g_rx = nullptr; return false; }
-    g_rx_floats = want; g_rx_dev = dev;
-    return true;
-}
-
 static inline bool tf_chan_ok(int c) { return c == 8 || c == 16 || (c >= 32 && c % 32 == 0); }
 
 // fills the launch geometry; false = shape outside this kernel (the per-tap kernel of wgrad_mfma.hip takes it)
@@ -565,7 +550,6 @@ bool m1_tf_wgrad_supported(const WgradSpec& g) { TfP p; return tf_plan(g, p) || 
 bool m1_tf64_wgrad_supported(const WgradSpec& g) { TfP p; return tf64_plan(g, p); }
 
 // shared with the per-tap kernel (wgrad_mfma.hip), which uses the same partial-copy scheme for small weight tensors
-float* m1_wg_rx_get(long long floats, hipStream_t st) { return tf_rx_ensure(floats, st) ? g_rx : nullptr; }
 int m1_wg_rx_finish(float* rx, long long stride, int ncopies, const WgradSpec& g, long long nw, hipStream_t st) {
     TfFin f{rx, stride, ncopies, g.R, g.kd * g.kh * g.kw, g.CA, g.CB, g.RT, g.RSA, g.a_off, g.b_off, g.bsum, nw, g.bsum ? g.CB : 0, 32};
     const long long n = (long long)f.NT * f.CA * f.CB + f.nb;
@@ -588,11 +572,12 @@ int m1_tf_wgrad(const WgradSpec& g, long long nw, int nb, hipStream_t st) {
     if (big) nsplit = (tgt + ctiles * g.kd - 1) / (ctiles * g.kd);
     const long long stride = nw + nb;
     if (nsplit * stride * 4 > TF_MAX_COPY_BYTES) nsplit = TF_MAX_COPY_BYTES / (stride * 4);
+    if (!g.rx || g.rx_floats < stride) return M1_ERR_WORKSPACE;
+    if (nsplit * stride > g.rx_floats) nsplit = g.rx_floats / stride;      // as many copies as the caller's scratch holds
     if (nsplit > p.ntiles) nsplit = p.ntiles;
     if (nsplit < 1) return M1_ERR_UNSUPPORTED;
     p.nsplit = (int)nsplit;
-    if (!tf_rx_ensure(nsplit * stride, st)) return M1_ERR_WORKSPACE;
-    p.Rx = g_rx; p.rx_stride = stride; p.rx_bias = nw;
+    p.Rx = g.rx; p.rx_stride = stride; p.rx_bias = nw;
     const size_t smem = (size_t)p.stages * (p.a_bytes + p.b_bytes);
     dim3 grid(ctiles, (unsigned)nsplit, big ? g.kd : 1);
     const int kparts = 4 / ((g.CA > 16 ? 2 : 1) * (g.CB > 16 ? 2 : 1));
@@ -613,5 +598,5 @@ int m1_tf_wgrad(const WgradSpec& g, long long nw, int nb, hipStream_t st) {
     }
     hipLaunchKernelGGL(kern, grid, dim3(256), smem, st, p);
     int rc = m1_check_launch(); if (rc) return rc;
-    return m1_wg_rx_finish(g_rx, stride, (int)nsplit, g, nw, st);
+    return m1_wg_rx_finish(p.Rx, stride, (int)nsplit, g, nw, st);
 }

@@ -166,12 +166,14 @@ class SEResNetBottleNeck(nn.Module):
     def forward(self, input_tensor: Tensors, dropout: Optional[_DropoutBase] = None) -> torch.Tensor:
         pairs = [ops.fanout(t, 2) for t in _as_list(input_tensor)]          # every member feeds conv1 and conv4
         srcs, srcs4 = [a for a, _ in pairs], [b for _, b in pairs]
+        with ops.branch(srcs[0].device, 0) as br:                               # the shortcut next to the bottleneck chain
+            y4, s4 = self.conv4(srcs4, stats=True)                              # B:64
         y1, s1 = self.conv1(srcs, stats=True)
         a = self.norm1(y1, 0.1, s1)                                             # B:53-55
         y2, s2 = self.conv2(a, stats=True)
         a = self.norm2(y2, 0.1, s2)                                             # B:56-58
         y3, s3 = self.conv3(a, stats=True)                                      # B:59
-        y4, s4 = self.conv4(srcs4, stats=True)                                  # B:64
+        br.join(y4, s4)
         rate = dropout.effective_rate() if dropout is not None else 0.0
         gate, self._gate = self._gate, None              # evaluated up front by the owning core (precompute_gates), once per pass
         return ops.se_combine(y3, y4, self.norm3.gamma, self.norm3.beta, self.norm4.gamma, self.norm4.beta,

@@ -201,10 +201,17 @@ class M1Core(nn.Module):
         convm = self.serse4(c3_e, dropout=self.drope4)
         m_use = list(fo(convm, 7 if prob else 5))          # 4 gates, convtd3 (+ latent head and latent decoder of level 3)
         # networks.py:585-588
-        att_conv0, _ = self.att0(x_a, m_use.pop())
-        att_conv1, _ = self.att1(c1_a, m_use.pop())
-        att_conv2, _ = self.att2(c2_a, m_use.pop())
-        att_conv3, _ = self.att3(c3_a, m_use.pop())
+        # the four gates depend on the encoder only: each runs on a side stream of its own, next to the decoder (ops.branch),
+        # and is joined where the decoder first reads it
+        dvc = convm.device
+        with ops.branch(dvc, 1) as br3:
+            att_conv3, _ = self.att3(c3_a, m_use.pop())
+        with ops.branch(dvc, 2) as br2:
+            att_conv2, _ = self.att2(c2_a, m_use.pop())
+        with ops.branch(dvc, 3) as br1:
+            att_conv1, _ = self.att1(c1_a, m_use.pop())
+        with ops.branch(dvc, 4) as br0:
+            att_conv0, _ = self.att0(x_a, m_use.pop())
         # networks.py:591-597
         deconv3 = self.convtd3(m_use.pop())
         if dense:
@@ -212,6 +219,7 @@ class M1Core(nn.Module):
             deconv3_up1, d3u1 = fo(self.convtd3_up1(d3), 2)
             deconv3_up2, d3u2 = fo(self.convtd3_up2(d3u1), 2)
             deconv3_up3 = self.convtd3_up3(d3u2)
+        br3.join(att_conv3)
         uconv3_ = [deconv3, att_conv3]
         if prob:
             uconv3_, uconv3_p = (list(v) for v in zip(*[fo(t, 2) for t in uconv3_]))
@@ -224,8 +232,10 @@ class M1Core(nn.Module):
             deconv2, d2 = fo(deconv2, 2)
             deconv2_up1, d2u1 = fo(self.convtd2_up1(d2), 2)
             deconv2_up2 = self.convtd2_up2(d2u1)
+            br2.join(att_conv2)
             uconv2_ = [deconv2, deconv3_up1, att_conv2]
         else:
+            br2.join(att_conv2)
             uconv2_ = [deconv2, att_conv2]
         if prob:
             uconv2_, uconv2_p = (list(v) for v in zip(*[fo(t, 2) for t in uconv2_]))
@@ -236,8 +246,10 @@ class M1Core(nn.Module):
         if dense:
             deconv1, d1 = fo(deconv1, 2)
             deconv1_up1 = self.convtd1_up1(d1)
+            br1.join(att_conv1)
             uconv1_ = [deconv1, deconv2_up1, deconv3_up2, att_conv1]
         else:
+            br1.join(att_conv1)
             uconv1_ = [deconv1, att_conv1]
         if prob:
             uconv1_, uconv1_p = (list(v) for v in zip(*[fo(t, 2) for t in uconv1_]))
@@ -246,8 +258,10 @@ class M1Core(nn.Module):
         # networks.py:619-624
         deconv0 = self.convtd0(u1_up)
         if dense:
+            br0.join(att_conv0)
             uconv0_ = [deconv0, deconv1_up1, deconv2_up2, deconv3_up3, att_conv0]
         else:
+            br0.join(att_conv0)
             uconv0_ = [deconv0, att_conv0]
 
         cat_c = lambda ts: sum(int(t.shape[-1]) for t in ts)
