@@ -124,7 +124,19 @@ def _slot_written(slot: Optional[_GradSlot]) -> None:
 # independent branches on side streams
 # ---------------------------------------------------------------------------------------------------------
 import os as _os
-_BRANCH = {"on": _os.environ.get("M1_STREAMS", "1") != "0", "streams": {}}
+_BRANCH = {"on": _os.environ.get("M1_STREAMS", "1") != "0", "streams": {}, "used": set()}
+
+
+def join_side_streams() -> None:
+    """The current stream waits for every side stream used since the last call.  Backward kernels that only add into
+    parameter-gradient sinks return nothing to autograd, so the engine never orders them before the caller: gather_grads /
+    zero_grad do it here (inside a capture this is also what rejoins the forked streams)."""
+    if _BRANCH["used"]:
+        cur = torch.cuda.current_stream()
+        for s in _BRANCH["used"]:
+            if s != cur:
+                cur.wait_stream(s)
+        _BRANCH["used"].clear()
 
 
 class branch:
@@ -147,6 +159,7 @@ class branch:
     def __enter__(self):
         if self.on:
             self.side.wait_stream(self.cur)
+            _BRANCH["used"].add(self.side)
             self.ctx.__enter__()
         return self
 
@@ -439,6 +452,7 @@ _SE_DEFER: list = []      # (m1_se_gate_job_t, tensors kept alive) queued by _SE
 def flush_deferred() -> None:
     """Run the queued SE gate backwards (m1_se_gate_bwd_batch).  optim.FlatParams.gather_grads calls this before anything
     reads the flat gradient buffer; the tensors the jobs point at are held until the launch is enqueued."""
+    join_side_streams()
     if not _SE_DEFER:
         return
     jobs = (L.SeGateJob * len(_SE_DEFER))(*[j for j, _ in _SE_DEFER])
@@ -450,6 +464,7 @@ def flush_deferred() -> None:
 
 def drop_deferred() -> None:
     """Forget queued jobs of a backward pass whose gradients are being discarded (optimiser zero_grad)."""
+    join_side_streams()
     _SE_DEFER.clear()
 
 

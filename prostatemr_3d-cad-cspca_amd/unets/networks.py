@@ -427,6 +427,8 @@ class M1Net(nn.Module):
             label = inputs[..., C - (nc - 1) - 1:C - 1].contiguous()
             post_in = [image, label]                                               # tf.concat([image,label]) virtual
             if train_outputs:
+                # (two lanes -- posterior mean -> prior -> logits next to posterior sample -> prior -> KL -- were measured: no gain,
+                # the full model is dominated by kernels that fill the GPU on their own; nested forks also break graph capture)
                 q_sample = self.posterior(post_in, prob_mean=False, prob_z_q=None, eps=eps_q)          # networks.py:348
                 q_mean = self.posterior(post_in, prob_mean=True, prob_z_q=None)                          # networks.py:349
                 p_z_q = self.prior(image, prob_mean=False, prob_z_q=q_sample['prob_used_latents'])      # networks.py:351
