@@ -7,6 +7,7 @@ path: ops raise RuntimeError on non-GPU tensors.
 from __future__ import annotations
 
 import ctypes as C
+import os as _os
 import weakref
 from typing import List, Optional, Sequence, Tuple
 
@@ -123,7 +124,6 @@ def _slot_written(slot: Optional[_GradSlot]) -> None:
 # ---------------------------------------------------------------------------------------------------------
 # independent branches on side streams
 # ---------------------------------------------------------------------------------------------------------
-import os as _os
 _BRANCH = {"on": _os.environ.get("M1_STREAMS", "1") != "0", "streams": {}, "used": set()}
 
 
@@ -144,7 +144,8 @@ class branch:
     shortcut of an SE block next to its conv1-conv2-conv3 chain; the attention gates next to the decoder) on side stream
     ``k``; autograd runs the backward of these ops on the same stream, so both directions overlap, inside a captured graph
     as well (fork/join become graph dependencies).  Most kernels of the deep levels fill a fraction of the 256 CUs: measured
-    -4.5 % (batch 2) / -5.3 % (batch 1) per C2 step with the SE shortcuts alone.  M1_STREAMS=0 runs everything in order."""
+    -8 % per C2 train step (SE shortcuts + gates), -4 % on the full probabilistic model.  M1_STREAMS=0 runs everything in order.
+    Tensors handed to the branch must stay referenced until ``join`` (they are read on the side stream)."""
 
     def __init__(self, device, k: int = 0):
         self.on = _BRANCH["on"] and device.type == "cuda"
