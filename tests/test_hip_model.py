@@ -8,7 +8,7 @@ import pytest
 import torch
 
 from oracle import m1_oracle as O
-from util import C1_FILTERS, C1_STRIDES, PKG, build_m1, load_params_into, rel_err, rel_l2, rnd
+from util import C1_FILTERS, C1_STRIDES, PKG, build_m1, load_params_into, ops, rel_err, rel_l2, rnd
 
 pytestmark = pytest.mark.gpu
 
@@ -217,3 +217,39 @@ def test_forward_and_data_gradients_are_run_to_run_deterministic(dev):
         o, g = run()
         assert torch.equal(o, o0)
         assert torch.equal(g, g0)
+
+
+@pytest.mark.parametrize("prob", [False, True])
+def test_side_stream_branches_do_not_change_results(dev, prob):
+    """ops.branch (SE shortcut / attention gates on side streams) only changes WHERE kernels run: outputs, input gradients and
+    parameter gradients equal the in-order run (gradient slots shared across streams are ordered by events)."""
+    cfg = O.M1Config(input_spatial_dims=(8, 32, 32), filters=(8, 16, 32, 64, 128), strides=C1_STRIDES, probabilistic=prob,
+                     dense_skip=prob, prob_latent_dims=(3, 2, 1, 0), input_channels=4 if prob else 3)
+    m = build_m1(cfg, dev)
+    load_params_into(m, O.fixture_params(cfg, seed=3))
+    x = rnd((2, 8, 32, 32, cfg.input_channels), 2).to(dev).requires_grad_(True)
+
+    def run(on):
+        ops._BRANCH["on"] = on
+        try:
+            x.grad = None
+            for p in m.parameters():
+                p.grad = None
+            torch.manual_seed(0)
+            out = m(x)
+            outs = out if isinstance(out, (list, tuple)) else [out]
+            sum((o.float() * (0.5 + 0.01 * i)).sum() for i, o in enumerate(outs)).backward()
+            torch.cuda.synchronize()
+            return [o.detach().clone() for o in outs], x.grad.clone(), [p.grad.clone() for p in m.parameters() if p.grad is not None]
+        finally:
+            ops._BRANCH["on"] = True
+    o_off, gx_off, gp_off = run(False)
+    for _ in range(3):
+        o_on, gx_on, gp_on = run(True)
+        for a, b in zip(o_on, o_off):
+            assert torch.equal(a, b)
+        assert torch.equal(gx_on, gx_off)
+        gmax = max(float(b.abs().max()) for b in gp_off)
+        for a, b in zip(gp_on, gp_off):          # weight gradients of large blocks sum voxel splits with fp32 atomics;
+            # gradients that cancel to ~0 (a bias in front of an InstanceNorm) are compared on the scale of the whole gradient
+            assert float((a - b).abs().max()) <= 1e-5 * max(float(b.abs().max()), 1e-2 * gmax)
