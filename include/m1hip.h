@@ -70,9 +70,11 @@ size_t m1_conv_ws_bytes(const m1_conv_desc_t* d, int transposed, int role);
  * a job record in front of it inside ws; ws must therefore be ZERO-FILLED when it is first handed over.
  * m1_conv_pack_jobs writes the device addresses of the records of (d, transposed, role in {0,1}) into jobs_out
  * (room for M1_MAX_SRC entries) and returns their number; m1_pack_batch re-packs, in one launch, every filled record
- * of the device array jobs_dev[njobs] from the current weight values (records never filled are skipped). */
+ * of the device array jobs_dev[njobs] from the current weight values (records never filled are skipped).
+ * block_prefix_dev (optional, device, njobs + 1 ints, prefix[0] = 0, prefix[njobs] = total_blocks): blocks of 256 threads per
+ * job, sized by the caller in proportion to each job's weight count (>= 1 each); NULL = 48 blocks for every job. */
 int m1_conv_pack_jobs(const m1_conv_desc_t* d, int transposed, int role, void* ws, void** jobs_out);
-int m1_pack_batch(const void* const* jobs_dev, int njobs, void* stream);
+int m1_pack_batch(const void* const* jobs_dev, const int* block_prefix_dev, int njobs, int total_blocks, void* stream);
 /* ws_packed != 0: ws still holds the weight panels a previous call with the SAME descriptor geometry, role and
  * (unchanged) weights left there -- the pack pass is skipped (the prior / posterior cores run twice per step). */
 /* stats (optional, (N,Cout,2) fp32): {mean, rstd} (eps 1e-3, biased variance) of y per (n, channel) for the

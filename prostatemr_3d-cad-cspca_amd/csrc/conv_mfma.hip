@@ -556,9 +556,32 @@ __global__ void __launch_bounds__(256) pack_batch_kernel(const PackJob* const* _
         else pack_class_elems<float>(j.p, cls, (float*)j.out, first, stride);
     }
 }
-int m1_pack_batch_internal(const void* const* jobs_dev, int njobs, hipStream_t st) {
+// balanced variant: 1-D grid, block b serves job j with prefix[j] <= b < prefix[j+1] (the caller sizes the block count of a
+// job by its weight count: with a fixed 48 blocks per job the 3.5 M-weight res3/res4 kernels set the run time of the launch)
+__global__ void __launch_bounds__(256) pack_batch_balanced_kernel(const PackJob* const* __restrict__ jobs, const int* __restrict__ prefix,
+                                                                  int njobs) {
+    __shared__ PackJob j;
+    int lo = 0, hi = njobs - 1;                      // last j with prefix[j] <= blockIdx.x
+    const int b = blockIdx.x;
+    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (prefix[mid] <= b) lo = mid; else hi = mid - 1; }
+    const unsigned* src = reinterpret_cast<const unsigned*>(jobs[lo]);
+    for (int i = threadIdx.x; i < (int)(sizeof(PackJob) / 4); i += blockDim.x) reinterpret_cast<unsigned*>(&j)[i] = src[i];
+    __syncthreads();
+    if (j.magic != M1_PACK_MAGIC) return;
+    const int nb = prefix[lo + 1] - prefix[lo];
+    const long long first = (long long)(b - prefix[lo]) * blockDim.x + threadIdx.x, stride = (long long)nb * blockDim.x;
+    for (int cls = 0; cls < j.p.nclasses; ++cls) {
+        if (j.dtype == M1_BF16) pack_class_elems<bf16_t>(j.p, cls, (bf16_t*)j.out, first, stride);
+        else pack_class_elems<float>(j.p, cls, (float*)j.out, first, stride);
+    }
+}
+int m1_pack_batch_internal(const void* const* jobs_dev, const int* prefix_dev, int njobs, int total_blocks, hipStream_t st) {
     if (njobs <= 0) return M1_OK;
-    hipLaunchKernelGGL(pack_batch_kernel, dim3(48, (unsigned)njobs), dim3(256), 0, st, reinterpret_cast<const PackJob* const*>(jobs_dev));
+    if (prefix_dev && total_blocks > 0)
+        hipLaunchKernelGGL(pack_batch_balanced_kernel, dim3((unsigned)total_blocks), dim3(256), 0, st,
+                           reinterpret_cast<const PackJob* const*>(jobs_dev), prefix_dev, njobs);
+    else
+        hipLaunchKernelGGL(pack_batch_kernel, dim3(48, (unsigned)njobs), dim3(256), 0, st, reinterpret_cast<const PackJob* const*>(jobs_dev));
     return m1_check_launch();
 }
 

@@ -195,10 +195,10 @@ extern "C" int m1_conv_pack_jobs(const m1_conv_desc_t* d, int transposed, int ro
     }
     return n;
 }
-extern "C" int m1_pack_batch(const void* const* jobs_dev, int njobs, void* stream) {
-    if (njobs < 0 || (njobs > 0 && !jobs_dev)) return M1_ERR_BAD_ARG;
+extern "C" int m1_pack_batch(const void* const* jobs_dev, const int* block_prefix_dev, int njobs, int total_blocks, void* stream) {
+    if (njobs < 0 || (njobs > 0 && !jobs_dev) || (block_prefix_dev && total_blocks < njobs)) return M1_ERR_BAD_ARG;
     M1ProfScope ps("pack_batch", 0.0, 0.0, (hipStream_t)stream);
-    return m1_pack_batch_internal(jobs_dev, njobs, (hipStream_t)stream);
+    return m1_pack_batch_internal(jobs_dev, block_prefix_dev, njobs, total_blocks, (hipStream_t)stream);
 }
 
 // ---- Conv3D ------------------------------------------------------------------------------------------------------

@@ -43,7 +43,7 @@ int m1_skinny_wgrad(const WgradSpec& g, hipStream_t st);
 bool m1_mfma_supported(const GatherSpec& g);
 size_t m1_mfma_ws_bytes(const GatherSpec& g);
 int m1_mfma_gather(const GatherSpec& g, void* ws, int ws_packed, hipStream_t st);
-int m1_pack_batch_internal(const void* const* jobs_dev, int njobs, hipStream_t st);
+int m1_pack_batch_internal(const void* const* jobs_dev, const int* prefix_dev, int njobs, int total_blocks, hipStream_t st);
 bool m1_mfma_wgrad_supported(const WgradSpec& g);
 int m1_mfma_wgrad(const WgradSpec& g, hipStream_t st);
 bool m1_tf_wgrad_supported(const WgradSpec& g);      // tap-fused variant (wgrad_tf.hip)

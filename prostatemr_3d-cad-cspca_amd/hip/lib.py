@@ -64,7 +64,7 @@ SIGNATURES = {
     "m1_abi_version": (_i, []),
     "m1_conv_ws_bytes": (_sz, [_desc_p, _i, _i]),
     "m1_conv_pack_jobs": (_i, [_desc_p, _i, _i, _vp, C.POINTER(_vp)]),
-    "m1_pack_batch": (_i, [_vp, _i, _vp]),
+    "m1_pack_batch": (_i, [_vp, _vp, _i, _i, _vp]),
     "m1_set_force_direct": (_i, [_i]),
     "m1_conv3d_fwd": (_i, [_desc_p, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
     "m1_conv3d_dgrad": (_i, [_desc_p, _vp, _vp, C.POINTER(_vp), C.POINTER(_i), _vp, _i, _vp]),

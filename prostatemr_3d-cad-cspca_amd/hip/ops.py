@@ -255,10 +255,16 @@ def repack_all() -> None:
         if torch.cuda.is_current_stream_capturing():
             raise RuntimeError("weight-panel registry changed during graph capture: run one eager step first")
         ws0 = next(iter(_PACK_REG.values()))[2]
-        ptrs = [j for (_, _, _, jobs) in _PACK_REG.values() for j in jobs]
-        _PACK_TABLE[0] = torch.tensor(ptrs, dtype=torch.int64).to(ws0.device)
-    t = _PACK_TABLE[0]
-    L.check(L.load().m1_pack_batch(_p(t), int(t.numel()), _stream()), "m1_pack_batch")
+        ptrs, blocks = [], [0]
+        for (r, _, _, jobs) in _PACK_REG.values():
+            per = max(1, int(r().numel()) // max(1, len(jobs)))          # weights per job (a dgrad panel per concat member)
+            for j in jobs:
+                ptrs.append(j)
+                blocks.append(blocks[-1] + min(512, max(1, -(-per // 16384))))   # ~8 segments of 8 weights per thread
+        _PACK_TABLE[0] = (torch.tensor(ptrs, dtype=torch.int64).to(ws0.device),
+                          torch.tensor(blocks, dtype=torch.int32).to(ws0.device), blocks[-1])
+    t, pref, total = _PACK_TABLE[0]
+    L.check(L.load().m1_pack_batch(_p(t), _p(pref), int(t.numel()), int(total), _stream()), "m1_pack_batch")
 
 
 def _panel_ws(w: torch.Tensor, d, transposed: bool, role: int, need_mask=None):
