@@ -233,6 +233,29 @@ __global__ void __launch_bounds__(NTHR) conv_halo_kernel(HaloP p) {
         __syncthreads();
         const int oh0 = c_th * p.TH, ow0 = c_tw * p.TW;
         const long long slice0 = ((long long)c_n * m.OD + c_od) * m.OH;
+        if (m.accumulate) {       // out += : fold what is there into the tile first, so that the statistics below (a conv run as
+            // one launch per member group: the last group owns them) and the stores see the sum
+            constexpr int SPRa = BN / SEG;
+            for (int e = tid; e < HL_BM * SPRa; e += NTHR) {
+                const int row = e / SPRa, cs = e % SPRa;
+                const int th = row / p.TW, tw = row - th * p.TW;
+                const int oc = oc0 + cs * SEG;
+                if (oh0 + th >= m.OH || oc >= m.OCn) continue;
+                const long long orow = (slice0 + oh0 + th) * m.OW + ow0 + tw;
+                const bf16_t* src = (const bf16_t*)m.out + orow * m.OC + oc;
+                bf16_t* ct = C_s + row * CP + cs * SEG;
+                if (m.OC % SEG != 0 || oc + SEG > m.OCn) {
+                    for (int k = 0; k < SEG && oc + k < m.OCn; ++k) Act<bf16_t>::st(ct + k, Act<bf16_t>::ld(ct + k) + Act<bf16_t>::ld(src + k));
+                } else {
+                    float a[SEG], b[SEG];
+                    VecIO<bf16_t, SEG>::ld(ct, a); VecIO<bf16_t, SEG>::ld(src, b);
+#pragma unroll
+                    for (int k = 0; k < SEG; ++k) a[k] += b[k];
+                    VecIO<bf16_t, SEG>::st(ct, a);
+                }
+            }
+            __syncthreads();
+        }
         if (m.stat_partial) {
             constexpr int G = NTHR / BN;
             const int col = tid % BN, rg = tid / BN;
@@ -261,17 +284,7 @@ __global__ void __launch_bounds__(NTHR) conv_halo_kernel(HaloP p) {
             bf16_t* dst = out + orow * m.OC + oc;
             if (m.OC % SEG != 0 || oc + SEG > m.OCn) {
                 const bf16_t* ve = reinterpret_cast<const bf16_t*>(&v);
-                for (int k = 0; k < SEG && oc + k < m.OCn; ++k) {
-                    if (m.accumulate) Act<bf16_t>::st(dst + k, Act<bf16_t>::ld(ve + k) + Act<bf16_t>::ld(dst + k));
-                    else dst[k] = ve[k];
-                }
-            } else if (m.accumulate) {                    // dx += (a gradient with several consumers sums in place)
-                float a[SEG], b[SEG];
-                VecIO<bf16_t, SEG>::ld(reinterpret_cast<const bf16_t*>(&v), a);
-                VecIO<bf16_t, SEG>::ld(dst, b);
-#pragma unroll
-                for (int k = 0; k < SEG; ++k) a[k] += b[k];
-                VecIO<bf16_t, SEG>::st(dst, a);
+                for (int k = 0; k < SEG && oc + k < m.OCn; ++k) dst[k] = ve[k];
             } else {
                 *reinterpret_cast<uint4*>(dst) = v;
             }

@@ -755,7 +755,8 @@ static int run_mfma(const GatherSpec& g, void* ws, int ws_packed, hipStream_t st
     static int c8 = -1; if (c8 < 0) { const char* e = getenv("M1_CONV8"); c8 = e ? atoi(e) : 0; }
     const bool use8 = c8 && BN == 128 && pl.ksplit == 1 && cdiv_ll(spec_maxM(g), 128) * spec_ncls(g) * (OCpad / 128) >= 160;
     const int bm_eff = use8 ? 128 : pl.BM;
-    bool fuse_stats = g.stats_out && g.stats_ws && g.mode == 0 && pl.ksplit == 1 && (g.N == 1 || Vout % bm_eff == 0);
+    bool fuse_stats = g.stats_out && g.stats_ws && g.mode == 0 && pl.ksplit == 1 && (g.N == 1 || Vout % bm_eff == 0) &&
+                      !g.accumulate;           // (this kernel's statistics come from its own tile, before the add)
     if (fuse_stats) { mp.stat_partial = g.stats_ws; mp.stat_tiles = (int)cdiv_ll(Vout, bm_eff); }
     for (int i = 0; i < g.nsrc; ++i) if (g.srcC[i] % (4 * SEG)) mp.aligned = 0;
     for (int i = 0; i < g.nsrc; ++i)          // the LDS-DMA loader addresses a member with 31-bit byte offsets

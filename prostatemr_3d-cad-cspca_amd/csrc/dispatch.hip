@@ -111,6 +111,39 @@ static int run_gather(const GatherSpec& g, void* ws, int ws_packed, hipStream_t 
     return m1_direct_gather(dr, st);
 }
 
+// ---- forward of a wide concat as one halo-tile launch per member group ----------------------------------------------
+// The halo-tile kernel (conv_halo.hip) stages an input tile once for all taps but holds at most 64 contraction channels; the
+// dense-skip concats of the full model (160 channels at res0, 256 at res1: networks.py:604-623) fell back to the per-tap
+// gather (160->32 at res0: 470 us, bound by 9x re-reads from L2).  Split the members into groups of 8/16/32/64 channels: the
+// first group writes y (+ bias), the others add into it in their epilogue, the last one also emits the InstanceNorm statistics
+// of the sum.  Each group is an ordinary conv over its members with a channel offset into the weights (own panel, own job).
+struct FwdGroups { int n; int first[M1_MAX_SRC], count[M1_MAX_SRC], coff[M1_MAX_SRC]; };
+static bool fwd_groups(const m1_conv_desc_t* d, bool T, FwdGroups* fg) {
+    static int en = -1; if (en < 0) { const char* e = getenv("M1_HALO_GROUPS"); en = e ? atoi(e) : 1; }
+    if (!en || T || g_force_direct || d->dtype != M1_BF16 || d->nsrc < 2 || d->Cin <= 64) return false;
+    if (d->kd * d->kh * d->kw < 2) return false;
+    Geo q = conv_geo(d);
+    if (q.OW % 8 || (long long)d->N * q.OD * q.OH * q.OW < 32768) return false;
+    auto ok = [](int c) { return c == 8 || c == 16 || c == 32 || c == 64; };
+    fg->n = 0; int cur = 0, off = 0;
+    for (int i = 0; i < d->nsrc; ++i) {
+        const int c = d->src[i].C;
+        if (!ok(c)) return false;
+        if (fg->n > 0 && ok(cur + c) && cur + c <= 64) { fg->count[fg->n - 1]++; cur += c; }
+        else { fg->first[fg->n] = i; fg->count[fg->n] = 1; fg->coff[fg->n] = off; fg->n++; cur = c; }
+        off += c;
+    }
+    return fg->n >= 2;
+}
+static GatherSpec fwd_group_spec(const m1_conv_desc_t* d, const FwdGroups& fg, int gi, const float* w, const float* bias, void* y) {
+    GatherSpec g = fwd_spec(d, false, w, gi == 0 ? bias : nullptr, y);
+    g.nsrc = fg.count[gi];
+    for (int i = 0; i < g.nsrc; ++i) { g.src[i] = d->src[fg.first[gi] + i].ptr; g.srcC[i] = d->src[fg.first[gi] + i].C; }
+    g.cc_off = fg.coff[gi];
+    g.accumulate = gi > 0 ? 1 : 0;
+    return g;
+}
+
 // ---- stem weight gradient (Cin < 8: the image channels, networks.py:472) -----------------------------------------------
 // 3 (or 2) input channels are 6 (4) bytes per voxel: no 16-byte segments for the LDS-DMA loaders, so this layer used to run
 // on the generic per-tap kernel, re-reading dY once per tap (157 us at batch 2 = the slowest weight gradient of the step for
@@ -160,8 +193,11 @@ extern "C" size_t m1_conv_ws_bytes(const m1_conv_desc_t* d, int transposed, int 
     const bool T = transposed != 0;
     if (role == 0) {
         Geo q0 = T ? convT_geo(d) : conv_geo(d);
-        return gather_ws_bytes(fwd_spec(d, T, nullptr, nullptr, nullptr)) +
-               align256(m1_stats_ws_floats(d->N, (long long)q0.OD * q0.OH * q0.OW, d->Cout) * sizeof(float)) + 256;
+        size_t panels = 0;
+        FwdGroups fg;
+        if (fwd_groups(d, T, &fg)) { for (int gi = 0; gi < fg.n; ++gi) panels += gather_ws_bytes(fwd_group_spec(d, fg, gi, nullptr, nullptr, nullptr)); }
+        else panels = gather_ws_bytes(fwd_spec(d, T, nullptr, nullptr, nullptr));
+        return panels + align256(m1_stats_ws_floats(d->N, (long long)q0.OD * q0.OH * q0.OW, d->Cout) * sizeof(float)) + 256;
     }
     if (role == 1) {
         size_t m = 0; int off = 0;
@@ -184,7 +220,15 @@ extern "C" int m1_conv_pack_jobs(const m1_conv_desc_t* d, int transposed, int ro
     const bool T = transposed != 0;
     int n = 0;
     if (role == 0) {
-        if (gather_ws_bytes(fwd_spec(d, T, nullptr, nullptr, nullptr))) jobs_out[n++] = ws;
+        FwdGroups fg;
+        if (fwd_groups(d, T, &fg)) {
+            size_t woff = 0;
+            for (int gi = 0; gi < fg.n; ++gi) {
+                const size_t b = gather_ws_bytes(fwd_group_spec(d, fg, gi, nullptr, nullptr, nullptr));
+                if (b) jobs_out[n++] = (unsigned char*)ws + woff;
+                woff += b;
+            }
+        } else if (gather_ws_bytes(fwd_spec(d, T, nullptr, nullptr, nullptr))) jobs_out[n++] = ws;
     } else if (role == 1) {
         int off = 0; size_t woff = 0;
         for (int i = 0; i < d->nsrc; ++i) {
@@ -206,6 +250,21 @@ extern "C" int m1_conv3d_fwd(const m1_conv_desc_t* d, const float* w, const floa
                              int ws_packed, void* stream) {
     if (!desc_ok(d) || !w || !y) return M1_ERR_BAD_ARG;
     M1ProfScope ps("conv3d_fwd", 2.0 * conv_macs(d, false), conv_bytes(d, false), (hipStream_t)stream);
+    FwdGroups fg;
+    if (ws && fwd_groups(d, false, &fg)) {
+        size_t woff = 0, total = 0;
+        for (int gi = 0; gi < fg.n; ++gi) total += gather_ws_bytes(fwd_group_spec(d, fg, gi, nullptr, nullptr, nullptr));
+        for (int gi = 0; gi < fg.n; ++gi) {
+            GatherSpec gg = fwd_group_spec(d, fg, gi, w, bias, y);
+            if (stats && gi == fg.n - 1) {
+                gg.stats_out = stats; gg.stats_eps = 1e-3f;
+                gg.stats_ws = reinterpret_cast<float*>((unsigned char*)ws + total);
+            }
+            int rc = run_gather(gg, (unsigned char*)ws + woff, ws_packed, (hipStream_t)stream); if (rc) return rc;
+            woff += gather_ws_bytes(gg);
+        }
+        return M1_OK;
+    }
     GatherSpec g = fwd_spec(d, false, w, bias, y);
     if (stats) {
         if (!ws) return M1_ERR_WORKSPACE;

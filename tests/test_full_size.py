@@ -22,6 +22,8 @@ FULL = [
     ("res0 conv2 8->8 3x3x3", (1, 20, 160, 160), [8], 8, (3, 3, 3), (1, 1, 1), False, (0, 6, 0, 24, 120, 160)),
     ("res0->res1 32->64 stride (1,2,2)", (1, 20, 160, 160), [32], 64, (1, 3, 3), (1, 2, 2), False, (18, 20, 100, 160, 0, 40)),
     ("res1 dense concat 4x64->64", (1, 20, 80, 80), [64, 64, 64, 64], 64, (1, 3, 3), (1, 1, 1), False, (3, 5, 20, 44, 30, 62)),
+    ("res0 dense concat 5x32->32 (halo tile per member group)", (1, 20, 160, 160), [32, 32, 32, 32, 32], 32, (1, 3, 3), (1, 1, 1), False, (9, 12, 120, 150, 0, 36)),
+    ("res0 dense concat 5x32->8", (1, 20, 160, 160), [32, 32, 32, 32, 32], 8, (1, 3, 3), (1, 1, 1), False, (0, 3, 60, 84, 100, 140)),
     ("res2 256->128 3x3x3, batch 2", (2, 20, 40, 40), [128, 128], 128, (3, 3, 3), (1, 1, 1), False, (8, 14, 10, 26, 16, 40)),
     ("res2->res3 128->256 stride 2", (1, 20, 40, 40), [128], 256, (3, 3, 3), (2, 2, 2), False, (4, 14, 0, 20, 20, 40)),
     ("convT res1->res0 64->32", (1, 20, 80, 80), [64], 32, (1, 3, 3), (1, 2, 2), True, (5, 8, 30, 50, 0, 24)),
@@ -56,6 +58,14 @@ def test_full_size_conv_locality_and_adjointness(dev, case):
     y = fh(xd, wd, bd, k, s)
     dy = rnd(tuple(y.shape), 5).to(bf)
     y.backward(dy.to(dev))
+
+    if not transposed:      # the fused InstanceNorm statistics (of the rounded output; of the SUM when the conv ran as member groups)
+        with torch.no_grad():
+            y_s, st = ops.conv3d_same([t.detach() for t in xd], wd.detach(), bd.detach(), k, s, stats=True)
+        assert torch.equal(y_s, y.detach())
+        yf = y_s.double()
+        mean = yf.mean(dim=(1, 2, 3)); var = yf.var(dim=(1, 2, 3), unbiased=False)
+        assert rel_err(st[..., 0], mean.float()) < 1e-4 and rel_err(st[..., 1], (1.0 / torch.sqrt(var + 1e-3)).float()) < 1e-4, f"{name}: stats"
 
     # ---- locality: oracle on the cropped inputs, interior voxels ----
     xc = torch.cat([_crop(x, win) for x in xs], dim=-1).double().requires_grad_(True)
