@@ -6,11 +6,15 @@
 
 One "step" = forward (all core passes) + Focal (+10*KL) loss + backward + gradient all-reduce (N>1) +
 fused Adam-amsgrad/L2 update, on synthetic volumes already resident in HBM.
-Rank 0 prints ONE JSON line; `value` = volumes/s over all ranks; `roofline` describes the dominant kernel
-(algorithmic work / hipEvent-measured duration on the launch stream); `cpu_baseline` is the CPU oracle
-(stand-in for the TF 2.5 CPU path, which cannot be installed) timed on this box's host cores.
+Rank 0 prints ONE JSON line.  The headline workload is C3 -- the north-star model: full hierarchical-probabilistic
+M1 (dense_skip, deep_supervision, latents (3,2,1,0)) on (20,160,160,3) volumes, bf16, batch 2 per GPU (C4 = the same
+on 8 GPUs); at N=1 the line also carries C2 (deterministic Attention-U-Net, same volume) under ``secondary``.
+`value` = volumes/s over all ranks; `roofline` describes the dominant kernel family (algorithmic work / hipEvent-measured
+duration on the launch stream); `cpu_baseline` is the CPU oracle (stand-in for the TF 2.5 CPU path, which cannot be
+installed) timed on this box's host cores.
 """
 import argparse
+import gc
 import importlib
 import json
 import os
@@ -29,9 +33,12 @@ WORKLOADS = {
     "C3": ((20, 160, 160), (32, 64, 128, 256, 512), True, True, True),
     "C5": ((32, 256, 256), (32, 64, 128, 256, 512), False, False, False),
 }
+WORKLOAD_NAMES = {"C1": "C1 tiny deterministic (8,64,64,3) filters (8..128)",
+                  "C2": "C2 M1 deterministic Attention-U-Net (20,160,160,3) filters (32..512)",
+                  "C3": "C3 M1 full hierarchical-probabilistic dense_skip+deep_supervision latents (3,2,1,0) (20,160,160,3)",
+                  "C5": "C5 M1 deterministic high-res (32,256,256,3)"}
 PEAK_HBM_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 PEAK_MFMA_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}
-
 
 # volumes per GPU when --batch is not given: the reference trainer's default batch (train_model.py:83, --BATCH_SIZE 2), which is
 # also the per-GPU batch BASELINE.json names for C4; C1 is the reference's batch-1 plumbing case, C5 the single-volume stress case
@@ -43,8 +50,8 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default=os.environ.get("M1_BENCH_WORKLOAD", "C2"), choices=sorted(WORKLOADS))
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--workload", default=os.environ.get("M1_BENCH_WORKLOAD", "C3"), choices=sorted(WORKLOADS))
+    ap.add_argument("--dtype", default=None, choices=["bf16", "fp32"], help="default bf16 (C5: fp32, as BASELINE.json names it)")
     ap.add_argument("--batch", type=int, default=None,
                     help="volumes per GPU (default: 2 for C2/C3 = train_model.py:83's --BATCH_SIZE default and C4's per-GPU batch; "
                          "1 for C1/C5).  C4 = C3 at its default batch on 8 GPUs")
@@ -52,6 +59,7 @@ def parse():
     ap.add_argument("--no-graph", action="store_true", help="do not capture the step in a hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="N=1, C3: do not also measure C2")
     ap.add_argument("--prof-steps", type=int, default=2)
     return ap.parse_args()
 
@@ -71,10 +79,10 @@ def ball_targets(B, dims, seed, device):
     return torch.from_numpy(t).to(device)
 
 
-def cpu_baseline(workload, prob, dense, deep, dims, filters, kl_w, budget_s=20.0):
-    """The CPU oracle's full train step (fwd + Focal [+10 KL] + L2 + bwd, torch-CPU fp32) on a BOUNDED sample: the same
-    model on a sub-volume; throughput is scaled by the voxel ratio (the path is convolutional, i.e. linear in
-    voxels).  A small probe is timed first and the largest sub-volume predicted to fit the time budget is used."""
+def cpu_baseline(workload, prob, dense, deep, dims, filters, kl_w, budget_s=45.0):
+    """The CPU oracle's full train step (fwd + Focal [+10 KL] + L2 + bwd, torch-CPU fp32) on ONE WHOLE VOLUME of the
+    workload when a probe predicts that fits the time budget (it does for C2 and C3 on the GPU box's host), else on the
+    largest sub-volume that does, scaled by the voxel ratio (the path is convolutional: linear in voxels)."""
     import torch
     from oracle import m1_oracle as O
     cores = min(os.cpu_count() or 1, 32)          # more threads than this only adds contention on these small convs
@@ -99,17 +107,16 @@ def cpu_baseline(workload, prob, dense, deep, dims, filters, kl_w, budget_s=20.0
     vox = lambda c: c[0] * c[1] * c[2]
     probe = min(cands, key=vox)
     run(probe)                                       # warm-up (thread pools, oneDNN primitives)
-    t_probe = run(probe)
-    pick = probe
-    for c in sorted(cands, key=vox):
-        if t_probe * vox(c) / vox(probe) <= budget_s:
-            pick = c
-    t = t_probe if pick == probe else run(pick)
+    pick, t = probe, run(probe)
+    for c in sorted(cands, key=vox)[1:]:             # climb while the next size, predicted from the last measured one, fits
+        if t * vox(c) / vox(pick) > budget_s:        # (small volumes are less efficient: the prediction errs on the safe side)
+            break
+        pick, t = c, run(c)
     frac = vox(pick) / float(D * H * W)
+    whole = "one WHOLE volume" if frac == 1.0 else f"a ({pick[0]},{pick[1]},{pick[2]}) sub-volume = {frac:.4f} of a volume, scaled by voxel ratio"
     return {"value": frac / t, "unit": "volumes/s", "cores": cores, "kind": "port",
             "sample": f"oracle (torch-CPU fp32 restatement of the TF2.5 path, stand-in: TF cannot be installed) full train "
-                      f"step fwd+loss+bwd of {workload} on a ({pick[0]},{pick[1]},{pick[2]}) sub-volume = {frac:.4f} of a volume, "
-                      f"{t:.2f} s/step on {cores} threads, scaled by voxel ratio"}
+                      f"step fwd+loss+bwd of {workload} on {whole}; {t:.2f} s/step on {cores} threads"}
 
 
 # kernel names behind each C-ABI entry-point family (the PMC pass sees kernels, the hipEvent timer sees entry points)
@@ -120,27 +127,30 @@ _FAMILY_KERNELS = {
 }
 
 
-def hbm_traffic(a, B, recs, family):
+def hbm_traffic(wl, dtype, B, recs, family, prof_steps):
     """HBM bytes per launch of the dominant entry-point family, from the committed rocprofv3 --pmc FETCH_SIZE /
-    WRITE_SIZE passes of this same workload (profiles/r01_c2_bf16_hbm_traffic.json, tools/collect_profiles.sh; FETCH_SIZE
-    doubled as MI355X_MICROARCH.md prescribes for gfx950).  None when no committed measurement matches the run."""
-    if not (a.workload == "C2" and a.dtype == "bf16"):
+    WRITE_SIZE passes of this same workload (profiles/r0N_<wl>_<dtype>_hbm_traffic.json, tools/collect_profiles.sh;
+    FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).  None when no committed measurement matches."""
+    pdir = os.path.join(ROOT, "profiles")
+    path = None
+    for rnd in ("r02", "r01"):
+        cand = os.path.join(pdir, f"{rnd}_{wl.lower()}_{dtype}_hbm_traffic.json")
+        if os.path.exists(cand):
+            path = cand
+            break
+    if path is None:
         return None, "no committed PMC pass for this workload"
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_c2_bf16_hbm_traffic.json")
-    try:
-        with open(path) as f:
-            pm = json.load(f)
-    except OSError:
-        return None, "profiles/r01_c2_bf16_hbm_traffic.json not found"
+    with open(path) as f:
+        pm = json.load(f)
     if int(pm.get("batch", 1)) != B:
         return None, f"the committed PMC pass was taken at batch {pm.get('batch', 1)} per GPU"
     for fams, kernels in _FAMILY_KERNELS.values():
         if family in fams:
             gb = sum(pm["kernels"].get(k, {}).get("fetch_GB_per_step", 0.0) + pm["kernels"].get(k, {}).get("write_GB_per_step", 0.0)
                      for k in kernels)
-            launches = sum(q["launches"] for q in recs if q["name"] in fams) / a.prof_steps
-            return gb * 1e9 / max(launches, 1.0), ("bytes per entry-point launch, kernels " + "+".join(kernels) +
-                                                   " shared by " + "+".join(fams) + "; rocprofv3 --pmc FETCH_SIZE(x2)/WRITE_SIZE")
+            launches = sum(q["launches"] for q in recs if q["name"] in fams) / prof_steps
+            return gb * 1e9 / max(launches, 1.0), ("bytes per entry-point launch, kernels " + "+".join(kernels) + " shared by " +
+                                                   "+".join(fams) + f"; rocprofv3 --pmc FETCH_SIZE(x2)/WRITE_SIZE, {os.path.basename(path)}")
     return None, "family not mapped to kernels"
 
 
@@ -149,34 +159,15 @@ def _dbg(msg):
         print(f"[rank {os.environ.get('RANK', '0')}] {msg}", file=sys.stderr, flush=True)
 
 
-def main():
-    a = parse()
+def run_workload(a, wl, ctx, want_roofline, want_cpu):
+    """Build the workload's model, time K steps, return the fields of its JSON object."""
     import torch
     import torch.distributed as dist
-    pkg = importlib.import_module("prostatemr_3d-cad-cspca_amd")
-    ops = pkg.hip.ops
-
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != a.gpus and world > 1:
-        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
-    # (M1_BENCH_BACKEND=gloo: functional check of the N > 1 code path with every rank on one GPU; never a measurement)
-    backend = os.environ.get("M1_BENCH_BACKEND", "nccl")
-    if backend != "nccl":
-        local = local % max(1, torch.cuda.device_count())
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if backend == "nccl":
-            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
-        else:
-            dist.init_process_group(backend=backend, rank=rank, world_size=world)
-
-    dims, filters, prob, dense, deep = WORKLOADS[a.workload]
-    B = a.batch or DEFAULT_BATCH[a.workload]
-    act_dtype = torch.bfloat16 if a.dtype == "bf16" else torch.float32
+    pkg, ops, dev, world, rank, backend, dist_on = (ctx[k] for k in ("pkg", "ops", "dev", "world", "rank", "backend", "dist_on"))
+    dims, filters, prob, dense, deep = WORKLOADS[wl]
+    B = a.batch or DEFAULT_BATCH[wl]
+    dtype = a.dtype or ("fp32" if wl == "C5" else "bf16")
+    act_dtype = torch.bfloat16 if dtype == "bf16" else torch.float32
     kl_w = 10.0
 
     pkg.unets.network_blocks.set_init_seed(0)
@@ -204,15 +195,18 @@ def main():
     losses, weights = ([focal, elbo], [1.0, kl_w]) if prob else ([focal], [1.0])
     opt = pkg.optim.Adam(learning_rate=1e-3, amsgrad=True)
     model.compile(optimizer=opt, loss=losses, loss_weights=weights)
-    if world > 1:
-        opt.reducer = pkg.ddp.GradReducer(world_size=world)
-        opt.grad_scale = opt.reducer.grad_scale
+    reducer = None
+    if dist_on:
+        reducer = pkg.ddp.GradReducer(world_size=world, bucket_mb=float(os.environ.get("M1_DDP_BUCKET_MB", "64")),
+                                      force=(world == 1))
+        opt.attach_reducer(reducer)
     opt.set_lr_device()
     model.train()
     loss_buf = torch.zeros(1, device=dev)
 
     def fwd_bwd():
-        """forward (all core passes) + loss + backward: gradients land in the flat buffer (kernels accumulate there)."""
+        """forward (all core passes) + loss + backward: gradients land in the flat buffer (kernels accumulate there);
+        data-parallel runs send each exchange group from the communication stream as backward completes it."""
         opt.zero_grad()
         outs = model(x)
         total, _ = model.compute_loss(outs, {"detection": tgt})
@@ -221,9 +215,8 @@ def main():
         loss_buf.copy_(total.detach().reshape(1))
 
     def update():
-        """gradient exchange (N > 1) + fused Adam-amsgrad/L2 + counters."""
-        if opt.reducer is not None:
-            opt.reducer.all_reduce(opt.flatp.grad)
+        """rest of the gradient exchange (N > 1) + fused Adam-amsgrad/L2 + counters."""
+        opt.exchange()
         opt.apply_flat()
         ops.step_advance(None, model.rng_state)
 
@@ -231,48 +224,72 @@ def main():
         fwd_bwd()
         update()
 
-    # ---- eager warm-up (also primes the allocator), then optional whole-step hipGraph ----
-    _dbg("model built; eager warm-up")
+    # ---- eager warm-up (also primes the allocator and the RCCL communicator), then the hipGraph ----
+    _dbg(f"{wl}: model built; eager warm-up")
     for _ in range(max(1, min(a.warmup, 2))):
         step()
     torch.cuda.synchronize()
     _dbg("eager warm-up done")
-    use_graph, graph, graph_err = (not a.no_graph), None, None
-    # N = 1: the whole step is one hipGraph.  N > 1: forward+backward are captured, the RCCL exchange and the
-    # optimiser kernel are launched eagerly behind the replay (no collective inside a captured graph).
-    captured = step if world == 1 else fwd_bwd
-    if use_graph:
-        try:
-            s = torch.cuda.Stream()
-            s.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(s):
-                captured()
-                if world > 1:
-                    update()
-            torch.cuda.current_stream().wait_stream(s)
-            torch.cuda.synchronize()
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                captured()
-            torch.cuda.synchronize()
-            if world > 1:
+    # N = 1: the whole step is one hipGraph.  N > 1 over RCCL ("full"): the same, the collectives are captured on the
+    # communication stream inside it; "split" (fallback): forward+backward are captured without collectives, the exchange
+    # and the optimiser kernel follow eagerly; "off" (gloo default: its collectives run on the host): eager launches.
+    if a.no_graph:
+        gmode = "off"
+    elif dist_on:
+        gmode = os.environ.get("M1_DDP_GRAPH", "full" if backend == "nccl" else "off")
+    else:
+        gmode = "full"
+    graph, graph_err = None, None
+
+    def capture(fn, thread_local):
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            fn()
+            if fn is fwd_bwd:
                 update()
-        except Exception as e:  # noqa: BLE001 -- fall back to eager launches, report it
-            graph, graph_err = None, f"{type(e).__name__}: {str(e)[:200]}"
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        gr = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gr, capture_error_mode="thread_local" if thread_local else "global"):
+            fn()
+        torch.cuda.synchronize()
+        if fn is fwd_bwd:
+            update()
+        return gr
+
+    if gmode == "full":
+        try:
+            graph = capture(step, thread_local=dist_on)
+        except Exception as e:  # noqa: BLE001 -- fall back, report it
+            graph, graph_err = None, f"full: {type(e).__name__}: {str(e)[:200]}"
             torch.cuda.synchronize()
+            gmode = "split" if dist_on else "off"
+    if gmode == "split":
+        try:
+            if reducer is not None:
+                reducer.overlap = False                 # no collective inside the captured forward+backward
+            graph = capture(fwd_bwd, thread_local=True)
+        except Exception as e:  # noqa: BLE001
+            graph, graph_err = None, (graph_err or "") + f" split: {type(e).__name__}: {str(e)[:200]}"
+            torch.cuda.synchronize()
+            gmode = "off"
+            if reducer is not None:
+                reducer.overlap = True
     if graph is None:
         run = step
-    elif world == 1:
+    elif gmode == "full":
         run = graph.replay
     else:
         def run():
+            reducer.begin_step()         # the replayed zero_grad cannot: nothing of this step has been sent yet
             graph.replay()
             update()
 
-    _dbg(f"graph={'yes' if graph is not None else 'no'} err={graph_err}; timed warm-up")
+    _dbg(f"graph mode={gmode} err={graph_err}; timed warm-up")
     for _ in range(a.warmup):
         run()
-    if world > 1:
+    if dist_on:
         dist.barrier()
     torch.cuda.synchronize()
     _dbg("timing")
@@ -280,23 +297,36 @@ def main():
     for _ in range(a.steps):
         run()
     torch.cuda.synchronize()
-    if world > 1:
+    if dist_on:
         dist.barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    exchange = None
+    if dist_on:
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt)
+        # the replicas must still hold identical parameters (same initial weights, averaged gradients): a group that was
+        # sent too early / never sent shows up here
+        chk = torch.stack([opt.flatp.flat.double().sum(), opt.flatp.flat.double().abs().sum()])
+        lo, hi = chk.clone(), chk.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN); dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        st = reducer.stats
+        exchange = {"backend": backend, "graph_mode": gmode, "groups": len(reducer.order), "buckets": len(reducer.order) + 1,
+                    "groups_sent_during_backward": st["early_groups"], "groups_sent_after_backward": st["late_groups"],
+                    "collectives_issued": st["collectives"], "host_steps": reducer._step,
+                    "bytes_per_step": 4 * opt.flatp.grad.numel(), "replicas_in_sync": bool(torch.equal(lo, hi)),
+                    "note": "groups are sent from the communication stream as backward completes them (ddp.py); counters "
+                            "count host-side calls (in graph mode 'full' the captured collectives replay without them)"}
     final_loss = float(loss_buf)
 
     # ---- per-kernel-family hipEvent timing on the launch stream (eager launches of the same step) ----
     roof = None
-    if not a.no_roofline and rank == 0:
-        ops.prof_reset(); ops.prof_enable(True)
+    if want_roofline and rank == 0:
         saved_reducer, opt.reducer = opt.reducer, None     # rank 0 alone: no collective in the profiled steps (timing is over)
+        model.set_grad_marker(None)
+        ops.prof_reset(); ops.prof_enable(True)
         for _ in range(a.prof_steps):
             step()
-        opt.reducer = saved_reducer
         torch.cuda.synchronize()
         recs = ops.prof_read()
         ops.prof_enable(False)
@@ -306,18 +336,18 @@ def main():
             r = recs[0]
             sec = r["total_ms"] * 1e-3
             tf_ach, gb_ach = r["flops"] / sec / 1e12, r["bytes"] / sec / 1e9
-            f_m, f_h = tf_ach / PEAK_MFMA_TFLOPS[a.dtype], gb_ach / PEAK_HBM_GBS
+            f_m, f_h = tf_ach / PEAK_MFMA_TFLOPS[dtype], gb_ach / PEAK_HBM_GBS
             if f_m >= f_h:
-                roof = {"bound": "mfma", "achieved": tf_ach, "peak": PEAK_MFMA_TFLOPS[a.dtype], "unit": "TFLOP/s", "frac": f_m}
+                roof = {"bound": "mfma", "achieved": tf_ach, "peak": PEAK_MFMA_TFLOPS[dtype], "unit": "TFLOP/s", "frac": f_m}
             else:
                 roof = {"bound": "hbm", "achieved": gb_ach, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": f_h}
             roof.update({"traffic": None, "kernel": r["name"], "launches_per_step": r["launches"] / a.prof_steps,
                          "algorithmic_bytes_per_launch": r["bytes"] / r["launches"],
+                         "algorithmic_flops_per_launch": r["flops"] / r["launches"],
                          "avg_launch_ms": r["total_ms"] / r["launches"],
                          "kernel_ms_per_step": r["total_ms"] / a.prof_steps,
                          "all_kernels_ms_per_step": {q["name"]: round(q["total_ms"] / a.prof_steps, 4) for q in recs}})
-
-            roof["traffic"], roof["traffic_note"] = hbm_traffic(a, B, recs, r["name"])
+            roof["traffic"], roof["traffic_note"] = hbm_traffic(wl, dtype, B, recs, r["name"], a.prof_steps)
             # The timed region runs independent branches on side streams (ops.branch): kernels share the GPU there and their
             # individual durations stretch.  Second pass with the branches in order: the same family with every kernel alone
             # on the GPU (what the per-kernel roofline means); reported next to the in-situ figure above, never instead of it.
@@ -325,10 +355,8 @@ def main():
                 ops._BRANCH["on"] = False
                 try:
                     ops.prof_reset(); ops.prof_enable(True)
-                    saved_reducer, opt.reducer = opt.reducer, None
                     for _ in range(a.prof_steps):
                         step()
-                    opt.reducer = saved_reducer
                     torch.cuda.synchronize()
                     iso = [q for q in ops.prof_read() if q["name"] == r["name"] and q["total_ms"] > 0]
                     ops.prof_enable(False)
@@ -341,35 +369,79 @@ def main():
                     roof["isolated"] = {"achieved": ach, "frac": ach / roof["peak"], "avg_launch_ms": q["total_ms"] / q["launches"],
                                         "kernel_ms_per_step": q["total_ms"] / a.prof_steps,
                                         "note": "same family, side-stream branches off: every kernel alone on the GPU"}
+        opt.reducer = saved_reducer
 
-    if world > 1:
+    if dist_on:
         dist.barrier()
+    cpu = None
+    if want_cpu and rank == 0:
+        try:
+            cpu = cpu_baseline(wl, prob, dense, deep, dims, filters, kl_w)
+        except Exception as e:  # noqa: BLE001
+            cpu = {"value": None, "unit": "volumes/s", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {e}"}
+    vols = B * world * a.steps
+    out = {
+        "metric": "train-step volumes/sec (whole job), M1 (20,160,160,3)" if wl in ("C2", "C3") else
+                  f"train-step volumes/sec (whole job), M1 {dims}",
+        "value": vols / dt, "unit": "volumes/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": dtype, "data": "synthetic",
+        "config": {"workload": WORKLOAD_NAMES[wl], "batch_per_gpu": B, "global_batch": B * world,
+                   "batch_note": "train_model.py:83 default (--BATCH_SIZE 2)" if a.batch is None and B == 2 else "--batch",
+                   "params": nparams, "dropout": a.dropout, "parallelism": f"dp{world}", "hip_graph": graph is not None,
+                   "graph_error": graph_err, "loss": final_loss, "exchange": exchange},
+        "roofline": roof, "cpu_baseline": cpu,
+    }
+    # free this workload before the next one is built
+    del graph, run, model, opt, x, tgt
+    ops.invalidate_panels()
+    gc.collect()
+    torch.cuda.empty_cache()
+    return out
+
+
+def main():
+    a = parse()
+    if os.environ.get("M1_BENCH_DEBUG"):
+        import faulthandler
+        faulthandler.dump_traceback_later(60, repeat=False, file=sys.stderr)   # where a hung rank is standing
+    if os.environ.get("M1_NOGRAPH"):
+        a.no_graph = True
+    import torch
+    import torch.distributed as dist
+    pkg = importlib.import_module("prostatemr_3d-cad-cspca_amd")
+    ops = pkg.hip.ops
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus and world > 1:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    # M1_BENCH_BACKEND=gloo: functional check of the N > 1 code path with every rank on one GPU; M1_BENCH_FORCE_DIST=1: a world
+    # of one takes the N > 1 path (RCCL init, collectives from the communication stream, barrier, destroy).  Never measurements.
+    backend = os.environ.get("M1_BENCH_BACKEND", "nccl")
+    dist_on = world > 1 or os.environ.get("M1_BENCH_FORCE_DIST") == "1"
+    if backend != "nccl":
+        local = local % max(1, torch.cuda.device_count())
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if dist_on:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    ctx = dict(pkg=pkg, ops=ops, dev=dev, world=world, rank=rank, backend=backend, dist_on=dist_on)
+
+    out = run_workload(a, a.workload, ctx, want_roofline=not a.no_roofline, want_cpu=(not a.no_cpu_baseline and not dist_on))
+    if a.workload == "C3" and not dist_on and not a.no_secondary and a.batch is None:
+        # the light deterministic variant of the same volume (BASELINE.json configs[1]) next to the headline
+        sec = run_workload(a, "C2", ctx, want_roofline=not a.no_roofline, want_cpu=False)
+        out["secondary"] = {"C2": {k: sec[k] for k in ("value", "unit", "ms_per_step", "dtype", "config", "roofline")}}
     if rank == 0:
-        cpu = None
-        if not a.no_cpu_baseline and world == 1:
-            try:
-                cpu = cpu_baseline(a.workload, prob, dense, deep, dims, filters, kl_w)
-            except Exception as e:  # noqa: BLE001
-                cpu = {"value": None, "unit": "volumes/s", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {e}"}
-        vols = B * world * a.steps
-        out = {
-            "metric": "train-step volumes/sec (whole job), M1 (20,160,160,3)" if a.workload in ("C2", "C3") else
-                      f"train-step volumes/sec (whole job), M1 {dims}",
-            "value": vols / dt, "unit": "volumes/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": a.dtype, "data": "synthetic",
-            "config": {"workload": {"C1": "C1 tiny deterministic (8,64,64,3) filters (8..128)",
-                                    "C2": "C2 M1 deterministic Attention-U-Net (20,160,160,3) filters (32..512)",
-                                    "C3": "C3 M1 full hierarchical-probabilistic dense_skip+deep_supervision latents (3,2,1,0) (20,160,160,3)",
-                                    "C5": "C5 M1 deterministic high-res (32,256,256,3)"}[a.workload],
-                       "batch_per_gpu": B, "global_batch": B * world,
-                       "batch_note": "train_model.py:83 default (--BATCH_SIZE 2)" if a.batch is None and B == 2 else "--batch", "params": nparams, "dropout": a.dropout,
-                       "parallelism": f"dp{world}", "hip_graph": graph is not None, "graph_error": graph_err,
-                       "loss": final_loss},
-            "roofline": roof, "cpu_baseline": cpu,
-        }
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist_on:
         dist.destroy_process_group()
 
 

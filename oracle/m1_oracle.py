@@ -415,6 +415,81 @@ def m1_forward(P: Dict[str, torch.Tensor], cfg: M1Config, inputs: torch.Tensor,
 
 
 # --------------------------------------------------------------------------------------------------
+# cascaded two-stage model, decision fusion, detect models (N:109-223)
+# --------------------------------------------------------------------------------------------------
+def decision_fusion(prior_softmax: torch.Tensor, follow_up_softmax: torch.Tensor, strategy: str = "identity"):
+    """M1.decision_fusion (N:209-223): both arguments are the LAST class channel (B,D,H,W)."""
+    if strategy == "identity":                                                     # N:212
+        joint = follow_up_softmax.unsqueeze(-1)
+    elif strategy == "noisy-or":                                                   # N:213
+        joint = (1 - ((1 - prior_softmax) * (1 - follow_up_softmax))).unsqueeze(-1)
+    elif strategy == "bayes":                                                      # N:214-216
+        joint = (((prior_softmax * follow_up_softmax) + 1e-9)
+                 / ((prior_softmax * follow_up_softmax) + 1e-9 + ((1 - prior_softmax) * (1 - follow_up_softmax)))).unsqueeze(-1)
+    else:
+        raise ValueError(strategy)
+    prior_pred = torch.cat([(1 - prior_softmax).unsqueeze(-1), prior_softmax.unsqueeze(-1)], dim=-1)   # N:219-220
+    joint_pred = torch.cat([1 - joint, joint], dim=-1)                                                   # N:221
+    return prior_pred, joint_pred
+
+
+def stage2_config(cfg: M1Config) -> M1Config:
+    """Stage 2 sees cat[stage-1 softmax[..., :nc-1], image_2] (N:135-136): nc-1 extra input channels."""
+    import dataclasses
+    return dataclasses.replace(cfg, input_channels=cfg.input_channels + cfg.num_classes - 1)
+
+
+def _sub(P: Dict[str, torch.Tensor], prefix: str) -> Dict[str, torch.Tensor]:
+    return {k[len(prefix):]: v for k, v in P.items() if k.startswith(prefix)}
+
+
+def m1_cascaded_forward(P: Dict[str, torch.Tensor], cfg: M1Config, image_1: torch.Tensor, image_2: torch.Tensor,
+                        strategy: str, eps_q: Optional[Sequence] = None, eps_p: Optional[Sequence] = None,
+                        with_infer: bool = False) -> Dict[str, torch.Tensor]:
+    """The cascaded branch of M1.__init__ (N:109-193).  Parameters of the two ``m1`` graphs carry the prefixes
+    ``stage1.`` / ``stage2.``; ``eps_q`` / ``eps_p`` = (draws for stage 1, draws for stage 2).
+    Outputs as the Keras model names them: detection_1 (stage-1 prediction), detection_2 (fused prediction),
+    KL_1, KL_2 (N:168-171); with ``with_infer`` also the tensors get_detect_model serves (N:196-201)."""
+    nc = cfg.num_classes
+    key = "prob_softmax" if cfg.probabilistic else "y_softmax"
+    e_q = eps_q if eps_q is not None else (None, None)
+    e_p = eps_p if eps_p is not None else (None, None)
+    o1 = m1_forward(_sub(P, "stage1."), cfg, image_1, eps_q=e_q[0], eps_p=e_p[0], with_infer=with_infer)     # N:115-132
+    x2 = torch.cat([o1[key][..., :nc - 1], image_2], dim=-1)                                                     # N:135-136
+    o2 = m1_forward(_sub(P, "stage2."), stage2_config(cfg), x2, eps_q=e_q[1], eps_p=e_p[1], with_infer=with_infer)  # N:135-153
+    out: Dict[str, torch.Tensor] = {"_stage1": o1, "_stage2": o2}
+    out["detection_1"], out["detection_2"] = decision_fusion(o1[key][..., nc - 1], o2[key][..., nc - 1], strategy)  # N:156-160
+    if cfg.probabilistic:
+        out["KL_1"], out["KL_2"] = o1["prob_kl"], o2["prob_kl"]                                                  # N:170-171
+        if with_infer:
+            out["infer_softmax_1"] = torch.softmax(o1["prob_infer_conv"], dim=-1)                                # N:174
+            out["infer_softmax_2"] = torch.softmax(o2["prob_infer_conv"], dim=-1)                                # N:175
+            out["prior_pred_infer"], out["joint_pred_infer"] = decision_fusion(                                  # N:162-166
+                out["infer_softmax_1"][..., nc - 1], out["infer_softmax_2"][..., nc - 1], strategy)
+    return out
+
+
+def detect_model_outputs(P: Dict[str, torch.Tensor], cfg: M1Config, inputs, cascaded=False, eps_q=None, eps_p=None):
+    """M1.get_detect_model() (N:196-206): the tensors the reconfigured inference model returns."""
+    nc = cfg.num_classes
+    if cascaded is not False:
+        o = m1_cascaded_forward(P, cfg, inputs[0], inputs[1], cascaded, eps_q=eps_q, eps_p=eps_p, with_infer=True)
+        if cfg.probabilistic:
+            return [o["infer_softmax_1"], o["infer_softmax_2"]]                                                  # N:199-200
+        return [o["_stage1"]["y_softmax"][..., :nc], o["_stage2"]["y_softmax"][..., :nc]]                        # N:202-203
+    o = m1_forward(P, cfg, inputs, eps_q=eps_q, eps_p=eps_p, with_infer=True)
+    if cfg.probabilistic:
+        return torch.softmax(o["prob_infer_conv"], dim=-1)                                                       # N:94,205
+    return o["y_softmax"][..., :nc]                                                                              # N:206
+
+
+def cascade_param_shapes(cfg: M1Config) -> Dict[str, Tuple[int, ...]]:
+    d = {"stage1." + k: v for k, v in m1_param_shapes(cfg).items()}
+    d.update({"stage2." + k: v for k, v in m1_param_shapes(stage2_config(cfg)).items()})
+    return d
+
+
+# --------------------------------------------------------------------------------------------------
 # losses (L:20-63) and regularisers (N:456-460; App. B-7, C-7)
 # --------------------------------------------------------------------------------------------------
 K_EPSILON = 1e-7     # tf.keras.backend.epsilon()
@@ -573,7 +648,7 @@ def m1_param_shapes(cfg: M1Config) -> Dict[str, Tuple[int, ...]]:
     return d
 
 
-def fixture_params(cfg: M1Config, seed: int, dtype=torch.float32) -> Dict[str, torch.Tensor]:
+def fixture_params(cfg: M1Config, seed: int, dtype=torch.float32, shapes=None) -> Dict[str, torch.Tensor]:
     """Deterministic, platform-independent fixture weights (numpy PCG64, no LAPACK): kernels
     N(0, 1/fan_in) scaled (variance preserving, like an orthogonal init on average), biases N(0,1e-2),
     gamma 1+N(0,0.1), beta N(0,0.1) so that every code path (beta in the SE gate, bias in the psi gate)
@@ -582,7 +657,7 @@ def fixture_params(cfg: M1Config, seed: int, dtype=torch.float32) -> Dict[str, t
     import numpy as np
     rng = np.random.default_rng(seed)
     P = {}
-    for name, shp in m1_param_shapes(cfg).items():
+    for name, shp in (shapes if shapes is not None else m1_param_shapes(cfg)).items():
         if name.endswith(".kernel"):
             if len(shp) == 5:
                 # fan_in = kvol*Cin for Conv3D; for Conv3DTranspose layout (k,k,k,Cout,Cin) use kvol*Cin/prod(stride)~

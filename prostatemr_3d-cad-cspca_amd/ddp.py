@@ -1,18 +1,29 @@
-"""Data parallelism of the M1 train step: one process per GPU, batch sharded across ranks, ONE exchange per
-step -- a sum all-reduce of the flat gradient buffer over RCCL/xGMI (``torch.distributed`` backend "nccl" on
-ROCm), replacing the reference's single-process tf.distribute.MirroredStrategy (train_model.py:167-170).
+"""Data parallelism of the M1 train step: one process per GPU, batch sharded across ranks, the only exchange a sum
+all-reduce of the flat gradient buffer over RCCL/xGMI (``torch.distributed`` backend "nccl" on ROCm), replacing the
+reference's single-process tf.distribute.MirroredStrategy (train_model.py:167-170).
 
-Volumes are independent in forward and backward (InstanceNorm is per sample, the SE gate depends on
-parameters only, Focal and KL are batch means), so the average of per-rank gradients equals the global-batch
-gradient; the 1/world_size factor is folded into the optimiser kernel (``grad_scale``).
+Volumes are independent in forward and backward (InstanceNorm is per sample, the SE gate depends on parameters only,
+Focal and KL are batch means), so the average of per-rank gradients equals the global-batch gradient; the 1/world_size
+factor is folded into the optimiser kernel (``grad_scale``).
 
-xGMI is point-to-point (7 links per GPU): the flat buffer is cut into a few large buckets that are issued
-asynchronously back-to-back so RCCL can keep every link busy, instead of per-tensor collectives.
+**Overlap with backward** (SURVEY.md 8(e)).  The flat gradient buffer is laid out ``[kernels of group 1 | kernels of
+group 2 | ... | biases | everything else]`` (optim.FlatParams) where a *group* is a set of layers whose weight gradients
+are complete at a known point of the backward pass: per core ``a`` = decoder + latent branch + heads, ``b`` = attention
+gates + bottleneck block, ``c`` = encoder (M1Net.exchange_groups).  The model marks the autograd nodes that close a group
+(``M1Core.forward`` -> ``GradReducer.mark``); when the last marked node of a group has run in every core pass of the
+step, the group's range is all-reduced **from a communication stream** that waits for exactly the kernels enqueued so
+far (main stream + the side streams of ops.branch), while the backward of the remaining layers keeps the main stream
+busy.  ``finish()`` sends whatever is left (groups whose marks never fired, then the small bias/norm/SE tail) and makes
+the main stream wait for the communication stream before the optimiser kernel reads the buffer.  Inside a hipGraph
+capture the same calls become graph edges, so the whole step -- RCCL kernels included -- replays as one graph.
+
+xGMI is point-to-point (7 links per GPU): a group is cut into a few large chunks (``bucket_mb``) issued back-to-back,
+never one collective per tensor.
 """
 from __future__ import annotations
 
 import os
-from typing import List, Optional
+from typing import Callable, Dict, List, Optional, Sequence, Tuple
 
 import torch
 import torch.distributed as dist
@@ -46,23 +57,123 @@ def bucket_bounds(n: int, bucket_elems: int) -> List[tuple]:
 
 
 class GradReducer:
-    """Bucketed asynchronous sum all-reduce of a flat gradient buffer."""
+    """Sum all-reduce of a flat gradient buffer: all at once (``all_reduce``) or group by group as the backward pass
+    completes them (``begin_step`` / ``mark`` / ``finish``)."""
 
-    def __init__(self, world_size: Optional[int] = None, bucket_mb: float = 64.0, group=None):
+    def __init__(self, world_size: Optional[int] = None, bucket_mb: float = 64.0, group=None, force: bool = False):
         self.group = group
         self.world_size = world_size if world_size is not None else (dist.get_world_size(group) if dist.is_initialized() else 1)
         self.bucket_elems = int(bucket_mb * (1 << 20) / 4)
+        self.force = bool(force)            # issue the collectives even in a world of one (exercises the RCCL branch)
+        self.overlap = True                 # False: marks are ignored, finish() sends everything in order
+        self.flat: Optional[torch.Tensor] = None
+        self.ranges: Dict[str, Tuple[int, int]] = {}
+        self.order: List[str] = []
+        self.tail: Tuple[int, int] = (0, 0)
+        self._step = 0
+        self._pending: Dict[str, int] = {}
+        self._sent: set = set()
+        self._comm = None
+        self._side_streams: Callable[[], Sequence] = lambda: ()
+        self.stats = {"buckets": 0, "early_groups": 0, "late_groups": 0, "collectives": 0}
 
+    # ------------------------------------------------------------------------------------------------------
     @property
     def grad_scale(self) -> float:
         return 1.0 / float(self.world_size)
 
+    @property
+    def active(self) -> bool:
+        return dist.is_initialized() and (self.world_size > 1 or self.force)
+
+    def bind(self, flat_grad: torch.Tensor, ranges: Dict[str, Tuple[int, int]], order: Sequence[str], tail: Tuple[int, int],
+             side_streams: Optional[Callable[[], Sequence]] = None) -> None:
+        """``ranges[key]`` = [lo, hi) of group ``key`` inside ``flat_grad``; ``order`` = the order groups are expected to
+        complete in; ``tail`` = the range exchanged last (biases, norms, SE); ``side_streams()`` = the streams besides the
+        current one that may hold backward kernels (ops.branch)."""
+        self.flat, self.ranges, self.order, self.tail = flat_grad, dict(ranges), list(order), tuple(tail)
+        if side_streams is not None:
+            self._side_streams = side_streams
+        if flat_grad.is_cuda and self._comm is None:
+            self._comm = torch.cuda.Stream(device=flat_grad.device)
+
+    # ------------------------------------------------------------------------------------------------------
+    def _reduce_range(self, lo: int, hi: int) -> None:
+        for a, b in bucket_bounds(hi - lo, self.bucket_elems):
+            dist.all_reduce(self.flat[lo + a:lo + b], op=dist.ReduceOp.SUM, group=self.group)
+            self.stats["collectives"] += 1
+
+    def _send(self, key: str, early: bool) -> None:
+        if key in self._sent:
+            return
+        self._sent.add(key)
+        lo, hi = self.ranges[key]
+        if hi <= lo or not self.active:
+            return
+        self.stats["early_groups" if early else "late_groups"] += 1
+        self.stats["buckets"] += 1
+        if self._comm is None:
+            self._reduce_range(lo, hi)
+            return
+        cur = torch.cuda.current_stream(self.flat.device)
+        self._comm.wait_stream(cur)                       # everything enqueued so far on the main stream ...
+        for s in self._side_streams():                    # ... and on the branch streams (their weight gradients land in flat too)
+            if s != cur:
+                self._comm.wait_stream(s)
+        with torch.cuda.stream(self._comm):
+            self._reduce_range(lo, hi)
+
+    # ------------------------------------------------------------------------------------------------------
+    def begin_step(self) -> None:
+        """Call before the forward pass of a step (optimiser zero_grad does)."""
+        self._step += 1
+        self._pending = {}
+        self._sent = set()
+
+    def mark(self, key: str, tensor: torch.Tensor) -> None:
+        """The gradients of group ``key`` are complete once the autograd node that produced ``tensor`` has run (in addition
+        to every other node marked for ``key`` in this step).  No-op outside autograd or when the exchange is off."""
+        if not (self.active and self.overlap) or key not in self.ranges:
+            return
+        node = getattr(tensor, "grad_fn", None)
+        if node is None:
+            return
+        self._pending[key] = self._pending.get(key, 0) + 1
+        step = self._step
+
+        def fired(*_):
+            if step != self._step or key in self._sent:
+                return
+            self._pending[key] -= 1
+            if self._pending[key] == 0:
+                self._send(key, early=True)
+        node.register_hook(fired)
+
+    def finish(self) -> None:
+        """After backward: send what the marks did not (in completion order), then the tail; the current stream waits
+        for the communication stream."""
+        if self.flat is None:
+            raise RuntimeError("GradReducer.finish() before bind()")
+        if not self.active:
+            return
+        for key in self.order:
+            self._send(key, early=False)
+        lo, hi = self.tail
+        if hi > lo:
+            self.ranges["__tail__"] = (lo, hi)
+            self._send("__tail__", early=False)
+        if self._comm is not None:
+            torch.cuda.current_stream(self.flat.device).wait_stream(self._comm)
+
+    # ------------------------------------------------------------------------------------------------------
     def all_reduce(self, flat_grad: torch.Tensor) -> None:
-        if self.world_size <= 1 or not dist.is_initialized():
+        """The whole buffer in a few large asynchronous buckets, after backward (no overlap)."""
+        if not self.active:
             return
         works = []
         for lo, hi in bucket_bounds(flat_grad.numel(), self.bucket_elems):
             works.append(dist.all_reduce(flat_grad[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            self.stats["collectives"] += 1
         for w in works:
             w.wait()
 

@@ -37,10 +37,19 @@ class CosineDecayRestarts:
 class FlatParams:
     """All parameters of a model as views into one flat fp32 buffer ordered
     [regularised kernels | regularised biases | everything else] so the optimiser kernel can apply the right
-    L2 coefficient by range, and one flat gradient buffer for bucketed all-reduce (ddp.py)."""
+    L2 coefficient by range, and one flat gradient buffer for the gradient exchange (ddp.py).  The kernels are ordered by
+    *exchange group* (``model.exchange_groups()``: layers whose weight gradients are complete at the same point of the
+    backward pass), so that a group is one contiguous range that can be all-reduced while backward continues;
+    ``group_ranges[key]`` = its [lo, hi), ``group_order`` = completion order, ``tail`` = [n_kernel, n)."""
 
     def __init__(self, model):
         ks, bs = model.regularized_parameters() if hasattr(model, "regularized_parameters") else ([], [])
+        groups = model.exchange_groups() if hasattr(model, "exchange_groups") else []
+        gidx = {}
+        for gi, (_, plist) in enumerate(groups):
+            for p in plist:
+                gidx.setdefault(id(p), gi)
+        ks = sorted(ks, key=lambda p: gidx.get(id(p), len(groups)))       # stable: model order inside a group
         kid, bid = {id(p) for p in ks}, {id(p) for p in bs}
         rest = [p for p in model.parameters() if id(p) not in kid and id(p) not in bid]
         self.params: List[torch.nn.Parameter] = list(ks) + list(bs) + rest
@@ -64,6 +73,17 @@ class FlatParams:
                 self.gviews.append(gv)
                 p._m1_gsink = gv          # the HIP backward kernels accumulate this parameter's gradient here
                 off += n
+        self.group_ranges, self.group_order = {}, []
+        off = 0
+        names = [k for k, _ in groups] + ["__ungrouped__"]
+        for p in ks:
+            key = names[gidx.get(id(p), len(groups))]
+            lo, hi = self.group_ranges.get(key, (off, off))
+            self.group_ranges[key] = (lo, off + p.numel())
+            if key not in self.group_order:
+                self.group_order.append(key)
+            off += p.numel()
+        self.tail = (self.n_kernel, n_pad)
 
     def zero_grad(self):
         """One memset of the flat gradient buffer (the kernels accumulate into it during backward)."""
@@ -127,6 +147,26 @@ class Adam:
         for p in self.flatp.params:
             p.grad = None
         self.flatp.zero_grad()
+        if self.reducer is not None:
+            self.reducer.begin_step()
+
+    def attach_reducer(self, reducer):
+        """Data parallelism: ``reducer`` (ddp.GradReducer) exchanges the flat gradient buffer group by group during
+        backward (the model marks the closing autograd nodes through ``model.set_grad_marker``) and 1/world_size is
+        folded into the update."""
+        from .hip import ops as _ops
+        f = self.flatp
+        reducer.bind(f.grad, f.group_ranges, f.group_order, f.tail,
+                     side_streams=lambda: tuple(_ops._BRANCH["used"]))
+        self.reducer, self.grad_scale = reducer, reducer.grad_scale
+        if hasattr(self.model, "set_grad_marker"):
+            self.model.set_grad_marker(reducer.mark)
+        return self
+
+    def exchange(self):
+        """Complete the flat gradient buffer across ranks (no-op without a reducer)."""
+        if self.reducer is not None:
+            self.reducer.finish()
 
     def set_lr_device(self):
         self.lr_dev.fill_(self.lr)
@@ -142,7 +182,6 @@ class Adam:
     def step(self):
         self.set_lr_device()
         self.flatp.gather_grads()
-        if self.reducer is not None:
-            self.reducer.all_reduce(self.flatp.grad)
+        self.exchange()
         self.apply_flat()
         self.iterations += 1

@@ -106,9 +106,23 @@ class LoadableModel(nn.Module):
     def from_config(cls, config, custom_objects=None):
         return cls(**config)
 
-    # ---- weights: .npz with Keras tensor layouts ----
+    # ---- weights: .npz with Keras tensor layouts and the stable names of SURVEY App. E ----
+    _NAME_MAP = (("m1_model.", ""), ("m1_stage1.", "stage1."), ("m1_stage2.", "stage2."))
+
+    @classmethod
+    def _export_name(cls, k: str) -> str:
+        """state_dict key -> App. E name: ``{prior|posterior|core}.{layer}.{sub}.{kernel|bias|gamma|beta}``,
+        ``stitch.logits.*``; cascaded models prefix ``stage1.`` / ``stage2.``."""
+        for a, b in cls._NAME_MAP:
+            if k.startswith(a):
+                return b + k[len(a):]
+        return k
+
     def get_weights_dict(self) -> Dict[str, np.ndarray]:
-        return {k: v.detach().float().cpu().numpy() for k, v in self.state_dict().items()}
+        """Every weight tensor in its Keras layout (Conv3D kernel (kd,kh,kw,Cin,Cout), Conv3DTranspose kernel
+        (kd,kh,kw,Cout,Cin), bias (Cout,), InstanceNormalization gamma/beta (C,)) under its App. E name."""
+        return {self._export_name(k): v.detach().float().cpu().numpy() for k, v in self.state_dict().items()
+                if k != "rng_state"}
 
     def save_weights(self, path: str):
         meta = json.dumps({"class_name": type(self).__name__, "config": {k: _jsonable(v) for k, v in self.get_config().items()}})
@@ -120,8 +134,8 @@ class LoadableModel(nn.Module):
 
     def load_weights(self, path: str, by_name: bool = False):
         with np.load(path) as f:
-            sd = {k: torch.from_numpy(np.array(f[k])) for k in f.files if k != "__model_config__"}
-        own = self.state_dict()
+            sd = {self._export_name(k): torch.from_numpy(np.array(f[k])) for k in f.files if k != "__model_config__"}
+        own = {self._export_name(k): v for k, v in self.state_dict().items() if k != "rng_state"}
         if not by_name:
             missing = sorted(set(own) - set(sd)); extra = sorted(set(sd) - set(own))
             if missing or extra:
@@ -129,6 +143,9 @@ class LoadableModel(nn.Module):
         with torch.no_grad():
             for k, v in sd.items():
                 if k in own:
+                    if tuple(v.shape) != tuple(own[k].shape):
+                        raise RuntimeError(f"weight file does not match model: {k} has shape {tuple(v.shape)}, "
+                                           f"the layer expects {tuple(own[k].shape)} (Keras layouts, SURVEY App. E)")
                     own[k].copy_(v.to(own[k].device, own[k].dtype))
         from ..hip import ops
         ops.invalidate_panels()

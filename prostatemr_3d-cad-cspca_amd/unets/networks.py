@@ -175,11 +175,24 @@ class M1Core(nn.Module):
         self._shapes: Dict[str, tuple] = {}
 
     # ---------------------------------------------------------------------------------------------------------
-    def forward(self, inputs, prob_mean=False, prob_z_q=None, eps: Optional[List[torch.Tensor]] = None):
+    def exchange_groups(self, prefix: str):
+        """[(key, [parameters])] in the order the weight gradients of this core complete during a backward pass (ddp.py):
+        ``a`` decoder + latent branch + heads (closed by the backward of ``convtd3`` / ``dec_hi3``), ``b`` the four gates
+        and the bottleneck block (closed by the backward of ``serse3``'s last kernel), ``c`` the encoder."""
+        enc = [self.conve0, self.norme0, self.serse1, self.serse2, self.serse3]
+        mid = [self.att0, self.att1, self.att2, self.att3, self.serse4]
+        taken = {id(m) for m in enc + mid}
+        dec = [m for m in self.children() if id(m) not in taken]
+        plist = lambda mods: [p for m in mods for p in m.parameters()]
+        return [(prefix + "a", plist(dec)), (prefix + "b", plist(mid)), (prefix + "c", plist(enc))]
+
+    def forward(self, inputs, prob_mean=False, prob_z_q=None, eps: Optional[List[torch.Tensor]] = None, mark=None):
         """M1Core.__call__(inputs, prob_mean, prob_z_q) (networks.py:568-759).  ``inputs`` is an NDHWC tensor or
         a list of tensors forming a virtual channel concat.  ``eps``: optional injected N(0,1) draws per level
-        (MultivariateNormalDiag.sample() = mu + sigma*eps)."""
+        (MultivariateNormalDiag.sample() = mu + sigma*eps).  ``mark(group, tensor)``: data-parallel runs register the
+        autograd nodes that close an exchange group of this core (see exchange_groups)."""
         outputs = {}
+        mark = mark if mark is not None else (lambda *_: None)
         S = self.strides
         # networks.py:574-576
         SEResNetBottleNeck.precompute_gates([m for m in self.children() if isinstance(m, SEResNetBottleNeck)
@@ -197,6 +210,7 @@ class M1Core(nn.Module):
         conv2 = self.serse2(c1_e, dropout=self.drope2)
         c2_e, c2_a = fo(conv2, 2)
         conv3 = self.serse3(c2_e, dropout=self.drope3)
+        mark("b", conv3)
         c3_e, c3_a = fo(conv3, 2)
         convm = self.serse4(c3_e, dropout=self.drope4)
         m_use = list(fo(convm, 7 if prob else 5))          # 4 gates, convtd3 (+ latent head and latent decoder of level 3)
@@ -214,6 +228,7 @@ class M1Core(nn.Module):
             att_conv0, _ = self.att0(x_a, m_use.pop())
         # networks.py:591-597
         deconv3 = self.convtd3(m_use.pop())
+        mark("a", deconv3)
         if dense:
             deconv3, d3 = fo(deconv3, 2)
             deconv3_up1, d3u1 = fo(self.convtd3_up1(d3), 2)
@@ -311,8 +326,14 @@ class M1Core(nn.Module):
                     distributions.append(ml)
                     used_latents.append(z)
                     up = getattr(self, "dec_hi" + sfx)([z, f_up])                  # networks.py:652-653
+                    if lvl == 0:
+                        mark("a", up)
+                        if prob_z_q is None:
+                            mark("a", ml)       # reached through z (otherwise only through a KL term: the caller marks it)
                 else:
                     up = getattr(self, "dec_hi" + sfx)(f_up)                       # networks.py:655-656
+                    if lvl == 0:
+                        mark("a", up)
                 feats = getattr(self, "sersp" + sfx)([up, *skips[lvl]], dropout=getattr(self, "dropp" + sfx))
                 if lvl < 3:
                     ds_ops.append(feats)                                           # networks.py:657,681,705
@@ -381,6 +402,7 @@ class M1Net(nn.Module):
         self.num_classes, self.probabilistic, self.deep_supervision = int(num_classes), bool(probabilistic), bool(deep_supervision)
         self.show_summary = bool(summary)
         self._summarised = False
+        self.grad_marker = None          # ddp.GradReducer.mark of a data-parallel run (M1.set_grad_marker)
         self.last: Dict[str, torch.Tensor] = {}
         common = dict(num_classes=num_classes, dropout_mode=dropout_mode, dropout_rate=dropout_rate, filters=filters,
                       strides=strides, kernel_sizes=kernel_sizes, se_reduction=se_reduction, att_sub_samp=att_sub_samp,
@@ -405,11 +427,27 @@ class M1Net(nn.Module):
     def __getitem__(self, key):
         return self.last[key]
 
+    def exchange_groups(self, prefix: str = ""):
+        """Exchange groups of the whole graph in backward-completion order (ddp.py).  Probabilistic: the prior core's
+        gradients are complete after the backward of its FIRST forward pass (the last one autograd reaches), the
+        posterior's at the very end; the stitch decoder closes with the prior's decoder group."""
+        if not self.probabilistic:
+            return self.core.exchange_groups(prefix + "core.")
+        g = self.prior.exchange_groups(prefix + "prior.")
+        g[0] = (g[0][0], g[0][1] + list(self.stitch.parameters()))
+        return g + self.posterior.exchange_groups(prefix + "posterior.")
+
+    def _marker(self, prefix):
+        gm = self.grad_marker
+        if gm is None or not torch.is_grad_enabled():
+            return None
+        return lambda group, t: gm(prefix + group, t)
+
     def forward(self, inputs: torch.Tensor, eps_q=None, eps_p=None, with_infer=False, train_outputs=True):
         outputs: Dict[str, torch.Tensor] = {}
         nc = self.num_classes
         if not self.probabilistic:
-            o = self.core(inputs, prob_mean=False, prob_z_q=None)                  # networks.py:281 (+ App. C-1)
+            o = self.core(inputs, prob_mean=False, prob_z_q=None, mark=self._marker("core."))   # networks.py:281 (+ App. C-1)
             outputs['y_softmax'] = o['y_softmax']
             outputs['logits'] = o['logits']
             outputs['_heads'], outputs['_ups'] = o['_heads'], o['_ups']
@@ -429,15 +467,20 @@ class M1Net(nn.Module):
             if train_outputs:
                 # (two lanes -- posterior mean -> prior -> logits next to posterior sample -> prior -> KL -- were measured: no gain,
                 # the full model is dominated by kernels that fill the GPU on their own; nested forks also break graph capture)
-                q_sample = self.posterior(post_in, prob_mean=False, prob_z_q=None, eps=eps_q)          # networks.py:348
-                q_mean = self.posterior(post_in, prob_mean=True, prob_z_q=None)                          # networks.py:349
-                p_z_q = self.prior(image, prob_mean=False, prob_z_q=q_sample['prob_used_latents'])      # networks.py:351
-                p_z_qm = self.prior(image, prob_mean=False, prob_z_q=q_mean['prob_used_latents'])       # networks.py:352
+                # every pass marks the nodes that close its exchange groups: a group is sent once ALL its marks of the step
+                # have fired, i.e. after the backward of the last pass through that core, whatever order autograd picks
+                mq, mp = self._marker("posterior."), self._marker("prior.")
+                q_sample = self.posterior(post_in, prob_mean=False, prob_z_q=None, eps=eps_q, mark=mq)  # networks.py:348
+                q_mean = self.posterior(post_in, prob_mean=True, prob_z_q=None, mark=mq)                 # networks.py:349
+                p_z_q = self.prior(image, prob_mean=False, prob_z_q=q_sample['prob_used_latents'], mark=mp)   # networks.py:351
+                p_z_qm = self.prior(image, prob_mean=False, prob_z_q=q_mean['prob_used_latents'], mark=mp)    # networks.py:352
                 train_conv = self.stitch(p_z_qm['prob_decoder_features'])                               # networks.py:356
                 kl = None                                                                               # networks.py:373-385
-                for q, p in zip(q_sample['prob_distributions'], p_z_q['prob_distributions']):
+                for lvl, (q, p) in enumerate(zip(q_sample['prob_distributions'], p_z_q['prob_distributions'])):
                     k = ops.kl_mvn_diag(q, p)
                     kl = k if kl is None else kl + k
+                    if lvl == 0 and mp is not None:
+                        mp("a", p)           # the prior's coarsest latent head is reached through its KL term only
                 outputs['prob_train_conv'] = train_conv
                 outputs['prob_kl'] = kl
                 # networks.py:388-390: with deep_supervision the concat partner y_softmax[..., nc:] is EMPTY
@@ -591,6 +634,20 @@ class M1(LoadableModel):
         self.compute_dtype = dtype
         return self
 
+    def exchange_groups(self):
+        """Layers grouped by the point of the backward pass at which their weight gradients are complete, in completion
+        order (optim.FlatParams lays the flat gradient buffer out by these groups; ddp.GradReducer sends them)."""
+        if self.references.cascaded != False:  # noqa: E712 -- stage 2 is differentiated first, stage 1 closes last
+            return self.m1_stage2.exchange_groups("stage2.") + self.m1_stage1.exchange_groups("stage1.")
+        return self.m1_model.exchange_groups()
+
+    def set_grad_marker(self, fn):
+        if self.references.cascaded != False:  # noqa: E712
+            self.m1_stage1.grad_marker = (lambda k, t: fn("stage1." + k, t)) if fn is not None else None
+            self.m1_stage2.grad_marker = (lambda k, t: fn("stage2." + k, t)) if fn is not None else None
+        else:
+            self.m1_model.grad_marker = fn
+
     def seed_dropout(self, seed: int):
         with torch.no_grad():
             self.rng_state[0] = int(seed)
@@ -600,7 +657,7 @@ class M1(LoadableModel):
         """Move the dropout stream to the next step (so consecutive forward passes draw fresh masks)."""
         ops.step_advance(None, self.rng_state)
 
-    def _prep(self, x) -> torch.Tensor:
+    def _prep(self, x, channels: Optional[int] = None) -> torch.Tensor:
         if isinstance(x, dict):
             x = x[self.inputs[0].name]
         if isinstance(x, (list, tuple)) and len(x) == 1:
@@ -610,7 +667,7 @@ class M1(LoadableModel):
         if not x.is_cuda:
             raise RuntimeError("M1 runs on the HIP extension only: move the model and inputs to a GPU device "
                                "(no CPU fallback exists in this package)")
-        want = (*self.input_spatial_dims, self.input_channels)
+        want = (*self.input_spatial_dims, self.input_channels if channels is None else channels)
         if tuple(x.shape[1:]) != want:
             raise ValueError(f"expected input of shape (B,{','.join(map(str, want))}), got {tuple(x.shape)}")
         x = x.contiguous()
@@ -620,51 +677,77 @@ class M1(LoadableModel):
 
     # ---- forward: returns the Keras outputs (networks.py:89-90,99) ----------------------------------------------
     def forward(self, x, training: Optional[bool] = None, eps_q=None):
+        """``eps_q``: optional injected N(0,1) draws of the posterior's latent samples (cascaded: one list per stage)."""
         if self.references.cascaded != False:  # noqa: E712
-            return self._forward_cascaded(x)
+            return self._forward_cascaded(x, eps_q=eps_q)
         o = self.m1_model(self._prep(x), eps_q=eps_q)
         if self.references.probabilistic:
             return [o['prob_softmax'], o['prob_kl']]
         return o['y_softmax']
 
-    def _forward_cascaded(self, x):
-        """networks.py:109-193.  Stage 2 sees cat[stage-1 softmax[..., :nc-1], image_2]; fusion per decision_fusion."""
+    def _cascade_inputs(self, x):
         if isinstance(x, dict):
-            x1, x2 = x[self.inputs[0].name], x[self.inputs[1].name]
-        else:
-            x1, x2 = x
+            return x[self.inputs[0].name], x[self.inputs[1].name]
+        return x
+
+    def _stage2_input(self, p1, x2):
+        """networks.py:135-136: cat[stage-1 softmax[..., :nc-1], image_2]; the softmax channel stays on the autograd tape (the
+        stage-2 loss trains stage 1 through it)."""
+        nc = self.num_classes
+        prior_in = p1[..., :nc - 1].to(self.compute_dtype)
+        return torch.cat([prior_in, self._prep(x2, channels=self.input_channels)], dim=-1).contiguous()
+
+    def _forward_cascaded(self, x, eps_q=None, eps_p=None, with_infer=False):
+        """networks.py:109-193.  Stage 2 sees cat[stage-1 softmax[..., :nc-1], image_2]; fusion per decision_fusion.
+        Returns [detection_1, detection_2 (, KL_1, KL_2)] (networks.py:168-171,181-182)."""
+        x1, x2 = self._cascade_inputs(x)
         nc, prob = self.num_classes, self.references.probabilistic
         key = 'prob_softmax' if prob else 'y_softmax'
-        o1 = self.m1_stage1(self._prep(x1))
+        e_q = eps_q if eps_q is not None else (None, None)
+        e_p = eps_p if eps_p is not None else (None, None)
+        o1 = self.m1_stage1(self._prep(x1, channels=self.input_channels), eps_q=e_q[0], eps_p=e_p[0], with_infer=with_infer)
         p1 = o1[key]
-        prior_in = ops.cast(p1[..., :nc - 1].contiguous(), self.compute_dtype)                   # networks.py:135-136
-        o2 = self.m1_stage2(torch.cat([prior_in, self._prep(x2)], dim=-1).contiguous())
+        o2 = self.m1_stage2(self._stage2_input(p1, x2), eps_q=e_q[1], eps_p=e_p[1], with_infer=with_infer)
         p2 = o2[key]
         prior_pred, joint_pred = self.decision_fusion(p1[..., nc - 1], p2[..., nc - 1], strategy=self.references.cascaded)
+        self._last_cascade = (o1, o2)
         if prob:
             return [prior_pred, joint_pred, o1['prob_kl'], o2['prob_kl']]
         return [prior_pred, joint_pred]
 
     # ---- networks.py:196-206 ---------------------------------------------------------------------------------
     def get_detect_model(self):
-        """Model reconfigured to predict segment probabilities only: probabilistic -> softmax(prob_infer_conv)
-        with z ~ P at every level; deterministic -> y_softmax[..., :num_classes]."""
+        """Model reconfigured to predict segment probabilities only (networks.py:196-206).
+        Standalone: probabilistic -> softmax(prob_infer_conv), the prior net with z ~ P at every level (networks.py:94,205);
+        deterministic -> y_softmax[..., :num_classes].
+        Cascaded: probabilistic -> [softmax(stage-1 prob_infer_conv), softmax(stage-2 prob_infer_conv)] where stage 2 is fed
+        the stage-1 TRAINING softmax exactly as the reference's graph is wired (networks.py:135-136,174-175,199-200);
+        deterministic -> [stage-1 y_softmax[..., :nc], stage-2 y_softmax[..., :nc]].
+        ``eps_q`` / ``eps_p``: optional injected draws (tests), per stage when cascaded."""
         outer = self
 
         class _Detect(nn.Module):
-            def forward(self, x):
+            def forward(self, x, eps_q=None, eps_p=None):
                 nc = outer.references.num_classes
-                if outer.references.cascaded != False:  # noqa: E712
-                    raise NotImplementedError("cascaded detect model: use M1.forward outputs")
+                prob = outer.references.probabilistic
                 with torch.no_grad():
-                    if outer.references.probabilistic:
-                        o = outer.m1_model(outer._prep(x), train_outputs=False)
+                    if outer.references.cascaded != False:  # noqa: E712
+                        if not prob:
+                            outer._forward_cascaded(x)
+                            o1, o2 = outer._last_cascade
+                            return [o1['y_softmax'][..., :nc], o2['y_softmax'][..., :nc]]
+                        outer._forward_cascaded(x, eps_q=eps_q, eps_p=eps_p, with_infer=True)
+                        o1, o2 = outer._last_cascade
+                        return [ops.softmax_heads([o1['prob_infer_conv']], [(1, 1, 1)]),
+                                ops.softmax_heads([o2['prob_infer_conv']], [(1, 1, 1)])]
+                    if prob:
+                        o = outer.m1_model(outer._prep(x), train_outputs=False, eps_p=eps_p)
                         return ops.softmax_heads([o['prob_infer_conv']], [(1, 1, 1)])
                     o = outer.m1_model(outer._prep(x))
                     return o['y_softmax'][..., :nc]
 
-            def predict(self, x):
-                return self.forward(x)
+            def predict(self, x, **kw):
+                return self.forward(x, **kw)
         return _Detect()
 
     # ---- networks.py:209-223 ---------------------------------------------------------------------------------
@@ -725,12 +808,12 @@ class M1(LoadableModel):
         c = self._compiled
         opt = c["optimizer"]
         self.train()
+        opt.zero_grad()                       # before the forward pass: a data-parallel run registers its exchange marks there
         outputs = self(x)
         total, parts = self.compute_loss(outputs, y)
         fused_l2 = bool(getattr(opt, "handles_l2", False))
         reg = self.regularization_loss()
         loss = total if fused_l2 else total + reg
-        opt.zero_grad()
         loss.backward()
         opt.step()
         self.advance_rng()

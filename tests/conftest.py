@@ -11,6 +11,22 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "subprocess_last: harness tests that spawn bench.py / the trainer; collected last")
+
+
+# Oracle-parity tests first, whole-model tests next, full-size property tests after them, subprocess harness tests
+# last: with `-x` one flaky harness test must never hide the parity suite (round-1 lesson).
+_ORDER = ["test_oracle_kat", "test_host_logic", "test_abi", "test_hip_ops", "test_hip_model", "test_hip_fused",
+          "test_readme_model", "test_cascade", "test_trainer", "test_full_size"]
+
+
+def pytest_collection_modifyitems(session, config, items):
+    def key(it):
+        mod = os.path.splitext(os.path.basename(str(it.fspath)))[0]
+        last = 1 if it.get_closest_marker("subprocess_last") is not None else 0
+        rank = _ORDER.index(mod) if mod in _ORDER else len(_ORDER)
+        return (last, rank)
+    items.sort(key=key)          # stable: the order inside a module is kept
 
 
 @pytest.fixture(scope="session")

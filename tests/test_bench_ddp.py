@@ -1,28 +1,78 @@
 """The N > 1 code path of bench.py (captured forward+backward, eager gradient exchange + optimiser, rank-0-only
-roofline pass) run as two ranks on ONE GPU with the gloo backend: a functional check that it neither hangs nor
-diverges in structure -- never a measurement.  (RCCL refuses two ranks on one device; the collective itself is
-covered by the 2-rank gloo test of ddp.GradReducer on the CPU.)"""
+roofline pass) run as two ranks on ONE GPU with the gloo backend, and the RCCL branch as a world of one: functional
+checks that the path neither hangs nor diverges in structure -- never a measurement.  (RCCL refuses two ranks on one
+device; the collective over two ranks is covered by the 2-rank gloo tests of ddp.GradReducer on the CPU.)
+
+These are subprocess tests: conftest.py orders them AFTER every oracle-parity test, each child runs under a short
+timeout with a stack dump of a stuck rank (M1_BENCH_DEBUG), and a child that has to be killed fails the test."""
 import json
 import os
+import signal
 import subprocess
 import sys
 
 import pytest
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.subprocess_last]
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CHILD_TIMEOUT_S = 150
 
 
-@pytest.mark.timeout(600)
-def test_bench_two_ranks_one_gpu_gloo():
-    env = dict(os.environ, M1_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+def _run(cmd, env):
+    """Run ``cmd`` in its own process group; on timeout kill the whole group and fail with both streams."""
+    p = subprocess.Popen(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                         start_new_session=True)
+    try:
+        out, err = p.communicate(timeout=CHILD_TIMEOUT_S)
+    except subprocess.TimeoutExpired:
+        try:
+            os.killpg(p.pid, signal.SIGTERM)      # faulthandler in the ranks has already dumped where they stand
+            out, err = p.communicate(timeout=10)
+        except subprocess.TimeoutExpired:
+            os.killpg(p.pid, signal.SIGKILL)
+            out, err = p.communicate()
+        pytest.fail(f"bench.py child exceeded {CHILD_TIMEOUT_S} s and was killed\n--- stdout\n{out[-3000:]}\n--- stderr\n{err[-6000:]}")
+    return p.returncode, out, err
+
+
+def _check_line(rc, out, err, world):
+    lines = [l for l in out.splitlines() if l.startswith("{")]
+    assert rc == 0 and len(lines) == 1, f"rc={rc}\n--- stdout\n{out[-2000:]}\n--- stderr\n{err[-4000:]}"
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == world and d["config"]["global_batch"] == world and d["scaling"] == "weak"
+    assert d["config"]["graph_error"] is None and d["value"] > 0
+    assert d["roofline"] is not None and d["cpu_baseline"] is None
+    return d
+
+
+@pytest.mark.timeout(CHILD_TIMEOUT_S + 60)
+@pytest.mark.parametrize("gmode", ["off", "split"])
+def test_bench_two_ranks_one_gpu_gloo(gmode):
+    """off: eager launches, exchange groups sent from the communication stream while backward runs; split: captured
+    forward+backward, exchange after the replay.  Either way the two replicas (different volumes) must stay in sync."""
+    env = dict(os.environ, M1_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1", M1_BENCH_DEBUG="1", M1_DDP_GRAPH=gmode)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", "29533", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "C1", "--steps", "3",
            "--warmup", "1", "--no-cpu-baseline"]
-    out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=540)
-    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
-    assert out.returncode == 0 and len(lines) == 1, out.stderr[-2000:]
-    d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 2 and d["scaling"] == "weak"
-    assert d["config"]["graph_error"] is None and d["value"] > 0
-    assert d["roofline"] is not None and d["cpu_baseline"] is None
+    rc, out, err = _run(cmd, env)
+    d = _check_line(rc, out, err, 2)
+    ex = d["config"]["exchange"]
+    assert ex["graph_mode"] == gmode and ex["replicas_in_sync"] is True and ex["groups"] == 3 and ex["collectives_issued"] > 0
+    assert d["config"]["hip_graph"] is (gmode == "split")
+    if gmode == "off":
+        assert ex["groups_sent_during_backward"] >= 2 * ex["host_steps"] - 2      # groups a and b close before backward ends
+
+
+@pytest.mark.timeout(CHILD_TIMEOUT_S + 60)
+def test_bench_rccl_world_of_one():
+    """bench.py's RCCL branch (init_process_group('nccl', device_id), bucketed all-reduce from the comm stream, barrier,
+    destroy) executed on one GPU: M1_BENCH_FORCE_DIST=1 makes a world of one take the N > 1 code path."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29534", RANK="0", LOCAL_RANK="0", WORLD_SIZE="1",
+               M1_BENCH_FORCE_DIST="1", M1_BENCH_DEBUG="1")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--workload", "C1", "--steps", "3", "--warmup", "1",
+           "--no-cpu-baseline"]
+    rc, out, err = _run(cmd, env)
+    d = _check_line(rc, out, err, 1)
+    ex = d["config"]["exchange"]
+    assert ex["backend"] == "nccl" and ex["graph_mode"] == "full" and ex["replicas_in_sync"] is True
+    assert ex["collectives_issued"] > 0 and ex["groups_sent_during_backward"] > 0

@@ -177,6 +177,20 @@ def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
+class _WritesGrad(torch.autograd.Function):
+    """Stand-in for a layer whose backward kernel accumulates its weight gradient straight into the flat buffer."""
+    @staticmethod
+    def forward(ctx, x, flat, lo, hi, val):
+        ctx.a = (flat, lo, hi, val)
+        return x * 1.0
+
+    @staticmethod
+    def backward(ctx, g):
+        flat, lo, hi, val = ctx.a
+        flat[lo:hi] += val
+        return g, None, None, None, None
+
+
 def _ddp_worker(rank, world, port, q):
     sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
     import importlib
@@ -188,7 +202,29 @@ def _ddp_worker(rank, world, port, q):
     flat = torch.randn(5003, generator=g)
     mine = flat.clone()
     red.all_reduce(flat)
-    q.put((rank, mine.numpy(), flat.numpy(), red.grad_scale))
+    # group-by-group exchange driven by autograd marks: layer order in forward L_c -> L_b -> L_a (two passes through L_a)
+    fg = torch.zeros(40)
+    red2 = pkg.ddp.GradReducer(bucket_mb=0.00002)
+    red2.bind(fg, {"a": (0, 16), "b": (16, 24), "c": (24, 32)}, ["a", "b", "c"], (32, 40))
+    sent_when = {}
+    orig = red2._send
+    red2._send = lambda key, early: (sent_when.setdefault(key, (early, fg.clone())), orig(key, early))[1]
+    for _ in range(2):
+        fg.zero_()
+        red2.begin_step()
+        sent_when.clear()
+        x = torch.ones(3, requires_grad=True)
+        hc = _WritesGrad.apply(x, fg, 24, 32, float(rank + 1))
+        hb = _WritesGrad.apply(hc, fg, 16, 24, float(10 * (rank + 1)))
+        red2.mark("b", hc)                                   # closing node of b = the producer of its input
+        p1 = _WritesGrad.apply(hb, fg, 0, 16, float(100 * (rank + 1)))
+        p2 = _WritesGrad.apply(hb, fg, 0, 16, float(100 * (rank + 1)))
+        red2.mark("a", hb); red2.mark("a", hb)               # one mark per pass: a is sent after BOTH have run
+        (p1.sum() + p2.sum()).backward()
+        fg[32:40] += float(rank + 1)                          # tail (biases etc.)
+        red2.finish()
+    early = {k: v[0] for k, v in sent_when.items()}
+    q.put((rank, mine.numpy(), flat.numpy(), red.grad_scale, fg.numpy(), early, sent_when["a"][1].numpy(), dict(red2.stats)))
     dist.barrier(); dist.destroy_process_group()
 
 
@@ -202,6 +238,12 @@ def test_two_rank_gloo_gradient_exchange_equals_global_batch_mean():
     [p.join(60) for p in ps]
     assert all(p.exitcode == 0 for p in ps)
     total = res[0][1] + res[1][1]
-    for _, _, reduced, scale in res:
+    for _, _, reduced, scale, fg, early, a_at_send, stats in res:
         assert np.allclose(reduced, total, atol=1e-6) and scale == 0.5
         assert np.allclose(reduced * scale, total / 2, atol=1e-6)           # what the optimiser kernel consumes
+        # marks: a and b went out during backward (a only after its second pass had written), c and the tail at finish()
+        assert early == {"a": True, "b": True, "c": False, "__tail__": False}
+        assert stats["early_groups"] == 4 and stats["late_groups"] == 4 and stats["collectives"] >= 8
+        want = np.concatenate([np.full(16, 600.0), np.full(8, 30.0), np.full(8, 3.0), np.full(8, 3.0)])
+        assert np.array_equal(fg, want), fg
+    assert np.array_equal(res[0][6][:16], np.full(16, 200.0)) and np.array_equal(res[1][6][:16], np.full(16, 400.0))
