@@ -85,3 +85,46 @@ def kl_mvn_diag(ml_q, ml_p, L, clip=0.1):
     rc = f(_p(ml_q), _p(ml_p), ctypes.byref(out), N, V, L, clip)
     assert rc == 0
     return out.value
+
+
+def m1_det_param_order(se_blocks=("serse1", "serse2", "serse3", "serse4"), pre="core"):
+    """The order in which naive_m1_det_forward consumes parameter tensors (documented in naive_ops.c)."""
+    def se(n):
+        out = []
+        for c, nm in (("conv1", "norm1"), ("conv2", "norm2"), ("conv3", "norm3"), ("conv4", "norm4")):
+            out += [f"{n}.{c}.kernel", f"{n}.{c}.bias", f"{n}.{nm}.gamma", f"{n}.{nm}.beta"]
+        return out + [f"{n}.conv6.kernel", f"{n}.conv6.bias", f"{n}.conv7.kernel", f"{n}.conv7.bias"]
+
+    def gate(n):
+        out = []
+        for c in ("theta", "phi", "psi", "W"):
+            out += [f"{n}.{c}.kernel", f"{n}.{c}.bias"]
+        return out + [f"{n}.normW.gamma", f"{n}.normW.beta"]
+    names = ["conve0.kernel", "conve0.bias", "norme0.gamma", "norme0.beta"]
+    for b in se_blocks:
+        names += se(b)
+    for i in range(4):
+        names += gate(f"att{i}")
+    for lvl in (3, 2, 1, 0):
+        names += [f"convtd{lvl}.kernel", f"convtd{lvl}.bias"] + se(f"sersd{lvl}")
+    names += ["logits.kernel", "logits.bias"]
+    return [f"{pre}.{n}" for n in names]
+
+
+def m1_det_forward(P, x, filters, strides, kernel_sizes, se_reduction, num_classes=2):
+    """Whole deterministic M1 forward in plain C loops (KAT-7): ``P`` maps App. E names to arrays; returns the logits."""
+    x = _c(x)
+    N, D, H, W, Cin = x.shape
+    names = m1_det_param_order()
+    assert set(names) == set(P), sorted(set(names) ^ set(P))[:6]
+    arrs = [_c(P[n]) for n in names]
+    ptrs = (ctypes.POINTER(ctypes.c_double) * len(arrs))(*[_p(a) for a in arrs])
+    iv = lambda v: (ctypes.c_int * len(v))(*[int(a) for a in v])
+    out = np.empty((N, D // strides[0][0], H // strides[0][1], W // strides[0][2], num_classes), dtype=np.float64)
+    f = lib().naive_m1_det_forward
+    f.argtypes = [ctypes.POINTER(ctypes.c_double)] + [ctypes.c_int] * 5 + [ctypes.POINTER(ctypes.c_int)] * 4 + [
+        ctypes.c_int, ctypes.POINTER(ctypes.POINTER(ctypes.c_double)), ctypes.c_int, ctypes.POINTER(ctypes.c_double)]
+    rc = f(_p(x), N, D, H, W, Cin, iv(filters), iv([a for s in strides for a in s]), iv([a for k in kernel_sizes for a in k]),
+           iv(se_reduction), int(num_classes), ptrs, len(arrs), _p(out))
+    assert rc == 0, "naive_m1_det_forward did not consume its parameter list exactly"
+    return out

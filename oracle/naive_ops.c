@@ -159,3 +159,158 @@ int naive_kl_mvn_diag(const double *ml_q, const double *ml_p, double *kl,
     *kl = tot / (double)N;
     return 0;
 }
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * KAT-7: the WHOLE deterministic M1 forward in plain C loops -- an independent code path for the
+ * wiring of networks.py:568-630 (stem, 4 strided SE encoders, 4 attention gates, transposed-conv up-path with channel
+ * concats, 4 SE decoders, 1x1x1 logits) and of network_blocks.py:48-80,106-130, written from the reference, sharing
+ * nothing with oracle/m1_oracle.py.  dense_skip = deep_supervision = probabilistic = False, att_sub_samp = (1,1,1).
+ *
+ * Parameters arrive as an array of pointers consumed IN THIS ORDER (each conv: kernel, bias; each norm: gamma, beta):
+ *   conve0, norme0,
+ *   serse1..serse4            each: conv1,norm1, conv2,norm2, conv3,norm3, conv4,norm4, conv6, conv7
+ *   att0..att3                each: theta, phi, psi, W, normW
+ *   convtd3, sersd3, convtd2, sersd2, convtd1, sersd1, convtd0, sersd0, logits
+ * filters[5], strides[15], kernels[15] as in the M1 constructor (networks.py:38-40).
+ * ------------------------------------------------------------------------------------------------------------------ */
+typedef struct { const double **p; int cur, n; } cursor_t;
+static const double *nextp(cursor_t *c) { return c->cur < c->n ? c->p[c->cur++] : NULL; }
+typedef struct { double *v; int D, H, W, C; } vol_t;                  /* one NDHWC tensor of batch size N (N is global) */
+
+static size_t vox(const vol_t *t) { return (size_t)t->D * t->H * t->W; }
+static vol_t valloc(int N, int D, int H, int W, int C) {
+    vol_t t = { (double *)malloc(sizeof(double) * (size_t)N * D * H * W * C), D, H, W, C };
+    return t;
+}
+
+static vol_t conv_layer(cursor_t *c, int N, const vol_t *x, int Co, const int *k, const int *s) {
+    const double *w = nextp(c), *b = nextp(c);
+    vol_t y = valloc(N, ceil_div(x->D, s[0]), ceil_div(x->H, s[1]), ceil_div(x->W, s[2]), Co);
+    naive_conv3d_same(x->v, w, b, y.v, N, x->D, x->H, x->W, x->C, Co, k[0], k[1], k[2], s[0], s[1], s[2]);
+    return y;
+}
+static vol_t convT_layer(cursor_t *c, int N, const vol_t *x, int Co, const int *k, const int *s) {
+    const double *w = nextp(c), *b = nextp(c);
+    vol_t y = valloc(N, x->D * s[0], x->H * s[1], x->W * s[2], Co);
+    naive_conv3d_transpose_same(x->v, w, b, y.v, N, x->D, x->H, x->W, x->C, Co, k[0], k[1], k[2], s[0], s[1], s[2]);
+    return y;
+}
+static void norm_inplace(cursor_t *c, int N, vol_t *x, double slope) {
+    const double *g = nextp(c), *b = nextp(c);
+    naive_instance_norm(x->v, g, b, x->v, N, vox(x), x->C, 1e-3, slope);        /* element-wise after the statistics: in place is safe */
+}
+static vol_t concat2(int N, const vol_t *a, const vol_t *b) {                   /* tf.concat([a, b], axis=-1) */
+    vol_t y = valloc(N, a->D, a->H, a->W, a->C + b->C);
+    size_t V = (size_t)N * vox(a);
+    for (size_t v = 0; v < V; ++v) {
+        memcpy(y.v + v * y.C, a->v + v * a->C, sizeof(double) * a->C);
+        memcpy(y.v + v * y.C + a->C, b->v + v * b->C, sizeof(double) * b->C);
+    }
+    return y;
+}
+static const int ONE3[3] = { 1, 1, 1 }, K333[3] = { 3, 3, 3 };
+
+/* network_blocks.py:48-80 */
+static vol_t se_block(cursor_t *c, int N, const vol_t *x, int F, const int *k, const int *s, int red) {
+    vol_t a = conv_layer(c, N, x, F / 4, k, s);            norm_inplace(c, N, &a, 0.1);       /* B:53-55 */
+    vol_t b = conv_layer(c, N, &a, F / 4, K333, ONE3);     norm_inplace(c, N, &b, 0.1);       /* B:56-58 */
+    vol_t x_ = conv_layer(c, N, &b, F, ONE3, ONE3);        norm_inplace(c, N, &x_, 1.0);      /* B:59-60 */
+    vol_t r = conv_layer(c, N, x, F, k, s);                norm_inplace(c, N, &r, 1.0);       /* B:63-65 (C_in != F always) */
+    const double *w6 = nextp(c), *b6 = nextp(c), *w7 = nextp(c), *b7 = nextp(c);
+    int Fr = F / red;
+    size_t V = vox(&x_);
+    double *pool = (double *)malloc(sizeof(double) * F), *hid = (double *)malloc(sizeof(double) * Fr);
+    double *gate = (double *)malloc(sizeof(double) * F);
+    for (int n = 0; n < N; ++n) {
+        double *xn = x_.v + (size_t)n * V * F, *rn = r.v + (size_t)n * V * F;
+        for (int f = 0; f < F; ++f) {                                                          /* B:68 GlobalAveragePooling3D */
+            double sum = 0.0;
+            for (size_t v = 0; v < V; ++v) sum += xn[v * F + f];
+            pool[f] = sum / (double)V;
+        }
+        for (int j = 0; j < Fr; ++j) {                                                         /* B:70-71 */
+            double t = b6[j];
+            for (int f = 0; f < F; ++f) t += pool[f] * w6[(size_t)f * Fr + j];
+            hid[j] = t >= 0.0 ? t : 0.1 * t;
+        }
+        for (int f = 0; f < F; ++f) {                                                          /* B:72-73 */
+            double t = b7[f];
+            for (int j = 0; j < Fr; ++j) t += hid[j] * w7[(size_t)j * F + f];
+            gate[f] = 1.0 / (1.0 + exp(-t));
+        }
+        for (size_t v = 0; v < V; ++v)
+            for (int f = 0; f < F; ++f) {                                                      /* B:74-78: multiply, multiply, leaky */
+                double u = xn[v * F + f] * gate[f] * rn[v * F + f];
+                xn[v * F + f] = u >= 0.0 ? u : 0.1 * u;
+            }
+    }
+    free(pool); free(hid); free(gate); free(a.v); free(b.v); free(r.v);
+    return x_;
+}
+
+/* network_blocks.py:106-130 with sub_samp = (1,1,1) */
+static vol_t gate_block(cursor_t *c, int N, const vol_t *x, const vol_t *g, int Fi) {
+    vol_t th = conv_layer(c, N, x, Fi, ONE3, ONE3);                                            /* B:111 */
+    vol_t ph = conv_layer(c, N, g, Fi, ONE3, ONE3);                                            /* B:112 */
+    int ud = th.D / ph.D, uh = th.H / ph.H, uw = th.W / ph.W;                                  /* B:113-116 nearest repeat */
+    const double *wpsi = nextp(c), *bpsi = nextp(c);
+    vol_t y = valloc(N, x->D, x->H, x->W, x->C);
+    for (int n = 0; n < N; ++n)
+    for (int d = 0; d < th.D; ++d)
+    for (int h = 0; h < th.H; ++h)
+    for (int w = 0; w < th.W; ++w) {
+        size_t it = (((size_t)n * th.D + d) * th.H + h) * th.W + w;
+        size_t ip = (((size_t)n * ph.D + d / ud) * ph.H + h / uh) * ph.W + w / uw;
+        double psi = bpsi[0];
+        for (int f = 0; f < Fi; ++f) {
+            double t = th.v[it * Fi + f] + ph.v[ip * Fi + f];                                   /* B:117 */
+            t = t >= 0.0 ? t : 0.1 * t;
+            psi += t * wpsi[f];                                                                /* B:118 */
+        }
+        double sig = 1.0 / (1.0 + exp(-psi));                                                  /* B:119 (sub_samp 1: B:120-123 identity) */
+        for (int f = 0; f < x->C; ++f) y.v[it * x->C + f] = sig * x->v[it * x->C + f];         /* B:124 */
+    }
+    vol_t wy = conv_layer(c, N, &y, Fi, ONE3, ONE3);                                           /* B:127 */
+    norm_inplace(c, N, &wy, 1.0);                                                              /* B:128 */
+    free(th.v); free(ph.v); free(y.v);
+    return wy;
+}
+
+int naive_m1_det_forward(const double *x, int N, int D, int H, int W, int Cin, const int *filters, const int *strides,
+                         const int *kernels, const int *se_red, int num_classes, const double **params, int nparams,
+                         double *logits) {
+    cursor_t c = { params, 0, nparams };
+    const int *F = filters;
+    #define S(i) (strides + 3 * (i))
+    #define K(i) (kernels + 3 * (i))
+    vol_t in = { (double *)x, D, H, W, Cin };
+    vol_t x0 = conv_layer(&c, N, &in, F[0], K(0), S(0)); norm_inplace(&c, N, &x0, 0.1);       /* N:574-576 */
+    vol_t e1 = se_block(&c, N, &x0, F[1], K(1), S(1), se_red[1]);                              /* N:579 */
+    vol_t e2 = se_block(&c, N, &e1, F[2], K(2), S(2), se_red[2]);
+    vol_t e3 = se_block(&c, N, &e2, F[3], K(3), S(3), se_red[3]);
+    vol_t em = se_block(&c, N, &e3, F[4], K(4), S(4), se_red[4]);                              /* N:582 */
+    vol_t a0 = gate_block(&c, N, &x0, &em, F[0]);                                              /* N:585-588 */
+    vol_t a1 = gate_block(&c, N, &e1, &em, F[1]);
+    vol_t a2 = gate_block(&c, N, &e2, &em, F[2]);
+    vol_t a3 = gate_block(&c, N, &e3, &em, F[3]);
+    vol_t d3 = convT_layer(&c, N, &em, F[3], K(4), S(4));                                      /* N:591 */
+    vol_t c3 = concat2(N, &d3, &a3);                                                           /* N:596 */
+    vol_t u3 = se_block(&c, N, &c3, F[3], K(3), ONE3, se_red[3]);                              /* N:597 */
+    vol_t d2 = convT_layer(&c, N, &u3, F[2], K(3), S(3));                                      /* N:600 */
+    vol_t c2 = concat2(N, &d2, &a2);                                                           /* N:606 */
+    vol_t u2 = se_block(&c, N, &c2, F[2], K(2), ONE3, se_red[2]);
+    vol_t d1 = convT_layer(&c, N, &u2, F[1], K(2), S(2));                                      /* N:610 */
+    vol_t c1 = concat2(N, &d1, &a1);                                                           /* N:615 */
+    vol_t u1 = se_block(&c, N, &c1, F[1], K(1), ONE3, se_red[1]);
+    vol_t d0 = convT_layer(&c, N, &u1, F[0], K(1), S(1));                                      /* N:619 */
+    vol_t c0 = concat2(N, &d0, &a0);                                                           /* N:623 */
+    vol_t u0 = se_block(&c, N, &c0, F[0], K(0), ONE3, se_red[0]);                              /* N:624 */
+    vol_t lg = conv_layer(&c, N, &u0, num_classes, ONE3, ONE3);                                /* N:627 */
+    #undef S
+    #undef K
+    int ok = (c.cur == nparams);               /* every parameter consumed exactly once */
+    memcpy(logits, lg.v, sizeof(double) * (size_t)N * vox(&lg) * num_classes);
+    vol_t all[] = { x0, e1, e2, e3, em, a0, a1, a2, a3, d3, c3, u3, d2, c2, u2, d1, c1, u1, d0, c0, u0, lg };
+    for (size_t i = 0; i < sizeof(all) / sizeof(all[0]); ++i) free(all[i].v);
+    return ok ? 0 : -1;
+}

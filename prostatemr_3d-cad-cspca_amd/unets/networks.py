@@ -483,6 +483,7 @@ class M1Net(nn.Module):
                         mp("a", p)           # the prior's coarsest latent head is reached through its KL term only
                 outputs['prob_train_conv'] = train_conv
                 outputs['prob_kl'] = kl
+                outputs['_q_latents'] = q_sample['prob_used_latents']
                 # networks.py:388-390: with deep_supervision the concat partner y_softmax[..., nc:] is EMPTY
                 outputs['prob_softmax'] = ops.softmax_heads([train_conv], [(1, 1, 1)])
                 outputs['_heads'], outputs['_ups'] = [train_conv], [(1, 1, 1)]

@@ -38,23 +38,22 @@ def _oracle_loss_and_grads(cfg, P, x, tgt, eps=None):
     return out
 
 
-def _check_grads(m, g64, g32):
+def _check_grads(m, g64, g32, strip=("m1_model.",)):
     """Every parameter gradient of the HIP path (fp32) against the fp64 oracle: relative L2 error below
-    max(1e-3, 3 x the error an fp32 CPU evaluation of the same graph makes on that parameter).  (With random
-    fixture weights the loss is dominated by a few saturated voxels and some early-encoder gradients are
-    ill-conditioned in fp32 -- the fp32 oracle itself is 1.6e-2 off on one of them -- so a flat 1e-3 would test
-    the conditioning of the problem, not the kernels.)  Parameters whose true gradient is (numerically) zero --
-    a conv bias feeding an InstanceNorm is mean-subtracted away; sersd0/logits of a probabilistic core reach no
-    loss -- are checked on the absolute scale of the largest gradient."""
+    max(1e-3, 3 x the error the fp32 CPU evaluation of the same graph makes ON THAT PARAMETER) -- SURVEY.md 8(c)'s 1e-3,
+    relaxed per parameter only where fp32 arithmetic itself cannot do better (with random fixture weights the loss is
+    dominated by a few saturated voxels and some early-encoder gradients are ill-conditioned in fp32: the fp32 oracle is
+    1.6e-2 off on one of them).  There is no global floor: a well-conditioned gradient must meet 1e-3.
+    Parameters whose true gradient is (numerically) zero -- a conv bias feeding an InstanceNorm is mean-subtracted away;
+    sersd0/logits of a probabilistic core reach no loss -- are checked on the absolute scale of the largest
+    gradient."""
     gmax = max(float(g.norm()) for g in g64.values() if g is not None)
-    # the fp32 oracle's own worst per-parameter error: two fp32 evaluations with different summation orders
-    # scatter by this much on the ill-conditioned parameters, whichever of them one happens to look at
-    e32_max = max(float((g32[k] - g).norm() / g.norm()) for k, g in g64.items()
-                  if g is not None and g32[k] is not None and float(g.norm()) >= 1e-6 * gmax)
     num = den = num32 = 0.0
-    worst = ("", 0.0, 0.0)
+    bad = []
     for k, p in m.named_parameters():
-        name = k.replace("m1_model.", "")
+        name = k
+        for pre in strip:
+            name = name.replace(pre, "")
         go = g64[name] if g64[name] is not None else torch.zeros_like(p.detach().cpu().double())
         gh = p.grad.detach().double().cpu() if p.grad is not None else torch.zeros_like(go)
         if float(go.norm()) < 1e-6 * gmax:
@@ -64,10 +63,10 @@ def _check_grads(m, g64, g32):
         e32 = float((g32[name] - go).norm() / go.norm()) if g32[name] is not None else 0.0
         num += float((gh - go).norm()) ** 2; den += float(go.norm()) ** 2
         num32 += float((g32[name] - go).norm()) ** 2 if g32[name] is not None else 0.0
-        tol = max(1e-3, 3.0 * e32, e32_max)
-        if e / tol > worst[1]:
-            worst = (name, e / tol, e)
-    assert worst[1] < 1.0, worst
+        tol = max(1e-3, 3.0 * e32)
+        if e > tol:
+            bad.append((name, e, e32))
+    assert not bad, sorted(bad, key=lambda t: -t[1] / max(1e-3, 3 * t[2]))[:8]
     # whole-gradient-vector error: 1e-3, or twice what the fp32 oracle achieves when that is worse
     assert (num / den) ** 0.5 < max(1e-3, 2.0 * (num32 / den) ** 0.5), ((num / den) ** 0.5, (num32 / den) ** 0.5)
 
@@ -199,8 +198,7 @@ def test_train_step_reduces_loss_and_is_batch_shardable(dev):
 
 def test_forward_and_data_gradients_are_run_to_run_deterministic(dev):
     """No floating-point atomics on any activation path (split-K partial sums go to per-split slabs that are added in
-    a fixed order): repeated identical calls give bit-identical outputs and input gradients.  (Weight gradients are
-    accumulated with fp32 atomics over voxel splits and may differ in the last bits.)"""
+    a fixed order): repeated identical calls give bit-identical outputs and input gradients."""
     cfg = O.M1Config(input_spatial_dims=(8, 32, 32), filters=(8, 16, 32, 64, 128), strides=C1_STRIDES)
     m = build_m1(cfg, dev)
     load_params_into(m, O.fixture_params(cfg, seed=1))

@@ -168,6 +168,47 @@ def test_kat7_naive_c_composed_se_block_c1():
     assert np.abs(np.where(u >= 0, u, 0.1 * u) - want).max() < 1e-11
 
 
+def test_kat7_naive_c_whole_c1_forward():
+    """KAT-7 as SURVEY.md 7.1 wrote it: the whole deterministic C1 forward (stem, SE encoders, attention gates, transposed
+    up-path with concats, SE decoders, logits) in plain C loops -- an independent restatement of the WIRING, not only of the
+    ops -- equals the torch restatement in fp64, and the committed golden logits."""
+    cfg = O.M1Config(**C1)
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "c1_det.npz"))
+    P = {k: v.double() for k, v in O.fixture_params(cfg, int(g["seed"])).items()}
+    want = O.m1_forward(P, cfg, torch.from_numpy(g["x"]).double())["logits"].numpy()
+    got = naive.m1_det_forward({k: v.numpy() for k, v in P.items()}, g["x"], cfg.filters, cfg.strides, cfg.kernel_sizes,
+                               cfg.se_reduction, cfg.num_classes)
+    assert got.shape == want.shape == (1, 8, 64, 64, 2)
+    assert np.abs(got - want).max() < 1e-10
+    assert np.abs(got - g["logits"]).max() < 1e-5
+
+
+def test_decision_fusion_known_answers_and_cascade_wiring():
+    """networks.py:209-223 by hand; networks.py:135-136: stage 2 is fed cat[stage-1 softmax[..., :nc-1], image_2]."""
+    a, b = torch.tensor([0.2, 0.9]), torch.tensor([0.5, 0.1])
+    pp, jp = O.decision_fusion(a, b, "identity")
+    assert torch.allclose(pp, torch.tensor([[0.8, 0.2], [0.1, 0.9]])) and torch.allclose(jp, torch.tensor([[0.5, 0.5], [0.9, 0.1]]))
+    _, jp = O.decision_fusion(a, b, "noisy-or")
+    assert torch.allclose(jp[:, 1], torch.tensor([1 - 0.8 * 0.5, 1 - 0.1 * 0.9]))
+    _, jp = O.decision_fusion(a, b, "bayes")
+    want = torch.tensor([(0.1 + 1e-9) / (0.1 + 1e-9 + 0.8 * 0.5), (0.09 + 1e-9) / (0.09 + 1e-9 + 0.1 * 0.9)])
+    assert torch.allclose(jp[:, 1], want) and torch.allclose(jp.sum(-1), torch.ones(2))
+    with pytest.raises(ValueError):
+        O.decision_fusion(a, b, "mean")
+    cfg = O.M1Config(input_spatial_dims=(4, 32, 32), filters=(8, 16, 32, 64, 128), strides=README_STRIDES)
+    sh = O.cascade_param_shapes(cfg)
+    assert sh["stage1.core.conve0.kernel"] == (1, 3, 3, 3, 8) and sh["stage2.core.conve0.kernel"] == (1, 3, 3, 4, 8)
+    P = O.fixture_params(cfg, 7, shapes=sh)
+    g = torch.Generator().manual_seed(8)
+    x1, x2 = torch.randn(1, 4, 32, 32, 3, generator=g), torch.randn(1, 4, 32, 32, 3, generator=g)
+    o = O.m1_cascaded_forward(P, cfg, x1, x2, "noisy-or")
+    s1 = O.m1_forward(O._sub(P, "stage1."), cfg, x1)["y_softmax"]
+    s2 = O.m1_forward(O._sub(P, "stage2."), O.stage2_config(cfg), torch.cat([s1[..., :1], x2], -1))["y_softmax"]
+    assert torch.allclose(o["detection_1"][..., 1], s1[..., 1]) and torch.allclose(o["detection_2"][..., 1], 1 - (1 - s1[..., 1]) * (1 - s2[..., 1]))
+    det = O.detect_model_outputs(P, cfg, (x1, x2), cascaded="noisy-or")
+    assert torch.equal(det[0], s1[..., :2]) and torch.allclose(det[1], s2[..., :2])
+
+
 def test_kat8_finite_difference_gradients_of_blocks():
     cfg = O.M1Config(input_spatial_dims=(2, 8, 8), filters=(8, 16, 32, 64, 128), strides=README_STRIDES)
     P = {k: v.double().requires_grad_(True) for k, v in O.fixture_params(cfg, 1).items()}
