@@ -644,6 +644,8 @@ class _LatentSample(torch.autograd.Function):
     @staticmethod
     def forward(ctx, ml, eps, mode):
         _req(ml, eps)
+        if eps is not None and eps.dtype != ml.dtype:
+            raise RuntimeError(f"latent_sample: eps is {eps.dtype}, the head output {ml.dtype} (the kernel reads both as one type)")
         N = int(ml.shape[0]); Lc = int(ml.shape[-1]) // 2
         V = ml.numel() // (N * 2 * Lc)
         z = torch.empty((*ml.shape[:-1], Lc), dtype=ml.dtype, device=ml.device)

@@ -186,108 +186,144 @@ class M1Core(nn.Module):
         plist = lambda mods: [p for m in mods for p in m.parameters()]
         return [(prefix + "a", plist(dec)), (prefix + "b", plist(mid)), (prefix + "c", plist(enc))]
 
-    def forward(self, inputs, prob_mean=False, prob_z_q=None, eps: Optional[List[torch.Tensor]] = None, mark=None):
+    def forward(self, inputs, prob_mean=False, prob_z_q=None, eps: Optional[List[torch.Tensor]] = None, mark=None,
+                need: str = "full"):
         """M1Core.__call__(inputs, prob_mean, prob_z_q) (networks.py:568-759).  ``inputs`` is an NDHWC tensor or
         a list of tensors forming a virtual channel concat.  ``eps``: optional injected N(0,1) draws per level
         (MultivariateNormalDiag.sample() = mu + sigma*eps).  ``mark(group, tensor)``: data-parallel runs register the
-        autograd nodes that close an exchange group of this core (see exchange_groups)."""
+        autograd nodes that close an exchange group of this core (see exchange_groups).
+
+        ``need="latents"`` (probabilistic cores): the caller consumes only ``prob_distributions`` / ``prob_used_latents``
+        -- three of the four core passes of a training step (networks.py:348,349,351: both posterior passes and the prior
+        pass that feeds the KL term).  Layers no requested output depends on are then not evaluated, exactly what the
+        Keras functional model does when it prunes the graph to its outputs (networks.py:89-90): with latents (3,2,1,0) that
+        is everything past the res2 latent head -- att1, att0, sersd2/1, sersp1/0, the res1/res0 transposed convs --
+        i.e. most of the res0/res1 work of the pass.  Results are identical; the pruned layers receive no gradient either way."""
         outputs = {}
         mark = mark if mark is not None else (lambda *_: None)
         S = self.strides
+        fo = ops.fanout
+        prob, dense = self.probabilistic, self.dense_skip
+        n_lat = 0
+        if prob:
+            while n_lat < 4 and self.prob_latent_dims[n_lat] != 0:
+                n_lat += 1
+        full = not (prob and need == "latents")
+        n_up = 4 if full else max(0, n_lat - 1)       # latent-decoder levels evaluated (dec_hi + sersp)
+        n_stage = 4 if full else n_up                  # decoder concat stages evaluated (uconv3_ ... uconv0_)
+        # SE gates are functions of parameters only: one launch for the blocks this pass will run
+        used = [self.serse1, self.serse2, self.serse3, self.serse4]
+        used += [m for k, m in enumerate((self.sersd3, self.sersd2, self.sersd1)) if n_stage > k + 1]
+        if not prob:
+            used.append(self.sersd0)
+        else:
+            used += [getattr(self, "sersp" + str(3 - lvl)) for lvl in range(n_up)]
+        SEResNetBottleNeck.precompute_gates(used)
         # networks.py:574-576
-        SEResNetBottleNeck.precompute_gates([m for m in self.children() if isinstance(m, SEResNetBottleNeck)
-                                             and not (self.probabilistic and m is self.sersd0)])
         x_raw, s0 = self.conve0(inputs, stats=True)
         x = self.norme0(x_raw, 0.1, s0)
         # A tensor read by several layers is handed out as one alias per reader (ops.fanout): the readers' backward kernels
         # then sum its gradient in one buffer instead of autograd adding per-reader gradient tensors.
-        fo = ops.fanout
-        prob, dense = self.probabilistic, self.dense_skip
+        split = lambda t, on: fo(t, 2) if on else (t, None)
         # networks.py:579-582 (dropout fused into the block's last kernel)
-        x_e, x_a = fo(x, 2)
+        x_e, x_a = split(x, n_stage > 3)
         conv1 = self.serse1(x_e, dropout=self.drope1)
-        c1_e, c1_a = fo(conv1, 2)
+        c1_e, c1_a = split(conv1, n_stage > 2)
         conv2 = self.serse2(c1_e, dropout=self.drope2)
-        c2_e, c2_a = fo(conv2, 2)
+        c2_e, c2_a = split(conv2, n_stage > 1)
         conv3 = self.serse3(c2_e, dropout=self.drope3)
         mark("b", conv3)
-        c3_e, c3_a = fo(conv3, 2)
+        c3_e, c3_a = split(conv3, n_stage > 0)
         convm = self.serse4(c3_e, dropout=self.drope4)
-        m_use = list(fo(convm, 7 if prob else 5))          # 4 gates, convtd3 (+ latent head and latent decoder of level 3)
+        # readers of convm: the gates, convtd3 (+ the coarsest latent head and latent decoder)
+        n_m = n_stage + (1 if n_stage > 0 else 0) + ((1 if n_lat > 0 else 0) + (1 if n_up > 0 else 0) if prob else 0)
+        m_use = list(fo(convm, n_m)) if n_m > 1 else [convm]
         # networks.py:585-588
-        # the four gates depend on the encoder only: each runs on a side stream of its own, next to the decoder (ops.branch),
+        # the gates depend on the encoder only: each runs on a side stream of its own, next to the decoder (ops.branch),
         # and is joined where the decoder first reads it
         dvc = convm.device
-        with ops.branch(dvc, 1) as br3:
-            att_conv3, _ = self.att3(c3_a, m_use.pop())
-        with ops.branch(dvc, 2) as br2:
-            att_conv2, _ = self.att2(c2_a, m_use.pop())
-        with ops.branch(dvc, 3) as br1:
-            att_conv1, _ = self.att1(c1_a, m_use.pop())
-        with ops.branch(dvc, 4) as br0:
-            att_conv0, _ = self.att0(x_a, m_use.pop())
-        # networks.py:591-597
-        deconv3 = self.convtd3(m_use.pop())
-        mark("a", deconv3)
-        if dense:
-            deconv3, d3 = fo(deconv3, 2)
-            deconv3_up1, d3u1 = fo(self.convtd3_up1(d3), 2)
-            deconv3_up2, d3u2 = fo(self.convtd3_up2(d3u1), 2)
-            deconv3_up3 = self.convtd3_up3(d3u2)
-        br3.join(att_conv3)
-        uconv3_ = [deconv3, att_conv3]
-        if prob:
-            uconv3_, uconv3_p = (list(v) for v in zip(*[fo(t, 2) for t in uconv3_]))
-        uconv3 = self.sersd3(uconv3_, dropout=self.dropd3)
+        att_conv = [None] * 4
+        brs = [None] * 4
+        for k, (gate, src) in enumerate(((self.att3, c3_a), (self.att2, c2_a), (self.att1, c1_a), (self.att0, x_a))):
+            if n_stage > k:
+                with ops.branch(dvc, 1 + k) as br:
+                    att_conv[k], _ = gate(src, m_use.pop())
+                brs[k] = br
+        att_conv3, att_conv2, att_conv1, att_conv0 = att_conv
         heads_on = self.deep_supervision and not prob
-        u3_up, u3_h = fo(uconv3, 2) if heads_on else (uconv3, uconv3)
-        # networks.py:600-607
-        deconv2 = self.convtd2(u3_up)
-        if dense:
-            deconv2, d2 = fo(deconv2, 2)
-            deconv2_up1, d2u1 = fo(self.convtd2_up1(d2), 2)
-            deconv2_up2 = self.convtd2_up2(d2u1)
-            br2.join(att_conv2)
-            uconv2_ = [deconv2, deconv3_up1, att_conv2]
-        else:
-            br2.join(att_conv2)
-            uconv2_ = [deconv2, att_conv2]
-        if prob:
-            uconv2_, uconv2_p = (list(v) for v in zip(*[fo(t, 2) for t in uconv2_]))
-        uconv2 = self.sersd2(uconv2_, dropout=self.dropd2)
-        u2_up, u2_h = fo(uconv2, 2) if heads_on else (uconv2, uconv2)
-        # networks.py:610-616
-        deconv1 = self.convtd1(u2_up)
-        if dense:
-            deconv1, d1 = fo(deconv1, 2)
-            deconv1_up1 = self.convtd1_up1(d1)
-            br1.join(att_conv1)
-            uconv1_ = [deconv1, deconv2_up1, deconv3_up2, att_conv1]
-        else:
-            br1.join(att_conv1)
-            uconv1_ = [deconv1, att_conv1]
-        if prob:
-            uconv1_, uconv1_p = (list(v) for v in zip(*[fo(t, 2) for t in uconv1_]))
-        uconv1 = self.sersd1(uconv1_, dropout=self.dropd1)
-        u1_up, u1_h = fo(uconv1, 2) if heads_on else (uconv1, uconv1)
-        # networks.py:619-624
-        deconv0 = self.convtd0(u1_up)
-        if dense:
-            br0.join(att_conv0)
-            uconv0_ = [deconv0, deconv1_up1, deconv2_up2, deconv3_up3, att_conv0]
-        else:
-            br0.join(att_conv0)
-            uconv0_ = [deconv0, att_conv0]
-
         cat_c = lambda ts: sum(int(t.shape[-1]) for t in ts)
         self._shapes = {"inputs": tuple(inputs.shape) if isinstance(inputs, torch.Tensor) else (*inputs[0].shape[:-1], cat_c(inputs)),
-                        "x": tuple(x.shape), "att_conv0": tuple(att_conv0.shape), "conv1": tuple(conv1.shape),
-                        "att_conv1": tuple(att_conv1.shape), "conv2": tuple(conv2.shape), "att_conv2": tuple(att_conv2.shape),
-                        "conv3": tuple(conv3.shape), "att_conv3": tuple(att_conv3.shape), "convm": tuple(convm.shape),
-                        "uconv3_": (*deconv3.shape[:-1], cat_c(uconv3_)), "uconv3": tuple(uconv3.shape),
-                        "uconv2_": (*deconv2.shape[:-1], cat_c(uconv2_)), "uconv2": tuple(uconv2.shape),
-                        "uconv1_": (*deconv1.shape[:-1], cat_c(uconv1_)), "uconv1": tuple(uconv1.shape),
-                        "uconv0_": (*deconv0.shape[:-1], cat_c(uconv0_))}
+                        "x": tuple(x.shape), "conv1": tuple(conv1.shape), "conv2": tuple(conv2.shape), "conv3": tuple(conv3.shape),
+                        "convm": tuple(convm.shape)}
+        for k, a in enumerate(att_conv):
+            if a is not None:
+                self._shapes[f"att_conv{3 - k}"] = tuple(a.shape)
+        uconv3_p = uconv2_p = uconv1_p = uconv0_ = None
+        u1_h = u2_h = u3_h = None
+        # networks.py:591-597
+        if n_stage > 0:
+            deconv3 = self.convtd3(m_use.pop())
+            mark("a", deconv3)
+            if dense and n_stage > 1:
+                deconv3, d3 = fo(deconv3, 2)
+                deconv3_up1 = self.convtd3_up1(d3)
+                if n_stage > 2:
+                    deconv3_up1, d3u1 = fo(deconv3_up1, 2)
+                    deconv3_up2 = self.convtd3_up2(d3u1)
+                    if n_stage > 3:
+                        deconv3_up2, d3u2 = fo(deconv3_up2, 2)
+                        deconv3_up3 = self.convtd3_up3(d3u2)
+            brs[0].join(att_conv3)
+            uconv3_ = [deconv3, att_conv3]
+            self._shapes["uconv3_"] = (*deconv3.shape[:-1], cat_c(uconv3_))
+            if prob and n_stage > 1:
+                uconv3_, uconv3_p = (list(v) for v in zip(*[fo(t, 2) for t in uconv3_]))
+            elif prob:
+                uconv3_p = uconv3_
+        if n_stage > 1:
+            uconv3 = self.sersd3(uconv3_, dropout=self.dropd3)
+            self._shapes["uconv3"] = tuple(uconv3.shape)
+            u3_up, u3_h = fo(uconv3, 2) if heads_on else (uconv3, uconv3)
+            # networks.py:600-607
+            deconv2 = self.convtd2(u3_up)
+            if dense and n_stage > 2:
+                deconv2, d2 = fo(deconv2, 2)
+                deconv2_up1 = self.convtd2_up1(d2)
+                if n_stage > 3:
+                    deconv2_up1, d2u1 = fo(deconv2_up1, 2)
+                    deconv2_up2 = self.convtd2_up2(d2u1)
+            brs[1].join(att_conv2)
+            uconv2_ = [deconv2, deconv3_up1, att_conv2] if dense else [deconv2, att_conv2]
+            self._shapes["uconv2_"] = (*deconv2.shape[:-1], cat_c(uconv2_))
+            if prob and n_stage > 2:
+                uconv2_, uconv2_p = (list(v) for v in zip(*[fo(t, 2) for t in uconv2_]))
+            elif prob:
+                uconv2_p = uconv2_
+        if n_stage > 2:
+            uconv2 = self.sersd2(uconv2_, dropout=self.dropd2)
+            self._shapes["uconv2"] = tuple(uconv2.shape)
+            u2_up, u2_h = fo(uconv2, 2) if heads_on else (uconv2, uconv2)
+            # networks.py:610-616
+            deconv1 = self.convtd1(u2_up)
+            if dense and n_stage > 3:
+                deconv1, d1 = fo(deconv1, 2)
+                deconv1_up1 = self.convtd1_up1(d1)
+            brs[2].join(att_conv1)
+            uconv1_ = [deconv1, deconv2_up1, deconv3_up2, att_conv1] if dense else [deconv1, att_conv1]
+            self._shapes["uconv1_"] = (*deconv1.shape[:-1], cat_c(uconv1_))
+            if prob and n_stage > 3:
+                uconv1_, uconv1_p = (list(v) for v in zip(*[fo(t, 2) for t in uconv1_]))
+            elif prob:
+                uconv1_p = uconv1_
+        if n_stage > 3:
+            uconv1 = self.sersd1(uconv1_, dropout=self.dropd1)
+            self._shapes["uconv1"] = tuple(uconv1.shape)
+            u1_up, u1_h = fo(uconv1, 2) if heads_on else (uconv1, uconv1)
+            # networks.py:619-624
+            deconv0 = self.convtd0(u1_up)
+            brs[3].join(att_conv0)
+            uconv0_ = [deconv0, deconv1_up1, deconv2_up2, deconv3_up3, att_conv0] if dense else [deconv0, att_conv0]
+            self._shapes["uconv0_"] = (*deconv0.shape[:-1], cat_c(uconv0_))
 
         # In the probabilistic training graph nothing downstream of sersd0/logits reaches an output
         # (networks.py:389 takes an empty slice; SURVEY 7.3): the deterministic head is skipped there.
@@ -303,12 +339,14 @@ class M1Core(nn.Module):
             skips = [uconv3_p, uconv2_p, uconv1_p, uconv0_]
             feats = convm
             zi = 0
-            for lvl in range(4):
+            for lvl in range(4 if full else n_lat):
                 sfx = str(3 - lvl)
                 Ld = self.prob_latent_dims[lvl]
+                up_on = lvl < n_up
                 if lvl == 0:
-                    f_ml, f_up = m_use.pop(), m_use.pop()
-                elif Ld != 0:
+                    f_ml = m_use.pop() if Ld != 0 else None
+                    f_up = m_use.pop() if up_on else None
+                elif Ld != 0 and up_on:
                     f_ml, f_up = fo(feats, 2)
                 else:
                     f_ml = f_up = feats
@@ -320,26 +358,26 @@ class M1Core(nn.Module):
                         z = ops.latent_sample(ml, None, True)
                     else:                                                          # networks.py:647
                         e = eps[zi] if eps is not None else torch.randn((*ml.shape[:-1], Ld), device=ml.device,
-                                                                         dtype=torch.float32).to(ml.dtype)
-                        z = ops.latent_sample(ml, e.contiguous(), False)
+                                                                         dtype=torch.float32)
+                        z = ops.latent_sample(ml, e.to(ml.dtype).contiguous(), False)   # draws in the activation storage type
                     zi += 1
                     distributions.append(ml)
                     used_latents.append(z)
+                    if lvl == 0 and prob_z_q is None:
+                        mark("a", ml)           # reached through z (otherwise only through a KL term: the caller marks it)
+                    if not up_on:
+                        break                   # the finest latent head of a latents-only pass: nothing further is consumed
                     up = getattr(self, "dec_hi" + sfx)([z, f_up])                  # networks.py:652-653
-                    if lvl == 0:
-                        mark("a", up)
-                        if prob_z_q is None:
-                            mark("a", ml)       # reached through z (otherwise only through a KL term: the caller marks it)
                 else:
                     up = getattr(self, "dec_hi" + sfx)(f_up)                       # networks.py:655-656
-                    if lvl == 0:
-                        mark("a", up)
+                if lvl == 0:
+                    mark("a", up)
                 feats = getattr(self, "sersp" + sfx)([up, *skips[lvl]], dropout=getattr(self, "dropp" + sfx))
                 if lvl < 3:
                     ds_ops.append(feats)                                           # networks.py:657,681,705
             outputs['prob_distributions'] = distributions      # raw (mu|logsigma) maps; sigma = exp(clip(logsigma,+-0.1))
             outputs['prob_used_latents'] = used_latents
-            outputs['prob_decoder_features'] = feats
+            outputs['prob_decoder_features'] = feats if full else None
 
         # networks.py:737-757
         if y__ is not None:
@@ -470,9 +508,12 @@ class M1Net(nn.Module):
                 # every pass marks the nodes that close its exchange groups: a group is sent once ALL its marks of the step
                 # have fired, i.e. after the backward of the last pass through that core, whatever order autograd picks
                 mq, mp = self._marker("posterior."), self._marker("prior.")
-                q_sample = self.posterior(post_in, prob_mean=False, prob_z_q=None, eps=eps_q, mark=mq)  # networks.py:348
-                q_mean = self.posterior(post_in, prob_mean=True, prob_z_q=None, mark=mq)                 # networks.py:349
-                p_z_q = self.prior(image, prob_mean=False, prob_z_q=q_sample['prob_used_latents'], mark=mp)   # networks.py:351
+                # three of the four passes feed only latents / distributions into the outputs: they skip what nothing reads
+                # (M1Core.forward need="latents"; the first call prints the reference's full stage summary if asked to)
+                lat = "full" if (self.show_summary and not self._summarised) else "latents"
+                q_sample = self.posterior(post_in, prob_mean=False, prob_z_q=None, eps=eps_q, mark=mq, need=lat)   # networks.py:348
+                q_mean = self.posterior(post_in, prob_mean=True, prob_z_q=None, mark=mq, need=lat)                  # networks.py:349
+                p_z_q = self.prior(image, prob_mean=False, prob_z_q=q_sample['prob_used_latents'], mark=mp, need=lat)   # networks.py:351
                 p_z_qm = self.prior(image, prob_mean=False, prob_z_q=q_mean['prob_used_latents'], mark=mp)    # networks.py:352
                 train_conv = self.stitch(p_z_qm['prob_decoder_features'])                               # networks.py:356
                 kl = None                                                                               # networks.py:373-385

@@ -103,8 +103,9 @@ def test_standalone_detect_model_matches_oracle(dev, prob):
     P = O.fixture_params(cfg, seed=50)
     x = rnd((2, *DIMS, 3), 51)
     ep = [rnd((2, *s), 52 + i) for i, s in enumerate(O.latent_shapes(cfg))] if prob else None
+    # (the oracle's m1 graph also evaluates the training passes; their draws do not reach the inference output)
     want = O.detect_model_outputs({k: v.double() for k, v in P.items()}, cfg, x.double(),
-                                  eps_p=[e.double() for e in ep] if prob else None)
+                                  eps_q=[e.double() for e in ep] if prob else None, eps_p=[e.double() for e in ep] if prob else None)
     m = build_m1(cfg, dev)
     from util import load_params_into
     load_params_into(m, P)

@@ -35,7 +35,7 @@ FULL_FP32 = [
     ("fp32 res0 conv4 64->32 (2 members)", (1, 20, 160, 160), [32, 32], 32, (1, 3, 3), (1, 1, 1), False, (7, 10, 40, 64, 96, 136)),
     ("fp32 res2 256->128 3x3x3", (1, 20, 40, 40), [128, 128], 128, (3, 3, 3), (1, 1, 1), False, (8, 14, 10, 26, 16, 40)),
     ("fp32 res1->res2 64->128 stride (1,2,2)", (1, 20, 80, 80), [64], 128, (3, 3, 3), (1, 2, 2), False, (4, 10, 20, 60, 0, 40)),
-    ("fp32 convT res2->res1 128->64", (1, 20, 40, 40), [128], 64, (3, 3, 3), (1, 2, 2), True, (5, 9, 10, 26, 0, 16)),
+    ("fp32 convT res2->res1 128->64", (1, 20, 40, 40), [128], 64, (3, 3, 3), (1, 2, 2), True, (4, 12, 10, 26, 0, 16)),
 ]
 
 
@@ -126,7 +126,7 @@ def test_full_size_conv_locality_and_adjointness(dev, case):
         terms = dyd * y_w2
         rhs, noise = float(terms.sum()), float(terms.pow(2).sum().sqrt()) * rnd_eps
         if pi == 0:
-            assert abs(lhs - rhs) < 5.0 * noise + 1e-6 * abs(rhs), f"{name}: <dW,W'> {lhs} vs <dy,conv(x;W')> {rhs} (noise {noise})"
+            assert abs(lhs - rhs) < 5.0 * noise + (1e-5 if fp32 else 1e-6) * abs(rhs), f"{name}: <dW,W'> {lhs} vs <dy,conv(x;W')> {rhs} (noise {noise})"
         else:
             assert abs(lhs - rhs) < (1e-4 if fp32 else 1e-2) * abs(lhs), f"{name}: <dW,dW c> {lhs} vs <dy,conv(x;dW c)> {rhs}"
     b2 = rnd((cout,), 7)
@@ -210,7 +210,7 @@ def test_full_size_c3_model_properties(dev):
     x[..., 2] = tgt[..., 1]
     x = x.to(dev)
     lat = [(5, 10, 10, 3), (10, 20, 20, 2), (20, 40, 40, 1)]
-    eps = [rnd((1, *s), 2 + i).to(dev) for i, s in enumerate(lat)]
+    eps = [rnd((1, *s), 2 + i).to(dev) for i, s in enumerate(lat)]          # fp32 draws: cast to the activation type by the model
     focal = PKG.losses.Focal(alpha=[0.75, 0.25], gamma=2.0).loss
 
     def step():
@@ -231,9 +231,14 @@ def test_full_size_c3_model_properties(dev):
     assert tuple(z["prob_train_conv"].shape) == (1, 20, 160, 160, 2)
     assert float((p1.sum(dim=-1) - 1.0).abs().max()) < 1e-5 and float(p1.min()) >= 0.0
     assert kl1 >= 0.0 and kl1 == kl1 and l1 > 0.0 and l1 == l1
+    # layers no training output depends on get no gradient (the Keras functional model prunes them): the
+    # deterministic head of both cores, and in the posterior -- it only supplies latents down to res2 -- everything past that head
     dead = ("sersd0.", ".logits.")
+    dead_post = ("att0.", "att1.", "sersd2.", "sersd1.", "sersp1.", "sersp0.", "convtd1", "convtd0.", "dec_hi1.", "dec_hi0.",
+                 "convtd3_up2.", "convtd3_up3.", "convtd2_up")
     for n, p in m.named_parameters():
-        if "stitch" not in n and any(d in n for d in dead):
+        is_dead = ("stitch" not in n and any(d in n for d in dead)) or ("posterior." in n and any(d in n for d in dead_post))
+        if is_dead:
             assert p.grad is None or float(p.grad.abs().max()) == 0.0, n
         else:
             assert p.grad is not None and bool(torch.isfinite(p.grad).all()), n
@@ -245,9 +250,11 @@ def test_full_size_c3_model_properties(dev):
 
 def test_full_size_c5_fp32_model_properties(dev):
     """C5 (BASELINE.json configs[4]): deterministic M1 at (32,256,256,3), fp32 -- App. A.1's stage shapes, parameter count,
-    output simplex, finite loss and gradients, bit-identical forward run to run; and LOCALITY of the whole network: the
-    probabilities in a window far from a perturbed input patch change only through the InstanceNorm statistics, i.e. by
-    orders of magnitude less than inside the patch's receptive field."""
+    output simplex, finite loss and gradients, bit-identical forward run to run; the backward pass is the derivative of the
+    forward pass at this size (central finite difference of the loss along a random direction of an ENCODER parameter, so the
+    whole decoder, the gates and the encoder's data-gradient chain are inside the check); and per-sample independence
+    (InstanceNorm is per sample: volume 0 of a batch of two gives the probabilities it gives alone -- the batch-sharding
+    contract at the largest size)."""
     dims = (32, 256, 256)
     m = _readme_m1(dev, dims, False, torch.float32)
     assert sum(p.numel() for p in m.parameters()) == 17_525_866
@@ -268,9 +275,19 @@ def test_full_size_c5_fp32_model_properties(dev):
     with torch.no_grad():
         p2 = m(x)
         assert torch.equal(p2, probs.detach())
-        x2 = x.clone()
-        x2[0, 2:6, 20:40, 20:40] += 1.0
-        p3 = m(x2)
-    d = (p3 - p2).abs()
-    near, far = float(d[0, 0:8, 10:50, 10:50].max()), float(d[0, 24:32, 180:256, 180:256].max())
-    assert near > 1e-4 and far < 0.2 * near, (near, far)
+        # directional derivative through the whole network
+        par = m.m1_model.core.serse2.norm3.beta
+        d = rnd(tuple(par.shape), 9).to(dev)
+        d = d / d.norm()
+        analytic = float((par.grad * d).sum())
+        eps = 2e-2
+        par.add_(eps * d); lp = float(focal(tgt, m(x)))
+        par.add_(-2 * eps * d); lm = float(focal(tgt, m(x)))
+        par.add_(eps * d)
+        fd = (lp - lm) / (2 * eps)
+        assert abs(fd - analytic) < 0.05 * abs(analytic) + 1e-3 * abs(float(loss)), (fd, analytic, float(loss))
+        # per-sample independence
+        x2 = torch.cat([x, rnd((1, *dims, 3), 2).to(dev)], dim=0).contiguous()
+        pb = m(x2)
+        assert float((pb[0] - p2[0]).abs().max()) < 1e-4
+        assert float((pb[1] - p2[0]).abs().max()) > 1e-2

@@ -8,7 +8,7 @@ import pytest
 import torch
 
 from oracle import m1_oracle as O
-from util import C1_FILTERS, C1_STRIDES, PKG, build_m1, load_params_into, ops, rel_err, rel_l2, rnd
+from util import C1_FILTERS, C1_STRIDES, PKG, activation_pattern, build_m1, load_params_into, ops, rel_err, rel_l2, rnd
 
 pytestmark = pytest.mark.gpu
 
@@ -27,12 +27,16 @@ def _ball_target(shape, seed):
     return torch.from_numpy(t)
 
 
-def _oracle_loss_and_grads(cfg, P, x, tgt, eps=None):
-    """Oracle train loss and parameter gradients in fp64 (the truth) and in fp32 (the conditioning yardstick)."""
+def _oracle_loss_and_grads(cfg, P, x, tgt, eps=None, masks=None):
+    """Oracle train loss and parameter gradients in fp64 (the truth) and in fp32 (the conditioning yardstick), both on
+    the LeakyReLU activation pattern ``masks`` of the HIP run under test (util.activation_pattern ->
+    O.forced_activation_pattern; None = the oracle's own pattern)."""
+    import contextlib
     out = {}
     for dt in (torch.float64, torch.float32):
         Pd = {k: v.to(dt).requires_grad_(True) for k, v in P.items()}
-        loss, parts, o = O.train_loss(Pd, cfg, x.to(dt), tgt.to(dt), eps_q=[e.to(dt) for e in eps] if eps else None)
+        with (O.forced_activation_pattern(masks) if masks is not None else contextlib.nullcontext()):
+            loss, parts, o = O.train_loss(Pd, cfg, x.to(dt), tgt.to(dt), eps_q=[e.to(dt) for e in eps] if eps else None)
         loss.backward()
         out[dt] = (loss.detach(), o, {k: (v.grad.double() if v.grad is not None else None) for k, v in Pd.items()})
     return out
@@ -40,16 +44,24 @@ def _oracle_loss_and_grads(cfg, P, x, tgt, eps=None):
 
 def _check_grads(m, g64, g32, strip=("m1_model.",)):
     """Every parameter gradient of the HIP path (fp32) against the fp64 oracle: relative L2 error below
-    max(1e-3, 3 x the error the fp32 CPU evaluation of the same graph makes ON THAT PARAMETER) -- SURVEY.md 8(c)'s 1e-3,
-    relaxed per parameter only where fp32 arithmetic itself cannot do better (with random fixture weights the loss is
-    dominated by a few saturated voxels and some early-encoder gradients are ill-conditioned in fp32: the fp32 oracle is
-    1.6e-2 off on one of them).  There is no global floor: a well-conditioned gradient must meet 1e-3.
+    ``max(1e-3, 3 e32[k])`` -- SURVEY.md 8(c)'s 1e-3, relaxed PER PARAMETER only where fp32 arithmetic itself cannot do
+    better: e32[k] is the error the fp32 CPU evaluation of the same graph makes on that parameter (sums with heavy
+    cancellation, e.g. a bias gradient in front of a sigmoid gate).  There is no global floor: a well-conditioned gradient
+    must meet 1e-3.
+
+    Both oracle evaluations run on the activation pattern of the HIP run (O.forced_activation_pattern).  The gradient is
+    discontinuous at LeakyReLU kinks and an fp32 pre-activation carries an error of up to 1e-5: with ~10^7 activations a
+    handful lie closer to zero than that and take the other branch.  Measured on the README-filter probabilistic model:
+    ONE such element (fp64 |pre| = 1.3e-6, HIP value 1.3e-5 away with the other sign) in prior.sersd2.norm1's 16k-element
+    tensor moved that layer's d(beta) by 5.5e-3 and its conv kernel gradient by 4.5e-3 while every kernel involved
+    agreed with the oracle to 1e-6 on its own inputs.  On the common pattern the comparison measures kernels, not kinks.
+
     Parameters whose true gradient is (numerically) zero -- a conv bias feeding an InstanceNorm is mean-subtracted away;
     sersd0/logits of a probabilistic core reach no loss -- are checked on the absolute scale of the largest
     gradient."""
     gmax = max(float(g.norm()) for g in g64.values() if g is not None)
     num = den = num32 = 0.0
-    bad = []
+    bad, relaxed = [], 0
     for k, p in m.named_parameters():
         name = k
         for pre in strip:
@@ -62,13 +74,15 @@ def _check_grads(m, g64, g32, strip=("m1_model.",)):
         e = float((gh - go).norm() / go.norm())
         e32 = float((g32[name] - go).norm() / go.norm()) if g32[name] is not None else 0.0
         num += float((gh - go).norm()) ** 2; den += float(go.norm()) ** 2
-        num32 += float((g32[name] - go).norm()) ** 2 if g32[name] is not None else 0.0
+        num32 += (e32 * float(go.norm())) ** 2
         tol = max(1e-3, 3.0 * e32)
+        relaxed += tol > 1e-3
         if e > tol:
             bad.append((name, e, e32))
     assert not bad, sorted(bad, key=lambda t: -t[1] / max(1e-3, 3 * t[2]))[:8]
     # whole-gradient-vector error: 1e-3, or twice what the fp32 oracle achieves when that is worse
     assert (num / den) ** 0.5 < max(1e-3, 2.0 * (num32 / den) ** 0.5), ((num / den) ** 0.5, (num32 / den) ** 0.5)
+    return relaxed
 
 
 def test_native_library_is_the_loaded_compute_path(dev):
@@ -84,12 +98,12 @@ def test_c1_deterministic_forward_and_gradients(dev, deep_sup):
     P = O.fixture_params(cfg, seed=0)
     x = rnd((1, 8, 64, 64, 3), 1)
     tgt = _ball_target((1, 8, 64, 64), 2)
-    orc = _oracle_loss_and_grads(cfg, P, x, tgt)
-    loss_o, o, g64 = orc[torch.float64]
-
     m = build_m1(cfg, dev)
     load_params_into(m, P)
-    probs = m(x.to(dev))
+    with activation_pattern(m) as ap:
+        probs = m(x.to(dev))
+    orc = _oracle_loss_and_grads(cfg, P, x, tgt, masks=ap.masks)
+    loss_o, o, g64 = orc[torch.float64]
     logits = m.references.m1_model['logits']
     assert rel_err(logits, o["logits"]) < 1e-3 and float((logits.double().cpu() - o["logits"]).abs().max()) < 1e-3
     assert float((probs.double().cpu() - o["y_softmax"]).abs().max()) < 1e-3
@@ -110,12 +124,12 @@ def test_c1_probabilistic_forward_kl_and_gradients(dev):
     tgt = _ball_target((1, 8, 64, 64), 5)
     x[..., 2] = tgt[..., 1]                                    # label channel, like data_generators.py:82
     eps = [rnd((1, *s), 6 + i) for i, s in enumerate(O.latent_shapes(cfg))]
-    orc = _oracle_loss_and_grads(cfg, P, x, tgt, eps)
-    loss_o, o, g64 = orc[torch.float64]
-
     m = build_m1(cfg, dev)
     load_params_into(m, P)
-    det, kl = m(x.to(dev), eps_q=[e.to(dev) for e in eps])
+    with activation_pattern(m) as ap:
+        det, kl = m(x.to(dev), eps_q=[e.to(dev) for e in eps])
+    orc = _oracle_loss_and_grads(cfg, P, x, tgt, eps, masks=ap.masks)
+    loss_o, o, g64 = orc[torch.float64]
     assert det.shape[-1] == 2                                  # KAT-10: deep supervision is a no-op in prob. mode
     tc = m.references.m1_model['prob_train_conv']
     assert float((tc.double().cpu() - o["prob_train_conv"]).abs().max()) < 1e-3

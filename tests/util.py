@@ -55,3 +55,57 @@ def build_m1(cfg, device, dtype=torch.float32, **extra):
     m = m.to(device)
     m.set_compute_dtype(dtype)
     return m
+
+
+class activation_pattern:
+    """``with activation_pattern(model) as ap: model(x)`` records, through forward hooks only, which branch every LeakyReLU
+    of the HIP path took: ``ap.masks[tag][k]`` = boolean CPU tensor of the k-th pass through the core that owns the layer,
+    tags as in oracle.m1_oracle.lrelu (``{core}.{layer}.norm1|norm2|out``, ``{core}.norme0``, ``{core}.att{i}.f``).  Fed to
+    ``O.forced_activation_pattern`` the oracle evaluates the gradient of the same piecewise-linear branch."""
+
+    def __init__(self, model):
+        self.model, self.masks, self.handles, self.passes = model, {}, [], {}
+
+    def _tag(self, name):
+        for a, b in (("m1_model.", ""), ("m1_stage1.", "stage1."), ("m1_stage2.", "stage2.")):
+            if name.startswith(a):
+                return b + name[len(a):]
+        return name
+
+    def __enter__(self):
+        NB, NW = PKG.unets.network_blocks, PKG.unets.networks
+        cores = {}
+
+        def add(tag, m):
+            core = next(c for c in sorted(cores, key=len, reverse=True) if tag.startswith(c + "."))
+            self.masks.setdefault(tag, {})[self.passes[core]] = m.cpu()
+        for name, mod in self.model.named_modules():
+            tag = self._tag(name)
+            if isinstance(mod, NW.M1Core):
+                cores[tag] = mod
+                self.passes[tag] = -1
+                self.handles.append(mod.register_forward_pre_hook(lambda m_, i_, tag=tag: self.passes.__setitem__(tag, self.passes[tag] + 1)))
+            elif isinstance(mod, NB.InstanceNormalization):
+                def h(mod, inp, out, tag=tag):
+                    if len(inp) > 1 and float(inp[1]) == 0.1:           # (x, slope, stats): LeakyReLU(0.1) follows
+                        add(tag, out.detach() >= 0)
+                self.handles.append(mod.register_forward_hook(h))
+            elif isinstance(mod, NB.SEResNetBottleNeck):
+                self.handles.append(mod.register_forward_hook(lambda mod, inp, out, tag=tag: add(tag + ".out", out.detach() >= 0)))
+            elif isinstance(mod, NB.GridAttentionBlock3D):
+                st = {}
+                self.handles.append(mod.theta.register_forward_hook(lambda m_, i_, o_, st=st: st.__setitem__("theta", o_.detach())))
+                self.handles.append(mod.phi.register_forward_hook(lambda m_, i_, o_, st=st: st.__setitem__("phi", o_.detach())))
+
+                def hg(mod, inp, out, tag=tag, st=st):
+                    th, ph = st["theta"].float(), st["phi"].float()
+                    for ax in range(3):
+                        ph = ph.repeat_interleave(th.shape[1 + ax] // ph.shape[1 + ax], dim=1 + ax)
+                    add(tag + ".f", (th + ph) >= 0)                     # the same fp32 add the gate kernel makes
+                self.handles.append(mod.register_forward_hook(hg))
+        return self
+
+    def __exit__(self, *exc):
+        for h in self.handles:
+            h.remove()
+        return False

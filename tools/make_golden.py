@@ -87,6 +87,21 @@ def readme_goldens(out):
             del P
         loss, o, g64 = res[torch.float64]
         g32 = res[torch.float32][2]
+        # kink conditioning (tests/test_hip_model._check_grads): fp64 gradients at (1 +- 1e-5 u) around weights and input
+        gen = torch.Generator().manual_seed(777)
+        P0 = O.fixture_params(cfg, seed=seed)
+        u = {k: torch.randn(v.shape, generator=gen, dtype=torch.float64) for k, v in P0.items()}
+        ux = torch.randn(x.shape, generator=gen, dtype=torch.float64)
+        cond = {k: 0.0 for k in P0}
+        for sgn in (1.0, -1.0):
+            Pp = {k: (v.double() * (1 + sgn * 1e-5 * u[k])).requires_grad_(True) for k, v in P0.items()}
+            lp, _, _ = O.train_loss(Pp, cfg, torch.from_numpy(x).double() * (1 + sgn * 1e-5 * ux), torch.from_numpy(tgt).double(),
+                                    eps_q=[torch.from_numpy(e).double() for e in eps] if prob else None)
+            lp.backward()
+            for k, v in Pp.items():
+                if v.grad is not None and g64[k] is not None and float(g64[k].norm()) > 0:
+                    cond[k] = max(cond[k], float((v.grad - g64[k]).norm() / g64[k].norm()))
+            del Pp
         names = list(g64)
         summ, e32 = np.zeros((len(names), 2)), np.zeros(len(names))
         for i, n in enumerate(names):
@@ -101,7 +116,8 @@ def readme_goldens(out):
         extra = dict(train_conv=o["prob_train_conv"].detach().float().numpy(), kl=np.float64(o["prob_kl"].detach()),
                      eps0=eps[0], eps1=eps[1], eps2=eps[2]) if prob else dict(logits=o["logits"].detach().float().numpy())
         np.savez_compressed(os.path.join(out, f"readme_{kind}.npz"), seed=seed, x=x, target=tgt, loss=np.float64(loss),
-                            grad_names=np.array(names), grad_summary=summ, grad_e32=e32, **extra)
+                            grad_names=np.array(names), grad_summary=summ, grad_e32=e32,
+                            grad_cond=np.array([cond[n] for n in names]), **extra)
 
 
 def keras_layout_fixture(out):
