@@ -5,6 +5,8 @@
 // into the same output.
 #include "common.h"
 #include "gather.h"
+#include <stdio.h>
+#include <stdlib.h>
 
 static inline bool desc_ok(const m1_conv_desc_t* d) {
     if (!(d && d->N > 0 && d->D > 0 && d->H > 0 && d->W > 0 && d->Cin > 0 && d->Cout > 0 && d->kd > 0 && d->kh > 0 &&
@@ -42,6 +44,17 @@ static inline double conv_macs(const m1_conv_desc_t* d, bool T) {
 static inline double conv_bytes(const m1_conv_desc_t* d, bool T) {
     Geo g = T ? convT_geo(d) : conv_geo(d);
     return ((double)d->N * d->D * d->H * d->W * d->Cin + (double)d->N * g.OD * g.OH * g.OW * d->Cout) * esz(d->dtype);
+}
+
+// M1_PROF_DETAIL=1: the profiler hooks (prof.hip) key conv records by geometry, not only by entry point
+struct ProfName { char s[48]; };
+static ProfName prof_name(const char* fam, const m1_conv_desc_t* d) {
+    static int detail = -1; if (detail < 0) { const char* e = getenv("M1_PROF_DETAIL"); detail = e ? atoi(e) : 0; }
+    ProfName n; 
+    if (!detail) { snprintf(n.s, sizeof(n.s), "%s", fam); return n; }
+    snprintf(n.s, sizeof(n.s), "%s %dx%dx%d c%d>%d k%d%d%d s%d%d%d m%d", fam, d->D, d->H, d->W, d->Cin, d->Cout, d->kd, d->kh, d->kw,
+             d->sd, d->sh, d->sw, d->nsrc);
+    return n;
 }
 
 extern "C" const char* m1_status_name(int s) {
@@ -181,7 +194,8 @@ __global__ void __launch_bounds__(256) stem_fold_kernel(const float* __restrict_
 // share it (the library keeps no device memory of its own).  Large weight tensors use the atomic path: no scratch.
 static size_t wgrad_rx_bytes(const m1_conv_desc_t* d) {
     const size_t nw = (size_t)d->kd * d->kh * d->kw * d->Cin * d->Cout, stride = (nw > (size_t)8 * d->Cout * d->kd * d->kh * d->kw ? nw : (size_t)8 * d->Cout * d->kd * d->kh * d->kw) + d->Cout;
-    if (nw > ((size_t)1 << 18)) return 0;
+    static long long maxw = -1; if (maxw < 0) { const char* e = getenv("M1_WG_RX_MAXW"); maxw = e ? atoll(e) : (1ll << 20); }
+    if ((long long)nw > maxw) return 0;
     size_t b = 512 * stride * sizeof(float);
     if (b > ((size_t)96 << 20)) b = (size_t)96 << 20;
     return align256(b);
@@ -249,7 +263,7 @@ extern "C" int m1_pack_batch(const void* const* jobs_dev, const int* block_prefi
 extern "C" int m1_conv3d_fwd(const m1_conv_desc_t* d, const float* w, const float* bias, void* y, float* stats, void* ws,
                              int ws_packed, void* stream) {
     if (!desc_ok(d) || !w || !y) return M1_ERR_BAD_ARG;
-    M1ProfScope ps("conv3d_fwd", 2.0 * conv_macs(d, false), conv_bytes(d, false), (hipStream_t)stream);
+    M1ProfScope ps(prof_name("conv3d_fwd", d).s, 2.0 * conv_macs(d, false), conv_bytes(d, false), (hipStream_t)stream);
     FwdGroups fg;
     if (ws && fwd_groups(d, false, &fg)) {
         size_t woff = 0, total = 0;
@@ -282,7 +296,7 @@ extern "C" int m1_conv3d_fwd(const m1_conv_desc_t* d, const float* w, const floa
 extern "C" int m1_convT3d_fwd(const m1_conv_desc_t* d, const float* w, const float* bias, void* y, void* ws, int ws_packed,
                               void* stream) {
     if (!desc_ok(d) || !w || !y) return M1_ERR_BAD_ARG;
-    M1ProfScope ps("convT3d_fwd", 2.0 * conv_macs(d, true), conv_bytes(d, true), (hipStream_t)stream);
+    M1ProfScope ps(prof_name("convT3d_fwd", d).s, 2.0 * conv_macs(d, true), conv_bytes(d, true), (hipStream_t)stream);
     return run_gather(fwd_spec(d, true, w, bias, y), ws, ws_packed, (hipStream_t)stream);
 }
 static int dgrad_common(const m1_conv_desc_t* d, bool T, const float* w, const void* dy, void* const* dx, const int* accumulate,
@@ -302,13 +316,13 @@ static int dgrad_common(const m1_conv_desc_t* d, bool T, const float* w, const v
 extern "C" int m1_conv3d_dgrad(const m1_conv_desc_t* d, const float* w, const void* dy, void* const* dx, const int* accumulate,
                                void* ws, int ws_packed, void* stream) {
     if (!desc_ok(d) || !w || !dy || !dx) return M1_ERR_BAD_ARG;
-    M1ProfScope ps("conv3d_dgrad", 2.0 * conv_macs(d, false), conv_bytes(d, false), (hipStream_t)stream);
+    M1ProfScope ps(prof_name("conv3d_dgrad", d).s, 2.0 * conv_macs(d, false), conv_bytes(d, false), (hipStream_t)stream);
     return dgrad_common(d, false, w, dy, dx, accumulate, ws, ws_packed, (hipStream_t)stream);
 }
 extern "C" int m1_convT3d_dgrad(const m1_conv_desc_t* d, const float* w, const void* dy, void* const* dx, const int* accumulate,
                                 void* ws, int ws_packed, void* stream) {
     if (!desc_ok(d) || !w || !dy || !dx) return M1_ERR_BAD_ARG;
-    M1ProfScope ps("convT3d_dgrad", 2.0 * conv_macs(d, true), conv_bytes(d, true), (hipStream_t)stream);
+    M1ProfScope ps(prof_name("convT3d_dgrad", d).s, 2.0 * conv_macs(d, true), conv_bytes(d, true), (hipStream_t)stream);
     return dgrad_common(d, true, w, dy, dx, accumulate, ws, ws_packed, (hipStream_t)stream);
 }
 
@@ -316,8 +330,11 @@ extern "C" int m1_convT3d_dgrad(const m1_conv_desc_t* d, const float* w, const v
 #include <stdlib.h>
 static bool tf_wanted(const WgradSpec& g) {
     static int maxc = -1;
-    if (maxc < 0) { const char* e = getenv("M1_TF_MAXC"); maxc = e ? atoi(e) : 64; }
+    if (maxc < 0) { const char* e = getenv("M1_TF_MAXC"); maxc = e ? atoi(e) : 128; }
     if (m1_tf64_wgrad_supported(g)) return true;
+    // 32x32 channel tiles re-read dY once per 32 input channels and X once per 32 output channels: a win while the OUTPUT side
+    // is narrow (conv1 of an SE block: F/4 <= 32 channels -- 512->32 at res2: 1.70 -> 1.08 ms per step), a loss beyond (512->128: 2x slower)
+    if (g.CA > 64 && g.CB > 32) return false;
     return g.CA <= maxc && g.CB <= maxc && m1_tf_wgrad_supported(g);
 }
 static bool m1_tf_wgrad_supported_stem(const m1_conv_desc_t* d, const Geo& q) {
@@ -405,12 +422,12 @@ static int wgrad_common(const m1_conv_desc_t* d, bool T, const void* dy, float* 
 extern "C" int m1_conv3d_wgrad(const m1_conv_desc_t* d, const void* dy, float* dw, float* db, void* ws, int accumulate,
                                void* stream) {
     if (!desc_ok(d) || !dy || !dw) return M1_ERR_BAD_ARG;
-    M1ProfScope ps("conv3d_wgrad", 2.0 * conv_macs(d, false), conv_bytes(d, false), (hipStream_t)stream);
+    M1ProfScope ps(prof_name("conv3d_wgrad", d).s, 2.0 * conv_macs(d, false), conv_bytes(d, false), (hipStream_t)stream);
     return wgrad_common(d, false, dy, dw, db, ws, (hipStream_t)stream, accumulate);
 }
 extern "C" int m1_convT3d_wgrad(const m1_conv_desc_t* d, const void* dy, float* dw, float* db, void* ws, int accumulate,
                                 void* stream) {
     if (!desc_ok(d) || !dy || !dw) return M1_ERR_BAD_ARG;
-    M1ProfScope ps("convT3d_wgrad", 2.0 * conv_macs(d, true), conv_bytes(d, true), (hipStream_t)stream);
+    M1ProfScope ps(prof_name("convT3d_wgrad", d).s, 2.0 * conv_macs(d, true), conv_bytes(d, true), (hipStream_t)stream);
     return wgrad_common(d, true, dy, dw, db, ws, (hipStream_t)stream, accumulate);
 }

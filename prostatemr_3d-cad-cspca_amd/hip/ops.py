@@ -850,7 +850,7 @@ def prof_reset():
 
 
 def prof_read():
-    arr = (L.m1_prof_rec_t * 64)()
-    n = L.load().m1_prof_read(arr, 64)
+    arr = (L.m1_prof_rec_t * 512)()
+    n = L.load().m1_prof_read(arr, 512)
     return [dict(name=arr[i].name.decode(), total_ms=arr[i].total_ms, flops=arr[i].flops, bytes=arr[i].bytes,
                  launches=arr[i].launches) for i in range(n)]

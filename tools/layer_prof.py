@@ -1,0 +1,24 @@
+"""Per-layer hipEvent timing of one train step (M1_PROF_DETAIL=1: conv records keyed by geometry).
+usage: M1_PROF_DETAIL=1 python tools/layer_prof.py [C3|C2] [batch]   (side-stream branches off: every kernel alone on the GPU)"""
+import os, sys
+os.environ["M1_PROF_DETAIL"] = "1"
+os.environ.setdefault("M1_STREAMS", "0")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
+import torch, importlib
+import bench as B
+pkg = importlib.import_module("prostatemr_3d-cad-cspca_amd"); ops = pkg.hip.ops
+wl = sys.argv[1] if len(sys.argv) > 1 else "C3"
+class A: pass
+a = A(); a.batch = int(sys.argv[2]) if len(sys.argv) > 2 else None; a.dtype = None; a.dropout = 0.5; a.warmup = 2; a.steps = 2; a.no_graph = True; a.prof_steps = 3
+dev = torch.device("cuda:0"); torch.cuda.set_device(0)
+ctx = dict(pkg=pkg, ops=ops, dev=dev, world=1, rank=0, backend="nccl", dist_on=False)
+out = B.run_workload(a, wl, ctx, want_roofline=True, want_cpu=False)
+r = out["roofline"]["all_kernels_ms_per_step"]
+tot = sum(r.values())
+print(f"{wl}: {out['ms_per_step']:.2f} ms/step eager; sum of families {tot:.2f} ms")
+fam = {}
+for k, v in r.items():
+    fam[k.split(" ")[0]] = fam.get(k.split(" ")[0], 0) + v
+print("  ".join(f"{k} {v:.2f}" for k, v in sorted(fam.items(), key=lambda t: -t[1])))
+for k, v in sorted(r.items(), key=lambda t: -t[1])[:70]:
+    print(f"{v:8.3f} ms  {k}")
