@@ -189,15 +189,20 @@ __global__ void __launch_bounds__(256) stem_fold_kernel(const float* __restrict_
     }
 }
 
-// Scratch for per-split partial copies of a SMALL weight gradient (+ bias sums): up to 512 copies, at most 96 MB.  It lives in
-// the caller's wgrad workspace -- one region per call, so weight gradients that run concurrently on different streams never
-// share it (the library keeps no device memory of its own).  Large weight tensors use the atomic path: no scratch.
+// Scratch for the per-split partial copies of a weight gradient (+ bias sums): compact copies of ONE concat member's block
+// ([tap][C_member][Cout] + Cout floats), up to 512 of them, at most 64 MB.  It lives in the caller's wgrad workspace -- one region
+// per call, so weight gradients that run concurrently on different streams never share it (the library keeps no device memory
+// of its own).  All weight-gradient kernels fold copies in a fixed order instead of using floating-point atomics.
 static size_t wgrad_rx_bytes(const m1_conv_desc_t* d) {
-    const size_t nw = (size_t)d->kd * d->kh * d->kw * d->Cin * d->Cout, stride = (nw > (size_t)8 * d->Cout * d->kd * d->kh * d->kw ? nw : (size_t)8 * d->Cout * d->kd * d->kh * d->kw) + d->Cout;
-    static long long maxw = -1; if (maxw < 0) { const char* e = getenv("M1_WG_RX_MAXW"); maxw = e ? atoll(e) : (1ll << 20); }
-    if ((long long)nw > maxw) return 0;
+    const size_t taps = (size_t)d->kd * d->kh * d->kw;
+    size_t cmax = 8;                                           // (the padded stem runs as an 8-channel member)
+    for (int i = 0; i < d->nsrc; ++i) if ((size_t)d->src[i].C > cmax) cmax = d->src[i].C;
+    const size_t other = cmax > (size_t)d->Cout ? cmax : (size_t)d->Cout;      // (transposed conv: the roles of the two sides swap)
+    const size_t stride = taps * cmax * d->Cout + other;
     size_t b = 512 * stride * sizeof(float);
-    if (b > ((size_t)96 << 20)) b = (size_t)96 << 20;
+    static long long cap = -1; if (cap < 0) { const char* e = getenv("M1_WG_RX_MB"); cap = (e ? atoll(e) : 64) << 20; }
+    if (b > (size_t)cap) b = (size_t)cap;
+    if (b < 2 * stride * sizeof(float)) b = 2 * stride * sizeof(float);
     return align256(b);
 }
 

@@ -205,7 +205,7 @@ __global__ void __launch_bounds__(256) wgrad_mfma_kernel(WgP p) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int b = b0 + wn * (TB / 2) + j * 16 + fr;
-            if (b < p.CB) { if (Rx) Rx[p.rx_bias + b + p.b_off] = accb[j][0]; else atomicAdd(p.bsum + b + p.b_off, accb[j][0]); }
+            if (b < p.CB) { if (Rx) Rx[p.rx_bias + b] = accb[j][0]; else atomicAdd(p.bsum + b + p.b_off, accb[j][0]); }
         }
     }
     // D[i = a][j = b]: lane holds a = 4*fs + r, b = fr
@@ -219,7 +219,7 @@ __global__ void __launch_bounds__(256) wgrad_mfma_kernel(WgP p) {
                 const int a = a0 + wm * (TA / 2) + i * 16 + fs * 4 + r;
                 if (a < p.CA && b < p.CB) {
                     const long long idx = (long long)tap * p.RT + (long long)(a + p.a_off) * p.RSA + (b + p.b_off);
-                    if (Rx) Rx[idx] = acc[i][j][r]; else atomicAdd(p.R + idx, acc[i][j][r]);
+                    if (Rx) Rx[((long long)tap * p.CA + a) * p.CB + b] = acc[i][j][r]; else atomicAdd(p.R + idx, acc[i][j][r]);
                 }
             }
         }
@@ -249,12 +249,21 @@ static int launch_wg(WgP p, hipStream_t st) {
     splits = cdiv_ll(TV, vps);
     p.vox_per_split = vps;
     dim3 grid(aTiles * bTiles, taps, (unsigned)splits);
-    // partial copies instead of atomics when the member's weight block is small and many splits would contend for it
+    // Partial copies instead of atomics: every voxel split stores its tile into its own compact copy ([tap][a][b] of THIS member +
+    // CB bias sums) and m1_wg_rx_finish folds the copies in a fixed order -- no floating-point atomics, so the weight gradient is
+    // bit-reproducible run to run (M1_WG_DET=0 restores the atomic path for large blocks).  Fewer splits when the caller's
+    // scratch holds fewer copies; one split needs none (a single add per element and launch is ordered by the stream).
     bool partial = false;
-    const long long stride = p.rx_stride;                      // = nw + nb (set by the caller) or 0
-    if (stride > 0 && (long long)taps * p.CA * p.CB <= 32768 && splits >= 24 && splits * stride * 4 <= (64ll << 20)) {
-        float* rx = m1_wg_rx_get(p, splits * stride);
-        if (rx) { p.Rx = rx; partial = true; }
+    const long long stride = (long long)taps * p.CA * p.CB + p.CB;
+    p.rx_stride = stride; p.rx_bias = (long long)taps * p.CA * p.CB;
+    static int det = -1; if (det < 0) { const char* e = getenv("M1_WG_DET"); det = e ? atoi(e) : 1; }
+    const bool small = (long long)taps * p.CA * p.CB <= 32768 && splits >= 24;
+    if (splits >= 2 && (det || small)) {
+        long long fit = p.rx ? p.rx_floats / stride : 0;
+        if (fit >= 2) {
+            if (splits > fit) { splits = fit; vps = cdiv_ll(cdiv_ll(TV, splits), KS) * KS; splits = cdiv_ll(TV, vps); p.vox_per_split = vps; grid.z = (unsigned)splits; }
+            if (splits >= 2) { p.Rx = p.rx; partial = true; }
+        } else if (det) { splits = 1; vps = cdiv_ll(TV, KS) * KS; p.vox_per_split = vps; grid.z = 1; }
     }
     if (!partial) { p.Rx = nullptr; }
     static int xr = -1; if (xr < 0) { const char* e = getenv("M1_WG_XCD"); xr = e ? atoi(e) : 1; }

@@ -231,7 +231,7 @@ __global__ void __launch_bounds__(256) wgrad_tap_kernel(TapP p) {
 #pragma unroll
     for (int y = 0; y < SUBB; ++y) {
         const int b = b0 + (wb * SUBB + y) * 16 + i;
-        if (do_bsum && g == 0 && b < p.CB) { if (Rx) Rx[p.rx_bias + b + p.b_off] = accb[y][0]; else atomicAdd(p.bsum + b + p.b_off, accb[y][0]); }
+        if (do_bsum && g == 0 && b < p.CB) { if (Rx) Rx[p.rx_bias + b] = accb[y][0]; else atomicAdd(p.bsum + b + p.b_off, accb[y][0]); }
 #pragma unroll
         for (int x = 0; x < SUBA; ++x)
 #pragma unroll
@@ -239,7 +239,7 @@ __global__ void __launch_bounds__(256) wgrad_tap_kernel(TapP p) {
                 const int a = a0 + (wa * SUBA + x) * 16 + g * 4 + r;
                 if (a < p.CA && b < p.CB) {
                     const long long idx = (long long)tap * p.RT + (long long)(a + p.a_off) * p.RSA + (b + p.b_off);
-                    if (Rx) Rx[idx] = acc[x][y][r]; else atomicAdd(p.R + idx, acc[x][y][r]);
+                    if (Rx) Rx[((long long)tap * p.CA + a) * p.CB + b] = acc[x][y][r]; else atomicAdd(p.R + idx, acc[x][y][r]);
                 }
             }
     }
@@ -274,9 +274,10 @@ int m1_tap_wgrad(const WgradSpec& g, long long nw, int nb, hipStream_t st) {
     TapP p;
     if (!tap_plan(g, p)) return M1_ERR_UNSUPPORTED;
     const int TA = tap_side(g.CA), TB = tap_side(g.CB);
-    const int aTiles = (g.CA + TA - 1) / TA; p.bTiles = (g.CB + TB - 1) / TB;
-    const int taps = g.kd * g.kh * g.kw, ctiles = aTiles * p.bTiles;
+    const int taps = g.kd * g.kh * g.kw;
     static int tgt = -1; if (tgt < 0) { const char* e = getenv("M1_WG_TAP_BLOCKS"); tgt = e ? atoi(e) : 512; }
+    const int aTiles = (g.CA + TA - 1) / TA; p.bTiles = (g.CB + TB - 1) / TB;
+    const int ctiles = aTiles * p.bTiles;
     // round DOWN: 2 blocks per CU x 256 CUs = 512 slots; one block more than that is a second round for its whole XCD
     static int rdn = -1; if (rdn < 0) { const char* e = getenv("M1_WG_FLOOR"); rdn = e ? atoi(e) : 1; }
     long long nsplit = rdn ? tgt / ((long long)ctiles * taps) : (tgt + (long long)ctiles * taps - 1) / ((long long)ctiles * taps);
@@ -302,11 +303,17 @@ int m1_tap_wgrad(const WgradSpec& g, long long nw, int nb, hipStream_t st) {
             if (ndone < 4) done[ndone++] = (const void*)kern;
         }
     }
-    // M1_WG_TAP_COPIES=1: partial copies + fold instead of atomics (measured: kernel 89 -> 76 us, fold +19 us: off)
-    static int cp = -1; if (cp < 0) { const char* e = getenv("M1_WG_TAP_COPIES"); cp = e ? atoi(e) : 0; }
-    const long long stride = nw + nb;
-    p.Rx = nullptr; p.rx_stride = stride; p.rx_bias = nw;
-    if (cp && nw > 0 && nsplit >= 2 && nsplit * stride * 4 <= (256ll << 20)) p.Rx = m1_wg_rx_get(g, nsplit * stride);
+    // partial copies + fixed-order fold instead of atomics (compact per-member copies, see wgrad_mfma.hip): bit-reproducible
+    // weight gradients; M1_WG_DET=0 restores the atomic path
+    static int det = -1; if (det < 0) { const char* e = getenv("M1_WG_DET"); det = e ? atoi(e) : 1; }
+    const long long stride = (long long)taps * g.CA * g.CB + g.CB;
+    p.Rx = nullptr; p.rx_stride = stride; p.rx_bias = (long long)taps * g.CA * g.CB;
+    if (det && nsplit >= 2) {
+        long long fit = g.rx ? g.rx_floats / stride : 0;
+        if (fit >= 2) { if (nsplit > fit) nsplit = fit; p.Rx = g.rx; }
+        else nsplit = 1;
+        p.nsplit = (int)nsplit;
+    }
     static int xr = -1; if (xr < 0) { const char* e = getenv("M1_WG_XCD"); xr = e ? atoi(e) : 1; }
     p.ctiles = ctiles; p.taps = taps; p.xcd_total = 0;
     if (xr && taps > 1) {
@@ -316,6 +323,6 @@ int m1_tap_wgrad(const WgradSpec& g, long long nw, int nb, hipStream_t st) {
         hipLaunchKernelGGL(kern, dim3(ctiles, (unsigned)nsplit, taps), dim3(256), smem, st, p);
     }
     int rc = m1_check_launch(); if (rc) return rc;
-    if (p.Rx) return m1_wg_rx_finish(p.Rx, stride, (int)nsplit, g, nw, st);
+    if (p.Rx) return m1_wg_rx_finish(p.Rx, stride, (int)nsplit, g, p.rx_bias, st);
     return M1_OK;
 }

@@ -259,13 +259,13 @@ __global__ void __launch_bounds__(256) wgrad_tf_kernel(TfP p) {
     // (copy = K-split index); tf_finish_kernel adds the copies.
     float* Rx = p.Rx + (long long)blockIdx.y * p.rx_stride;
     const int b = b0 + tb * 16 + i;
-    if (do_bsum && g == 0 && b < p.CB) Rx[p.rx_bias + b + p.b_off] = accb[0];
+    if (do_bsum && g == 0 && b < p.CB) Rx[p.rx_bias + b] = accb[0];
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int a = a0 + ta * 16 + g * 4 + r;
-            if ((t % kparts) == part && a < p.CA && b < p.CB) Rx[(long long)t * p.RT + (long long)(a + p.a_off) * p.RSA + (b + p.b_off)] = acc[t][r];
+            if ((t % kparts) == part && a < p.CA && b < p.CB) Rx[((long long)t * p.CA + a) * p.CB + b] = acc[t][r];
         }
 #endif
 }
@@ -439,7 +439,7 @@ __global__ void __launch_bounds__(256, 2) wgrad_tf64_kernel(TfP p) {
 #pragma unroll
     for (int sbi = 0; sbi < 2; ++sbi) {
         const int b = b0 + (2 * wb + sbi) * 16 + i;
-        if (do_bsum && g == 0 && b < p.CB) Rx[p.rx_bias + b + p.b_off] = accb[sbi][0];
+        if (do_bsum && g == 0 && b < p.CB) Rx[p.rx_bias + b] = accb[sbi][0];
 #pragma unroll
         for (int t = 0; t < NT9; ++t)
 #pragma unroll
@@ -448,7 +448,7 @@ __global__ void __launch_bounds__(256, 2) wgrad_tf64_kernel(TfP p) {
                 for (int r = 0; r < 4; ++r) {
                     const int a = a0 + (2 * wa + sa) * 16 + g * 4 + r;
                     if (a < p.CA && b < p.CB)
-                        Rx[(long long)(kd0 * NT9 + t) * p.RT + (long long)(a + p.a_off) * p.RSA + (b + p.b_off)] = acc[t][sa][sbi][r];
+                        Rx[((long long)(kd0 * NT9 + t) * p.CA + a) * p.CB + b] = acc[t][sa][sbi][r];
                 }
     }
 }
@@ -463,11 +463,12 @@ __global__ void __launch_bounds__(256) tf_finish_kernel(TfFin f) {
     const long long n = (long long)f.NT * f.CA * f.CB;
     const int e = threadIdx.x % f.EL, y = threadIdx.x / f.EL, YL = 256 / f.EL;
     const long long i = (long long)blockIdx.x * f.EL + e;
-    long long idx = 0; float* dst = nullptr;
+    const long long idx = i;                              // the copies are compact: [tap][a][b] of this member, then CB bias sums
+    float* dst = nullptr;
     if (i < n) {
         const int b = (int)(i % f.CB); const long long q = i / f.CB; const int a = (int)(q % f.CA), t = (int)(q / f.CA);
-        idx = (long long)t * f.RT + (long long)(a + f.a_off) * f.RSA + b + f.b_off; dst = f.R + idx;
-    } else if (i < n + f.nb) { idx = f.rx_bias + (i - n) + f.b_off; dst = f.bsum + (i - n) + f.b_off; }
+        dst = f.R + (long long)t * f.RT + (long long)(a + f.a_off) * f.RSA + b + f.b_off;
+    } else if (i < n + f.nb) { dst = f.bsum + (i - n) + f.b_off; }
     float s = 0.f;
     if (dst) {
 #pragma unroll 8
@@ -479,6 +480,30 @@ __global__ void __launch_bounds__(256) tf_finish_kernel(TfFin f) {
         for (int q = 1; q < YL; ++q) s += red[q * f.EL + e];
         *dst += s;
     }
+}
+
+// Few copies of a large block (deep layers: 2..16 voxel splits of a multi-MB weight block): one thread folds 4 consecutive
+// elements over all copies with 16-byte loads -- bandwidth-bound, where the kernel above (built for hundreds of copies of a
+// small block) spends its time in 55k nearly empty blocks.  Same fixed order of additions.
+__global__ void __launch_bounds__(256) tf_finish_vec_kernel(TfFin f) {
+    const long long n = (long long)f.NT * f.CA * f.CB, n4 = n >> 2;
+    for (long long q = (long long)blockIdx.x * 256 + threadIdx.x; q < n4; q += (long long)gridDim.x * 256) {
+        const long long i = q << 2;
+        float4 s = *reinterpret_cast<const float4*>(f.Rx + i);
+        for (int c = 1; c < f.ncopies; ++c) {
+            const float4 v = *reinterpret_cast<const float4*>(f.Rx + (long long)c * f.stride + i);
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+        const int b = (int)(i % f.CB); const long long r = i / f.CB; const int a = (int)(r % f.CA), t = (int)(r / f.CA);
+        float* dst = f.R + (long long)t * f.RT + (long long)(a + f.a_off) * f.RSA + b + f.b_off;
+        dst[0] += s.x; dst[1] += s.y; dst[2] += s.z; dst[3] += s.w;
+    }
+    if (blockIdx.x == 0)
+        for (int j = threadIdx.x; j < f.nb; j += 256) {
+            float s = 0.f;
+            for (int c = 0; c < f.ncopies; ++c) s += f.Rx[(long long)c * f.stride + n + j];
+            f.bsum[j + f.b_off] += s;
+        }
 }
 
 static inline bool tf_chan_ok(int c) { return c == 8 || c == 16 || (c >= 32 && c % 32 == 0); }
@@ -553,6 +578,11 @@ bool m1_tf64_wgrad_supported(const WgradSpec& g) { TfP p; return tf64_plan(g, p)
 int m1_wg_rx_finish(float* rx, long long stride, int ncopies, const WgradSpec& g, long long nw, hipStream_t st) {
     TfFin f{rx, stride, ncopies, g.R, g.kd * g.kh * g.kw, g.CA, g.CB, g.RT, g.RSA, g.a_off, g.b_off, g.bsum, nw, g.bsum ? g.CB : 0, 32};
     const long long n = (long long)f.NT * f.CA * f.CB + f.nb;
+    if (ncopies <= 16 && f.CB % 4 == 0 && n >= (1 << 16)) {
+        long long blocks = (n / 4 + 255) / 256; if (blocks > 4096) blocks = 4096;
+        hipLaunchKernelGGL(tf_finish_vec_kernel, dim3((unsigned)blocks), dim3(256), 0, st, f);
+        return m1_check_launch();
+    }
     while (f.EL > 4 && n / f.EL < 128) f.EL >>= 1;           // small blocks of R: more lane rows per element, more blocks
     hipLaunchKernelGGL(tf_finish_kernel, dim3((unsigned)((n + f.EL - 1) / f.EL)), dim3(256), 0, st, f);
     return m1_check_launch();
@@ -570,14 +600,15 @@ int m1_tf_wgrad(const WgradSpec& g, long long nw, int nb, hipStream_t st) {
     static int tgt = -1; if (tgt < 0) { const char* e = getenv("M1_TF_SPLIT"); tgt = e ? atoi(e) : 512; }
     long long nsplit = (tgt + ctiles - 1) / ctiles;          // ~2 blocks per CU
     if (big) nsplit = (tgt + ctiles * g.kd - 1) / (ctiles * g.kd);
-    const long long stride = nw + nb;
+    const long long nloc = (long long)g.kd * g.kh * g.kw * g.CA * g.CB;
+    const long long stride = nloc + g.CB;                      // compact copy of this member's block (+ bias sums)
     if (nsplit * stride * 4 > TF_MAX_COPY_BYTES) nsplit = TF_MAX_COPY_BYTES / (stride * 4);
     if (!g.rx || g.rx_floats < stride) return M1_ERR_WORKSPACE;
     if (nsplit * stride > g.rx_floats) nsplit = g.rx_floats / stride;      // as many copies as the caller's scratch holds
     if (nsplit > p.ntiles) nsplit = p.ntiles;
     if (nsplit < 1) return M1_ERR_UNSUPPORTED;
     p.nsplit = (int)nsplit;
-    p.Rx = g.rx; p.rx_stride = stride; p.rx_bias = nw;
+    p.Rx = g.rx; p.rx_stride = stride; p.rx_bias = nloc;
     const size_t smem = (size_t)p.stages * (p.a_bytes + p.b_bytes);
     dim3 grid(ctiles, (unsigned)nsplit, big ? g.kd : 1);
     const int kparts = 4 / ((g.CA > 16 ? 2 : 1) * (g.CB > 16 ? 2 : 1));
@@ -598,5 +629,5 @@ int m1_tf_wgrad(const WgradSpec& g, long long nw, int nb, hipStream_t st) {
     }
     hipLaunchKernelGGL(kern, grid, dim3(256), smem, st, p);
     int rc = m1_check_launch(); if (rc) return rc;
-    return m1_wg_rx_finish(p.Rx, stride, (int)nsplit, g, nw, st);
+    return m1_wg_rx_finish(p.Rx, stride, (int)nsplit, g, nloc, st);
 }
