@@ -175,6 +175,14 @@ class M1Core(nn.Module):
         self._shapes: Dict[str, tuple] = {}
 
     # ---------------------------------------------------------------------------------------------------------
+    def latent_shapes(self, dims):
+        """(D,H,W,L) of each latent z for an input of spatial size ``dims``: L_0 lives at res4, L_1 at res3, ... (networks.py:636-637)."""
+        res, cur = [], tuple(int(v) for v in dims)
+        for st in self.strides:
+            cur = tuple(_same_out(c, v) for c, v in zip(cur, st))
+            res.append(cur)
+        return [(*res[4 - lvl], Ld) for lvl, Ld in enumerate(self.prob_latent_dims) if Ld != 0]
+
     def exchange_groups(self, prefix: str):
         """[(key, [parameters])] in the order the weight gradients of this core complete during a backward pass (ddp.py):
         ``a`` decoder + latent branch + heads (closed by the backward of ``convtd3`` / ``dec_hi3``), ``b`` the four gates
@@ -187,7 +195,7 @@ class M1Core(nn.Module):
         return [(prefix + "a", plist(dec)), (prefix + "b", plist(mid)), (prefix + "c", plist(enc))]
 
     def forward(self, inputs, prob_mean=False, prob_z_q=None, eps: Optional[List[torch.Tensor]] = None, mark=None,
-                need: str = "full"):
+                need: str = "full", tail_from: Optional[int] = None):
         """M1Core.__call__(inputs, prob_mean, prob_z_q) (networks.py:568-759).  ``inputs`` is an NDHWC tensor or
         a list of tensors forming a virtual channel concat.  ``eps``: optional injected N(0,1) draws per level
         (MultivariateNormalDiag.sample() = mu + sigma*eps).  ``mark(group, tensor)``: data-parallel runs register the
@@ -198,7 +206,11 @@ class M1Core(nn.Module):
         pass that feeds the KL term).  Layers no requested output depends on are then not evaluated, exactly what the
         Keras functional model does when it prunes the graph to its outputs (networks.py:89-90): with latents (3,2,1,0) that
         is everything past the res2 latent head -- att1, att0, sersd2/1, sersp1/0, the res1/res0 transposed convs --
-        i.e. most of the res0/res1 work of the pass.  Results are identical; the pruned layers receive no gradient either way."""
+        i.e. most of the res0/res1 work of the pass.  Results are identical; the pruned layers receive no gradient either way.
+
+        ``tail_from=B`` (with ``need="full"``): the batch holds two passes of the reference stacked along the batch axis
+        (M1Net.forward) and only the samples ``[B:]`` need the full output: the "latents" part runs on the whole batch,
+        the layers behind it on the batch slice ``[B:]`` (a contiguous view: every op of the model is per sample)."""
         outputs = {}
         mark = mark if mark is not None else (lambda *_: None)
         S = self.strides
@@ -209,8 +221,14 @@ class M1Core(nn.Module):
             while n_lat < 4 and self.prob_latent_dims[n_lat] != 0:
                 n_lat += 1
         full = not (prob and need == "latents")
-        n_up = 4 if full else max(0, n_lat - 1)       # latent-decoder levels evaluated (dec_hi + sersp)
-        n_stage = 4 if full else n_up                  # decoder concat stages evaluated (uconv3_ ... uconv0_)
+        n_pr = max(0, n_lat - 1)                       # decoder stages / latent-decoder levels the latent heads depend on
+        n_up = 4 if full else n_pr                     # latent-decoder levels evaluated (dec_hi + sersp)
+        n_stage = 4 if full else n_pr                  # decoder concat stages evaluated (uconv3_ ... uconv0_)
+        tail = int(tail_from) if (full and prob and tail_from) else None
+        T = (lambda t: t[tail:]) if tail is not None else (lambda t: t)          # batch slice of the second stacked pass
+        tl = lambda k: tail is not None and k >= n_pr                              # stage / level k runs on the slice
+        # X(t, from_k, to_k): tensor produced at stage from_k, consumed at stage to_k
+        X = lambda t, a, b: T(t) if (tl(b) and not tl(a)) else t
         # SE gates are functions of parameters only: one launch for the blocks this pass will run
         used = [self.serse1, self.serse2, self.serse3, self.serse4]
         used += [m for k, m in enumerate((self.sersd3, self.sersd2, self.sersd1)) if n_stage > k + 1]
@@ -247,7 +265,7 @@ class M1Core(nn.Module):
         for k, (gate, src) in enumerate(((self.att3, c3_a), (self.att2, c2_a), (self.att1, c1_a), (self.att0, x_a))):
             if n_stage > k:
                 with ops.branch(dvc, 1 + k) as br:
-                    att_conv[k], _ = gate(src, m_use.pop())
+                    att_conv[k], _ = gate(X(src, -1, k), X(m_use.pop(), -1, k))
                 brs[k] = br
         att_conv3, att_conv2, att_conv1, att_conv0 = att_conv
         heads_on = self.deep_supervision and not prob
@@ -260,19 +278,19 @@ class M1Core(nn.Module):
                 self._shapes[f"att_conv{3 - k}"] = tuple(a.shape)
         uconv3_p = uconv2_p = uconv1_p = uconv0_ = None
         u1_h = u2_h = u3_h = None
-        # networks.py:591-597
+        # networks.py:591-597   (stage k = the concat uconv{3-k}_; X(t, a, b) slices a tensor made at stage a for a reader at stage b)
         if n_stage > 0:
-            deconv3 = self.convtd3(m_use.pop())
+            deconv3 = self.convtd3(X(m_use.pop(), -1, 0))
             mark("a", deconv3)
             if dense and n_stage > 1:
                 deconv3, d3 = fo(deconv3, 2)
-                deconv3_up1 = self.convtd3_up1(d3)
+                deconv3_up1 = self.convtd3_up1(X(d3, 0, 1))
                 if n_stage > 2:
                     deconv3_up1, d3u1 = fo(deconv3_up1, 2)
-                    deconv3_up2 = self.convtd3_up2(d3u1)
+                    deconv3_up2 = self.convtd3_up2(X(d3u1, 1, 2))
                     if n_stage > 3:
                         deconv3_up2, d3u2 = fo(deconv3_up2, 2)
-                        deconv3_up3 = self.convtd3_up3(d3u2)
+                        deconv3_up3 = self.convtd3_up3(X(d3u2, 2, 3))
             brs[0].join(att_conv3)
             uconv3_ = [deconv3, att_conv3]
             self._shapes["uconv3_"] = (*deconv3.shape[:-1], cat_c(uconv3_))
@@ -281,17 +299,17 @@ class M1Core(nn.Module):
             elif prob:
                 uconv3_p = uconv3_
         if n_stage > 1:
-            uconv3 = self.sersd3(uconv3_, dropout=self.dropd3)
+            uconv3 = self.sersd3([X(t, 0, 1) for t in uconv3_], dropout=self.dropd3)      # (its output feeds stage 1)
             self._shapes["uconv3"] = tuple(uconv3.shape)
             u3_up, u3_h = fo(uconv3, 2) if heads_on else (uconv3, uconv3)
             # networks.py:600-607
             deconv2 = self.convtd2(u3_up)
             if dense and n_stage > 2:
                 deconv2, d2 = fo(deconv2, 2)
-                deconv2_up1 = self.convtd2_up1(d2)
+                deconv2_up1 = self.convtd2_up1(X(d2, 1, 2))
                 if n_stage > 3:
                     deconv2_up1, d2u1 = fo(deconv2_up1, 2)
-                    deconv2_up2 = self.convtd2_up2(d2u1)
+                    deconv2_up2 = self.convtd2_up2(X(d2u1, 2, 3))
             brs[1].join(att_conv2)
             uconv2_ = [deconv2, deconv3_up1, att_conv2] if dense else [deconv2, att_conv2]
             self._shapes["uconv2_"] = (*deconv2.shape[:-1], cat_c(uconv2_))
@@ -300,14 +318,14 @@ class M1Core(nn.Module):
             elif prob:
                 uconv2_p = uconv2_
         if n_stage > 2:
-            uconv2 = self.sersd2(uconv2_, dropout=self.dropd2)
+            uconv2 = self.sersd2([X(t, 1, 2) for t in uconv2_], dropout=self.dropd2)
             self._shapes["uconv2"] = tuple(uconv2.shape)
             u2_up, u2_h = fo(uconv2, 2) if heads_on else (uconv2, uconv2)
             # networks.py:610-616
             deconv1 = self.convtd1(u2_up)
             if dense and n_stage > 3:
                 deconv1, d1 = fo(deconv1, 2)
-                deconv1_up1 = self.convtd1_up1(d1)
+                deconv1_up1 = self.convtd1_up1(X(d1, 2, 3))
             brs[2].join(att_conv1)
             uconv1_ = [deconv1, deconv2_up1, deconv3_up2, att_conv1] if dense else [deconv1, att_conv1]
             self._shapes["uconv1_"] = (*deconv1.shape[:-1], cat_c(uconv1_))
@@ -316,7 +334,7 @@ class M1Core(nn.Module):
             elif prob:
                 uconv1_p = uconv1_
         if n_stage > 3:
-            uconv1 = self.sersd1(uconv1_, dropout=self.dropd1)
+            uconv1 = self.sersd1([X(t, 2, 3) for t in uconv1_], dropout=self.dropd1)
             self._shapes["uconv1"] = tuple(uconv1.shape)
             u1_up, u1_h = fo(uconv1, 2) if heads_on else (uconv1, uconv1)
             # networks.py:619-624
@@ -350,6 +368,8 @@ class M1Core(nn.Module):
                     f_ml, f_up = fo(feats, 2)
                 else:
                     f_ml = f_up = feats
+                if up_on and tl(lvl) and not tl(lvl - 1):
+                    f_up = T(f_up)                     # the latent decoder continues on the slice; the head below still sees the whole batch
                 if Ld != 0:
                     ml = getattr(self, "mu_logsig" + sfx)(f_ml)                    # networks.py:639 (mu | logsigma)
                     if prob_z_q is not None:                                       # networks.py:645
@@ -367,12 +387,15 @@ class M1Core(nn.Module):
                         mark("a", ml)           # reached through z (otherwise only through a KL term: the caller marks it)
                     if not up_on:
                         break                   # the finest latent head of a latents-only pass: nothing further is consumed
+                    if tl(lvl) and z.shape[0] != f_up.shape[0]:
+                        z = T(z).contiguous()
                     up = getattr(self, "dec_hi" + sfx)([z, f_up])                  # networks.py:652-653
                 else:
                     up = getattr(self, "dec_hi" + sfx)(f_up)                       # networks.py:655-656
                 if lvl == 0:
                     mark("a", up)
-                feats = getattr(self, "sersp" + sfx)([up, *skips[lvl]], dropout=getattr(self, "dropp" + sfx))
+                feats = getattr(self, "sersp" + sfx)([up, *[X(t, lvl, lvl) if t.shape[0] == up.shape[0] else T(t) for t in skips[lvl]]],
+                                                     dropout=getattr(self, "dropp" + sfx))
                 if lvl < 3:
                     ds_ops.append(feats)                                           # networks.py:657,681,705
             outputs['prob_distributions'] = distributions      # raw (mu|logsigma) maps; sigma = exp(clip(logsigma,+-0.1))
@@ -441,6 +464,7 @@ class M1Net(nn.Module):
         self.show_summary = bool(summary)
         self._summarised = False
         self.grad_marker = None          # ddp.GradReducer.mark of a data-parallel run (M1.set_grad_marker)
+        self.stack_passes = True         # probabilistic training graph: 4 core passes as 2 stacked along the batch axis
         self.last: Dict[str, torch.Tensor] = {}
         common = dict(num_classes=num_classes, dropout_mode=dropout_mode, dropout_rate=dropout_rate, filters=filters,
                       strides=strides, kernel_sizes=kernel_sizes, se_reduction=se_reduction, att_sub_samp=att_sub_samp,
@@ -504,7 +528,38 @@ class M1Net(nn.Module):
             # tf.concat([image, label]): materialised when it is the few-channel network input (one 16-byte segment per voxel
             # lets the stem's weight gradient take the padded tap-fused path: 0.85 -> 0.15 ms per step), virtual otherwise
             post_in = torch.cat([image, label], dim=-1).contiguous() if C <= 8 else [image, label]
-            if train_outputs:
+            if train_outputs and self.stack_passes and not (self.show_summary and not self._summarised):
+                # The four training passes (networks.py:348,349,351,352) as TWO, stacked along the batch axis: every op of the
+                # model is per sample (InstanceNorm statistics, SE gate, dropout draw per element), so
+                #   posterior([x; x], eps = [eps; 0])        = [q_sample; q_mean]       (z = mu + sigma*0 = mu: the prob_mean pass)
+                #   prior([img; img], z = [z_sample; z_mean]) = [p_z_q; p_z_qm]
+                # with half the launches at twice the batch (a 2-volume batch leaves the deep levels with 1,000-8,000 voxels per
+                # launch).  Only p_z_qm needs the decoder features: the layers behind the latent heads run on the batch slice
+                # [B:] (M1Core.forward tail_from); the posterior passes and p_z_q are latents-only (need="latents").
+                B = int(image.shape[0])
+                mq, mp = self._marker("posterior."), self._marker("prior.")
+                dup = lambda t: torch.cat([t, t], dim=0)
+                post2 = dup(post_in) if isinstance(post_in, torch.Tensor) else [dup(t) for t in post_in]
+                lshape = self.posterior.latent_shapes(image.shape[1:4])
+                eps2 = []
+                for i, shp in enumerate(lshape):
+                    e = eps_q[i].to(torch.float32) if eps_q is not None else torch.randn((B, *shp), device=image.device, dtype=torch.float32)
+                    eps2.append(torch.cat([e, torch.zeros_like(e)], dim=0))
+                q = self.posterior(post2, prob_mean=False, prob_z_q=None, eps=eps2, mark=mq, need="latents")
+                p = self.prior(dup(image), prob_mean=False, prob_z_q=q['prob_used_latents'], mark=mp, need="full", tail_from=B)
+                train_conv = self.stitch(p['prob_decoder_features'])                                    # networks.py:356 (p_z_qm)
+                kl = None                                                                               # networks.py:373-385
+                for lvl, (qd, pd) in enumerate(zip(q['prob_distributions'], p['prob_distributions'])):
+                    k = ops.kl_mvn_diag(qd[:B], pd[:B])                                                 # (q_sample, p_z_q)
+                    kl = k if kl is None else kl + k
+                    if lvl == 0 and mp is not None:
+                        mp("a", pd)          # the prior's coarsest latent head is reached through its KL term only
+                outputs['prob_train_conv'] = train_conv
+                outputs['prob_kl'] = kl
+                outputs['_q_latents'] = [z[:B] for z in q['prob_used_latents']]
+                outputs['prob_softmax'] = ops.softmax_heads([train_conv], [(1, 1, 1)])
+                outputs['_heads'], outputs['_ups'] = [train_conv], [(1, 1, 1)]
+            elif train_outputs:
                 # (two lanes -- posterior mean -> prior -> logits next to posterior sample -> prior -> KL -- were measured: no gain,
                 # the full model is dominated by kernels that fill the GPU on their own; nested forks also break graph capture)
                 # every pass marks the nodes that close its exchange groups: a group is sent once ALL its marks of the step

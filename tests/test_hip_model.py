@@ -238,6 +238,44 @@ def test_forward_and_all_gradients_are_run_to_run_deterministic(dev, filters, dt
         assert all(torch.equal(a, b) for a, b in zip(pg, pg0))
 
 
+def test_stacked_passes_equal_the_four_separate_passes(dev):
+    """M1Net runs the four training passes of the probabilistic graph (networks.py:348,349,351,352) as two passes stacked
+    along the batch axis, the layers behind the latent heads on the batch slice that needs them.  Every op is per sample, so
+    logits, KL and every parameter gradient must equal the four separate (pruned) passes up to fp32 summation order (tile
+    and split boundaries move with the batch size; a LeakyReLU element within 1e-6 of its kink may take the other branch, which
+    moves a single layer's gradient by a few 1e-3 -- see _check_grads -- hence 5e-3 per parameter, 5e-4 on the whole vector)."""
+    cfg = O.M1Config(input_spatial_dims=(8, 32, 32), filters=C1_FILTERS, strides=C1_STRIDES, dense_skip=True, deep_supervision=True,
+                     probabilistic=True, prob_latent_dims=(3, 2, 1, 0))
+    m = build_m1(cfg, dev)
+    load_params_into(m, O.fixture_params(cfg, seed=7))
+    x = rnd((2, 8, 32, 32, 3), 8).to(dev)
+    eps = [rnd((2, *s), 9 + i).to(dev) for i, s in enumerate(O.latent_shapes(cfg))]
+    rw = rnd((2, 8, 32, 32, 2), 12).to(dev)
+
+    def run(stack):
+        m.m1_model.stack_passes = stack
+        for p in m.parameters():
+            p.grad = None
+        det, kl = m(x, eps_q=eps)
+        ((det * rw).sum() + 3.0 * kl.sum()).backward()
+        return (m.references.m1_model['prob_train_conv'].detach().clone(), float(kl),
+                {n: (p.grad.clone() if p.grad is not None else None) for n, p in m.named_parameters()})
+    tc1, kl1, g1 = run(True)
+    tc0, kl0, g0 = run(False)
+    m.m1_model.stack_passes = True
+    assert float((tc1 - tc0).abs().max()) < 2e-5 and abs(kl1 - kl0) < 1e-5 * max(1.0, abs(kl0))
+    gmax = max(float(g.norm()) for g in g0.values() if g is not None)
+    num = den = 0.0
+    for n in g0:
+        if g0[n] is None:
+            assert g1[n] is None or float(g1[n].abs().max()) == 0.0, n
+            continue
+        assert g1[n] is not None, n
+        assert float((g1[n] - g0[n]).norm()) < 5e-3 * max(float(g0[n].norm()), 1e-2 * gmax), n
+        num += float((g1[n] - g0[n]).norm()) ** 2; den += float(g0[n].norm()) ** 2
+    assert (num / den) ** 0.5 < 5e-4
+
+
 @pytest.mark.parametrize("prob", [False, True])
 def test_side_stream_branches_do_not_change_results(dev, prob):
     """ops.branch (SE shortcut / attention gates on side streams) only changes WHERE kernels run: outputs, input gradients and

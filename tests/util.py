@@ -76,15 +76,36 @@ class activation_pattern:
         NB, NW = PKG.unets.network_blocks, PKG.unets.networks
         cores = {}
 
+        stacked = set()          # cores whose two reference passes run stacked along the batch axis (M1Net.stack_passes)
+        for name, mod in self.model.named_modules():
+            if isinstance(mod, NW.M1Net) and mod.probabilistic and mod.stack_passes and not mod.show_summary:
+                stacked |= {self._tag(name + ".prior"), self._tag(name + ".posterior")}
+        batch = {}
+
         def add(tag, m):
             core = next(c for c in sorted(cores, key=len, reverse=True) if tag.startswith(c + "."))
-            self.masks.setdefault(tag, {})[self.passes[core]] = m.cpu()
+            m = m.cpu()
+            if core in stacked and self.passes[core] == 0:
+                # one stacked pass = the oracle's passes 0 and 1: [0:B] / [B:2B]; a tensor of the tail slice belongs to pass 1
+                B2 = batch[core]
+                if m.shape[0] == B2:
+                    self.masks.setdefault(tag, {})[0] = m[:B2 // 2]
+                    self.masks[tag][1] = m[B2 // 2:]
+                else:
+                    self.masks.setdefault(tag, {})[1] = m
+                return
+            k = self.passes[core] + (1 if core in stacked else 0)      # (a later separate pass, e.g. the inference sample, is pass 2)
+            self.masks.setdefault(tag, {})[k] = m
         for name, mod in self.model.named_modules():
             tag = self._tag(name)
             if isinstance(mod, NW.M1Core):
                 cores[tag] = mod
                 self.passes[tag] = -1
-                self.handles.append(mod.register_forward_pre_hook(lambda m_, i_, tag=tag: self.passes.__setitem__(tag, self.passes[tag] + 1)))
+                def pre(m_, i_, tag=tag):
+                    self.passes[tag] += 1
+                    t0 = i_[0][0] if isinstance(i_[0], (list, tuple)) else i_[0]
+                    batch[tag] = int(t0.shape[0])
+                self.handles.append(mod.register_forward_pre_hook(pre))
             elif isinstance(mod, NB.InstanceNormalization):
                 def h(mod, inp, out, tag=tag):
                     if len(inp) > 1 and float(inp[1]) == 0.1:           # (x, slope, stats): LeakyReLU(0.1) follows
