@@ -506,6 +506,38 @@ __global__ void __launch_bounds__(256) tf_finish_vec_kernel(TfFin f) {
         }
 }
 
+// Many copies (tens to hundreds of voxel splits): a block owns 256 consecutive elements, its 4 waves take every 4th copy with
+// 16-byte loads (1 KB contiguous per wave and copy), fold through LDS in wave order, one store.  Fixed order, coalesced.
+__global__ void __launch_bounds__(256) tf_finish_wide_kernel(TfFin f) {
+    __shared__ float4 red[4][64];
+    const long long n = (long long)f.NT * f.CA * f.CB;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const long long i = ((long long)blockIdx.x * 64 + lane) << 2;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (i < n) {
+#pragma unroll 4
+        for (int c = w; c < f.ncopies; c += 4) {
+            const float4 v = *reinterpret_cast<const float4*>(f.Rx + (long long)c * f.stride + i);
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+    }
+    red[w][lane] = s;
+    __syncthreads();
+    if (w == 0 && i < n) {
+#pragma unroll
+        for (int q = 1; q < 4; ++q) { const float4 v = red[q][lane]; s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w; }
+        const int b = (int)(i % f.CB); const long long r = i / f.CB; const int a = (int)(r % f.CA), t = (int)(r / f.CA);
+        float* dst = f.R + (long long)t * f.RT + (long long)(a + f.a_off) * f.RSA + b + f.b_off;
+        dst[0] += s.x; dst[1] += s.y; dst[2] += s.z; dst[3] += s.w;
+    }
+    if (blockIdx.x == 0)
+        for (int j = threadIdx.x; j < f.nb; j += 256) {
+            float sb = 0.f;
+            for (int c = 0; c < f.ncopies; ++c) sb += f.Rx[(long long)c * f.stride + n + j];
+            f.bsum[j + f.b_off] += sb;
+        }
+}
+
 static inline bool tf_chan_ok(int c) { return c == 8 || c == 16 || (c >= 32 && c % 32 == 0); }
 
 // fills the launch geometry; false = shape outside this kernel (the per-tap kernel of wgrad_mfma.hip takes it)
@@ -583,6 +615,10 @@ int m1_wg_rx_finish(float* rx, long long stride, int ncopies, const WgradSpec& g
         hipLaunchKernelGGL(tf_finish_vec_kernel, dim3((unsigned)blocks), dim3(256), 0, st, f);
         return m1_check_launch();
     }
+    if (f.CB % 4 == 0 && n - f.nb >= (1 << 15)) {            // (n - nb) / 256 >= 128 blocks
+        hipLaunchKernelGGL(tf_finish_wide_kernel, dim3((unsigned)((n - f.nb + 255) / 256)), dim3(256), 0, st, f);
+        return m1_check_launch();
+    }
     while (f.EL > 4 && n / f.EL < 128) f.EL >>= 1;           // small blocks of R: more lane rows per element, more blocks
     hipLaunchKernelGGL(tf_finish_kernel, dim3((unsigned)((n + f.EL - 1) / f.EL)), dim3(256), 0, st, f);
     return m1_check_launch();
@@ -597,7 +633,7 @@ int m1_tf_wgrad(const WgradSpec& g, long long nw, int nb, hipStream_t st) {
     const int TS = big ? 64 : 32;
     const int aTiles = (g.CA + TS - 1) / TS; p.bTiles = (g.CB + TS - 1) / TS;
     const int ctiles = aTiles * p.bTiles;
-    static int tgt = -1; if (tgt < 0) { const char* e = getenv("M1_TF_SPLIT"); tgt = e ? atoi(e) : 512; }
+    static int tgt = -1; if (tgt < 0) { const char* e = getenv("M1_TF_SPLIT"); tgt = e ? atoi(e) : 256; }
     long long nsplit = (tgt + ctiles - 1) / ctiles;          // ~2 blocks per CU
     if (big) nsplit = (tgt + ctiles * g.kd - 1) / (ctiles * g.kd);
     const long long nloc = (long long)g.kd * g.kh * g.kw * g.CA * g.CB;
