@@ -233,7 +233,9 @@ __global__ void __launch_bounds__(NTHR) conv_halo_kernel(HaloP p) {
         __syncthreads();
         const int oh0 = c_th * p.TH, ow0 = c_tw * p.TW;
         const long long slice0 = ((long long)c_n * m.OD + c_od) * m.OH;
-        if (m.accumulate) {       // out += : fold what is there into the tile first, so that the statistics below (a conv run as
+        bool any_acc = m.accumulate != 0;
+        for (int q = 0; q < m.nout; ++q) any_acc |= m.outAcc[q] != 0;
+        if (any_acc) {            // out += : fold what is there into the tile first, so that the statistics below (a conv run as
             // one launch per member group: the last group owns them) and the stores see the sum
             constexpr int SPRa = BN / SEG;
             for (int e = tid; e < HL_BM * SPRa; e += NTHR) {
@@ -241,10 +243,12 @@ __global__ void __launch_bounds__(NTHR) conv_halo_kernel(HaloP p) {
                 const int th = row / p.TW, tw = row - th * p.TW;
                 const int oc = oc0 + cs * SEG;
                 if (oh0 + th >= m.OH || oc >= m.OCn) continue;
+                const OutRef o = m1_out_ref(m, oc);
+                if (!o.base || !o.acc) continue;
                 const long long orow = (slice0 + oh0 + th) * m.OW + ow0 + tw;
-                const bf16_t* src = (const bf16_t*)m.out + orow * m.OC + oc;
+                const bf16_t* src = (const bf16_t*)o.base + orow * o.C + o.col;
                 bf16_t* ct = C_s + row * CP + cs * SEG;
-                if (m.OC % SEG != 0 || oc + SEG > m.OCn) {
+                if (o.C % SEG != 0 || (m.nout == 0 && oc + SEG > m.OCn)) {
                     for (int k = 0; k < SEG && oc + k < m.OCn; ++k) Act<bf16_t>::st(ct + k, Act<bf16_t>::ld(ct + k) + Act<bf16_t>::ld(src + k));
                 } else {
                     float a[SEG], b[SEG];
@@ -273,16 +277,17 @@ __global__ void __launch_bounds__(NTHR) conv_halo_kernel(HaloP p) {
             }
         }
         constexpr int SPR = BN / SEG;
-        bf16_t* out = (bf16_t*)m.out;
         for (int e = tid; e < HL_BM * SPR; e += NTHR) {
             const int row = e / SPR, cs = e % SPR;
             const int th = row / p.TW, tw = row - th * p.TW;
             const int oc = oc0 + cs * SEG;
             if (oh0 + th >= m.OH || oc >= m.OCn) continue;
+            const OutRef o = m1_out_ref(m, oc);
+            if (!o.base) continue;
             const long long orow = (slice0 + oh0 + th) * m.OW + ow0 + tw;
             const uint4 v = *reinterpret_cast<const uint4*>(C_s + row * CP + cs * SEG);
-            bf16_t* dst = out + orow * m.OC + oc;
-            if (m.OC % SEG != 0 || oc + SEG > m.OCn) {
+            bf16_t* dst = (bf16_t*)o.base + orow * o.C + o.col;
+            if (o.C % SEG != 0 || (m.nout == 0 && oc + SEG > m.OCn)) {
                 const bf16_t* ve = reinterpret_cast<const bf16_t*>(&v);
                 for (int k = 0; k < SEG && oc + k < m.OCn; ++k) dst[k] = ve[k];
             } else {

@@ -18,6 +18,8 @@ struct MfmaP {
     int ID, IH, IW;             // gathered tensor extent
     void* out;
     int OC, OCn;                // out row stride (channels) / channels computed by this launch
+    int nout;                   // > 0: columns are spread over several tensors (GatherSpec::outs): member m owns [outOff[m], outOff[m+1])
+    void* outs[M1_MAX_SRC]; int outC[M1_MAX_SRC]; int outOff[M1_MAX_SRC + 1]; int outAcc[M1_MAX_SRC];
     int OD, OH, OW, N;
     const void* wp;             // packed weights
     const float* bias;
@@ -35,6 +37,16 @@ struct MfmaP {
     float* stat_partial;        // fused InstanceNorm statistics: [N][tiles per sample][OC][2] = {sum, sum of squares} of
     int stat_tiles;             //   the ROUNDED outputs of each 64/128-row tile (mode 0, tiles never straddle samples)
 };
+
+// where output column `oc` of a launch lives: tensor base (nullptr = nobody wants it), its row pitch, the column inside it,
+// and whether the kernel adds to what is there
+struct OutRef { void* base; int C, col, acc; };
+__device__ __forceinline__ OutRef m1_out_ref(const MfmaP& p, int oc) {
+    if (p.nout == 0) return OutRef{p.out, p.OC, oc, p.accumulate};
+    int m = 0;
+    while (m + 1 < p.nout && oc >= p.outOff[m + 1]) ++m;
+    return OutRef{p.outs[m], p.outC[m], oc - p.outOff[m], p.outAcc[m]};
+}
 
 template <typename T> struct MT;
 template <> struct MT<bf16_t> { static constexpr int SEG = 8; };

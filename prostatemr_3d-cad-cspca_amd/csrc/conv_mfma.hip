@@ -448,24 +448,25 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_mfma_kernel(MfmaP p) {
         }
     }
     constexpr int SPR = BN / SEG;                         // 16-B segments per tile row
-    T* out = (T*)p.out;
     for (int e = tid; e < BM * SPR; e += NTHR) {
         const int row = e / SPR, cs = e % SPR;
         const int orow = outrow[row];
         const int oc = oc0 + cs * SEG;
         if (orow < 0 || oc >= p.OCn) continue;
+        const OutRef o = m1_out_ref(p, oc);                // (a segment never straddles two destination tensors: their widths are multiples of SEG)
+        if (!o.base) continue;
         uint4 v = *reinterpret_cast<const uint4*>(C_s + row * CP + cs * SEG);
-        T* dst = out + (long long)orow * p.OC + oc;
-        if (p.OC % SEG != 0 || oc + SEG > p.OCn) {       // output row not 16-byte tiled (dz: 1..3 channels; class logits)
+        T* dst = (T*)o.base + (long long)orow * o.C + o.col;
+        if (o.C % SEG != 0 || (p.nout == 0 && oc + SEG > p.OCn)) {       // output row not 16-byte tiled (dz: 1..3 channels; class logits)
             const T* ve = reinterpret_cast<const T*>(&v);
             for (int k = 0; k < SEG && oc + k < p.OCn; ++k) {
                 float a = Act<T>::ld(ve + k);
-                if (p.accumulate) a += Act<T>::ld(dst + k);
+                if (o.acc) a += Act<T>::ld(dst + k);
                 Act<T>::st(dst + k, a);
             }
             continue;
         }
-        if (p.accumulate) {
+        if (o.acc) {
             float a[SEG], b[SEG];
             VecIO<T, SEG>::ld(reinterpret_cast<const T*>(&v), a);
             VecIO<T, SEG>::ld(dst, b);
@@ -585,15 +586,25 @@ int m1_pack_batch_internal(const void* const* jobs_dev, const int* prefix_dev, i
     return m1_check_launch();
 }
 
-// out = T(sum_ks slab[ks] + bias) [+ out]   (split-K finish, fixed summation order)
+// out = T(sum_ks slab[ks] + bias) [+ out]   (split-K finish, fixed summation order); the slabs are [voxel][OC], the output may be
+// spread over several tensors (MfmaP::outs)
+struct FinOut { int nout; void* outs[M1_MAX_SRC]; int outC[M1_MAX_SRC]; int outOff[M1_MAX_SRC + 1]; int outAcc[M1_MAX_SRC]; };
 template <typename T>
 __global__ void splitk_finish_kernel(const float* __restrict__ acc32, int ksplit, const float* __restrict__ bias, T* __restrict__ out,
-                                     long long n, int OC, int accumulate) {
+                                     long long n, int OC, int accumulate, FinOut fo) {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
-        float v = bias ? bias[i % OC] : 0.f;
+        const int oc = (int)(i % OC);
+        float v = bias ? bias[oc] : 0.f;
         for (int k = 0; k < ksplit; ++k) v += acc32[(long long)k * n + i];
-        if (accumulate) v += Act<T>::ld(out + i);
-        Act<T>::st(out + i, v);
+        T* dst = out + i; int acc = accumulate;
+        if (fo.nout > 0) {
+            int m = 0;
+            while (m + 1 < fo.nout && oc >= fo.outOff[m + 1]) ++m;
+            if (!fo.outs[m]) continue;
+            dst = (T*)fo.outs[m] + (i / OC) * fo.outC[m] + (oc - fo.outOff[m]); acc = fo.outAcc[m];
+        }
+        if (acc) v += Act<T>::ld(dst);
+        Act<T>::st(dst, v);
     }
 }
 
@@ -744,6 +755,8 @@ static int run_mfma(const GatherSpec& g, void* ws, int ws_packed, hipStream_t st
     void* panel = reinterpret_cast<unsigned char*>(ws) + M1_PACK_JOB_BYTES;    // [job record][panels][split-K accumulator]
     mp.OD = g.OD; mp.OH = g.OH; mp.OW = g.OW; mp.N = g.N; mp.wp = panel; mp.bias = g.bias; mp.mode = g.mode;
     mp.sd = g.sd; mp.sh = g.sh; mp.sw = g.sw; mp.pd = g.pd; mp.ph = g.ph; mp.pw = g.pw; mp.accumulate = g.accumulate;
+    mp.nout = g.nout; mp.outOff[0] = 0;
+    for (int i = 0; i < g.nout; ++i) { mp.outs[i] = g.outs[i]; mp.outC[i] = g.outC[i]; mp.outAcc[i] = g.outAcc[i]; mp.outOff[i + 1] = mp.outOff[i] + g.outC[i]; }
     const Plan pl = make_plan(g.OC, spec_maxM(g), spec_ncls(g), min_class_chunks(g, CC, SEG));
     const int BN = pl.BN, OCpad = (g.OC + BN - 1) / BN * BN;
     long long tot = 0;
@@ -812,7 +825,10 @@ static int run_mfma(const GatherSpec& g, void* ws, int ws_packed, hipStream_t st
     if (pl.ksplit <= 1) return rc2;
     const long long ne = (long long)out_elems(g);
     long long fb = cdiv_ll(ne, 256); if (fb > 2048) fb = 2048;
-    hipLaunchKernelGGL(splitk_finish_kernel<T>, dim3((unsigned)fb), dim3(256), 0, st, mp.acc32, pl.ksplit, g.bias, (T*)g.out, ne, g.OC, g.accumulate);
+    FinOut fo{}; fo.nout = mp.nout;
+    for (int i = 0; i < mp.nout; ++i) { fo.outs[i] = mp.outs[i]; fo.outC[i] = mp.outC[i]; fo.outOff[i] = mp.outOff[i]; fo.outAcc[i] = mp.outAcc[i]; }
+    fo.outOff[mp.nout] = mp.outOff[mp.nout];
+    hipLaunchKernelGGL(splitk_finish_kernel<T>, dim3((unsigned)fb), dim3(256), 0, st, mp.acc32, pl.ksplit, g.bias, (T*)g.out, ne, g.OC, g.accumulate, fo);
     rc2 = m1_check_launch(); if (rc2) return rc2;
     if (g.stats_out) return m1_stats_internal(g.out, g.N, Vout, g.OC, g.dtype, g.stats_eps, g.stats_out, g.stats_ws, st);
     return M1_OK;

@@ -97,6 +97,30 @@ static GatherSpec dgrad_spec(const m1_conv_desc_t* d, bool T, const float* w, co
     return g;
 }
 
+// the data gradient of ALL concat members as one problem: Cin output columns spread over the members' gradient tensors
+// (GatherSpec::outs).  One launch instead of one per member: dY is gathered once per tile instead of once per member, 32-channel
+// members stop running on 32-column tiles (the loader-bound shape), and a 5-member dense-skip concat costs 1 launch, not 5.
+static bool dgrad_fused_ok(const m1_conv_desc_t* d) {
+    static int en = -1; if (en < 0) { const char* e = getenv("M1_DGRAD_FUSED"); en = e ? atoi(e) : 1; }
+    if (!en || d->nsrc < 2) return false;
+    const int seg = d->dtype == M1_BF16 ? 8 : 4;
+    for (int i = 0; i < d->nsrc; ++i) if (d->src[i].C % seg) return false;
+    // the wide, shallow layers (res0/res1: <= 64 dY channels, stride 1, >= 32,768 voxels) run on the halo-tile kernel, whose blocks
+    // own one 32-column weight slice each: per-member launches are faster there (192->32 at res0: 0.76 vs 1.13 ms per step fused)
+    const long long vox = (long long)d->N * d->D * d->H * d->W;
+    if (d->dtype == M1_BF16 && d->Cout <= 64 && d->sd == 1 && d->sh == 1 && d->sw == 1 && vox >= 32768 && d->kd * d->kh * d->kw > 1) return false;
+    return true;
+}
+static GatherSpec dgrad_fused_spec(const m1_conv_desc_t* d, bool T, const float* w, const void* dy, void* const* dx, const int* accumulate) {
+    GatherSpec g = dgrad_spec(d, T, w, dy, nullptr, 0, 0);
+    g.OC = d->Cin; g.oc_off = 0; g.out = nullptr; g.accumulate = 0;
+    g.nout = d->nsrc;
+    for (int i = 0; i < d->nsrc; ++i) {
+        g.outs[i] = dx ? dx[i] : nullptr; g.outC[i] = d->src[i].C; g.outAcc[i] = (accumulate && accumulate[i]) ? 1 : 0;
+    }
+    return g;
+}
+
 static inline size_t align256(size_t v) { return (v + 255) / 256 * 256; }
 
 // Every channel count runs on the matrix-core kernels (unaligned members are zero-padded to whole 16-byte K
@@ -219,6 +243,8 @@ extern "C" size_t m1_conv_ws_bytes(const m1_conv_desc_t* d, int transposed, int 
         return panels + align256(m1_stats_ws_floats(d->N, (long long)q0.OD * q0.OH * q0.OW, d->Cout) * sizeof(float)) + 256;
     }
     if (role == 1) {
+        if (dgrad_fused_ok(d) && !g_force_direct && m1_mfma_supported(dgrad_fused_spec(d, T, nullptr, nullptr, nullptr, nullptr)))
+            return gather_ws_bytes(dgrad_fused_spec(d, T, nullptr, nullptr, nullptr, nullptr)) + 256;
         size_t m = 0; int off = 0;
         for (int i = 0; i < d->nsrc; ++i) {
             m += gather_ws_bytes(dgrad_spec(d, T, nullptr, nullptr, nullptr, i, off));
@@ -248,6 +274,8 @@ extern "C" int m1_conv_pack_jobs(const m1_conv_desc_t* d, int transposed, int ro
                 woff += b;
             }
         } else if (gather_ws_bytes(fwd_spec(d, T, nullptr, nullptr, nullptr))) jobs_out[n++] = ws;
+    } else if (role == 1 && dgrad_fused_ok(d) && !g_force_direct && m1_mfma_supported(dgrad_fused_spec(d, T, nullptr, nullptr, nullptr, nullptr))) {
+        if (gather_ws_bytes(dgrad_fused_spec(d, T, nullptr, nullptr, nullptr, nullptr))) jobs_out[n++] = ws;
     } else if (role == 1) {
         int off = 0; size_t woff = 0;
         for (int i = 0; i < d->nsrc; ++i) {
@@ -306,6 +334,14 @@ extern "C" int m1_convT3d_fwd(const m1_conv_desc_t* d, const float* w, const flo
 }
 static int dgrad_common(const m1_conv_desc_t* d, bool T, const float* w, const void* dy, void* const* dx, const int* accumulate,
                         void* ws, int ws_packed, hipStream_t st) {
+    if (dgrad_fused_ok(d) && !g_force_direct) {
+        GatherSpec gf = dgrad_fused_spec(d, T, w, dy, dx, accumulate);
+        if (m1_mfma_supported(gf)) {
+            bool any = false;
+            for (int i = 0; i < d->nsrc; ++i) any |= dx[i] != nullptr;
+            return any ? run_gather(gf, ws, ws_packed, st) : M1_OK;
+        }
+    }
     int off = 0; size_t woff = 0;                         // member i's panel lives at its own offset of ws (cacheable)
     for (int i = 0; i < d->nsrc; ++i) {
         GatherSpec g = dgrad_spec(d, T, w, dy, dx[i], i, off);

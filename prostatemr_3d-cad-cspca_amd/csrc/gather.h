@@ -10,6 +10,10 @@ struct GatherSpec {
     const void* src[M1_MAX_SRC]; int srcC[M1_MAX_SRC]; int nsrc;   // virtual concat of the contraction axis
     int ID, IH, IW;            // extent of the gathered tensors
     void* out; int OC;         // output tensor and its channel count
+    // nout > 0: the OC output channels are a virtual concat too -- columns [outOff(m), outOff(m)+outC[m]) go to tensor outs[m]
+    // (own row pitch outC[m], own accumulate flag, nullptr = not wanted).  The data gradient of a conv over a concat is ONE
+    // launch for all members then (dispatch.hip dgrad_common); `out` is unused.
+    int nout; void* outs[M1_MAX_SRC]; int outC[M1_MAX_SRC]; int outAcc[M1_MAX_SRC];
     int OD, OH, OW, N;
     const float* w; long long wST, wSC, wSO; int oc_off, cc_off;
     const float* bias;
