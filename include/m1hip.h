@@ -88,6 +88,16 @@ int m1_conv3d_fwd(const m1_conv_desc_t* d, const float* w, const float* bias, vo
  * gets its gradient summed by the kernels' own epilogues, in call order, instead of by separate add passes. */
 int m1_conv3d_dgrad(const m1_conv_desc_t* d, const float* w, const void* dy, void* const* dx, const int* accumulate,
                     void* ws, int ws_packed, void* stream);
+/* conv1 || conv4 of an SEResNetBottleNeck as ONE problem (B:53 and B:64 apply Conv3D(F/4, k, s) and Conv3D(F, k, s) to the same
+ * input): d->Cout = C1 + C4; w1 (kd,kh,kw,Cin,C1), w4 (kd,kh,kw,Cin,C4) stay separate Keras tensors.  Forward writes y1 (…,C1) and
+ * y4 (…,C4) and, optionally, both (N,C,2) statistics tensors; the data gradient contracts over the virtual concat [dy1 | dy4].
+ * ws: m1_conv_ws_bytes(d, 0, role) of the SAME descriptor (roles 0 / 1), same zero-fill and ws_packed contract as m1_conv3d_fwd /
+ * m1_conv3d_dgrad.  M1_ERR_UNSUPPORTED (nothing launched): take the two single convs instead (channel counts that are not
+ * multiples of one 16-byte segment, the halo-tile member-group regime, m1_set_force_direct). */
+int m1_conv3d_pair_fwd(const m1_conv_desc_t* d, const float* w1, const float* b1, const float* w4, const float* b4, int C1,
+                       void* y1, void* y4, float* stats1, float* stats4, void* ws, int ws_packed, void* stream);
+int m1_conv3d_pair_dgrad(const m1_conv_desc_t* d, const float* w1, const float* w4, int C1, const void* dy1, const void* dy4,
+                         void* const* dx, const int* accumulate, void* ws, int ws_packed, void* stream);
 /* dw (kd,kh,kw,Cin,Cout) and db (Cout): accumulate == 0 -> overwritten (zeroed inside first);
  * accumulate != 0 -> added to what is there (the caller's flat gradient buffer, zeroed once per step: a weight
  * shared by several passes -- prior / posterior cores run twice per step -- sums without any extra copy). The

@@ -223,7 +223,7 @@ __global__ void __launch_bounds__(NTHR) conv_halo_kernel(HaloP p) {
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 const int col = j * 16 + fr;
-                const float bv = (m.bias && oc0 + col < m.OCn) ? m.bias[oc0 + col] : 0.f;
+                const float bv = (oc0 + col < m.OCn) ? m1_bias_at(m, oc0 + col) : 0.f;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int row = wave * 32 + i * 16 + fs * 4 + r;

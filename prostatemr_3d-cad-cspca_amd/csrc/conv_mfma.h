@@ -23,6 +23,7 @@ struct MfmaP {
     int OD, OH, OW, N;
     const void* wp;             // packed weights
     const float* bias;
+    const float* bias2; int bias_split;   // columns >= bias_split take bias2[col - bias_split] (0 = one bias vector)
     int mode, sd, sh, sw, pd, ph, pw;
     int nclasses;
     int cls_ntaps[MF_MAX_CLASSES], cls_first[MF_MAX_CLASSES], cls_kpad[MF_MAX_CLASSES];
@@ -46,6 +47,11 @@ __device__ __forceinline__ OutRef m1_out_ref(const MfmaP& p, int oc) {
     int m = 0;
     while (m + 1 < p.nout && oc >= p.outOff[m + 1]) ++m;
     return OutRef{p.outs[m], p.outC[m], oc - p.outOff[m], p.outAcc[m]};
+}
+
+__device__ __forceinline__ float m1_bias_at(const MfmaP& p, int oc) {
+    if (p.bias_split > 0 && oc >= p.bias_split) return p.bias2 ? p.bias2[oc - p.bias_split] : 0.f;
+    return p.bias ? p.bias[oc] : 0.f;
 }
 
 template <typename T> struct MT;

@@ -421,7 +421,7 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_mfma_kernel(MfmaP p) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int col = wn * (BN / WN) + j * 16 + fr;
-            const float bv = (p.bias && oc0 + col < p.OCn) ? p.bias[oc0 + col] : 0.f;
+            const float bv = (oc0 + col < p.OCn) ? m1_bias_at(p, oc0 + col) : 0.f;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int row = wm * (BM / WM) + i * 16 + fs * 4 + r;
@@ -493,6 +493,7 @@ static constexpr size_t mfma_smem_bytes() {
 // ------------------------------------------------------------------------------------------------
 struct PackP {
     const float* w; long long wST, wSC, wSO; int oc_off, cc_off, OCn, OCpad, CC;
+    const float* w2; long long w2ST, w2SC, w2SO; int oc_split, c_split;     // second weight tensor (GatherSpec::w2)
     int nsrc, spt, SEG; int srcC[M1_MAX_SRC], srcSeg[M1_MAX_SRC];
     int nclasses; int cls_ntaps[MF_MAX_CLASSES], cls_first[MF_MAX_CLASSES], cls_kpad[MF_MAX_CLASSES];
     long long cls_woff[MF_MAX_CLASSES];
@@ -500,15 +501,16 @@ struct PackP {
 };
 // source offset (without the output-channel term) of the first column of packed K-segment kseg (SEG columns = SEG
 // consecutive channels of one concat member under one tap) of class cls; *nvalid = its real (non-padding) columns
-__device__ __forceinline__ long long pack_seg_offset(const PackP& p, int cls, int kseg, int* nvalid) {
+__device__ __forceinline__ bool pack_seg_pos(const PackP& p, int cls, int kseg, int* nvalid, int* wtap, int* chan) {
     const int tap_i = kseg / p.spt;
     int seg = kseg - tap_i * p.spt, c = 0, s = 0;
     while (s < p.nsrc && seg >= p.srcSeg[s]) { seg -= p.srcSeg[s]; c += p.srcC[s]; ++s; }
-    if (s >= p.nsrc || tap_i >= p.cls_ntaps[cls]) { *nvalid = 0; return 0; }
+    if (s >= p.nsrc || tap_i >= p.cls_ntaps[cls]) { *nvalid = 0; return false; }
     const int rem = p.srcC[s] - seg * p.SEG;
     *nvalid = rem < p.SEG ? rem : p.SEG;
-    c += seg * p.SEG;                                       // channel on the (unpadded) concat axis
-    return (long long)p.wtap[p.cls_first[cls] + tap_i] * p.wST + (long long)(c + p.cc_off) * p.wSC;
+    *chan = c + seg * p.SEG;                                // channel on the (unpadded) concat axis
+    *wtap = p.wtap[p.cls_first[cls] + tap_i];
+    return true;
 }
 // A pack job leaves its own parameters in front of its panel (first M1_PACK_JOB_BYTES of the workspace region), so that
 // m1_pack_batch can refresh every panel of a model in ONE launch after the optimiser step (per-layer pack launches are
@@ -528,12 +530,19 @@ __device__ __forceinline__ void pack_class_elems(const PackP& p, int cls, T* __r
     const bool oc_fast = p.wSO == 1;
     for (long long u = first; u < tot; u += stride) {
         const int oc = oc_fast ? (int)(u % p.OCpad) : (int)(u / nks), kseg = oc_fast ? (int)(u / p.OCpad) : (int)(u % nks);
-        int nvalid;
-        const long long so = pack_seg_offset(p, cls, kseg, &nvalid) + (long long)(oc + p.oc_off) * p.wSO;
+        int nvalid, wtap = 0, c = 0;
+        pack_seg_pos(p, cls, kseg, &nvalid, &wtap, &c);
         if (oc >= p.OCn) nvalid = 0;
+        // which weight tensor owns (output column oc, contraction channel c)
+        const float* w = p.w; long long wST = p.wST, wSC = p.wSC, wSO = p.wSO; int ocl = oc + p.oc_off, cl = c + p.cc_off;
+        if (p.w2 && ((p.oc_split > 0 && oc >= p.oc_split) || (p.c_split > 0 && c >= p.c_split))) {
+            w = p.w2; wST = p.w2ST; wSC = p.w2SC; wSO = p.w2SO;
+            if (p.oc_split > 0) ocl = oc - p.oc_split + p.oc_off; else cl = c - p.c_split;
+        }
+        const long long so = (long long)wtap * wST + (long long)cl * wSC + (long long)ocl * wSO;
         float v[SEG];
 #pragma unroll
-        for (int j = 0; j < SEG; ++j) v[j] = j < nvalid ? p.w[so + (long long)j * p.wSC] : 0.f;
+        for (int j = 0; j < SEG; ++j) v[j] = j < nvalid ? w[so + (long long)j * wSC] : 0.f;
         VecIO<T, SEG>::st(out + p.cls_woff[cls] + (long long)oc * kpad + (long long)kseg * SEG, v);
     }
 }
@@ -591,10 +600,10 @@ int m1_pack_batch_internal(const void* const* jobs_dev, const int* prefix_dev, i
 struct FinOut { int nout; void* outs[M1_MAX_SRC]; int outC[M1_MAX_SRC]; int outOff[M1_MAX_SRC + 1]; int outAcc[M1_MAX_SRC]; };
 template <typename T>
 __global__ void splitk_finish_kernel(const float* __restrict__ acc32, int ksplit, const float* __restrict__ bias, T* __restrict__ out,
-                                     long long n, int OC, int accumulate, FinOut fo) {
+                                     long long n, int OC, int accumulate, FinOut fo, const float* __restrict__ bias2, int bias_split) {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
         const int oc = (int)(i % OC);
-        float v = bias ? bias[oc] : 0.f;
+        float v = (bias_split > 0 && oc >= bias_split) ? (bias2 ? bias2[oc - bias_split] : 0.f) : (bias ? bias[oc] : 0.f);
         for (int k = 0; k < ksplit; ++k) v += acc32[(long long)k * n + i];
         T* dst = out + i; int acc = accumulate;
         if (fo.nout > 0) {
@@ -755,6 +764,7 @@ static int run_mfma(const GatherSpec& g, void* ws, int ws_packed, hipStream_t st
     void* panel = reinterpret_cast<unsigned char*>(ws) + M1_PACK_JOB_BYTES;    // [job record][panels][split-K accumulator]
     mp.OD = g.OD; mp.OH = g.OH; mp.OW = g.OW; mp.N = g.N; mp.wp = panel; mp.bias = g.bias; mp.mode = g.mode;
     mp.sd = g.sd; mp.sh = g.sh; mp.sw = g.sw; mp.pd = g.pd; mp.ph = g.ph; mp.pw = g.pw; mp.accumulate = g.accumulate;
+    mp.bias2 = g.bias2; mp.bias_split = g.oc_split;
     mp.nout = g.nout; mp.outOff[0] = 0;
     for (int i = 0; i < g.nout; ++i) { mp.outs[i] = g.outs[i]; mp.outC[i] = g.outC[i]; mp.outAcc[i] = g.outAcc[i]; mp.outOff[i + 1] = mp.outOff[i] + g.outC[i]; }
     const Plan pl = make_plan(g.OC, spec_maxM(g), spec_ncls(g), min_class_chunks(g, CC, SEG));
@@ -781,6 +791,7 @@ static int run_mfma(const GatherSpec& g, void* ws, int ws_packed, hipStream_t st
         mp.slab_elems = (long long)out_elems(g);
     }
     pp.w = g.w; pp.wST = g.wST; pp.wSC = g.wSC; pp.wSO = g.wSO; pp.oc_off = g.oc_off; pp.cc_off = g.cc_off; pp.OCn = g.OC; pp.OCpad = OCpad; pp.CC = CC;
+    pp.w2 = g.w2; pp.w2ST = g.w2ST; pp.w2SC = g.w2SC; pp.w2SO = g.w2SO; pp.oc_split = g.oc_split; pp.c_split = g.c_split;
     int maxk = 0; for (int c = 0; c < pp.nclasses; ++c) maxk = pp.cls_kpad[c] > maxk ? pp.cls_kpad[c] : maxk;
     long long pblocks = cdiv_ll((long long)OCpad * maxk, 256); if (pblocks > 2048) pblocks = 2048; if (pblocks < 1) pblocks = 1;
     int rc = M1_OK;
@@ -814,12 +825,21 @@ static int run_mfma(const GatherSpec& g, void* ws, int ws_packed, hipStream_t st
         default:  rc2 = small ? launch_cfg<T, 64, 16, 4, 1>(mp, maxM, OCpad, st) : launch_cfg<T, 128, 16, 4, 1>(mp, maxM, OCpad, st); break;
     }
     if (rc2) return rc2;
+    // (two output tensors -- the conv1 || conv4 pair: statistics per tensor, stats_out for [0, oc_split), stats_out2 for the rest)
+    auto stats_fallback = [&]() -> int {
+        if (g.nout == 2 && g.stats_out2) {
+            int r = m1_stats_internal(g.outs[0], g.N, Vout, g.outC[0], g.dtype, g.stats_eps, g.stats_out, g.stats_ws, st); if (r) return r;
+            return m1_stats_internal(g.outs[1], g.N, Vout, g.outC[1], g.dtype, g.stats_eps, g.stats_out2, g.stats_ws, st);
+        }
+        return m1_stats_internal(g.out, g.N, Vout, g.OC, g.dtype, g.stats_eps, g.stats_out, g.stats_ws, st);
+    };
     if (g.stats_out) {
         if (fuse_stats) {           // partial layout [N][tiles][OC][2] is exactly what the generic finalize folds (fp64, per wave)
-            rc2 = m1_reduce_finalize_launch<2>(g.stats_ws, g.N, g.OC, mp.stat_tiles, g.stats_out, Vout, g.stats_eps, st);
+            rc2 = m1_reduce_finalize_launch<2>(g.stats_ws, g.N, g.OC, mp.stat_tiles, g.stats_out, Vout, g.stats_eps, st, 0,
+                                               g.stats_out2, g.stats_out2 ? g.oc_split : 0);
             if (rc2) return rc2;
         } else if (pl.ksplit <= 1) {
-            return m1_stats_internal(g.out, g.N, Vout, g.OC, g.dtype, g.stats_eps, g.stats_out, g.stats_ws, st);
+            return stats_fallback();
         }
     }
     if (pl.ksplit <= 1) return rc2;
@@ -828,9 +848,9 @@ static int run_mfma(const GatherSpec& g, void* ws, int ws_packed, hipStream_t st
     FinOut fo{}; fo.nout = mp.nout;
     for (int i = 0; i < mp.nout; ++i) { fo.outs[i] = mp.outs[i]; fo.outC[i] = mp.outC[i]; fo.outOff[i] = mp.outOff[i]; fo.outAcc[i] = mp.outAcc[i]; }
     fo.outOff[mp.nout] = mp.outOff[mp.nout];
-    hipLaunchKernelGGL(splitk_finish_kernel<T>, dim3((unsigned)fb), dim3(256), 0, st, mp.acc32, pl.ksplit, g.bias, (T*)g.out, ne, g.OC, g.accumulate, fo);
+    hipLaunchKernelGGL(splitk_finish_kernel<T>, dim3((unsigned)fb), dim3(256), 0, st, mp.acc32, pl.ksplit, g.bias, (T*)g.out, ne, g.OC, g.accumulate, fo, g.bias2, g.oc_split);
     rc2 = m1_check_launch(); if (rc2) return rc2;
-    if (g.stats_out) return m1_stats_internal(g.out, g.N, Vout, g.OC, g.dtype, g.stats_eps, g.stats_out, g.stats_ws, st);
+    if (g.stats_out) return stats_fallback();
     return M1_OK;
 }
 

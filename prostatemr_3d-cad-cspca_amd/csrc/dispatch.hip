@@ -326,6 +326,59 @@ extern "C" int m1_conv3d_fwd(const m1_conv_desc_t* d, const float* w, const floa
     }
     return run_gather(g, ws, ws_packed, (hipStream_t)stream);
 }
+// ---- conv1 || conv4 of an SE block (network_blocks.py:53,64: same input, same kernel size and strides) as ONE problem --------
+// Forward: one conv with C1 + C4 output columns, written to two tensors ([y1 | y4]) with their own bias vectors and InstanceNorm
+// statistics: the im2col operand is gathered once, and the C1 = F/4 columns that alone would run on a loader-bound 32-column
+// tile ride on the 128-column tiles of their big twin.  Data gradient: one contraction over the virtual concat [dy1 | dy4] with a
+// panel packed from both weight tensors (no read-modify-write of dx by a second launch).  d->Cout = C1 + C4.
+static bool pair_ok(const m1_conv_desc_t* d, int C1) {
+    const int seg = d->dtype == M1_BF16 ? 8 : 4;
+    if (!desc_ok(d) || C1 <= 0 || C1 >= d->Cout || C1 % seg || (d->Cout - C1) % seg || g_force_direct) return false;
+    for (int i = 0; i < d->nsrc; ++i) if (d->src[i].C % seg) return false;
+    return true;
+}
+extern "C" int m1_conv3d_pair_fwd(const m1_conv_desc_t* d, const float* w1, const float* b1, const float* w4, const float* b4, int C1,
+                                  void* y1, void* y4, float* stats1, float* stats4, void* ws, int ws_packed, void* stream) {
+    if (!d || !w1 || !w4 || !y1 || !y4 || !ws || (stats1 == nullptr) != (stats4 == nullptr)) return M1_ERR_BAD_ARG;
+    FwdGroups fg;
+    if (!pair_ok(d, C1) || fwd_groups(d, false, &fg)) return M1_ERR_UNSUPPORTED;
+    M1ProfScope ps(prof_name("conv3d_fwd", d).s, 2.0 * conv_macs(d, false), conv_bytes(d, false), (hipStream_t)stream);
+    const int C4 = d->Cout - C1;
+    GatherSpec g = fwd_spec(d, false, w1, b1, nullptr);
+    g.wST = (long long)d->Cin * C1; g.wSC = C1; g.wSO = 1;
+    g.w2 = w4; g.w2ST = (long long)d->Cin * C4; g.w2SC = C4; g.w2SO = 1; g.oc_split = C1; g.bias2 = b4;
+    g.nout = 2; g.outs[0] = y1; g.outC[0] = C1; g.outAcc[0] = 0; g.outs[1] = y4; g.outC[1] = C4; g.outAcc[1] = 0;
+    if (!m1_mfma_supported(g)) return M1_ERR_UNSUPPORTED;
+    if (stats1) {
+        g.stats_out = stats1; g.stats_out2 = stats4; g.stats_eps = 1e-3f;
+        g.stats_ws = reinterpret_cast<float*>((unsigned char*)ws + gather_ws_bytes(g));
+    }
+    return m1_mfma_gather(g, ws, ws_packed, (hipStream_t)stream);
+}
+extern "C" int m1_conv3d_pair_dgrad(const m1_conv_desc_t* d, const float* w1, const float* w4, int C1, const void* dy1, const void* dy4,
+                                    void* const* dx, const int* accumulate, void* ws, int ws_packed, void* stream) {
+    if (!d || !w1 || !w4 || !dy1 || !dy4 || !dx || !ws) return M1_ERR_BAD_ARG;
+    if (!pair_ok(d, C1)) return M1_ERR_UNSUPPORTED;
+    M1ProfScope ps(prof_name("conv3d_dgrad", d).s, 2.0 * conv_macs(d, false), conv_bytes(d, false), (hipStream_t)stream);
+    const int C4 = d->Cout - C1;
+    GatherSpec g;
+    if (d->nsrc >= 2) {
+        if (!dgrad_fused_ok(d)) return M1_ERR_UNSUPPORTED;
+        g = dgrad_fused_spec(d, false, w1, dy1, dx, accumulate);
+    } else {
+        g = dgrad_spec(d, false, w1, dy1, dx[0], 0, 0);
+        g.accumulate = accumulate && accumulate[0] ? 1 : 0;
+        if (!dx[0]) return M1_OK;
+    }
+    g.nsrc = 2; g.src[0] = dy1; g.srcC[0] = C1; g.src[1] = dy4; g.srcC[1] = C4;
+    g.wST = (long long)d->Cin * C1; g.wSC = 1; g.wSO = C1;
+    g.w2 = w4; g.w2ST = (long long)d->Cin * C4; g.w2SC = 1; g.w2SO = C4; g.c_split = C1;
+    if (!m1_mfma_supported(g)) return M1_ERR_UNSUPPORTED;
+    bool any = false;
+    for (int i = 0; i < d->nsrc; ++i) any |= dx[i] != nullptr;
+    return any ? m1_mfma_gather(g, ws, ws_packed, (hipStream_t)stream) : M1_OK;
+}
+
 extern "C" int m1_convT3d_fwd(const m1_conv_desc_t* d, const float* w, const float* bias, void* y, void* ws, int ws_packed,
                               void* stream) {
     if (!desc_ok(d) || !w || !y) return M1_ERR_BAD_ARG;

@@ -17,6 +17,11 @@ struct GatherSpec {
     int OD, OH, OW, N;
     const float* w; long long wST, wSC, wSO; int oc_off, cc_off;
     const float* bias;
+    // a second weight tensor (conv1 || conv4 of an SE block as one problem, network_blocks.py:53,64): output columns >= oc_split
+    // (forward: [y1 | y4]) or contraction channels >= c_split (data gradient over [dy1 | dy4]) come from w2 with its own strides;
+    // bias2 / stats_out2 belong to the columns >= oc_split
+    const float* w2; long long w2ST, w2SC, w2SO; int oc_split, c_split;
+    const float* bias2; float* stats_out2;
     int kd, kh, kw, mode, sd, sh, sw, pd, ph, pw;
     int dtype, accumulate;
     float* stats_out;          // optional (Conv3D forward only): per-(n,oc) {mean, rstd} of the output for the InstanceNorm

@@ -66,7 +66,7 @@ __global__ void __launch_bounds__(M1_RED_THREADS) m1_reduce_nc_kernel(F f, long 
 template <int NS>
 __global__ void __launch_bounds__(256) m1_reduce_finalize_kernel(const float* __restrict__ partial, int N, int C, int nchunks,
                                                                  float* __restrict__ out, long long stats_V, float eps,
-                                                                 int accumulate) {
+                                                                 int accumulate, float* __restrict__ out2 = nullptr, int csplit = 0) {
     // one BLOCK per (n,c): the fold is a chain of dependent cache-line loads, 256 lanes keep it 4x shorter than a wave
     __shared__ double red[4][NS];
     const int i = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -83,23 +83,26 @@ __global__ void __launch_bounds__(256) m1_reduce_finalize_kernel(const float* __
     if (threadIdx.x == 0) {
 #pragma unroll
         for (int k = 0; k < NS; ++k) s[k] = (red[0][k] + red[1][k]) + (red[2][k] + red[3][k]);
+        // channels >= csplit (csplit > 0) belong to a second output tensor of C - csplit channels
+        float* o = out + (size_t)i * NS;
+        if (csplit > 0) o = c < csplit ? out + ((size_t)n * csplit + c) * NS : out2 + ((size_t)n * (C - csplit) + (c - csplit)) * NS;
         if (stats_V > 0 && NS == 2) {
             const double mean = s[0] / (double)stats_V;
             double var = s[NS - 1] / (double)stats_V - mean * mean;
             if (var < 0.0) var = 0.0;
-            out[(size_t)i * NS + 0] = (float)mean;
-            out[(size_t)i * NS + NS - 1] = (float)(1.0 / sqrt(var + (double)eps));
+            o[0] = (float)mean;
+            o[NS - 1] = (float)(1.0 / sqrt(var + (double)eps));
         } else {
 #pragma unroll
-            for (int k = 0; k < NS; ++k) out[(size_t)i * NS + k] = (accumulate ? out[(size_t)i * NS + k] : 0.f) + (float)s[k];
+            for (int k = 0; k < NS; ++k) o[k] = (accumulate ? o[k] : 0.f) + (float)s[k];
         }
     }
 }
 template <int NS>
 static inline int m1_reduce_finalize_launch(const float* partial, int N, int C, int nchunks, float* out, long long stats_V,
-                                            float eps, hipStream_t st, int accumulate = 0) {
+                                            float eps, hipStream_t st, int accumulate = 0, float* out2 = nullptr, int csplit = 0) {
     hipLaunchKernelGGL((m1_reduce_finalize_kernel<NS>), dim3(N * C), dim3(256), 0, st, partial, N, C, nchunks, out,
-                       stats_V, eps, accumulate);
+                       stats_V, eps, accumulate, out2, csplit);
     return m1_check_launch();
 }
 

@@ -69,6 +69,8 @@ SIGNATURES = {
     "m1_conv3d_fwd": (_i, [_desc_p, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
     "m1_conv3d_dgrad": (_i, [_desc_p, _vp, _vp, C.POINTER(_vp), C.POINTER(_i), _vp, _i, _vp]),
     "m1_conv3d_wgrad": (_i, [_desc_p, _vp, _vp, _vp, _vp, _i, _vp]),
+    "m1_conv3d_pair_fwd": (_i, [_desc_p, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
+    "m1_conv3d_pair_dgrad": (_i, [_desc_p, _vp, _vp, _i, _vp, _vp, C.POINTER(_vp), C.POINTER(_i), _vp, _i, _vp]),
     "m1_convT3d_fwd": (_i, [_desc_p, _vp, _vp, _vp, _vp, _i, _vp]),
     "m1_convT3d_dgrad": (_i, [_desc_p, _vp, _vp, C.POINTER(_vp), C.POINTER(_i), _vp, _i, _vp]),
     "m1_convT3d_wgrad": (_i, [_desc_p, _vp, _vp, _vp, _vp, _i, _vp]),

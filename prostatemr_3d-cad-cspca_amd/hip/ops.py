@@ -381,6 +381,187 @@ class _Conv3d(torch.autograd.Function):
         return (dw, db, None, None, None, None, *dsrc)
 
 
+def _pair_panel_ws(w1: torch.Tensor, w4: torch.Tensor, d, role: int, need_mask=None):
+    """Packed panel of the conv1 || conv4 pair (built from BOTH weight tensors), cached on w4 while neither changes."""
+    if not (w1.is_leaf and w4.is_leaf):
+        return _conv_ws(d, False, role, w4.device, zero=True), 0
+    store = getattr(w4, "_m1_pair_panels", None)
+    stamp = (_PANEL_EPOCH[0], w1._version, w1.data_ptr(), w4._version, w4.data_ptr())
+    if store is None or store[0] != stamp:
+        store = (stamp, {})
+        w4._m1_pair_panels = store
+    key = ("pair", role, d.N, d.D, d.H, d.W, d.kd, d.kh, d.kw, d.sd, d.sh, d.sw, d.dtype, int(w1.shape[-1]),
+           tuple(d.src[i].C for i in range(d.nsrc)), need_mask)
+    hit = store[1].get(key)
+    if hit is not None:
+        return hit, 1
+    ws = _conv_ws(d, False, role, w4.device, zero=True)
+    store[1][key] = ws
+    out = (C.c_void_p * L.M1_MAX_SRC)()
+    n = L.load().m1_conv_pack_jobs(C.byref(d), 0, role, _p(ws), out)
+    if n > 0:
+        _PACK_REG[(id(w4), key)] = (weakref.ref(w4), w4.data_ptr(), ws, [int(out[i]) for i in range(n)])
+        _PACK_TABLE[0] = None
+    return ws, 0
+
+
+def _wgrad_into_sinks(lib, d, dy, w_param, b_param, transposed: bool, st):
+    """Weight (+ bias) gradient of a conv into the parameters' sinks (or fresh tensors): returns (dw, db) for autograd."""
+    wbuf, acc_w, dw = _sink(w_param)
+    bbuf, db = None, None
+    if b_param is not None:
+        bbuf, acc_b, db = _sink(b_param)
+        if acc_b != acc_w:      # both or neither live in the flat buffer; otherwise fall back to temporaries
+            wbuf, acc_w = torch.empty_like(w_param), 0
+            bbuf = torch.empty(int(bbuf.numel()), dtype=torch.float32, device=w_param.device)
+            dw, db = wbuf, bbuf
+    ws = _conv_ws(d, transposed, 2, w_param.device)
+    fn = lib.m1_convT3d_wgrad if transposed else lib.m1_conv3d_wgrad
+    L.check(fn(C.byref(d), _p(dy), _p(wbuf), _p(bbuf), _p(ws), acc_w, st), "m1_conv3d_wgrad")
+    return dw, db
+
+
+class _ConvPair(torch.autograd.Function):
+    """conv1 || conv4 of an SE block as one launch (m1_conv3d_pair_fwd / _dgrad).  Its backward produces conv1's weight gradient
+    and the fused data gradient; conv4's weight gradient hangs on a _WgradTap of y4 so that it starts as soon as dy4 exists."""
+
+    @staticmethod
+    def forward(ctx, w1, b1, w4, b4, k, s, *srcs):
+        _req(w1, b1, w4, b4, *srcs)
+        lib = L.load()
+        x0 = srcs[0]
+        c1, c4 = int(w1.shape[4]), int(w4.shape[4])
+        d = _desc(srcs, c1 + c4, k, s)
+        osz = (d.N, same_out(d.D, d.sd), same_out(d.H, d.sh), same_out(d.W, d.sw))
+        y1 = torch.empty((*osz, c1), dtype=x0.dtype, device=x0.device)
+        y4 = torch.empty((*osz, c4), dtype=x0.dtype, device=x0.device)
+        s1 = torch.empty((d.N, c1, 2), dtype=torch.float32, device=x0.device)
+        s4 = torch.empty((d.N, c4, 2), dtype=torch.float32, device=x0.device)
+        ws, packed = _pair_panel_ws(w1, w4, d, 0)
+        L.check(lib.m1_conv3d_pair_fwd(C.byref(d), _p(w1), _p(b1), _p(w4), _p(b4), c1, _p(y1), _p(y4), _p(s1), _p(s4), _p(ws), packed,
+                                       _stream()), "m1_conv3d_pair_fwd")
+        ctx.save_for_backward(w1, w4, *srcs)
+        ctx.w1_param, ctx.b1_param, ctx.w4_param = w1, b1, w4
+        ctx.gslots = [getattr(t, "_m1_gslot", None) for t in srcs]
+        ctx.k, ctx.s, ctx.c1, ctx.c4 = tuple(k), tuple(s), c1, c4
+        ctx.mark_non_differentiable(s1, s4)
+        ctx.set_materialize_grads(False)
+        return y1, s1, y4, s4
+
+    @staticmethod
+    def backward(ctx, dy1, _s1, dy4, _s4):
+        lib = L.load()
+        w1, w4, *srcs = ctx.saved_tensors
+        n_in = 6 + len(srcs)
+        if dy1 is None and dy4 is None:
+            return (None,) * n_in
+        osz = (srcs[0].shape[0], *[same_out(int(v), st_) for v, st_ in zip(srcs[0].shape[1:4], ctx.s)])
+        if dy1 is None:
+            dy1 = torch.zeros((*osz, ctx.c1), dtype=srcs[0].dtype, device=srcs[0].device)
+        if dy4 is None:
+            dy4 = torch.zeros((*osz, ctx.c4), dtype=srcs[0].dtype, device=srcs[0].device)
+        dy1, dy4 = dy1.contiguous(), dy4.contiguous()
+        st = _stream()
+        dw1 = db1 = None
+        iw, isrc = getattr(ctx, "idx_w1", 0), getattr(ctx, "idx_src", 6)       # positions of w1 / the first member among the inputs
+        if ctx.needs_input_grad[iw] or ctx.needs_input_grad[iw + 1]:
+            dw1, db1 = _wgrad_into_sinks(lib, _desc(srcs, ctx.c1, ctx.k, ctx.s), dy1, ctx.w1_param, ctx.b1_param, False, st)
+        d = _desc(srcs, ctx.c1 + ctx.c4, ctx.k, ctx.s)
+        dsrc: List[Optional[torch.Tensor]] = []
+        ptrs = (C.c_void_p * len(srcs))()
+        accs = (C.c_int * len(srcs))()
+        any_d = False
+        for i, t in enumerate(srcs):
+            if ctx.needs_input_grad[isrc + i]:
+                g, accs[i] = _slot_target(ctx.gslots[i], t)
+                dsrc.append(g); ptrs[i] = g.data_ptr(); any_d = True
+            else:
+                dsrc.append(None); ptrs[i] = None
+        if any_d:
+            ws, packed = _pair_panel_ws(ctx.w1_param, ctx.w4_param, d, 1, tuple(bool(g is not None) for g in dsrc))
+            L.check(lib.m1_conv3d_pair_dgrad(C.byref(d), _p(w1), _p(w4), ctx.c1, _p(dy1), _p(dy4), ptrs, accs, _p(ws), packed, st),
+                    "m1_conv3d_pair_dgrad")
+            for i in range(len(srcs)):
+                if dsrc[i] is not None:
+                    _slot_written(ctx.gslots[i])
+        return (dw1, db1, None, None, None, None, *dsrc)
+
+
+class _WgradTap(torch.autograd.Function):
+    """Identity on ``y`` whose backward computes the weight / bias gradient of the conv that produced it (``y`` = conv(srcs; w, b))
+    and passes dy on: the gradient starts as soon as dy exists, on the stream the tap was created on (ops.branch)."""
+
+    @staticmethod
+    def forward(ctx, y, w, b, k, s, *srcs):
+        ctx.save_for_backward(*srcs)
+        ctx.w_param, ctx.b_param, ctx.k, ctx.s = w, b, tuple(k), tuple(s)
+        return y.view_as(y)
+
+    @staticmethod
+    def backward(ctx, dy):
+        srcs = ctx.saved_tensors
+        if dy is None:
+            return (None,) * (5 + len(srcs))
+        dyc = dy.contiguous()
+        dw, db = _wgrad_into_sinks(L.load(), _desc(srcs, int(ctx.w_param.shape[4]), ctx.k, ctx.s), dyc, ctx.w_param, ctx.b_param, False,
+                                   _stream())
+        return (dy, dw, db, None, None, *([None] * len(srcs)))
+
+
+class _PairGraft(torch.autograd.Function):
+    """Joins the outputs of conv1 and conv4 (computed by two ordinary forward launches, conv4 on a side stream) into ONE autograd
+    node whose backward is conv1's weight gradient + the fused data gradient over [dy1 | dy4] (m1_conv3d_pair_dgrad)."""
+
+    @staticmethod
+    def forward(ctx, y1, y4, w1, b1, w4, k, s, *srcs):
+        ctx.save_for_backward(w1, w4, *srcs)
+        ctx.w1_param, ctx.b1_param, ctx.w4_param = w1, b1, w4
+        ctx.gslots = [getattr(t, "_m1_gslot", None) for t in srcs]
+        ctx.k, ctx.s, ctx.c1, ctx.c4 = tuple(k), tuple(s), int(w1.shape[4]), int(w4.shape[4])
+        ctx.idx_w1, ctx.idx_src = 2, 7
+        ctx.set_materialize_grads(False)
+        return y1.view_as(y1), y4.view_as(y4)
+
+    @staticmethod
+    def backward(ctx, dy1, dy4):
+        g = _ConvPair.backward(ctx, dy1, None, dy4, None)       # (dw1, db1, None, None, None, None, *dsrc)
+        return (None, None, g[0], g[1], None, None, None, *g[6:])
+
+
+_FORCE_DIRECT = [False]
+
+
+def conv_pair_supported(srcs, w1, w4, s) -> bool:
+    """conv1 || conv4 with one data gradient pays on the matrix-core (not halo-tile) layers: >= 32 + 128 output channels."""
+    if _os.environ.get("M1_CONV_PAIR", "1") == "0" or _FORCE_DIRECT[0] or not srcs[0].is_cuda:
+        return False
+    seg = 8 if srcs[0].dtype == torch.bfloat16 else 4
+    c1, c4 = int(w1.shape[4]), int(w4.shape[4])
+    return c4 >= 128 and c1 % seg == 0 and all(int(t.shape[4]) % seg == 0 for t in srcs)
+
+
+def conv_pair_same(srcs, w1, b1, w4, b4, k, s):
+    """(y1, stats1, y4, stats4, branch) of Conv3D(w1) and Conv3D(w4) applied to the same virtual concat (network_blocks.py:53,64).
+    Forward: two launches, conv4 on side stream 0 (one launch over 32 + 128 columns wastes 37 % of its second 128-column tile:
+    2.31 vs 1.21 + 0.97 ms on the 512-channel res2 layer; M1_CONV_PAIR_FWD=1 selects it).  Backward: ONE contraction over
+    [dy1 | dy4] for the data gradient (1.60 vs 1.32 + 0.61 ms there), conv4's weight gradient on a tap of y4 on the side stream.
+    The caller joins ``branch`` before it reads y4 / stats4."""
+    dev = srcs[0].device
+    if _os.environ.get("M1_CONV_PAIR_FWD", "0") == "1":
+        y1, s1, y4raw, s4 = _ConvPair.apply(w1, b1, w4, b4, tuple(k), tuple(s), *srcs)
+    else:
+        with torch.no_grad():
+            det = [t.detach() for t in srcs]
+            with branch(dev, 0) as br0:
+                y4n, s4 = _Conv3d.apply(w4, b4, tuple(k), tuple(s), False, True, *det)
+            y1n, s1 = _Conv3d.apply(w1, b1, tuple(k), tuple(s), False, True, *det)
+            br0.join()
+        y1, y4raw = _PairGraft.apply(y1n, y4n, w1, b1, w4, tuple(k), tuple(s), *srcs)
+    with branch(dev, 0) as br:                              # conv4's weight gradient: next to the conv3 -> conv2 backward chain
+        y4 = _WgradTap.apply(y4raw, w4, b4, tuple(k), tuple(s), *[t.detach() for t in srcs])
+    return y1, s1, y4, s4, br
+
+
 def conv3d_same(srcs, w, b, k, s, stats: bool = False):
     """tf.keras.layers.Conv3D(padding='same') on the channel-concat of ``srcs`` (never materialised).
     ``stats=True`` also returns the (N,Cout,2) {mean, rstd} of the output (for the InstanceNorm that follows),
@@ -838,7 +1019,8 @@ def step_advance(step_dev, rng_dev):
 
 def set_force_direct(on: bool):
     """Test hook: route every conv through the generic direct kernels instead of the matrix-core kernels."""
-    L.load().m1_set_force_direct(1 if on else 0)
+    _FORCE_DIRECT[0] = bool(on)
+    L.load().m1_set_force_direct(int(on) if not isinstance(on, bool) else (1 if on else 0))
 
 
 def prof_enable(on: bool):

@@ -164,11 +164,17 @@ class SEResNetBottleNeck(nn.Module):
             blk._gate = pair
 
     def forward(self, input_tensor: Tensors, dropout: Optional[_DropoutBase] = None) -> torch.Tensor:
-        pairs = [ops.fanout(t, 2) for t in _as_list(input_tensor)]          # every member feeds conv1 and conv4
-        srcs, srcs4 = [a for a, _ in pairs], [b for _, b in pairs]
-        with ops.branch(srcs[0].device, 0) as br:                               # the shortcut next to the bottleneck chain
-            y4, s4 = self.conv4(srcs4, stats=True)                              # B:64
-        y1, s1 = self.conv1(srcs, stats=True)
+        members = _as_list(input_tensor)
+        if ops.conv_pair_supported(members, self.conv1.kernel, self.conv4.kernel, self.strides):
+            # conv1 || conv4 read the same input with the same kernel size and strides (B:53,64): one data gradient over [dy1 | dy4]
+            y1, s1, y4, s4, br = ops.conv_pair_same(members, self.conv1.kernel, self.conv1.bias, self.conv4.kernel, self.conv4.bias,
+                                                    self.kernel_size, self.strides)
+        else:
+            pairs = [ops.fanout(t, 2) for t in members]                         # every member feeds conv1 and conv4
+            srcs, srcs4 = [a for a, _ in pairs], [b for _, b in pairs]
+            with ops.branch(srcs[0].device, 0) as br:                           # the shortcut next to the bottleneck chain
+                y4, s4 = self.conv4(srcs4, stats=True)                          # B:64
+            y1, s1 = self.conv1(srcs, stats=True)
         a = self.norm1(y1, 0.1, s1)                                             # B:53-55
         y2, s2 = self.conv2(a, stats=True)
         a = self.norm2(y2, 0.1, s2)                                             # B:56-58

@@ -35,17 +35,29 @@ def _run(cmd, env):
     return p.returncode, out, err
 
 
+def _attempts(fn, n=2):
+    """Harness tests of a separate process group (rendezvous ports, RCCL bring-up): one retry, the first failure is reported."""
+    for k in range(n):
+        try:
+            return fn()
+        except AssertionError as e:            # pytest.fail raises Failed (not caught): a killed child fails at once
+            if k + 1 == n:
+                raise
+            print(f"[test_bench_ddp] attempt {k + 1} failed, retrying once:\n{e}", flush=True)
+
+
 def _check_line(rc, out, err, world):
     lines = [l for l in out.splitlines() if l.startswith("{")]
     assert rc == 0 and len(lines) == 1, f"rc={rc}\n--- stdout\n{out[-2000:]}\n--- stderr\n{err[-4000:]}"
     d = json.loads(lines[0])
-    assert d["n_gpus"] == world and d["config"]["global_batch"] == world and d["scaling"] == "weak"
-    assert d["config"]["graph_error"] is None and d["value"] > 0
-    assert d["roofline"] is not None and d["cpu_baseline"] is None
+    ctx = f"config={d['config']}\n--- stderr\n{err[-3000:]}"
+    assert d["n_gpus"] == world and d["config"]["global_batch"] == world and d["scaling"] == "weak", ctx
+    assert d["config"]["graph_error"] is None and d["value"] > 0, ctx
+    assert d["roofline"] is not None and d["cpu_baseline"] is None, ctx
     return d
 
 
-@pytest.mark.timeout(CHILD_TIMEOUT_S + 60)
+@pytest.mark.timeout(2 * CHILD_TIMEOUT_S + 60)
 @pytest.mark.parametrize("gmode", ["off", "split"])
 def test_bench_two_ranks_one_gpu_gloo(gmode):
     """off: eager launches, exchange groups sent from the communication stream while backward runs; split: captured
@@ -54,16 +66,18 @@ def test_bench_two_ranks_one_gpu_gloo(gmode):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", "29533", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "C1", "--steps", "3",
            "--warmup", "1", "--no-cpu-baseline"]
-    rc, out, err = _run(cmd, env)
-    d = _check_line(rc, out, err, 2)
-    ex = d["config"]["exchange"]
-    assert ex["graph_mode"] == gmode and ex["replicas_in_sync"] is True and ex["groups"] == 3 and ex["collectives_issued"] > 0
-    assert d["config"]["hip_graph"] is (gmode == "split")
-    if gmode == "off":
-        assert ex["groups_sent_during_backward"] >= 2 * ex["host_steps"] - 2      # groups a and b close before backward ends
+    def once():
+        rc, out, err = _run(cmd, env)
+        d = _check_line(rc, out, err, 2)
+        ex = d["config"]["exchange"]
+        assert ex["graph_mode"] == gmode and ex["replicas_in_sync"] is True and ex["groups"] == 3 and ex["collectives_issued"] > 0, ex
+        assert d["config"]["hip_graph"] is (gmode == "split"), d["config"]
+        if gmode == "off":
+            assert ex["groups_sent_during_backward"] >= 2 * ex["host_steps"] - 2, ex  # groups a and b close before backward ends
+    _attempts(once)
 
 
-@pytest.mark.timeout(CHILD_TIMEOUT_S + 60)
+@pytest.mark.timeout(2 * CHILD_TIMEOUT_S + 60)
 def test_bench_rccl_world_of_one():
     """bench.py's RCCL branch (init_process_group('nccl', device_id), bucketed all-reduce from the comm stream, barrier,
     destroy) executed on one GPU: M1_BENCH_FORCE_DIST=1 makes a world of one take the N > 1 code path."""
@@ -71,8 +85,10 @@ def test_bench_rccl_world_of_one():
                M1_BENCH_FORCE_DIST="1", M1_BENCH_DEBUG="1")
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--workload", "C1", "--steps", "3", "--warmup", "1",
            "--no-cpu-baseline"]
-    rc, out, err = _run(cmd, env)
-    d = _check_line(rc, out, err, 1)
-    ex = d["config"]["exchange"]
-    assert ex["backend"] == "nccl" and ex["graph_mode"] == "full" and ex["replicas_in_sync"] is True
-    assert ex["collectives_issued"] > 0 and ex["groups_sent_during_backward"] > 0
+    def once():
+        rc, out, err = _run(cmd, env)
+        d = _check_line(rc, out, err, 1)
+        ex = d["config"]["exchange"]
+        assert ex["backend"] == "nccl" and ex["graph_mode"] == "full" and ex["replicas_in_sync"] is True, (ex, d["config"]["graph_error"])
+        assert ex["collectives_issued"] > 0 and ex["groups_sent_during_backward"] > 0, ex
+    _attempts(once)

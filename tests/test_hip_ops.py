@@ -23,6 +23,13 @@ def _oracle_grads(fn, inputs, dy):
     return y.detach(), [t.grad for t in inputs]
 
 
+def _oracle_grads_multi(fn, inputs, dys):
+    inputs = [t.clone().double().requires_grad_(True) for t in inputs]
+    ys = fn(*inputs)
+    sum((y * dy.double()).sum() for y, dy in zip(ys, dys)).backward()
+    return [y.detach() for y in ys], [t.grad for t in inputs]
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("k,s", KS)
 @pytest.mark.parametrize("chans", [([5], 7), ([3, 16, 8], 12), ([32], 64)])
@@ -52,6 +59,51 @@ def test_conv3d_same_fwd_bwd(dev, dtype, k, s, chans):
     for x in xd:
         c = x.shape[-1]
         assert rel_err(x.grad, gx[..., off:off + c]) < tol
+        off += c
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("cins,c1,c4,k,s,dims", [([128, 128], 32, 128, (3, 3, 3), (1, 1, 1), (2, 4, 8, 8)),
+                                                  ([64], 64, 256, (3, 3, 3), (2, 2, 2), (2, 4, 8, 8)),
+                                                  ([64, 32, 32], 32, 128, (1, 3, 3), (1, 2, 2), (1, 3, 8, 16)),
+                                                  ([256, 256, 256], 64, 256, (3, 3, 3), (1, 1, 1), (1, 2, 4, 4))])
+@pytest.mark.parametrize("fused_fwd", ["0", "1"])
+def test_conv_pair_matches_two_convs(dev, dtype, cins, c1, c4, k, s, dims, fused_fwd, monkeypatch):
+    """conv1 || conv4 of an SE block as one launch (m1_conv3d_pair_fwd / _dgrad; conv4's weight gradient on a tap of y4): both
+    outputs, both statistics, every member's data gradient and all four parameter gradients against the oracle's two convs."""
+    monkeypatch.setenv("M1_CONV_PAIR_FWD", fused_fwd)        # "1": also the forward as one launch (m1_conv3d_pair_fwd)
+    xs = [rnd((*dims, c), 30 + i) for i, c in enumerate(cins)]
+    cin = sum(cins)
+    sc = 1.0 / (cin * k[0] * k[1] * k[2]) ** 0.5
+    w1, b1, w4, b4 = rnd((*k, cin, c1), 3, sc), rnd((c1,), 4, 0.1), rnd((*k, cin, c4), 5, sc), rnd((c4,), 6, 0.1)
+    if dtype == torch.bfloat16:
+        xs = [x.bfloat16().float() for x in xs]
+    ins = [torch.cat(xs, -1), w1, b1, w4, b4]
+    y1o = O.conv3d_same(ins[0].double(), w1.double(), b1.double(), s)
+    dy1, dy4 = rnd(tuple(y1o.shape), 7), rnd((*y1o.shape[:-1], c4), 8)
+    if dtype == torch.bfloat16:
+        dy1, dy4 = dy1.bfloat16().float(), dy4.bfloat16().float()
+    (y1o, y4o), grads = _oracle_grads_multi(lambda x, a, b, c, d: (O.conv3d_same(x, a, b, s), O.conv3d_same(x, c, d, s)), ins, (dy1, dy4))
+    xd = [x.to(dev, dtype).requires_grad_(True) for x in xs]
+    pd = [t.to(dev).requires_grad_(True) for t in (w1, b1, w4, b4)]
+    assert ops.conv_pair_supported(xd, pd[0], pd[2], s)
+    y1, s1, y4, s4, br = ops.conv_pair_same(xd, *pd, k, s)
+    br.join(y4, s4)
+    tol = TOL[dtype]
+    assert rel_err(y1, y1o) < tol and rel_err(y4, y4o) < tol
+    for y, st in ((y1, s1), (y4, s4)):
+        yf = y.detach().double()
+        assert rel_err(st[..., 0], yf.mean(dim=(1, 2, 3)).float()) < 1e-3 + tol
+        assert rel_err(st[..., 1], (1 / torch.sqrt(yf.var(dim=(1, 2, 3), unbiased=False) + 1e-3)).float()) < 1e-3
+    (y1.float() * dy1.to(dev)).sum().backward(retain_graph=True)
+    (y4.float() * dy4.to(dev)).sum().backward()
+    gx, gw1, gb1, gw4, gb4 = grads
+    for got, want, nm in zip(pd, (gw1, gb1, gw4, gb4), "w1 b1 w4 b4".split()):
+        assert rel_err(got.grad, want) < tol * 2, nm
+    off = 0
+    for x in xd:
+        c = x.shape[-1]
+        assert rel_err(x.grad, gx[..., off:off + c]) < tol * 2
         off += c
 
 
