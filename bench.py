@@ -347,6 +347,9 @@ def run_workload(a, wl, ctx, want_roofline, want_cpu):
                          "avg_launch_ms": r["total_ms"] / r["launches"],
                          "kernel_ms_per_step": r["total_ms"] / a.prof_steps,
                          "all_kernels_ms_per_step": {q["name"]: round(q["total_ms"] / a.prof_steps, 4) for q in recs}})
+            if os.environ.get("M1_PROF_DETAIL", "0") == "1":      # tools/layer_prof.py: work per record next to its time
+                roof["all_kernels_work_per_step"] = {q["name"]: [q["flops"] / a.prof_steps, q["bytes"] / a.prof_steps,
+                                                                 q["launches"] / a.prof_steps] for q in recs}
             roof["traffic"], roof["traffic_note"] = hbm_traffic(wl, dtype, B, recs, r["name"], a.prof_steps)
             # The timed region runs independent branches on side streams (ops.branch): kernels share the GPU there and their
             # individual durations stretch.  Second pass with the branches in order: the same family with every kernel alone

@@ -61,6 +61,7 @@ struct HaloP {
     int BNh;                         // output channels per block (16 or 32)
     int nthr;                        // 256 or 512 threads: the output tile is nthr/2 voxels
     int tiles_per_sample;
+    int spr_sh, tw_sh;               // log2 of spr / TW
 };
 
 // physical 16-byte slot of logical slot `sl` in tile row `row` (conflict-free ds_read_b128 of 16 consecutive rows)
@@ -71,18 +72,17 @@ __device__ __forceinline__ int b_swz(int row, int seg) { return seg ^ ((-(row >>
 
 template <int TN, int NTHR>
 __global__ void __launch_bounds__(NTHR) conv_halo_kernel(HaloP p) {
-    constexpr int TM = 2, BN = TN * 16, SEG = 8, CP = BN + SEG, HL_BM = NTHR / 2;     // each wave owns 32 voxels x BN channels
+    constexpr int TM = 2, BN = TN * 16, SEG = 8, NW = NTHR / 64;      // each wave owns 32 voxels x BN channels
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* const Bs = smem;                                   // [nchunks][BN][64]
-    bf16_t* const C_s = reinterpret_cast<bf16_t*>(smem + p.b_bytes);  // [128][CP]
-    float* const red = reinterpret_cast<float*>(smem + p.b_bytes + HL_BM * CP * 2);   // [NTHR][2]
+    float* const red = reinterpret_cast<float*>(smem + p.b_bytes);    // [NW][BN][2]  statistics of one sample, per wave
     unsigned char* const Xs0 = smem + p.b_bytes + p.c_bytes;          // [stages][x_bytes]
     const MfmaP& m = p.m;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int oc0 = blockIdx.x * BN;
     const unsigned char* zero_pg = reinterpret_cast<const unsigned char*>(m1_zero_page_h);
     const int fr = lane & 15, fs = lane >> 4;
-    const int spt = p.spr;                                            // 16-byte K segments per tap (= slots per row)
+    const int spt_sh = p.spr_sh;                                      // log2 of the 16-byte K segments per tap (= slots per row)
 
     // ---- weight panel slice -> LDS, once ----
     {
@@ -97,21 +97,21 @@ __global__ void __launch_bounds__(NTHR) conv_halo_kernel(HaloP p) {
         }
     }
 
-    // ---- per-lane description of its input-tile DMA pieces ----
-    const bf16_t* x_base[HL_MAX_XIT]; int x_C[HL_MAX_XIT], x_rel[HL_MAX_XIT], x_pk[HL_MAX_XIT], x_co[HL_MAX_XIT];
+    // ---- per-lane description of its input-tile DMA pieces: address at tile origin 0 + what the bounds check needs ----
+    const bf16_t* x_ptr[HL_MAX_XIT]; int x_C[HL_MAX_XIT], x_pk[HL_MAX_XIT];
     const int nxit = p.x_slots / NTHR;
     const int x_rows = p.KDs * p.IHt * p.IWt;
 #pragma unroll
     for (int it = 0; it < HL_MAX_XIT; ++it) {
         const int q = it * NTHR + tid;
-        const int row = q / p.spr, slp = q - row * p.spr;
+        const int row = q >> spt_sh, slp = q & (p.spr - 1);
         const int sl = x_swz(row, slp, p.spr);                        // XOR swizzles are involutions
         const int dd = row / (p.IHt * p.IWt); const int r2 = row - dd * (p.IHt * p.IWt);
         const int hh = r2 / p.IWt, ww = r2 - hh * p.IWt;
         int c = sl * SEG, s = 0;                                      // channel on the concat axis -> member
         while (s < m.nsrc - 1 && c >= m.srcC[s]) { c -= m.srcC[s]; ++s; }
-        x_base[it] = (const bf16_t*)m.src[s]; x_C[it] = m.srcC[s]; x_co[it] = c;
-        x_rel[it] = (dd * m.IH + hh) * m.IW + ww;
+        x_C[it] = m.srcC[s];
+        x_ptr[it] = (const bf16_t*)m.src[s] + (long long)((dd * m.IH + hh) * m.IW + ww) * m.srcC[s] + c;
         x_pk[it] = row < x_rows ? (dd | (hh << 8) | (ww << 16)) : -1;
     }
 
@@ -128,20 +128,20 @@ __global__ void __launch_bounds__(NTHR) conv_halo_kernel(HaloP p) {
         n += s_n + c;
     };
     auto issue = [&](int st) {
-        const bool live = q_kt < p.ntiles;
+        const int live = q_kt < p.ntiles;
         const int id0 = q_od * p.sde - p.pde + p.dmin, ih0 = q_th * p.TH * p.she - p.phe + p.hmin, iw0 = q_tw * p.TW * p.swe - p.pwe + p.wmin;
         const int lin0 = ((q_n * m.ID + id0) * m.IH + ih0) * m.IW + iw0;
         unsigned char* Xs = Xs0 + st * p.x_bytes;
+        const long long zp = (long long)zero_pg;
 #pragma unroll
         for (int it = 0; it < HL_MAX_XIT; ++it) {
             if (it < nxit) {
                 const int pk = x_pk[it];
                 const int dd = pk & 0xff, hh = (pk >> 8) & 0xff, ww = (pk >> 16) & 0xff;
-                const bool ok = live && pk >= 0 && (unsigned)(id0 + dd) < (unsigned)m.ID && (unsigned)(ih0 + hh) < (unsigned)m.IH &&
-                                (unsigned)(iw0 + ww) < (unsigned)m.IW;
-                // branch-free select (the compiler turns the ?: into a branch around the 64-bit address arithmetic)
-                const long long real = (long long)(x_base[it] + (long long)(lin0 + x_rel[it]) * x_C[it] + x_co[it]);
-                const long long zp = (long long)zero_pg;
+                // (bitwise, not &&: one straight line of compares; the select is arithmetic so that no branch guards the address)
+                const int ok = live & (int)(pk >= 0) & (int)((unsigned)(id0 + dd) < (unsigned)m.ID) & (int)((unsigned)(ih0 + hh) < (unsigned)m.IH) &
+                               (int)((unsigned)(iw0 + ww) < (unsigned)m.IW);
+                const long long real = (long long)(x_ptr[it] + (long long)lin0 * x_C[it]);
                 const unsigned char* src = reinterpret_cast<const unsigned char*>(zp + ((real - zp) & -(long long)ok));
                 glds16h(src, Xs + (it * NTHR + wave * 64) * 16);
             }
@@ -149,18 +149,19 @@ __global__ void __launch_bounds__(NTHR) conv_halo_kernel(HaloP p) {
         advance(q_kt, q_tw, q_th, q_od, q_n);
     };
 
-    // ---- fragment offsets (tile invariant): A per (chunk, 16-row tile), B per 16-column tile ----
+    // ---- fragment offsets (tile invariant): voxels per (chunk, 16-voxel tile), weights per 16-channel tile ----
     const unsigned lds0 = (unsigned)(unsigned long long)(lptr_t)smem;
+    const int tw_sh = p.tw_sh;
     unsigned a_off[HL_MAX_CH][TM];
 #pragma unroll
     for (int q = 0; q < HL_MAX_CH; ++q) {
         int kseg = q * 4 + fs; if (kseg >= p.nseg) kseg = 0;          // K padding: the panel holds zeros there
-        const int t = kseg / spt, sl = kseg - t * spt;
+        const int t = kseg >> spt_sh, sl = kseg & (p.spr - 1);
         const int ddr = m.tdd[t] - p.dmin, dhr = m.tdh[t] - p.hmin, dwr = m.tdw[t] - p.wmin;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             const int mv = wave * 32 + i * 16 + fr;
-            const int th = mv / p.TW, tw = mv - th * p.TW;
+            const int th = mv >> tw_sh, tw = mv & (p.TW - 1);
             const int row = (ddr * p.IHt + th * p.she + dhr) * p.IWt + tw * p.swe + dwr;
             a_off[q][i] = lds0 + p.b_bytes + p.c_bytes + row * p.PX + x_swz(row, sl, p.spr) * 16;
         }
@@ -169,12 +170,66 @@ __global__ void __launch_bounds__(NTHR) conv_halo_kernel(HaloP p) {
 #pragma unroll
     for (int j = 0; j < TN; ++j) b_off[j] = lds0 + (j * 16 + fr) * 64 + b_swz(fr, fs) * 16;
 
+    // ---- epilogue invariants.  The weights are the MFMA's A operand, so a lane ends up with FOUR CONSECUTIVE OUTPUT
+    // CHANNELS (oc = j*16 + fs*4 + r) of ONE voxel (wave*32 + i*16 + fr): bias, rounding, the optional add, the statistics
+    // and an 8-byte store all happen in registers -- no LDS tile, no block barrier in the epilogue ----
+    int e_th[TM], e_row[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int mv = wave * 32 + i * 16 + fr;
+        e_th[i] = mv >> tw_sh; e_row[i] = e_th[i] * m.OW + (mv & (p.TW - 1));
+    }
+    bf16_t* o_base[TN]; int o_C[TN], o_nv[TN], o_acc[TN], o_fast[TN]; float bias_r[TN][4];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int oc = oc0 + j * 16 + fs * 4;
+        int nv = m.OCn - oc; nv = nv > 4 ? 4 : (nv < 0 ? 0 : nv);
+        o_base[j] = nullptr; o_C[j] = 0; o_acc[j] = 0; o_fast[j] = 0;
+        if (nv > 0) {
+            const OutRef o = m1_out_ref(m, oc);       // (4 channels never straddle two destination tensors: widths are multiples of 8)
+            if (o.base) { o_base[j] = (bf16_t*)o.base + o.col; o_C[j] = o.C; o_acc[j] = o.acc; o_fast[j] = nv == 4 && (o.C & 3) == 0 && (o.col & 3) == 0; }
+            else nv = 0;
+        }
+        o_nv[j] = nv;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bias_r[j][r] = (oc + r < m.OCn) ? m1_bias_at(m, oc + r) : 0.f;
+    }
+    // running {sum, sum of squares} of the ROUNDED outputs of the current sample, per lane; folded over the block and written as
+    // ONE partial per (sample, block) when the walk leaves the sample: [N][nsplit][OC][2], fixed order -> deterministic
+    float ssum[TN][4], ssq[TN][4];
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { ssum[j][r] = 0.f; ssq[j][r] = 0.f; }
+    int cur_n = 0;
+    auto flush = [&](int n) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float s = ssum[j][r], q = ssq[j][r];
+#pragma unroll
+                for (int o = 1; o < 16; o <<= 1) { s += __shfl_xor(s, o); q += __shfl_xor(q, o); }
+                if (fr == 0) { red[(wave * BN + j * 16 + fs * 4 + r) * 2] = s; red[(wave * BN + j * 16 + fs * 4 + r) * 2 + 1] = q; }
+                ssum[j][r] = 0.f; ssq[j][r] = 0.f;
+            }
+        __syncthreads();
+        if (tid < BN && oc0 + tid < m.OCn) {
+            float s = 0.f, q = 0.f;
+            for (int w = 0; w < NW; ++w) { s += red[(w * BN + tid) * 2]; q += red[(w * BN + tid) * 2 + 1]; }
+            float* dst = m.stat_partial + (((long long)n * p.nsplit + blockIdx.y) * m.OC + oc0 + tid) * 2;
+            dst[0] = s; dst[1] = q;
+        }
+        __syncthreads();
+    };
+
     // ---- pipeline over the tiles ----
     const int S = p.stages, npiece = nxit;
     int c_kt = blockIdx.y, c_tw = q_tw, c_th = q_th, c_od = q_od, c_n = q_n;       // the tile being computed
     for (int s = 0; s < S - 1; ++s) issue(s);
     int st = 0;
     for (; c_kt < p.ntiles; advance(c_kt, c_tw, c_th, c_od, c_n)) {
+        if (m.stat_partial) { for (; cur_n < c_n; ++cur_n) flush(cur_n); }
         wait_vmh(npiece * (S - 2));
         __builtin_amdgcn_s_barrier();
         int stn = st + S - 1; if (stn >= S) stn -= S;
@@ -210,92 +265,52 @@ __global__ void __launch_bounds__(NTHR) conv_halo_kernel(HaloP p) {
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
-                    for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, af[cur][i]),
-                                                                            __builtin_bit_cast(bf16x8_t, bf[cur][j]), acc[i][j], 0, 0, 0);
+                    for (int j = 0; j < TN; ++j)      // D[oc][voxel]: weights as A, voxels as B
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, bf[cur][j]),
+                                                                            __builtin_bit_cast(bf16x8_t, af[cur][i]), acc[i][j], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
 
-        // ---- epilogue: acc (+bias) -> bf16 -> LDS tile -> 16-byte stores (+ statistics partials) ----
+        // ---- epilogue in registers ----
+        const int oh0 = c_th * p.TH;
+        const int row0 = ((c_n * m.OD + c_od) * m.OH + oh0) * m.OW + c_tw * p.TW;
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
+        for (int i = 0; i < TM; ++i) {
+            if (oh0 + e_th[i] >= m.OH) continue;
+            const long long orow = row0 + e_row[i];
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
-                const int col = j * 16 + fr;
-                const float bv = (oc0 + col < m.OCn) ? m1_bias_at(m, oc0 + col) : 0.f;
+                if (o_nv[j] == 0) continue;
+                bf16_t* dst = o_base[j] + orow * o_C[j];
+                float v[4];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int row = wave * 32 + i * 16 + fs * 4 + r;
-                    Act<bf16_t>::st(C_s + row * CP + col, acc[i][j][r] + bv);
-                }
-            }
-        __syncthreads();
-        const int oh0 = c_th * p.TH, ow0 = c_tw * p.TW;
-        const long long slice0 = ((long long)c_n * m.OD + c_od) * m.OH;
-        bool any_acc = m.accumulate != 0;
-        for (int q = 0; q < m.nout; ++q) any_acc |= m.outAcc[q] != 0;
-        if (any_acc) {            // out += : fold what is there into the tile first, so that the statistics below (a conv run as
-            // one launch per member group: the last group owns them) and the stores see the sum
-            constexpr int SPRa = BN / SEG;
-            for (int e = tid; e < HL_BM * SPRa; e += NTHR) {
-                const int row = e / SPRa, cs = e % SPRa;
-                const int th = row / p.TW, tw = row - th * p.TW;
-                const int oc = oc0 + cs * SEG;
-                if (oh0 + th >= m.OH || oc >= m.OCn) continue;
-                const OutRef o = m1_out_ref(m, oc);
-                if (!o.base || !o.acc) continue;
-                const long long orow = (slice0 + oh0 + th) * m.OW + ow0 + tw;
-                const bf16_t* src = (const bf16_t*)o.base + orow * o.C + o.col;
-                bf16_t* ct = C_s + row * CP + cs * SEG;
-                if (o.C % SEG != 0 || (m.nout == 0 && oc + SEG > m.OCn)) {
-                    for (int k = 0; k < SEG && oc + k < m.OCn; ++k) Act<bf16_t>::st(ct + k, Act<bf16_t>::ld(ct + k) + Act<bf16_t>::ld(src + k));
-                } else {
-                    float a[SEG], b[SEG];
-                    VecIO<bf16_t, SEG>::ld(ct, a); VecIO<bf16_t, SEG>::ld(src, b);
+                for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] + bias_r[j][r];
+                if (o_fast[j]) {
+                    if (o_acc[j]) {           // out += : an earlier launch wrote the other concat members' share
+                        float b[4]; VecIO<bf16_t, 4>::ld(dst, b);
 #pragma unroll
-                    for (int k = 0; k < SEG; ++k) a[k] += b[k];
-                    VecIO<bf16_t, SEG>::st(ct, a);
+                        for (int r = 0; r < 4; ++r) v[r] = bf2f(f2bf(v[r])) + b[r];
+                    }
+                    union { uint2 u; bf16_t e[4]; } o;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { o.e[r] = f2bf(v[r]); const float vr = bf2f(o.e[r]); ssum[j][r] += vr; ssq[j][r] += vr * vr; }
+                    *reinterpret_cast<uint2*>(dst) = o.u;
+                } else {                      // rows that are not 8-byte tiled (1..3 channels), or a partial group
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (r < o_nv[j]) {
+                            float a = v[r];
+                            if (o_acc[j]) a = bf2f(f2bf(a)) + bf2f(dst[r]);
+                            const bf16_t e = f2bf(a); dst[r] = e;
+                            const float vr = bf2f(e); ssum[j][r] += vr; ssq[j][r] += vr * vr;
+                        }
                 }
-            }
-            __syncthreads();
-        }
-        if (m.stat_partial) {
-            constexpr int G = NTHR / BN;
-            const int col = tid % BN, rg = tid / BN;
-            float s = 0.f, ss = 0.f;
-            for (int row = rg; row < HL_BM; row += G) {
-                if (oh0 + row / p.TW < m.OH) { const float v = Act<bf16_t>::ld(C_s + row * CP + col); s += v; ss += v * v; }
-            }
-            red[tid * 2] = s; red[tid * 2 + 1] = ss;
-            __syncthreads();
-            if (rg == 0 && oc0 + col < m.OCn) {
-                for (int q = 1; q < G; ++q) { s += red[(q * BN + col) * 2]; ss += red[(q * BN + col) * 2 + 1]; }
-                const long long tile = (long long)c_n * p.tiles_per_sample + ((long long)c_od * p.tiles_h + c_th) * p.tiles_w + c_tw;
-                float* dst = m.stat_partial + ((tile * m.OC) + oc0 + col) * 2;
-                dst[0] = s; dst[1] = ss;
-            }
-        }
-        constexpr int SPR = BN / SEG;
-        for (int e = tid; e < HL_BM * SPR; e += NTHR) {
-            const int row = e / SPR, cs = e % SPR;
-            const int th = row / p.TW, tw = row - th * p.TW;
-            const int oc = oc0 + cs * SEG;
-            if (oh0 + th >= m.OH || oc >= m.OCn) continue;
-            const OutRef o = m1_out_ref(m, oc);
-            if (!o.base) continue;
-            const long long orow = (slice0 + oh0 + th) * m.OW + ow0 + tw;
-            const uint4 v = *reinterpret_cast<const uint4*>(C_s + row * CP + cs * SEG);
-            bf16_t* dst = (bf16_t*)o.base + orow * o.C + o.col;
-            if (o.C % SEG != 0 || (m.nout == 0 && oc + SEG > m.OCn)) {
-                const bf16_t* ve = reinterpret_cast<const bf16_t*>(&v);
-                for (int k = 0; k < SEG && oc + k < m.OCn; ++k) dst[k] = ve[k];
-            } else {
-                *reinterpret_cast<uint4*>(dst) = v;
             }
         }
         if (++st == S) st = 0;
     }
+    if (m.stat_partial) { for (; cur_n < m.N; ++cur_n) flush(cur_n); }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
@@ -337,6 +352,7 @@ static bool halo_plan(const MfmaP& m, int OCpad, HaloP& p) {
     p.KDs = dmax - dmin + 1; p.IHt = (p.TH - 1) * p.she + (hmax - hmin + 1); p.IWt = (p.TW - 1) * p.swe + (wmax - wmin + 1);
     if (p.KDs > 255 || p.IHt > 255 || p.IWt > 255) return false;
     p.PX = CC * 2; p.spr = CC / 8;
+    p.spr_sh = p.spr == 8 ? 3 : (p.spr == 4 ? 2 : (p.spr == 2 ? 1 : 0)); p.tw_sh = p.TW == 32 ? 5 : (p.TW == 16 ? 4 : 3);
     const int x_rows = p.KDs * p.IHt * p.IWt;
     p.x_slots = (x_rows * p.spr + p.nthr - 1) / p.nthr * p.nthr;
     if (p.x_slots > HL_MAX_XIT * p.nthr) return false;
@@ -346,7 +362,7 @@ static bool halo_plan(const MfmaP& m, int OCpad, HaloP& p) {
     p.BNh = (m.OCn > 16 && OCpad >= 32) ? 32 : 16;
     if (OCpad % p.BNh) return false;
     p.b_bytes = p.nchunks * p.BNh * 64;
-    p.c_bytes = BMh * (p.BNh + 8) * 2 + p.nthr * 2 * 4;
+    p.c_bytes = (p.nthr / 64) * p.BNh * 2 * 4;                        // statistics fold, one row per wave
     const int fixed = p.b_bytes + p.c_bytes;
     static int kb = -1; if (kb < 0) { const char* e = getenv("M1_HALO_LDS_KB"); kb = e ? atoi(e) : 160; }
     int S = (kb * 1024 - fixed) / p.x_bytes;
@@ -358,17 +374,26 @@ static bool halo_plan(const MfmaP& m, int OCpad, HaloP& p) {
     return true;
 }
 
+// blocks along y: every block walks tiles blockIdx.y, + nsplit, ... (neighbouring tiles run at the same time and share halos in L2)
+static int halo_nsplit(const HaloP& p, int OCpad) {
+    const int slices = OCpad / p.BNh;
+    int nsplit = 256 / slices; if (nsplit < 1) nsplit = 1;
+    { static int tg = -1; if (tg < 0) { const char* e = getenv("M1_HALO_BLOCKS"); tg = e ? atoi(e) : 0; } if (tg > 0) nsplit = tg / slices > 0 ? tg / slices : 1; }
+    if (nsplit > p.ntiles) nsplit = p.ntiles;
+    return nsplit;
+}
+
 bool m1_halo_conv_supported(const MfmaP& mp, int OCpad) { HaloP p; return halo_plan(mp, OCpad, p); }
-int m1_halo_conv_tiles_per_sample(const MfmaP& mp) { HaloP p; return halo_plan(mp, 32, p) ? p.tiles_per_sample : 0; }
+// statistics partials per sample that the kernel writes (MfmaP::stat_tiles): one per block row
+int m1_halo_conv_stat_parts(const MfmaP& mp, int OCpad) { HaloP p; return halo_plan(mp, OCpad, p) ? halo_nsplit(p, OCpad) : 0; }
 
 int m1_halo_conv(const MfmaP& mp, int OCpad, hipStream_t st) {
     HaloP p;
     if (!halo_plan(mp, OCpad, p)) return M1_ERR_UNSUPPORTED;
     const int slices = OCpad / p.BNh;
-    int nsplit = 256 / slices; if (nsplit < 1) nsplit = 1;
-    { static int tg = -1; if (tg < 0) { const char* e = getenv("M1_HALO_BLOCKS"); tg = e ? atoi(e) : 0; } if (tg > 0) nsplit = tg / slices > 0 ? tg / slices : 1; }
-    if (nsplit > p.ntiles) nsplit = p.ntiles;
+    const int nsplit = halo_nsplit(p, OCpad);
     p.nsplit = nsplit;
+    if (mp.stat_partial && mp.stat_tiles != nsplit) return M1_ERR_BAD_ARG;
     const size_t smem = (size_t)p.b_bytes + p.c_bytes + (size_t)p.stages * p.x_bytes;
     void (*kern)(HaloP) = p.nthr == 512 ? (p.BNh == 32 ? conv_halo_kernel<2, 512> : conv_halo_kernel<1, 512>)
                                         : (p.BNh == 32 ? conv_halo_kernel<2, 256> : conv_halo_kernel<1, 256>);

@@ -35,8 +35,9 @@ struct MfmaP {
     float* acc32;               // [ksplit][out voxels][OC] fp32 slabs (ksplit > 1 only)
     long long slab_elems;
     int aligned;                // every concat member is a multiple of one 64-byte K-chunk: incremental addressing
-    float* stat_partial;        // fused InstanceNorm statistics: [N][tiles per sample][OC][2] = {sum, sum of squares} of
-    int stat_tiles;             //   the ROUNDED outputs of each 64/128-row tile (mode 0, tiles never straddle samples)
+    float* stat_partial;        // fused InstanceNorm statistics: [N][stat_tiles][OC][2] = {sum, sum of squares} of the ROUNDED
+    int stat_tiles;             //   outputs, one partial per 64/128-row tile (mode 0, tiles never straddle samples) or, in the
+                                //   halo kernel, per (sample, block row)
 };
 
 // where output column `oc` of a launch lives: tensor base (nullptr = nobody wants it), its row pitch, the column inside it,
@@ -61,5 +62,5 @@ template <> struct MT<float> { static constexpr int SEG = 4; };
 
 // halo-tile variant (conv_halo.hip): takes the same parameters and the same packed panel
 bool m1_halo_conv_supported(const MfmaP& mp, int OCpad);
-int m1_halo_conv_tiles_per_sample(const MfmaP& mp);
+int m1_halo_conv_stat_parts(const MfmaP& mp, int OCpad);
 int m1_halo_conv(const MfmaP& mp, int OCpad, hipStream_t st);

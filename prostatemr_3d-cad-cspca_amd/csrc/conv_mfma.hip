@@ -808,7 +808,7 @@ static int run_mfma(const GatherSpec& g, void* ws, int ws_packed, hipStream_t st
     if constexpr (sizeof(T) == 2) {
         static int hen = -1; if (hen < 0) { const char* e = getenv("M1_HALO"); hen = e ? atoi(e) : 1; }
         if (hen && (maxM >= 32768 || hen == 2) && m1_halo_conv_supported(mp, OCpad)) {      // (M1_HALO=2: no size floor, tests)
-            const int tps = m1_halo_conv_tiles_per_sample(mp);
+            const int tps = m1_halo_conv_stat_parts(mp, OCpad);
             if (g.stats_out && g.stats_ws && g.mode == 0 && tps > 0 && tps <= (Vout + 63) / 64) {
                 mp.stat_partial = g.stats_ws; mp.stat_tiles = tps; fuse_stats = true;
             } else { mp.stat_partial = nullptr; mp.stat_tiles = 0; fuse_stats = false; }

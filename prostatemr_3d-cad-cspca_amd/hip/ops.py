@@ -347,17 +347,7 @@ class _Conv3d(torch.autograd.Function):
         name = "convT3d" if ctx.transposed else "conv3d"
         dw = db = None
         if ctx.needs_input_grad[0] or (ctx.has_bias and ctx.needs_input_grad[1]):
-            wbuf, acc_w, dw = _sink(ctx.w_param)
-            bbuf = None
-            if ctx.has_bias:
-                bbuf, acc_b, db = _sink(ctx.b_param)
-                if acc_b != acc_w:      # both or neither live in the flat buffer; otherwise fall back to temporaries
-                    wbuf, acc_w, dw = torch.empty_like(w), 0, None
-                    bbuf, db = torch.empty(ctx.cout, dtype=torch.float32, device=w.device), None
-                    dw, db = wbuf, bbuf
-            ws = _conv_ws(d, ctx.transposed, 2, w.device)
-            fn = lib.m1_convT3d_wgrad if ctx.transposed else lib.m1_conv3d_wgrad
-            L.check(fn(C.byref(d), _p(dy), _p(wbuf), _p(bbuf), _p(ws), acc_w, st), f"m1_{name}_wgrad")
+            dw, db = _wgrad_into_sinks(lib, d, dy, ctx.w_param, ctx.b_param if ctx.has_bias else None, ctx.transposed, st, srcs)
         dsrc: List[Optional[torch.Tensor]] = []
         ptrs = (C.c_void_p * len(srcs))()
         accs = (C.c_int * len(srcs))()
@@ -405,8 +395,38 @@ def _pair_panel_ws(w1: torch.Tensor, w4: torch.Tensor, d, role: int, need_mask=N
     return ws, 0
 
 
-def _wgrad_into_sinks(lib, d, dy, w_param, b_param, transposed: bool, st):
-    """Weight (+ bias) gradient of a conv into the parameters' sinks (or fresh tensors): returns (dw, db) for autograd."""
+_WG = {"on": _os.environ.get("M1_WGRAD_STREAMS", "0"), "next": 0}
+
+
+def _wgrad_stream(param):
+    """The weight-gradient stream of ``param`` (M1_WGRAD_STREAMS of them, 0 = launch in order on the caller's stream).  A
+    parameter keeps its stream, so the passes that share it (prior / posterior run twice when not stacked) accumulate in order."""
+    n = int(_WG["on"])
+    device = param.device
+    if n <= 0 or not _BRANCH["on"] or device.type != "cuda":
+        return None
+    k = getattr(param, "_m1_wgs", None)
+    if k is None:
+        k = _WG["next"] % n
+        _WG["next"] += 1
+        try:
+            param._m1_wgs = k
+        except Exception:  # noqa: BLE001
+            return None
+    key = (device, "wg", k)
+    if key not in _BRANCH["streams"]:
+        _BRANCH["streams"][key] = torch.cuda.Stream(device=device)
+    return _BRANCH["streams"][key]
+
+
+def _wgrad_into_sinks(lib, d, dy, w_param, b_param, transposed: bool, st, srcs=()):
+    """Weight (+ bias) gradient of a conv into the parameters' sinks (or fresh tensors): returns (dw, db) for autograd.
+
+    Nothing downstream in the backward pass reads a weight gradient (the optimiser / the gradient exchange do, after
+    join_side_streams), and the data-gradient chain is the critical path: when both gradients go to the flat buffer the
+    kernels are enqueued on a weight-gradient stream that has waited for ``dy``, and run next to the data gradient of this
+    layer and the backward kernels of the following ones (the deep levels fill a fraction of the 256 CUs).  ``dy`` and the
+    saved inputs ``srcs`` are marked as in use on that stream so that the allocator does not hand their memory out early."""
     wbuf, acc_w, dw = _sink(w_param)
     bbuf, db = None, None
     if b_param is not None:
@@ -415,9 +435,20 @@ def _wgrad_into_sinks(lib, d, dy, w_param, b_param, transposed: bool, st):
             wbuf, acc_w = torch.empty_like(w_param), 0
             bbuf = torch.empty(int(bbuf.numel()), dtype=torch.float32, device=w_param.device)
             dw, db = wbuf, bbuf
-    ws = _conv_ws(d, transposed, 2, w_param.device)
     fn = lib.m1_convT3d_wgrad if transposed else lib.m1_conv3d_wgrad
-    L.check(fn(C.byref(d), _p(dy), _p(wbuf), _p(bbuf), _p(ws), acc_w, st), "m1_conv3d_wgrad")
+    side = _wgrad_stream(w_param) if (dw is None and db is None) else None
+    if side is None:
+        ws = _conv_ws(d, transposed, 2, w_param.device)
+        L.check(fn(C.byref(d), _p(dy), _p(wbuf), _p(bbuf), _p(ws), acc_w, st), "m1_conv3d_wgrad")
+        return dw, db
+    side.wait_stream(torch.cuda.current_stream(w_param.device))
+    _BRANCH["used"].add(side)
+    with torch.cuda.stream(side):
+        ws = _conv_ws(d, transposed, 2, w_param.device)      # scratch from (and back to) the side stream's pool
+        L.check(fn(C.byref(d), _p(dy), _p(wbuf), _p(bbuf), _p(ws), acc_w, _stream()), "m1_conv3d_wgrad")
+    dy.record_stream(side)
+    for t in srcs:
+        t.record_stream(side)
     return dw, db
 
 
@@ -465,7 +496,7 @@ class _ConvPair(torch.autograd.Function):
         dw1 = db1 = None
         iw, isrc = getattr(ctx, "idx_w1", 0), getattr(ctx, "idx_src", 6)       # positions of w1 / the first member among the inputs
         if ctx.needs_input_grad[iw] or ctx.needs_input_grad[iw + 1]:
-            dw1, db1 = _wgrad_into_sinks(lib, _desc(srcs, ctx.c1, ctx.k, ctx.s), dy1, ctx.w1_param, ctx.b1_param, False, st)
+            dw1, db1 = _wgrad_into_sinks(lib, _desc(srcs, ctx.c1, ctx.k, ctx.s), dy1, ctx.w1_param, ctx.b1_param, False, st, srcs)
         d = _desc(srcs, ctx.c1 + ctx.c4, ctx.k, ctx.s)
         dsrc: List[Optional[torch.Tensor]] = []
         ptrs = (C.c_void_p * len(srcs))()
@@ -504,7 +535,7 @@ class _WgradTap(torch.autograd.Function):
             return (None,) * (5 + len(srcs))
         dyc = dy.contiguous()
         dw, db = _wgrad_into_sinks(L.load(), _desc(srcs, int(ctx.w_param.shape[4]), ctx.k, ctx.s), dyc, ctx.w_param, ctx.b_param, False,
-                                   _stream())
+                                   _stream(), srcs)
         return (dy, dw, db, None, None, *([None] * len(srcs)))
 
 

@@ -1,0 +1,13 @@
+#!/bin/bash
+# kernel-only durations of the halo conv with parts of it switched off (M1_HALO_DBG bits: 1 MFMA loop, 2 stores/statistics,
+# 4 input DMA, 8 whole epilogue, 16 top-of-tile wait + barrier)
+ROOT=${GRAFT_REPO_ROOT:-/root/repo}
+mkdir -p $ROOT/gpurun_out
+cd /tmp && export TMPDIR=/tmp
+for d in ${DBGS:-0 7 15 31 2 6}; do
+  rm -rf /tmp/rp$d
+  M1_HALO_DBG=$d rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/rp$d -- python3 $ROOT/tools/bench_layer.py ${LAYER:-2 20 160 160 32+32 32 133 111} > /tmp/rp$d.log 2>&1
+  f=$(find /tmp/rp$d -name "*kernel_stats.csv" | head -1)
+  echo "== dbg=$d ($f)"
+  if [ -n "$f" ]; then grep "halo\|finalize" "$f" | cut -d, -f1-4 | cut -c1-140; else tail -5 /tmp/rp$d.log; fi
+done

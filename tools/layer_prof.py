@@ -20,5 +20,15 @@ fam = {}
 for k, v in r.items():
     fam[k.split(" ")[0]] = fam.get(k.split(" ")[0], 0) + v
 print("  ".join(f"{k} {v:.2f}" for k, v in sorted(fam.items(), key=lambda t: -t[1])))
-for k, v in sorted(r.items(), key=lambda t: -t[1])[:70]:
-    print(f"{v:8.3f} ms  {k}")
+w = out["roofline"].get("all_kernels_work_per_step", {})
+# "floor" = the time the record would take at 50 % of the MFMA peak / 70 % of the HBM peak (whichever binds); excess = time - floor
+PF, BW = 0.5 * (2500e12 if wl != "C5" else 157e12), 0.7 * 8e12
+rows = []
+for k, v in r.items():
+    fl, by, n = w.get(k, [0, 0, 0])
+    floor = max(fl / PF, by / BW) * 1e3
+    rows.append((v - floor, v, floor, fl / (v * 1e-3) / 1e12 if v else 0, by / (v * 1e-3) / 1e9 if v else 0, n, k))
+print("  excess    time   floor   TFLOP/s    GB/s  launches  record   (floor: 50 % MFMA peak / 70 % HBM peak)")
+for ex, v, floor, tf, gb, n, k in sorted(rows, key=lambda t: -t[0])[:90]:
+    print(f"{ex:8.3f} {v:7.3f} {floor:7.3f} {tf:9.1f} {gb:7.0f} {n:9.1f}  {k}")
+print(f"sum of excess {sum(t[0] for t in rows):.2f} ms of {tot:.2f}")
