@@ -17,6 +17,7 @@
 #include "conv_mfma.h"
 #include "reduce.h"
 #include <stdlib.h>
+#include <stdio.h>
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
@@ -70,9 +71,24 @@ __device__ __forceinline__ int x_swz(int row, int sl, int spr) {
 }
 __device__ __forceinline__ int b_swz(int row, int seg) { return seg ^ ((-(row >> 2)) & 3); }
 
-template <int TN, int NTHR>
+// pack two floats to bf16x2 (round to nearest even): one v_cvt_pk_bf16_f32
+typedef __attribute__((ext_vector_type(2))) __bf16 hbf2_t;
+typedef __attribute__((ext_vector_type(2))) float hf2_t;
+__device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b) {
+    return __builtin_bit_cast(unsigned, __builtin_convertvector((hf2_t){a, b}, hbf2_t));
+}
+template <int N_> __device__ __forceinline__ void wait_vm_c() {
+    static_assert(N_ >= 0 && N_ <= 63, "vmcnt immediate");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_) : "memory");
+}
+
+// NCH / NXIT > 0: the number of K chunks / of LDS-DMA pieces per thread are compile-time (the common layer shapes: straight-line
+// tile loop, immediate wait counts); 0 = taken from the plan at run time (predicated unrolling up to HL_MAX_CH / HL_MAX_XIT)
+template <int TN, int NTHR, int NCH, int NXIT>
 __global__ void __launch_bounds__(NTHR) conv_halo_kernel(HaloP p) {
     constexpr int TM = 2, BN = TN * 16, SEG = 8, NW = NTHR / 64;      // each wave owns 32 voxels x BN channels
+    constexpr bool RT = NCH == 0;
+    constexpr int CH = RT ? HL_MAX_CH : NCH, XIT = RT ? HL_MAX_XIT : NXIT;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* const Bs = smem;                                   // [nchunks][BN][64]
     float* const red = reinterpret_cast<float*>(smem + p.b_bytes);    // [NW][BN][2]  statistics of one sample, per wave
@@ -98,11 +114,12 @@ __global__ void __launch_bounds__(NTHR) conv_halo_kernel(HaloP p) {
     }
 
     // ---- per-lane description of its input-tile DMA pieces: address at tile origin 0 + what the bounds check needs ----
-    const bf16_t* x_ptr[HL_MAX_XIT]; int x_C[HL_MAX_XIT], x_pk[HL_MAX_XIT];
-    const int nxit = p.x_slots / NTHR;
+    const bf16_t* x_ptr[XIT]; int x_C[XIT], x_pk[XIT];
+    const int nxit = RT ? p.x_slots / NTHR : NXIT;
+    const int nchunks = RT ? p.nchunks : NCH;
     const int x_rows = p.KDs * p.IHt * p.IWt;
 #pragma unroll
-    for (int it = 0; it < HL_MAX_XIT; ++it) {
+    for (int it = 0; it < XIT; ++it) {
         const int q = it * NTHR + tid;
         const int row = q >> spt_sh, slp = q & (p.spr - 1);
         const int sl = x_swz(row, slp, p.spr);                        // XOR swizzles are involutions
@@ -133,17 +150,31 @@ __global__ void __launch_bounds__(NTHR) conv_halo_kernel(HaloP p) {
         const int lin0 = ((q_n * m.ID + id0) * m.IH + ih0) * m.IW + iw0;
         unsigned char* Xs = Xs0 + st * p.x_bytes;
         const long long zp = (long long)zero_pg;
+        // the whole input tile (halo included) inside the volume: no per-piece bounds checks (rows beyond the tile: pk < 0)
+        const bool inside = live && id0 >= 0 && id0 + p.KDs <= m.ID && ih0 >= 0 && ih0 + p.IHt <= m.IH && iw0 >= 0 && iw0 + p.IWt <= m.IW;
+        if (inside) {
 #pragma unroll
-        for (int it = 0; it < HL_MAX_XIT; ++it) {
-            if (it < nxit) {
-                const int pk = x_pk[it];
-                const int dd = pk & 0xff, hh = (pk >> 8) & 0xff, ww = (pk >> 16) & 0xff;
-                // (bitwise, not &&: one straight line of compares; the select is arithmetic so that no branch guards the address)
-                const int ok = live & (int)(pk >= 0) & (int)((unsigned)(id0 + dd) < (unsigned)m.ID) & (int)((unsigned)(ih0 + hh) < (unsigned)m.IH) &
-                               (int)((unsigned)(iw0 + ww) < (unsigned)m.IW);
-                const long long real = (long long)(x_ptr[it] + (long long)lin0 * x_C[it]);
-                const unsigned char* src = reinterpret_cast<const unsigned char*>(zp + ((real - zp) & -(long long)ok));
-                glds16h(src, Xs + (it * NTHR + wave * 64) * 16);
+            for (int it = 0; it < XIT; ++it) {
+                if (!RT || it < nxit) {
+                    const long long real = (long long)(x_ptr[it] + (long long)lin0 * x_C[it]);
+                    const int ok = x_pk[it] >= 0;
+                    const unsigned char* src = reinterpret_cast<const unsigned char*>(zp + ((real - zp) & -(long long)ok));
+                    glds16h(src, Xs + (it * NTHR + wave * 64) * 16);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int it = 0; it < XIT; ++it) {
+                if (!RT || it < nxit) {
+                    const int pk = x_pk[it];
+                    const int dd = pk & 0xff, hh = (pk >> 8) & 0xff, ww = (pk >> 16) & 0xff;
+                    // (bitwise, not &&: one straight line of compares; the select is arithmetic so that no branch guards the address)
+                    const int ok = live & (int)(pk >= 0) & (int)((unsigned)(id0 + dd) < (unsigned)m.ID) & (int)((unsigned)(ih0 + hh) < (unsigned)m.IH) &
+                                   (int)((unsigned)(iw0 + ww) < (unsigned)m.IW);
+                    const long long real = (long long)(x_ptr[it] + (long long)lin0 * x_C[it]);
+                    const unsigned char* src = reinterpret_cast<const unsigned char*>(zp + ((real - zp) & -(long long)ok));
+                    glds16h(src, Xs + (it * NTHR + wave * 64) * 16);
+                }
             }
         }
         advance(q_kt, q_tw, q_th, q_od, q_n);
@@ -152,9 +183,9 @@ __global__ void __launch_bounds__(NTHR) conv_halo_kernel(HaloP p) {
     // ---- fragment offsets (tile invariant): voxels per (chunk, 16-voxel tile), weights per 16-channel tile ----
     const unsigned lds0 = (unsigned)(unsigned long long)(lptr_t)smem;
     const int tw_sh = p.tw_sh;
-    unsigned a_off[HL_MAX_CH][TM];
+    unsigned a_off[CH][TM];
 #pragma unroll
-    for (int q = 0; q < HL_MAX_CH; ++q) {
+    for (int q = 0; q < CH; ++q) {
         int kseg = q * 4 + fs; if (kseg >= p.nseg) kseg = 0;          // K padding: the panel holds zeros there
         const int t = kseg >> spt_sh, sl = kseg & (p.spr - 1);
         const int ddr = m.tdd[t] - p.dmin, dhr = m.tdh[t] - p.hmin, dwr = m.tdw[t] - p.wmin;
@@ -202,6 +233,7 @@ __global__ void __launch_bounds__(NTHR) conv_halo_kernel(HaloP p) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) { ssum[j][r] = 0.f; ssq[j][r] = 0.f; }
     int cur_n = 0;
+    const bool want_stats = m.stat_partial != nullptr;
     auto flush = [&](int n) {
 #pragma unroll
         for (int j = 0; j < TN; ++j)
@@ -229,8 +261,9 @@ __global__ void __launch_bounds__(NTHR) conv_halo_kernel(HaloP p) {
     for (int s = 0; s < S - 1; ++s) issue(s);
     int st = 0;
     for (; c_kt < p.ntiles; advance(c_kt, c_tw, c_th, c_od, c_n)) {
-        if (m.stat_partial) { for (; cur_n < c_n; ++cur_n) flush(cur_n); }
-        wait_vmh(npiece * (S - 2));
+        if (want_stats) { for (; cur_n < c_n; ++cur_n) flush(cur_n); }
+        if constexpr (RT) wait_vmh(npiece * (S - 2));
+        else { if (S == 2) wait_vm_c<0>(); else if (S == 3) wait_vm_c<NXIT>(); else wait_vm_c<2 * NXIT>(); }
         __builtin_amdgcn_s_barrier();
         int stn = st + S - 1; if (stn >= S) stn -= S;
         issue(stn);
@@ -247,17 +280,17 @@ __global__ void __launch_bounds__(NTHR) conv_halo_kernel(HaloP p) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) bf[0][j] = lds_read128h(b_off[j]);
 #pragma unroll
-        for (int q = 0; q < HL_MAX_CH; ++q) {
-            if (q < p.nchunks) {
+        for (int q = 0; q < CH; ++q) {
+            if (!RT || q < nchunks) {
                 const int cur = q & 1;
                 lds_waith(af[cur][0]);
 #pragma unroll
                 for (int i = 1; i < TM; ++i) lds_tieh(af[cur][i]);
 #pragma unroll
                 for (int j = 0; j < TN; ++j) lds_tieh(bf[cur][j]);
-                if (q + 1 < HL_MAX_CH && q + 1 < p.nchunks) {
+                if (q + 1 < CH && (!RT || q + 1 < nchunks)) {
 #pragma unroll
-                    for (int i = 0; i < TM; ++i) af[cur ^ 1][i] = lds_read128h(a_off[q + 1 < HL_MAX_CH ? q + 1 : q][i] + sb);
+                    for (int i = 0; i < TM; ++i) af[cur ^ 1][i] = lds_read128h(a_off[q + 1 < CH ? q + 1 : q][i] + sb);
 #pragma unroll
                     for (int j = 0; j < TN; ++j) bf[cur ^ 1][j] = lds_read128h(b_off[j] + (q + 1) * BN * 64);
                 }
@@ -289,13 +322,19 @@ __global__ void __launch_bounds__(NTHR) conv_halo_kernel(HaloP p) {
                 if (o_fast[j]) {
                     if (o_acc[j]) {           // out += : an earlier launch wrote the other concat members' share
                         float b[4]; VecIO<bf16_t, 4>::ld(dst, b);
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) v[r] = bf2f(f2bf(v[r])) + b[r];
+                        const unsigned r01 = cvt_pk_bf16(v[0], v[1]), r23 = cvt_pk_bf16(v[2], v[3]);
+                        v[0] = __uint_as_float(r01 << 16) + b[0]; v[1] = __uint_as_float(r01 & 0xffff0000u) + b[1];
+                        v[2] = __uint_as_float(r23 << 16) + b[2]; v[3] = __uint_as_float(r23 & 0xffff0000u) + b[3];
                     }
-                    union { uint2 u; bf16_t e[4]; } o;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) { o.e[r] = f2bf(v[r]); const float vr = bf2f(o.e[r]); ssum[j][r] += vr; ssq[j][r] += vr * vr; }
-                    *reinterpret_cast<uint2*>(dst) = o.u;
+                    uint2 o;
+                    o.x = cvt_pk_bf16(v[0], v[1]); o.y = cvt_pk_bf16(v[2], v[3]);
+                    *reinterpret_cast<uint2*>(dst) = o;
+                    if (want_stats) {
+                        const float r0 = __uint_as_float(o.x << 16), r1 = __uint_as_float(o.x & 0xffff0000u);
+                        const float r2 = __uint_as_float(o.y << 16), r3 = __uint_as_float(o.y & 0xffff0000u);
+                        ssum[j][0] += r0; ssq[j][0] += r0 * r0; ssum[j][1] += r1; ssq[j][1] += r1 * r1;
+                        ssum[j][2] += r2; ssq[j][2] += r2 * r2; ssum[j][3] += r3; ssq[j][3] += r3 * r3;
+                    }
                 } else {                      // rows that are not 8-byte tiled (1..3 channels), or a partial group
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
@@ -310,7 +349,7 @@ __global__ void __launch_bounds__(NTHR) conv_halo_kernel(HaloP p) {
         }
         if (++st == S) st = 0;
     }
-    if (m.stat_partial) { for (; cur_n < m.N; ++cur_n) flush(cur_n); }
+    if (want_stats) { for (; cur_n < m.N; ++cur_n) flush(cur_n); }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
@@ -395,15 +434,25 @@ int m1_halo_conv(const MfmaP& mp, int OCpad, hipStream_t st) {
     p.nsplit = nsplit;
     if (mp.stat_partial && mp.stat_tiles != nsplit) return M1_ERR_BAD_ARG;
     const size_t smem = (size_t)p.b_bytes + p.c_bytes + (size_t)p.stages * p.x_bytes;
-    void (*kern)(HaloP) = p.nthr == 512 ? (p.BNh == 32 ? conv_halo_kernel<2, 512> : conv_halo_kernel<1, 512>)
-                                        : (p.BNh == 32 ? conv_halo_kernel<2, 256> : conv_halo_kernel<1, 256>);
+    // compile-time (K chunks, DMA pieces per thread) for the layer shapes of the M1 configurations; anything else: run-time counts
+    const int nxit = p.x_slots / p.nthr;
+    void (*kern)(HaloP) = nullptr;
+    if (p.nthr == 512) {
+#define HK(NCH_, NXIT_) if (!kern && p.nchunks == NCH_ && nxit == NXIT_) kern = p.BNh == 32 ? conv_halo_kernel<2, 512, NCH_, NXIT_> : conv_halo_kernel<1, 512, NCH_, NXIT_>;
+        HK(18, 6) HK(9, 3) HK(5, 2) HK(3, 1) HK(14, 4) HK(7, 2)
+#undef HK
+    }
+    { static int lg = -1; if (lg < 0) { const char* e = getenv("M1_HALO_LOG"); lg = e ? atoi(e) : 0; }
+      if (lg) fprintf(stderr, "halo: nthr %d BN %d nchunks %d nxit %d stages %d TW %d TH %d %s\n", p.nthr, p.BNh, p.nchunks, nxit, p.stages, p.TW, p.TH, kern ? "static" : "runtime"); }
+    if (!kern) kern = p.nthr == 512 ? (p.BNh == 32 ? conv_halo_kernel<2, 512, 0, 0> : conv_halo_kernel<1, 512, 0, 0>)
+                                    : (p.BNh == 32 ? conv_halo_kernel<2, 256, 0, 0> : conv_halo_kernel<1, 256, 0, 0>);
     {
-        static const void* done[4]; static int ndone = 0;
+        static const void* done[24]; static int ndone = 0;
         bool seen = false;
         for (int q = 0; q < ndone; ++q) seen |= done[q] == (const void*)kern;
         if (!seen) {
             if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return M1_ERR_LAUNCH;
-            if (ndone < 4) done[ndone++] = (const void*)kern;
+            if (ndone < 24) done[ndone++] = (const void*)kern;
         }
     }
     hipLaunchKernelGGL(kern, dim3(slices, nsplit), dim3(p.nthr), smem, st, p);
