@@ -77,6 +77,12 @@ typedef __attribute__((ext_vector_type(2))) float hf2_t;
 __device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b) {
     return __builtin_bit_cast(unsigned, __builtin_convertvector((hf2_t){a, b}, hbf2_t));
 }
+// 8-byte load the compiler does not track (its own bookkeeping would wait vmcnt(0) at the first use, draining the DMA issued behind it)
+__device__ __forceinline__ unsigned long long gload8_untracked(const void* p) {
+    unsigned long long v;
+    asm volatile("global_load_dwordx2 %0, %1, off" : "=&v"(v) : "v"(p) : "memory");
+    return v;
+}
 template <int N_> __device__ __forceinline__ void wait_vm_c() {
     static_assert(N_ >= 0 && N_ <= 63, "vmcnt immediate");
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_) : "memory");
@@ -225,6 +231,13 @@ __global__ void __launch_bounds__(NTHR) conv_halo_kernel(HaloP p) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) bias_r[j][r] = (oc + r < m.OCn) ? m1_bias_at(m, oc + r) : 0.f;
     }
+    // The bias values are global loads: consume them HERE.  Left to their first use in the tile loop the compiler puts an
+    // s_waitcnt vmcnt(0) in front of the epilogue of every tile, which also drains the input DMA of the next tile (loads
+    // retire in order) and serialises the pipeline.
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) asm volatile("" : "+v"(bias_r[j][r]));
     // running {sum, sum of squares} of the ROUNDED outputs of the current sample, per lane; folded over the block and written as
     // ONE partial per (sample, block) when the walk leaves the sample: [N][nsplit][OC][2], fixed order -> deterministic
     float ssum[TN][4], ssq[TN][4];
@@ -233,6 +246,10 @@ __global__ void __launch_bounds__(NTHR) conv_halo_kernel(HaloP p) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) { ssum[j][r] = 0.f; ssq[j][r] = 0.f; }
     int cur_n = 0;
+    bool any_acc = false;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) any_acc |= o_acc[j] != 0;
+    any_acc = __builtin_amdgcn_readfirstlane(__any(any_acc)) != 0;
     const bool want_stats = m.stat_partial != nullptr;
     auto flush = [&](int n) {
 #pragma unroll
@@ -265,6 +282,21 @@ __global__ void __launch_bounds__(NTHR) conv_halo_kernel(HaloP p) {
         if constexpr (RT) wait_vmh(npiece * (S - 2));
         else { if (S == 2) wait_vm_c<0>(); else if (S == 3) wait_vm_c<NXIT>(); else wait_vm_c<2 * NXIT>(); }
         __builtin_amdgcn_s_barrier();
+        // out += launches: fetch what is there BEFORE the next tile's DMA is issued -- loads retire in order, so a load issued
+        // behind the DMA could only be waited for together with it
+        const int oh0 = c_th * p.TH;
+        const int row0 = ((c_n * m.OD + c_od) * m.OH + oh0) * m.OW + c_tw * p.TW;
+        unsigned long long oldv[TM][TN];
+        if (any_acc) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    oldv[i][j] = 0ull;
+                    if (o_acc[j] && o_fast[j] && oh0 + e_th[i] < m.OH)
+                        oldv[i][j] = gload8_untracked(o_base[j] + (long long)(row0 + e_row[i]) * o_C[j]);
+                }
+        }
         int stn = st + S - 1; if (stn >= S) stn -= S;
         issue(stn);
         const unsigned sb = (unsigned)(st * p.x_bytes);
@@ -306,8 +338,13 @@ __global__ void __launch_bounds__(NTHR) conv_halo_kernel(HaloP p) {
         }
 
         // ---- epilogue in registers ----
-        const int oh0 = c_th * p.TH;
-        const int row0 = ((c_n * m.OD + c_od) * m.OH + oh0) * m.OW + c_tw * p.TW;
+        if (any_acc) {            // the fetched values: everything but the DMA pieces issued behind them has landed
+            if constexpr (RT) wait_vm_c<0>(); else wait_vm_c<NXIT>();
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) asm volatile("" : "+v"(oldv[i][j]));
+        }
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             if (oh0 + e_th[i] >= m.OH) continue;
@@ -321,7 +358,9 @@ __global__ void __launch_bounds__(NTHR) conv_halo_kernel(HaloP p) {
                 for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] + bias_r[j][r];
                 if (o_fast[j]) {
                     if (o_acc[j]) {           // out += : an earlier launch wrote the other concat members' share
-                        float b[4]; VecIO<bf16_t, 4>::ld(dst, b);
+                        const uint2 ov = make_uint2((unsigned)oldv[i][j], (unsigned)(oldv[i][j] >> 32));
+                        const float b[4] = {__uint_as_float(ov.x << 16), __uint_as_float(ov.x & 0xffff0000u),
+                                            __uint_as_float(ov.y << 16), __uint_as_float(ov.y & 0xffff0000u)};
                         const unsigned r01 = cvt_pk_bf16(v[0], v[1]), r23 = cvt_pk_bf16(v[2], v[3]);
                         v[0] = __uint_as_float(r01 << 16) + b[0]; v[1] = __uint_as_float(r01 & 0xffff0000u) + b[1];
                         v[2] = __uint_as_float(r23 << 16) + b[2]; v[3] = __uint_as_float(r23 & 0xffff0000u) + b[3];

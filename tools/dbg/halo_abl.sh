@@ -9,5 +9,9 @@ for d in ${DBGS:-0 7 15 31 2 6}; do
   M1_HALO_DBG=$d rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/rp$d -- python3 $ROOT/tools/bench_layer.py ${LAYER:-2 20 160 160 32+32 32 133 111} > /tmp/rp$d.log 2>&1
   f=$(find /tmp/rp$d -name "*kernel_stats.csv" | head -1)
   echo "== dbg=$d ($f)"
-  if [ -n "$f" ]; then grep "halo\|finalize" "$f" | cut -d, -f1-4 | cut -c1-140; else tail -5 /tmp/rp$d.log; fi
+  if [ -n "$f" ]; then python3 -c "
+import csv,sys
+for r in csv.DictReader(open('$f')):
+    if 'halo' in r['Name']: print('   %-48s calls %4s  avg %8.1f us' % (r['Name'][:48], r['Calls'], float(r['AverageNs'])/1e3))
+"; else tail -5 /tmp/rp$d.log; fi
 done
