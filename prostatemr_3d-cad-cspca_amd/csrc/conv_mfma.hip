@@ -773,9 +773,11 @@ static int run_mfma(const GatherSpec& g, void* ws, int ws_packed, hipStream_t st
     build_classes(g, CC, SEG, OCpad, &mp, &pp, &tot);
     mp.ksplit = pl.ksplit; mp.acc32 = nullptr; mp.aligned = 1; mp.stat_partial = nullptr; mp.stat_tiles = 0;
     const long long Vout = (long long)g.OD * g.OH * g.OW;
-    // M1_CONV8=1 (experiment, off): 128x128 tiles on 8 waves for the deep layers -- halves the weight-tile re-reads of the
-    // 64-row tiles at the same waves per CU; measured -8 % on the 512->128 forward, +4 % on its data gradient, neutral end to end
-    static int c8 = -1; if (c8 < 0) { const char* e = getenv("M1_CONV8"); c8 = e ? atoi(e) : 0; }
+    // M1_CONV8 (default 1): 128x128 tiles on 8 waves (64x32 per wave) for the deep layers -- the same waves per CU as two 4-wave
+    // 64x128 / 128x128 blocks with half the weight-tile re-reads.  Round 1 (2-volume launches): -8 % on the 512->128 forward, +4 % on
+    // its data gradient, neutral end to end; with the stacked passes (4 volumes per launch): 647 -> 624 us forward, 613 -> 557 us
+    // data gradient, -1.7 % per C3 step, C2 neutral.  256x128 tiles on 8 waves (one block per CU) were slower (702 / 678 us).
+    static int c8 = -1; if (c8 < 0) { const char* e = getenv("M1_CONV8"); c8 = e ? atoi(e) : 1; }
     const bool use8 = c8 && BN == 128 && pl.ksplit == 1 && cdiv_ll(spec_maxM(g), 128) * spec_ncls(g) * (OCpad / 128) >= 160;
     const int bm_eff = use8 ? 128 : pl.BM;
     bool fuse_stats = g.stats_out && g.stats_ws && g.mode == 0 && pl.ksplit == 1 && (g.N == 1 || Vout % bm_eff == 0) &&
