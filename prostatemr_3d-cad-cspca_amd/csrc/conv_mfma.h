@@ -64,3 +64,8 @@ template <> struct MT<float> { static constexpr int SEG = 4; };
 bool m1_halo_conv_supported(const MfmaP& mp, int OCpad);
 int m1_halo_conv_stat_parts(const MfmaP& mp, int OCpad);
 int m1_halo_conv(const MfmaP& mp, int OCpad, hipStream_t st);
+
+// pointwise (1x1x1, stride 1) streaming variant (conv_pw.hip): same parameters and panel; BN = output channels per block
+bool m1_pw_conv_supported(const MfmaP& mp, int OCpad, int BN);
+int m1_pw_conv_stat_parts(const MfmaP& mp, int OCpad, int BN);
+int m1_pw_conv(const MfmaP& mp, int OCpad, int BN, hipStream_t st);

@@ -817,7 +817,22 @@ static int run_mfma(const GatherSpec& g, void* ws, int ws_packed, hipStream_t st
             halo = true;
         }
     }
+    // pointwise layers: the streaming kernel (conv_pw.hip) -- no operand tiles, no barriers, epilogue in registers
+    bool pw = false; int pwBN = 0;
+    if constexpr (sizeof(T) == 2) {
+        pwBN = BN > 32 ? 32 : BN;
+        if (!halo && m1_pw_conv_supported(mp, OCpad, pwBN)) {
+            int parts = m1_pw_conv_stat_parts(mp, OCpad, pwBN);
+            const int cap = (int)((Vout + 63) / 64) / 4 * 4;          // what the statistics workspace holds per sample
+            if (parts > cap) parts = cap;
+            if (g.stats_out && g.stats_ws && g.mode == 0 && !g.accumulate && parts >= 4) {
+                mp.stat_partial = g.stats_ws; mp.stat_tiles = parts; fuse_stats = true;
+            } else { mp.stat_partial = nullptr; mp.stat_tiles = 0; fuse_stats = false; }
+            pw = true;
+        }
+    }
     if (halo) rc2 = m1_halo_conv(mp, OCpad, st);
+    else if (pw) rc2 = m1_pw_conv(mp, OCpad, pwBN, st);
     else
     switch (BN) {
         case 128: rc2 = use8 ? launch_cfg<T, 128, 128, 2, 4>(mp, maxM, OCpad, st)

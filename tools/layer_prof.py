@@ -29,6 +29,6 @@ for k, v in r.items():
     floor = max(fl / PF, by / BW) * 1e3
     rows.append((v - floor, v, floor, fl / (v * 1e-3) / 1e12 if v else 0, by / (v * 1e-3) / 1e9 if v else 0, n, k))
 print("  excess    time   floor   TFLOP/s    GB/s  launches  record   (floor: 50 % MFMA peak / 70 % HBM peak)")
-for ex, v, floor, tf, gb, n, k in sorted(rows, key=lambda t: -t[0])[:90]:
+for ex, v, floor, tf, gb, n, k in sorted(rows, key=lambda t: -t[0])[:int(os.environ.get("TOP", "90"))]:
     print(f"{ex:8.3f} {v:7.3f} {floor:7.3f} {tf:9.1f} {gb:7.0f} {n:9.1f}  {k}")
 print(f"sum of excess {sum(t[0] for t in rows):.2f} ms of {tot:.2f}")
