@@ -633,8 +633,12 @@ int m1_tf_wgrad(const WgradSpec& g, long long nw, int nb, hipStream_t st) {
     const int TS = big ? 64 : 32;
     const int aTiles = (g.CA + TS - 1) / TS; p.bTiles = (g.CB + TS - 1) / TS;
     const int ctiles = aTiles * p.bTiles;
-    static int tgt = -1; if (tgt < 0) { const char* e = getenv("M1_TF_SPLIT"); tgt = e ? atoi(e) : 256; }
-    long long nsplit = (tgt + ctiles - 1) / ctiles;          // ~2 blocks per CU
+    // blocks per launch (M1_TF_SPLIT, 0 = by size): 256 (one per CU) up to ~24k K-tiles, 512 beyond -- isolated, the 64 -> 32 layer
+    // at (20,160,160) runs 102 -> 67 us with 512, but every block adds a partial copy to fold and in the captured step other
+    // kernels fill the idle SIMDs: C3 (4 volumes per launch) -2 % with 512, C2 (2 volumes) +1 %
+    static int tgt_env = -1; if (tgt_env < 0) { const char* e = getenv("M1_TF_SPLIT"); tgt_env = e ? atoi(e) : 0; }
+    const int tgt = tgt_env > 0 ? tgt_env : (p.ntiles >= 24576 ? 512 : 256);
+    long long nsplit = (tgt + ctiles - 1) / ctiles;
     if (big) nsplit = (tgt + ctiles * g.kd - 1) / (ctiles * g.kd);
     const long long nloc = (long long)g.kd * g.kh * g.kw * g.CA * g.CB;
     const long long stride = nloc + g.CB;                      // compact copy of this member's block (+ bias sums)
