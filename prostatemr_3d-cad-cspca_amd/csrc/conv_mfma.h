@@ -35,6 +35,7 @@ struct MfmaP {
     float* acc32;               // [ksplit][out voxels][OC] fp32 slabs (ksplit > 1 only)
     long long slab_elems;
     int aligned;                // every concat member is a multiple of one 64-byte K-chunk: incremental addressing
+    int korder;                 // 1: K runs [64-byte chunk of the concat][tap] (needs aligned), 0: [tap][concat channel]
     float* stat_partial;        // fused InstanceNorm statistics: [N][stat_tiles][OC][2] = {sum, sum of squares} of the ROUNDED
     int stat_tiles;             //   outputs, one partial per 64/128-row tile (mode 0, tiles never straddle samples) or, in the
                                 //   halo kernel, per (sample, block row)

@@ -78,7 +78,8 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_mfma_kernel(MfmaP p) {
     int* s_srcC = reinterpret_cast<int*>(s_src + M1_MAX_SRC);                      // [6]
     int* s_srcSeg = s_srcC + M1_MAX_SRC;                                           // [6]
     int* s_tap = s_srcSeg + M1_MAX_SRC;                                            // [27] packed dd|dh|dw
-    constexpr int TBL_BYTES = (BM * 20 + M1_MAX_SRC * 16 + MF_MAX_TAPS * 4 + 15) / 16 * 16;
+    int* s_tdl = s_tap + MF_MAX_TAPS;                                              // [27] the same as a linear voxel delta
+    constexpr int TBL_BYTES = (BM * 20 + M1_MAX_SRC * 16 + 2 * MF_MAX_TAPS * 4 + 15) / 16 * 16;
     unsigned char* A_s = smem + TBL_BYTES;               // [2][KC][BM][64]
     unsigned char* B_s = A_s + 2 * KC * A_BYTES;         // [2][KC][BN][64]
 
@@ -122,6 +123,7 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_mfma_kernel(MfmaP p) {
     if (tid < ntaps) {
         const int t = tfirst + tid;
         s_tap[tid] = ((int)p.tdd[t] & 0xff) | (((int)p.tdh[t] & 0xff) << 8) | (((int)p.tdw[t] & 0xff) << 16);
+        s_tdl[tid] = ((int)p.tdd[t] * p.IH + (int)p.tdh[t]) * p.IW + (int)p.tdw[t];
     }
     __syncthreads();
 
@@ -167,24 +169,37 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_mfma_kernel(MfmaP p) {
     };
     // LDS-DMA variant: buffer loads -- the member tensor / weight panel is the resource, a lane keeps a 32-bit byte offset
     // (2^31 = out of range: the hardware range check returns the zeros of the padding), the chunk offset is the scalar
-    // offset: no per-lane 64-bit address arithmetic in the loop
+    // offset: no per-lane 64-bit address arithmetic in the loop.  Per row: the byte offset of its voxel under tap delta 0 in
+    // the current member and a bit mask of the taps that stay inside the volume; a tap is then one scalar byte delta.
     constexpr unsigned OOB = 0x80000000u;
-    unsigned st_vo[A_LD], b_vo[B_LD];
+    unsigned b_vo[B_LD];
+    unsigned rmask[A_LD]; int rvox[A_LD], rbyte[A_LD];
+    int tap_db = 0;                                      // byte delta of tap st_tap in member st_s
     __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc((void*)p.src[0], 0, 0, 0x00020000);
-    auto st_set_tap_vo = [&]() {
-        const int tp = s_tap[st_tap];
-        const int dd = (signed char)(tp & 0xff), dh = (signed char)((tp >> 8) & 0xff), dw = (signed char)((tp >> 16) & 0xff);
+    auto glds_set_member = [&]() {
         const int sC = __builtin_amdgcn_readfirstlane(s_srcC[st_s]);
+#pragma unroll
+        for (int i = 0; i < A_LD; ++i) rbyte[i] = (rvox[i] * sC + lseg * SEG) * (int)sizeof(T);
+        rs_a = __builtin_amdgcn_make_buffer_rsrc((void*)p.src[__builtin_amdgcn_readfirstlane(st_s)], 0, 0x7fffffff, 0x00020000);
+    };
+    auto glds_set_tap = [&]() {
+        tap_db = __builtin_amdgcn_readfirstlane(s_tdl[st_tap]) * __builtin_amdgcn_readfirstlane(s_srcC[st_s]) * (int)sizeof(T);
+    };
+    if constexpr (GLDS) {
 #pragma unroll
         for (int i = 0; i < A_LD; ++i) {
             const int4 ri = rowinfo[lrow + (NTHR / 4) * i];
-            const int id = ri.y + dd, ih = ri.z + dh, iw = ri.w + dw;
-            const bool ok = ri.x >= 0 && (unsigned)id < (unsigned)p.ID && (unsigned)ih < (unsigned)p.IH && (unsigned)iw < (unsigned)p.IW;
-            const int vox = ((ri.x * p.ID + id) * p.IH + ih) * p.IW + iw;
-            st_vo[i] = ok ? (unsigned)((vox * sC + lseg * SEG) * (int)sizeof(T)) : OOB;
+            unsigned mk = 0;
+            for (int t = 0; t < ntaps; ++t) {
+                const int tp = s_tap[t];
+                const int id = ri.y + (signed char)(tp & 0xff), ih = ri.z + (signed char)((tp >> 8) & 0xff), iw = ri.w + (signed char)((tp >> 16) & 0xff);
+                const bool ok = ri.x >= 0 && (unsigned)id < (unsigned)p.ID && (unsigned)ih < (unsigned)p.IH && (unsigned)iw < (unsigned)p.IW;
+                mk |= (ok ? 1u : 0u) << t;
+            }
+            rmask[i] = mk;
+            rvox[i] = ((ri.x * p.ID + ri.y) * p.IH + ri.z) * p.IW + ri.w;
         }
-        rs_a = __builtin_amdgcn_make_buffer_rsrc((void*)p.src[__builtin_amdgcn_readfirstlane(st_s)], 0, 0x7fffffff, 0x00020000);
-    };
+    }
     if constexpr (GLDS) {
 #pragma unroll
         for (int i = 0; i < B_LD; ++i) {
@@ -194,11 +209,12 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_mfma_kernel(MfmaP p) {
     }
     if (p.aligned && nchunks > 0) {
         const int cpt = spt >> 2;                          // chunks per tap
-        st_tap = c_beg / cpt;
-        int c = (c_beg - st_tap * cpt) * 4 * SEG;
+        int c;
+        if (p.korder) { const int cg = c_beg / ntaps; st_tap = c_beg - cg * ntaps; c = cg * 4 * SEG; }    // [chunk][tap] K order
+        else { st_tap = c_beg / cpt; c = (c_beg - st_tap * cpt) * 4 * SEG; }                               // [tap][chunk]
         while (c >= s_srcC[st_s]) { c -= s_srcC[st_s]; ++st_s; }
         st_c = c;
-        if constexpr (GLDS) st_set_tap_vo(); else st_set_tap();
+        if constexpr (GLDS) { glds_set_member(); glds_set_tap(); } else st_set_tap();
     }
 
     // loads the KC chunks of pipeline stage `sg` into registers (zero beyond this block's K range)
@@ -268,16 +284,30 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_mfma_kernel(MfmaP p) {
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lptr_t)(B_s + (buf * KC + kc) * B_BYTES + (wave_u + NW * i) * 1024), 16,
                                                          b_vo[i], chunk * 64, 0, 0);
 #pragma unroll
-        for (int i = 0; i < A_LD; ++i)
+        for (int i = 0; i < A_LD; ++i) {
+            const unsigned vo = ((rmask[i] >> st_tap) & 1u) ? (unsigned)(rbyte[i] + tap_db) : OOB;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lptr_t)(A_s + (buf * KC + kc) * A_BYTES + (wave_u + NW * i) * 1024), 16,
-                                                     st_vo[i], st_c * (int)sizeof(T), 0, 0);
+                                                     vo, st_c * (int)sizeof(T), 0, 0);
+        }
     };
+    // K order [32-channel chunk][tap] (p.korder): the 27 taps of one chunk follow each other, so the rows a block gathers for tap
+    // t+1 are the rows it (and its neighbours) just fetched for tap t, one voxel over -- they are still in L2.  In [tap][chunk]
+    // order a 128-row tile walks all Cin channels (128 KB at Cin = 512) before it returns to a voxel: with ~64 tiles in flight
+    // per XCD that is twice its 4 MB L2, and every tap re-fetches from the Infinity Cache / HBM.
     auto advance_chunk = [&]() {
-        st_c += 4 * SEG;
-        if (st_c >= s_srcC[st_s]) {
-            st_c = 0;
-            if (++st_s == p.nsrc) { st_s = 0; ++st_tap; }
-            if (st_tap < ntaps) st_set_tap_vo();
+        if (p.korder) {
+            if (++st_tap == ntaps) {
+                st_tap = 0; st_c += 4 * SEG;
+                if (st_c >= s_srcC[st_s]) { st_c = 0; if (++st_s < p.nsrc) glds_set_member(); }
+            }
+            if (st_s < p.nsrc) glds_set_tap();
+        } else {
+            st_c += 4 * SEG;
+            if (st_c >= s_srcC[st_s]) {
+                st_c = 0;
+                if (++st_s == p.nsrc) { st_s = 0; ++st_tap; }
+                if (st_tap < ntaps) { glds_set_member(); glds_set_tap(); }
+            }
         }
     };
     auto issue = [&](int sg, int buf) {
@@ -482,7 +512,7 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_mfma_kernel(MfmaP p) {
 
 template <typename T, int BM, int BN, int KC, int NTHR>
 static constexpr size_t mfma_smem_bytes() {
-    size_t tbl = (BM * 20 + M1_MAX_SRC * 16 + MF_MAX_TAPS * 4 + 15) / 16 * 16;
+    size_t tbl = (BM * 20 + M1_MAX_SRC * 16 + 2 * MF_MAX_TAPS * 4 + 15) / 16 * 16;      // = TBL_BYTES of the kernel
     size_t pipe = (size_t)KC * (2 * BM * 64 + 2 * BN * 64);
     size_t epi = ((size_t)BM * (BN + MT<T>::SEG) * sizeof(T) + 15) / 16 * 16;
     return tbl + (pipe > epi ? pipe : epi) + NTHR * 2 * sizeof(float);
@@ -498,12 +528,17 @@ struct PackP {
     int nclasses; int cls_ntaps[MF_MAX_CLASSES], cls_first[MF_MAX_CLASSES], cls_kpad[MF_MAX_CLASSES];
     long long cls_woff[MF_MAX_CLASSES];
     unsigned char wtap[MF_MAX_TAPS];
+    int korder;              // 0: K = [tap][concat channel]; 1: K = [64-byte chunk of the concat][tap] (MfmaP::korder)
 };
 // source offset (without the output-channel term) of the first column of packed K-segment kseg (SEG columns = SEG
 // consecutive channels of one concat member under one tap) of class cls; *nvalid = its real (non-padding) columns
 __device__ __forceinline__ bool pack_seg_pos(const PackP& p, int cls, int kseg, int* nvalid, int* wtap, int* chan) {
-    const int tap_i = kseg / p.spt;
-    int seg = kseg - tap_i * p.spt, c = 0, s = 0;
+    int tap_i, seg;
+    if (p.korder) {          // [chunk][tap]: 4 segments per chunk (every member is a multiple of one chunk)
+        const int chunk = kseg >> 2, nt = p.cls_ntaps[cls], cg = chunk / nt;
+        tap_i = chunk - cg * nt; seg = cg * 4 + (kseg & 3);
+    } else { tap_i = kseg / p.spt; seg = kseg - tap_i * p.spt; }
+    int c = 0, s = 0;
     while (s < p.nsrc && seg >= p.srcSeg[s]) { seg -= p.srcSeg[s]; c += p.srcC[s]; ++s; }
     if (s >= p.nsrc || tap_i >= p.cls_ntaps[cls]) { *nvalid = 0; return false; }
     const int rem = p.srcC[s] - seg * p.SEG;
@@ -792,6 +827,18 @@ static int run_mfma(const GatherSpec& g, void* ws, int ws_packed, hipStream_t st
         mp.acc32 = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(panel) + wbytes);
         mp.slab_elems = (long long)out_elems(g);
     }
+    // wide, shallow bf16 layers: the halo-tile kernel (conv_halo.hip) stages every input voxel once per tile, not per tap
+    const long long maxM = spec_maxM(g);
+    bool halo = false;
+    if constexpr (sizeof(T) == 2) {
+        static int hen = -1; if (hen < 0) { const char* e = getenv("M1_HALO"); hen = e ? atoi(e) : 1; }
+        halo = hen && (maxM >= 32768 || hen == 2) && m1_halo_conv_supported(mp, OCpad);      // (M1_HALO=2: no size floor, tests)
+    }
+    // K order of the panel and of the LDS-DMA gather: chunk-major ([64-byte chunk][tap]) for multi-tap problems on the
+    // implicit-GEMM kernel (see advance_chunk); the halo kernel and single-tap problems keep [tap][channel]
+    { static int ko = -1; if (ko < 0) { const char* e = getenv("M1_KORDER"); ko = e ? atoi(e) : 1; }
+      int maxtaps = 0; for (int c = 0; c < mp.nclasses; ++c) maxtaps = mp.cls_ntaps[c] > maxtaps ? mp.cls_ntaps[c] : maxtaps;
+      mp.korder = (ko && mp.aligned && !halo && maxtaps > 1) ? 1 : 0; pp.korder = mp.korder; }
     pp.w = g.w; pp.wST = g.wST; pp.wSC = g.wSC; pp.wSO = g.wSO; pp.oc_off = g.oc_off; pp.cc_off = g.cc_off; pp.OCn = g.OC; pp.OCpad = OCpad; pp.CC = CC;
     pp.w2 = g.w2; pp.w2ST = g.w2ST; pp.w2SC = g.w2SC; pp.w2SO = g.w2SO; pp.oc_split = g.oc_split; pp.c_split = g.c_split;
     int maxk = 0; for (int c = 0; c < pp.nclasses; ++c) maxk = pp.cls_kpad[c] > maxk ? pp.cls_kpad[c] : maxk;
@@ -802,20 +849,13 @@ static int run_mfma(const GatherSpec& g, void* ws, int ws_packed, hipStream_t st
         rc = m1_check_launch(); if (rc) return rc;
     }
 
-    const long long maxM = spec_maxM(g);
     const bool small = pl.BM == 64;
     int rc2;
-    // wide, shallow bf16 layers: the halo-tile kernel (conv_halo.hip) stages every input voxel once per tile, not per tap
-    bool halo = false;
-    if constexpr (sizeof(T) == 2) {
-        static int hen = -1; if (hen < 0) { const char* e = getenv("M1_HALO"); hen = e ? atoi(e) : 1; }
-        if (hen && (maxM >= 32768 || hen == 2) && m1_halo_conv_supported(mp, OCpad)) {      // (M1_HALO=2: no size floor, tests)
-            const int tps = m1_halo_conv_stat_parts(mp, OCpad);
-            if (g.stats_out && g.stats_ws && g.mode == 0 && tps > 0 && tps <= (Vout + 63) / 64) {
-                mp.stat_partial = g.stats_ws; mp.stat_tiles = tps; fuse_stats = true;
-            } else { mp.stat_partial = nullptr; mp.stat_tiles = 0; fuse_stats = false; }
-            halo = true;
-        }
+    if (halo) {
+        const int tps = m1_halo_conv_stat_parts(mp, OCpad);
+        if (g.stats_out && g.stats_ws && g.mode == 0 && tps > 0 && tps <= (Vout + 63) / 64) {
+            mp.stat_partial = g.stats_ws; mp.stat_tiles = tps; fuse_stats = true;
+        } else { mp.stat_partial = nullptr; mp.stat_tiles = 0; fuse_stats = false; }
     }
     // pointwise layers: the streaming kernel (conv_pw.hip) -- no operand tiles, no barriers, epilogue in registers
     bool pw = false; int pwBN = 0;

@@ -497,7 +497,10 @@ static int wgrad_common(const m1_conv_desc_t* d, bool T, const void* dy, float* 
             g.RT = (long long)d->Cout * d->Cin; g.RSA = d->Cin; g.a_off = 0; g.b_off = off;
         }
         int rc = M1_ERR_UNSUPPORTED;
+        static int wlog = -1; if (wlog < 0) { const char* e = getenv("M1_WG_LOG"); wlog = e ? atoi(e) : 0; }
         if (!g_force_direct && tf_wanted(g)) rc = m1_tf_wgrad(g, (long long)nw, nbias, st);   // may decline (no launch)
+        if (wlog) fprintf(stderr, "wgrad %s N%d B %dx%dx%d CA %d CB %d k%d%d%d s%d%d%d -> %s\n", T ? "convT" : "conv", g.N, g.BD, g.BH, g.BW, g.CA, g.CB,
+                          g.kd, g.kh, g.kw, g.sd, g.sh, g.sw, rc == M1_OK ? "tap-fused" : (m1_tap_wgrad_supported(g) ? "tap" : "mfma"));
         if (rc == M1_OK) { off += d->src[i].C; continue; }
         if (rc != M1_ERR_UNSUPPORTED && rc != M1_ERR_WORKSPACE) return rc;
         if (g_force_direct == 2 && m1_skinny_wgrad_supported(g)) rc = m1_skinny_wgrad(g, st);   // test hook for that kernel

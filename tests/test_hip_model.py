@@ -180,7 +180,10 @@ def test_bf16_mode_tracks_fp32(dev):
     m.set_compute_dtype(torch.bfloat16)
     p16 = m(x)
     assert p16.dtype == torch.float32
-    assert float((p16 - p32).abs().max()) < 0.1               # bf16 storage: loose, loss-curve level agreement
+    # bf16 storage: loose, loss-curve level agreement.  The worst voxel moves with every change of the accumulation order
+    # (0.09 .. 0.11 between K orders of the implicit GEMM), the mean does not
+    d = (p16 - p32).abs()
+    assert float(d.max()) < 0.15 and float(d.mean()) < 0.01, (float(d.max()), float(d.mean()))
 
 
 def test_train_step_reduces_loss_and_is_batch_shardable(dev):
