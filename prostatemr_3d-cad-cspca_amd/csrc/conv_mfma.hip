@@ -210,7 +210,8 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_mfma_kernel(MfmaP p) {
     if (p.aligned && nchunks > 0) {
         const int cpt = spt >> 2;                          // chunks per tap
         int c;
-        if (p.korder) { const int cg = c_beg / ntaps; st_tap = c_beg - cg * ntaps; c = cg * 4 * SEG; }    // [chunk][tap] K order
+        if (p.korder == 2) { const int cg = c_beg / (2 * ntaps), rem = c_beg - cg * 2 * ntaps; st_tap = rem >> 1; c = (cg * 2 + (rem & 1)) * 4 * SEG; }
+        else if (p.korder) { const int cg = c_beg / ntaps; st_tap = c_beg - cg * ntaps; c = cg * 4 * SEG; }    // [chunk][tap] K order
         else { st_tap = c_beg / cpt; c = (c_beg - st_tap * cpt) * 4 * SEG; }                               // [tap][chunk]
         while (c >= s_srcC[st_s]) { c -= s_srcC[st_s]; ++st_s; }
         st_c = c;
@@ -295,7 +296,17 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_mfma_kernel(MfmaP p) {
     // order a 128-row tile walks all Cin channels (128 KB at Cin = 512) before it returns to a voxel: with ~64 tiles in flight
     // per XCD that is twice its 4 MB L2, and every tap re-fetches from the Infinity Cache / HBM.
     auto advance_chunk = [&]() {
-        if (p.korder) {
+        if (p.korder == 2) {
+            if (((st_c / (4 * SEG)) & 1) == 0) st_c += 4 * SEG;           // second chunk of the pair, same tap
+            else {
+                st_c -= 4 * SEG;
+                if (++st_tap == ntaps) {
+                    st_tap = 0; st_c += 8 * SEG;
+                    if (st_c >= s_srcC[st_s]) { st_c = 0; if (++st_s < p.nsrc) glds_set_member(); }
+                }
+                if (st_s < p.nsrc) glds_set_tap();
+            }
+        } else if (p.korder) {
             if (++st_tap == ntaps) {
                 st_tap = 0; st_c += 4 * SEG;
                 if (st_c >= s_srcC[st_s]) { st_c = 0; if (++st_s < p.nsrc) glds_set_member(); }
@@ -534,7 +545,10 @@ struct PackP {
 // consecutive channels of one concat member under one tap) of class cls; *nvalid = its real (non-padding) columns
 __device__ __forceinline__ bool pack_seg_pos(const PackP& p, int cls, int kseg, int* nvalid, int* wtap, int* chan) {
     int tap_i, seg;
-    if (p.korder) {          // [chunk][tap]: 4 segments per chunk (every member is a multiple of one chunk)
+    if (p.korder == 2) {     // [pair of chunks][tap][chunk of the pair]: a tap reads 128 contiguous bytes of a voxel row
+        const int chunk = kseg >> 2, nt = p.cls_ntaps[cls], cg = chunk / (2 * nt), rem = chunk - cg * 2 * nt;
+        tap_i = rem >> 1; seg = (cg * 2 + (rem & 1)) * 4 + (kseg & 3);
+    } else if (p.korder) {   // [chunk][tap]: 4 segments per chunk (every member is a multiple of one chunk)
         const int chunk = kseg >> 2, nt = p.cls_ntaps[cls], cg = chunk / nt;
         tap_i = chunk - cg * nt; seg = cg * 4 + (kseg & 3);
     } else { tap_i = kseg / p.spt; seg = kseg - tap_i * p.spt; }
@@ -836,9 +850,11 @@ static int run_mfma(const GatherSpec& g, void* ws, int ws_packed, hipStream_t st
     }
     // K order of the panel and of the LDS-DMA gather: chunk-major ([64-byte chunk][tap]) for multi-tap problems on the
     // implicit-GEMM kernel (see advance_chunk); the halo kernel and single-tap problems keep [tap][channel]
-    { static int ko = -1; if (ko < 0) { const char* e = getenv("M1_KORDER"); ko = e ? atoi(e) : 1; }
+    { static int ko = -1; if (ko < 0) { const char* e = getenv("M1_KORDER"); ko = e ? atoi(e) : 2; }     // 2: pairs of chunks when every member allows
       int maxtaps = 0; for (int c = 0; c < mp.nclasses; ++c) maxtaps = mp.cls_ntaps[c] > maxtaps ? mp.cls_ntaps[c] : maxtaps;
-      mp.korder = (ko && mp.aligned && !halo && maxtaps > 1) ? 1 : 0; pp.korder = mp.korder; }
+      mp.korder = (ko && mp.aligned && !halo && maxtaps > 1) ? 1 : 0;
+      if (mp.korder && ko == 2) { bool pair = true; for (int i = 0; i < g.nsrc; ++i) pair &= g.srcC[i] % (8 * SEG) == 0; if (pair) mp.korder = 2; }
+      pp.korder = mp.korder; }
     pp.w = g.w; pp.wST = g.wST; pp.wSC = g.wSC; pp.wSO = g.wSO; pp.oc_off = g.oc_off; pp.cc_off = g.cc_off; pp.OCn = g.OC; pp.OCpad = OCpad; pp.CC = CC;
     pp.w2 = g.w2; pp.w2ST = g.w2ST; pp.w2SC = g.w2SC; pp.w2SO = g.w2SO; pp.oc_split = g.oc_split; pp.c_split = g.c_split;
     int maxk = 0; for (int c = 0; c < pp.nclasses; ++c) maxk = pp.cls_kpad[c] > maxk ? pp.cls_kpad[c] : maxk;
