@@ -34,7 +34,7 @@ __device__ __forceinline__ s16x4_t tr_read(const unsigned char* p) {
     return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)p);
 }
 
-#define TF_MAX_NKS 2        // k-steps (of 32 voxels) per K-tile (4 measured slower end to end)
+#define TF_MAX_NKS 4        // k-steps (of 32 voxels) per K-tile: 2, or 4 for the <= 16-channel layers (see tf_plan)
 #define TF_MAX_AIT 10       // LDS-DMA pieces per thread for the A tile
 
 struct TfP {
@@ -52,6 +52,7 @@ struct TfP {
     int stages;              // LDS pipeline depth (tiles staged ahead of the MFMAs + 1)
     float* Rx; long long rx_stride;      // per-XCD private copies of R (+ bias sums behind it): see the epilogue
     long long rx_bias;       // offset of the bias sums inside one copy
+    int nks;                 // k-steps per K-tile (template TF_NKS of the kernel)
 };
 
 typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
@@ -554,7 +555,11 @@ static bool tf_plan(const WgradSpec& g, TfP& p) {
     p.RT = g.RT; p.RSA = g.RSA; p.a_off = g.a_off; p.b_off = g.b_off;
     p.sd = g.sd; p.sh = g.sh; p.sw = g.sw; p.pd = g.pd; p.ph = g.ph; p.pw = g.pw;
     p.KWs = g.BW % 32 == 0 ? 32 : (g.BW % 16 == 0 ? 16 : 8);
-    const int nks = 2;
+    // K-tile: 64 voxels; 128 when both sides have <= 16 channels (res0 conv2, the narrow heads): those tiles are a few KB and
+    // 14 MFMAs per wave, the barrier and the DMA round trip per tile are the whole cost (M1_TF_NKS4=0: always 64)
+    static int n4 = -1; if (n4 < 0) { const char* e = getenv("M1_TF_NKS4"); n4 = e ? atoi(e) : 1; }
+    const int nks = (n4 && g.CA <= 16 && g.CB <= 16) ? 4 : 2;
+    p.nks = nks;
     p.TH = nks * (32 / p.KWs);
     p.AHt = (p.TH - 1) * g.sh + g.kh; p.AWt = (p.KWs - 1) * g.sw + g.kw;
     p.spra = (g.CA < 32 ? g.CA : 32) / 8; p.sprb = (g.CB < 32 ? g.CB : 32) / 8;
@@ -653,9 +658,10 @@ int m1_tf_wgrad(const WgradSpec& g, long long nw, int nb, hipStream_t st) {
     dim3 grid(ctiles, (unsigned)nsplit, big ? g.kd : 1);
     const int kparts = 4 / ((g.CA > 16 ? 2 : 1) * (g.CB > 16 ? 2 : 1));
     void (*kern)(TfP) = nullptr;
-#define TF_PICK(KD_, KP_) if ((g.kd == KD_) && kparts == KP_) kern = wgrad_tf_kernel<KD_, 3, 3, KP_, 2>;
+#define TF_PICK(KD_, KP_) if ((g.kd == KD_) && kparts == KP_ && p.nks == 2) kern = wgrad_tf_kernel<KD_, 3, 3, KP_, 2>;
     TF_PICK(1, 1) TF_PICK(1, 2) TF_PICK(1, 4) TF_PICK(3, 1) TF_PICK(3, 2) TF_PICK(3, 4)
 #undef TF_PICK
+    if (p.nks == 4 && kparts == 4) kern = g.kd == 1 ? wgrad_tf_kernel<1, 3, 3, 4, 4> : (g.kd == 3 ? wgrad_tf_kernel<3, 3, 3, 4, 4> : nullptr);
     if (big) kern = wgrad_tf64_kernel;
     if (!kern) return M1_ERR_UNSUPPORTED;
     {   // raise the dynamic-LDS limit once per instantiation
