@@ -251,6 +251,17 @@ int m1_adam_amsgrad(float* p, const float* g, float* m, float* v, float* vhat, l
 /* step_dev[0] += 1 (may be NULL); rng_dev[1] += 1 (may be NULL). */
 int m1_step_advance(int* step_dev, uint64_t* rng_dev, void* stream);
 
+/* Deferred folds of the weight-gradient partial copies (no reference counterpart; the reference's tf.GradientTape sums weight
+ * gradients inside each op).  m1_conv3d_wgrad / m1_convT3d_wgrad split the voxels over blocks, every block stores its partial
+ * tile into a copy inside `ws`, and a fold kernel adds the copies into dw / db in a fixed order.  After m1_wgrad_defer(1) the
+ * weight-gradient entry points QUEUE that fold instead of launching it (process-wide, host side); m1_wgrad_fold_pending runs
+ * everything queued in a few batched launches on `stream` -- the caller keeps every `ws` alive and orders `stream` behind the
+ * weight-gradient launches until then; dw / db are incomplete before.  m1_wgrad_fold_drop forgets the queue (gradients
+ * discarded).  A second fold into the same block of dw while one is queued first runs the queue on that call's stream. */
+int m1_wgrad_defer(int on);
+int m1_wgrad_fold_pending(void* stream);
+int m1_wgrad_fold_drop(void);
+
 /* ---- opt-in per-kernel-family timing with hipEvents on the launch stream (bench.py roofline) ---- */
 int m1_prof_enable(int on);
 int m1_prof_reset(void);

@@ -459,11 +459,11 @@ __global__ void __launch_bounds__(256, 2) wgrad_tf64_kernel(TfP p) {
 // total into R -- fixed order, no atomics: the weight gradient of these layers is run-to-run deterministic.
 struct TfFin { float* Rx; long long stride; int ncopies; float* R; int NT, CA, CB; long long RT, RSA; int a_off, b_off;
                float* bsum; long long rx_bias; int nb; int EL; };
-__global__ void __launch_bounds__(256) tf_finish_kernel(TfFin f) {
-    __shared__ float red[256];
+// (bodies take the block index / block count of THEIR fold, so that one launch can serve many folds: tf_finish_batch_kernel)
+__device__ __forceinline__ void tf_fold_generic(const TfFin& f, unsigned vb, float* red) {
     const long long n = (long long)f.NT * f.CA * f.CB;
     const int e = threadIdx.x % f.EL, y = threadIdx.x / f.EL, YL = 256 / f.EL;
-    const long long i = (long long)blockIdx.x * f.EL + e;
+    const long long i = (long long)vb * f.EL + e;
     const long long idx = i;                              // the copies are compact: [tap][a][b] of this member, then CB bias sums
     float* dst = nullptr;
     if (i < n) {
@@ -482,13 +482,17 @@ __global__ void __launch_bounds__(256) tf_finish_kernel(TfFin f) {
         *dst += s;
     }
 }
+__global__ void __launch_bounds__(256) tf_finish_kernel(TfFin f) {
+    __shared__ float red[256];
+    tf_fold_generic(f, blockIdx.x, red);
+}
 
 // Few copies of a large block (deep layers: 2..16 voxel splits of a multi-MB weight block): one thread folds 4 consecutive
 // elements over all copies with 16-byte loads -- bandwidth-bound, where the kernel above (built for hundreds of copies of a
 // small block) spends its time in 55k nearly empty blocks.  Same fixed order of additions.
-__global__ void __launch_bounds__(256) tf_finish_vec_kernel(TfFin f) {
+__device__ __forceinline__ void tf_fold_vec(const TfFin& f, unsigned vb, unsigned nblk) {
     const long long n = (long long)f.NT * f.CA * f.CB, n4 = n >> 2;
-    for (long long q = (long long)blockIdx.x * 256 + threadIdx.x; q < n4; q += (long long)gridDim.x * 256) {
+    for (long long q = (long long)vb * 256 + threadIdx.x; q < n4; q += (long long)nblk * 256) {
         const long long i = q << 2;
         float4 s = *reinterpret_cast<const float4*>(f.Rx + i);
         for (int c = 1; c < f.ncopies; ++c) {
@@ -499,21 +503,21 @@ __global__ void __launch_bounds__(256) tf_finish_vec_kernel(TfFin f) {
         float* dst = f.R + (long long)t * f.RT + (long long)(a + f.a_off) * f.RSA + b + f.b_off;
         dst[0] += s.x; dst[1] += s.y; dst[2] += s.z; dst[3] += s.w;
     }
-    if (blockIdx.x == 0)
+    if (vb == 0)
         for (int j = threadIdx.x; j < f.nb; j += 256) {
             float s = 0.f;
             for (int c = 0; c < f.ncopies; ++c) s += f.Rx[(long long)c * f.stride + n + j];
             f.bsum[j + f.b_off] += s;
         }
 }
+__global__ void __launch_bounds__(256) tf_finish_vec_kernel(TfFin f) { tf_fold_vec(f, blockIdx.x, gridDim.x); }
 
 // Many copies (tens to hundreds of voxel splits): a block owns 256 consecutive elements, its 4 waves take every 4th copy with
 // 16-byte loads (1 KB contiguous per wave and copy), fold through LDS in wave order, one store.  Fixed order, coalesced.
-__global__ void __launch_bounds__(256) tf_finish_wide_kernel(TfFin f) {
-    __shared__ float4 red[4][64];
+__device__ __forceinline__ void tf_fold_wide(const TfFin& f, unsigned vb, float4 (*red)[64]) {
     const long long n = (long long)f.NT * f.CA * f.CB;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const long long i = ((long long)blockIdx.x * 64 + lane) << 2;
+    const long long i = ((long long)vb * 64 + lane) << 2;
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
     if (i < n) {
 #pragma unroll 4
@@ -531,12 +535,32 @@ __global__ void __launch_bounds__(256) tf_finish_wide_kernel(TfFin f) {
         float* dst = f.R + (long long)t * f.RT + (long long)(a + f.a_off) * f.RSA + b + f.b_off;
         dst[0] += s.x; dst[1] += s.y; dst[2] += s.z; dst[3] += s.w;
     }
-    if (blockIdx.x == 0)
+    if (vb == 0)
         for (int j = threadIdx.x; j < f.nb; j += 256) {
             float sb = 0.f;
             for (int c = 0; c < f.ncopies; ++c) sb += f.Rx[(long long)c * f.stride + n + j];
             f.bsum[j + f.b_off] += sb;
         }
+}
+__global__ void __launch_bounds__(256) tf_finish_wide_kernel(TfFin f) {
+    __shared__ float4 red[4][64];
+    tf_fold_wide(f, blockIdx.x, red);
+}
+
+// Many folds in one launch (m1_wgrad_defer / m1_wgrad_fold_pending): a fold of one conv member is 5-10 us of a few dozen blocks;
+// ~130 of them per C3 step, each alone on its stream, were 4 % of the step.  The jobs travel by value in the kernel arguments.
+#define TF_FOLD_MAX 24
+struct TfFoldBatch { int n; int pref[TF_FOLD_MAX + 1]; int mode[TF_FOLD_MAX]; TfFin f[TF_FOLD_MAX]; };
+static_assert(sizeof(TfFoldBatch) <= 3800, "fold batch must fit the kernel argument segment");
+__global__ void __launch_bounds__(256) tf_finish_batch_kernel(TfFoldBatch B) {
+    __shared__ float4 red[4][64];
+    int j = 0;
+    while (j + 1 < B.n && (int)blockIdx.x >= B.pref[j + 1]) ++j;
+    const unsigned vb = blockIdx.x - B.pref[j], nblk = B.pref[j + 1] - B.pref[j];
+    const TfFin& f = B.f[j];
+    if (B.mode[j] == 1) tf_fold_vec(f, vb, nblk);
+    else if (B.mode[j] == 2) tf_fold_wide(f, vb, red);
+    else tf_fold_generic(f, vb, reinterpret_cast<float*>(red));
 }
 
 static inline bool tf_chan_ok(int c) { return c == 8 || c == 16 || (c >= 32 && c % 32 == 0); }
@@ -611,21 +635,61 @@ static bool tf64_plan(const WgradSpec& g, TfP& p) {
 bool m1_tf_wgrad_supported(const WgradSpec& g) { TfP p; return tf_plan(g, p) || tf64_plan(g, p); }
 bool m1_tf64_wgrad_supported(const WgradSpec& g) { TfP p; return tf64_plan(g, p); }
 
+// ---- deferred folds: queued (process-wide, the autograd engine calls the weight gradients from its own thread) and run
+//      in a few batched launches by m1_wgrad_fold_pending ----
+#include <mutex>
+#include <vector>
+struct TfPending { TfFin f; int mode; int blocks; };
+static std::mutex g_fold_mu;
+static std::vector<TfPending> g_fold_pending;
+static int g_fold_defer = 0;
+static int fold_launch_pending_locked(hipStream_t st) {
+    size_t i = 0;
+    while (i < g_fold_pending.size()) {
+        TfFoldBatch B{}; B.pref[0] = 0;
+        while (i < g_fold_pending.size() && B.n < TF_FOLD_MAX) {
+            const TfPending& q = g_fold_pending[i++];
+            B.f[B.n] = q.f; B.mode[B.n] = q.mode; B.pref[B.n + 1] = B.pref[B.n] + q.blocks; ++B.n;
+        }
+        hipLaunchKernelGGL(tf_finish_batch_kernel, dim3((unsigned)B.pref[B.n]), dim3(256), 0, st, B);
+        int rc = m1_check_launch(); if (rc) { g_fold_pending.clear(); return rc; }
+    }
+    g_fold_pending.clear();
+    return M1_OK;
+}
+extern "C" int m1_wgrad_defer(int on) { std::lock_guard<std::mutex> lk(g_fold_mu); g_fold_defer = on ? 1 : 0; return M1_OK; }
+extern "C" int m1_wgrad_fold_drop(void) { std::lock_guard<std::mutex> lk(g_fold_mu); g_fold_pending.clear(); return M1_OK; }
+extern "C" int m1_wgrad_fold_pending(void* stream) {
+    std::lock_guard<std::mutex> lk(g_fold_mu);
+    return fold_launch_pending_locked((hipStream_t)stream);
+}
+
 // shared with the per-tap kernel (wgrad_mfma.hip), which uses the same partial-copy scheme for small weight tensors
 int m1_wg_rx_finish(float* rx, long long stride, int ncopies, const WgradSpec& g, long long nw, hipStream_t st) {
     TfFin f{rx, stride, ncopies, g.R, g.kd * g.kh * g.kw, g.CA, g.CB, g.RT, g.RSA, g.a_off, g.b_off, g.bsum, nw, g.bsum ? g.CB : 0, 32};
     const long long n = (long long)f.NT * f.CA * f.CB + f.nb;
+    int mode = 0; long long blocks;
     if (ncopies <= 16 && f.CB % 4 == 0 && n >= (1 << 16)) {
-        long long blocks = (n / 4 + 255) / 256; if (blocks > 4096) blocks = 4096;
-        hipLaunchKernelGGL(tf_finish_vec_kernel, dim3((unsigned)blocks), dim3(256), 0, st, f);
-        return m1_check_launch();
+        mode = 1; blocks = (n / 4 + 255) / 256; if (blocks > 4096) blocks = 4096;
+    } else if (f.CB % 4 == 0 && n - f.nb >= (1 << 15)) {            // (n - nb) / 256 >= 128 blocks
+        mode = 2; blocks = (n - f.nb + 255) / 256;
+    } else {
+        while (f.EL > 4 && n / f.EL < 128) f.EL >>= 1;           // small blocks of R: more lane rows per element, more blocks
+        blocks = (n + f.EL - 1) / f.EL;
     }
-    if (f.CB % 4 == 0 && n - f.nb >= (1 << 15)) {            // (n - nb) / 256 >= 128 blocks
-        hipLaunchKernelGGL(tf_finish_wide_kernel, dim3((unsigned)((n - f.nb + 255) / 256)), dim3(256), 0, st, f);
-        return m1_check_launch();
+    {
+        std::lock_guard<std::mutex> lk(g_fold_mu);
+        if (g_fold_defer) {
+            // two folds into the same block of R (a parameter used by two passes) must not share a launch: run what is queued first
+            for (const TfPending& q : g_fold_pending)
+                if (q.f.R == f.R && q.f.a_off == f.a_off && q.f.b_off == f.b_off) { int rc = fold_launch_pending_locked(st); if (rc) return rc; break; }
+            g_fold_pending.push_back(TfPending{f, mode, (int)blocks});
+            return M1_OK;
+        }
     }
-    while (f.EL > 4 && n / f.EL < 128) f.EL >>= 1;           // small blocks of R: more lane rows per element, more blocks
-    hipLaunchKernelGGL(tf_finish_kernel, dim3((unsigned)((n + f.EL - 1) / f.EL)), dim3(256), 0, st, f);
+    if (mode == 1) hipLaunchKernelGGL(tf_finish_vec_kernel, dim3((unsigned)blocks), dim3(256), 0, st, f);
+    else if (mode == 2) hipLaunchKernelGGL(tf_finish_wide_kernel, dim3((unsigned)blocks), dim3(256), 0, st, f);
+    else hipLaunchKernelGGL(tf_finish_kernel, dim3((unsigned)blocks), dim3(256), 0, st, f);
     return m1_check_launch();
 }
 

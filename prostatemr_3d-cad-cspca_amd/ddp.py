@@ -75,6 +75,7 @@ class GradReducer:
         self._sent: set = set()
         self._comm = None
         self._side_streams: Callable[[], Sequence] = lambda: ()
+        self._before_send: Callable[[], None] = lambda: None
         self.stats = {"buckets": 0, "early_groups": 0, "late_groups": 0, "collectives": 0}
 
     # ------------------------------------------------------------------------------------------------------
@@ -87,13 +88,15 @@ class GradReducer:
         return dist.is_initialized() and (self.world_size > 1 or self.force)
 
     def bind(self, flat_grad: torch.Tensor, ranges: Dict[str, Tuple[int, int]], order: Sequence[str], tail: Tuple[int, int],
-             side_streams: Optional[Callable[[], Sequence]] = None) -> None:
+             side_streams: Optional[Callable[[], Sequence]] = None, before_send: Optional[Callable[[], None]] = None) -> None:
         """``ranges[key]`` = [lo, hi) of group ``key`` inside ``flat_grad``; ``order`` = the order groups are expected to
         complete in; ``tail`` = the range exchanged last (biases, norms, SE); ``side_streams()`` = the streams besides the
         current one that may hold backward kernels (ops.branch)."""
         self.flat, self.ranges, self.order, self.tail = flat_grad, dict(ranges), list(order), tuple(tail)
         if side_streams is not None:
             self._side_streams = side_streams
+        if before_send is not None:                       # runs on the current stream before a group goes out during backward
+            self._before_send = before_send
         if flat_grad.is_cuda and self._comm is None:
             self._comm = torch.cuda.Stream(device=flat_grad.device)
 
@@ -112,6 +115,8 @@ class GradReducer:
             return
         self.stats["early_groups" if early else "late_groups"] += 1
         self.stats["buckets"] += 1
+        if early:
+            self._before_send()                           # (host hook: finish queued gradient work on the current stream)
         if self._comm is None:
             self._reduce_range(lo, hi)
             return

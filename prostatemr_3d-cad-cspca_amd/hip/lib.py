@@ -101,6 +101,9 @@ SIGNATURES = {
     "m1_cast": (_i, [_vp, _i, _vp, _i, _ll, _vp]),
     "m1_adam_amsgrad": (_i, [_vp] * 5 + [_ll, _ll, _ll, _f, _f, _f, _vp, _f, _f, _f, _vp, _vp]),
     "m1_step_advance": (_i, [_vp, _vp, _vp]),
+    "m1_wgrad_defer": (_i, [_i]),
+    "m1_wgrad_fold_pending": (_i, [_vp]),
+    "m1_wgrad_fold_drop": (_i, []),
     "m1_prof_enable": (_i, [_i]),
     "m1_prof_reset": (_i, []),
     "m1_prof_read": (_i, [C.POINTER(m1_prof_rec_t), _i]),

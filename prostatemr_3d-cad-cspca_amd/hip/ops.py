@@ -127,6 +127,42 @@ def _slot_written(slot: Optional[_GradSlot]) -> None:
 _BRANCH = {"on": _os.environ.get("M1_STREAMS", "1") != "0", "streams": {}, "used": set()}
 
 
+# Deferred folds of the weight-gradient partial copies (m1_wgrad_defer): with gradients going to the flat buffer nothing reads a
+# weight gradient before join_side_streams, so the ~130 fold launches of a step (5-10 us each, a few dozen blocks, alone on
+# their stream) become a handful of batched ones there.  The workspaces holding the copies are kept until then.
+_FOLD = {"on": _os.environ.get("M1_WG_FOLD_BATCH", "1") != "0", "keep": []}
+
+
+def fold_pending() -> None:
+    """Run the queued weight-gradient folds on the current stream (which must be ordered behind the weight-gradient kernels)."""
+    if _FOLD["keep"]:
+        try:
+            L.check(L.load().m1_wgrad_fold_pending(_stream()), "m1_wgrad_fold_pending")
+            cur = torch.cuda.current_stream()
+            for ws, made_on in _FOLD["keep"]:
+                if made_on != cur:
+                    ws.record_stream(cur)             # read here, allocated on a branch stream
+        finally:
+            _FOLD["keep"].clear()
+
+
+def finish_queued_for_exchange() -> None:
+    """Before a gradient group is exchanged during backward (ddp.GradReducer): the current stream waits for the branch streams
+    (without retiring them) and runs the weight-gradient folds queued so far."""
+    if _FOLD["keep"]:
+        cur = torch.cuda.current_stream()
+        for s in _BRANCH["used"]:
+            if s != cur:
+                cur.wait_stream(s)
+        fold_pending()
+
+
+def fold_drop() -> None:
+    if _FOLD["keep"]:
+        L.load().m1_wgrad_fold_drop()
+        _FOLD["keep"].clear()
+
+
 def join_side_streams() -> None:
     """The current stream waits for every side stream used since the last call.  Backward kernels that only add into
     parameter-gradient sinks return nothing to autograd, so the engine never orders them before the caller: gather_grads /
@@ -137,6 +173,7 @@ def join_side_streams() -> None:
             if s != cur:
                 cur.wait_stream(s)
         _BRANCH["used"].clear()
+    fold_pending()
 
 
 class branch:
@@ -436,10 +473,19 @@ def _wgrad_into_sinks(lib, d, dy, w_param, b_param, transposed: bool, st, srcs=(
             bbuf = torch.empty(int(bbuf.numel()), dtype=torch.float32, device=w_param.device)
             dw, db = wbuf, bbuf
     fn = lib.m1_convT3d_wgrad if transposed else lib.m1_conv3d_wgrad
-    side = _wgrad_stream(w_param) if (dw is None and db is None) else None
+    flat = dw is None and db is None
+    side = _wgrad_stream(w_param) if flat else None
     if side is None:
         ws = _conv_ws(d, transposed, 2, w_param.device)
-        L.check(fn(C.byref(d), _p(dy), _p(wbuf), _p(bbuf), _p(ws), acc_w, st), "m1_conv3d_wgrad")
+        if flat and _FOLD["on"]:
+            lib.m1_wgrad_defer(1)
+            try:
+                L.check(fn(C.byref(d), _p(dy), _p(wbuf), _p(bbuf), _p(ws), acc_w, st), "m1_conv3d_wgrad")
+            finally:
+                lib.m1_wgrad_defer(0)
+            _FOLD["keep"].append((ws, torch.cuda.current_stream(w_param.device)))
+        else:
+            L.check(fn(C.byref(d), _p(dy), _p(wbuf), _p(bbuf), _p(ws), acc_w, st), "m1_conv3d_wgrad")
         return dw, db
     side.wait_stream(torch.cuda.current_stream(w_param.device))
     _BRANCH["used"].add(side)
@@ -683,6 +729,7 @@ def flush_deferred() -> None:
 
 def drop_deferred() -> None:
     """Forget queued jobs of a backward pass whose gradients are being discarded (optimiser zero_grad)."""
+    fold_drop()
     join_side_streams()
     _SE_DEFER.clear()
 
