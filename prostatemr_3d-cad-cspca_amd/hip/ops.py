@@ -90,18 +90,50 @@ class _GradSlot:
     kernel to produce a gradient for the tensor allocates the buffer, the following ones ACCUMULATE into it in their own
     epilogue (m1_conv3d_dgrad / m1_convT3d_dgrad ``accumulate``, m1_mul_sigma_bwd ``accumulate_dx``): the per-consumer
     gradient tensors and autograd's add passes over them disappear."""
-    __slots__ = ("buf", "event", "stream")
+    __slots__ = ("buf", "event", "stream", "tail_init")
 
     def __init__(self):
         self.buf = None
         self.event = None      # recorded after the last kernel that wrote ``buf`` (only when branches run on side streams)
         self.stream = None
+        self.tail_init = False # the region of ``buf`` behind a batch_tail() holds gradient sums already
 
 
-def _slot_target(slot: Optional[_GradSlot], like: torch.Tensor):
+class _TailRef:
+    """Gradient slot of ``x[start:]`` for an ``x`` that has a slot (batch_tail): the reader's backward kernel writes the tail
+    region of x's own gradient buffer."""
+    __slots__ = ("slot", "start", "full_shape")
+
+    def __init__(self, slot, start, full_shape):
+        self.slot, self.start, self.full_shape = slot, int(start), tuple(full_shape)
+
+
+def _slot_of(t: torch.Tensor):
+    ref = getattr(t, "_m1_gslot_tail", None)
+    return ref if ref is not None else getattr(t, "_m1_gslot", None)
+
+
+def _slot_target(slot, like: torch.Tensor):
     """(gradient tensor, accumulate flag) for a data gradient shaped like ``like``."""
     if slot is None:
         return torch.empty_like(like), 0
+    if isinstance(slot, _TailRef):
+        ref, slot = slot, slot.slot
+        b = slot.buf
+        if b is None or tuple(b.shape) != ref.full_shape or b.dtype != like.dtype:
+            if b is not None:
+                return torch.empty_like(like), 0          # (a buffer of another shape owns the slot: plain gradient tensor)
+            b = torch.empty(ref.full_shape, dtype=like.dtype, device=like.device)
+            b[:ref.start].zero_()                         # nobody has written the head of the batch yet
+            slot.buf, slot.tail_init = b, False
+        elif slot.event is not None and slot.stream != torch.cuda.current_stream():
+            torch.cuda.current_stream().wait_event(slot.event)
+        view = b[ref.start:]
+        if tuple(view.shape) != tuple(like.shape) or not view.is_contiguous():
+            return torch.empty_like(like), 0
+        acc = 1 if slot.tail_init else 0
+        slot.tail_init = True
+        return view, acc
     b = slot.buf
     if b is not None and b.shape == like.shape and b.dtype == like.dtype and b.is_contiguous():
         if slot.event is not None and slot.stream != torch.cuda.current_stream():
@@ -109,12 +141,14 @@ def _slot_target(slot: Optional[_GradSlot], like: torch.Tensor):
         return b, 1
     g = torch.empty_like(like)
     if b is None:
-        slot.buf = g
+        slot.buf, slot.tail_init = g, True               # (written whole by this kernel)
     return g, 0
 
 
-def _slot_written(slot: Optional[_GradSlot]) -> None:
+def _slot_written(slot) -> None:
     """Call after enqueueing the kernel that wrote / accumulated into ``slot.buf`` (orders readers on other streams)."""
+    if isinstance(slot, _TailRef):
+        slot = slot.slot
     if slot is not None and _BRANCH["on"]:
         ev = torch.cuda.Event()
         ev.record()
@@ -227,7 +261,7 @@ class _Fanout(torch.autograd.Function):
         slot = ctx.slot
         buf = slot.buf
         if ctx.owner:
-            slot.buf = None
+            slot.buf, slot.tail_init = None, False
         rest = None
         for g in gs:
             if g is None or (buf is not None and g.data_ptr() == buf.data_ptr() and g.shape == buf.shape):
@@ -253,6 +287,40 @@ def fanout(x: torch.Tensor, k: int):
     for o in outs:
         o._m1_gslot = slot
     return outs
+
+
+class _BatchTail(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, start, slot):
+        ctx.slot, ctx.start, ctx.full_shape = slot, int(start), tuple(x.shape)
+        ctx.set_materialize_grads(False)
+        return x[int(start):]
+
+    @staticmethod
+    def backward(ctx, g):
+        if g is None:
+            return None, None, None
+        buf = ctx.slot.buf
+        if buf is not None and tuple(buf.shape) == ctx.full_shape and g.dtype == buf.dtype:
+            tail = buf[ctx.start:]
+            if g.data_ptr() == tail.data_ptr() and tuple(g.shape) == tuple(tail.shape):
+                return buf, None, None                # the reader wrote straight into x's gradient buffer (_TailRef)
+        full = g.new_zeros(ctx.full_shape)
+        full[ctx.start:] = g
+        return full, None, None
+
+
+def batch_tail(x: torch.Tensor, start: int) -> torch.Tensor:
+    """``x[start:]`` along the batch axis for a reader that runs on the second of two stacked passes (M1Core.forward
+    ``tail_from``).  When ``x`` is a fanout alias the reader's backward kernel writes the tail of x's own gradient buffer:
+    autograd's slice backward (a zero-filled full-size tensor, a copy into it and an add into the buffer -- 4.5 passes over the
+    res0 / res1 skip tensors) disappears."""
+    slot = getattr(x, "_m1_gslot", None)
+    if slot is None or not torch.is_grad_enabled() or not x.requires_grad or _os.environ.get("M1_TAIL_SLOT", "1") == "0":
+        return x[int(start):]
+    y = _BatchTail.apply(x, int(start), slot)
+    y._m1_gslot_tail = _TailRef(slot, start, x.shape)
+    return y
 
 
 def _conv_ws(d, transposed: bool, role: int, device, zero: bool = False) -> torch.Tensor:
@@ -363,7 +431,7 @@ class _Conv3d(torch.autograd.Function):
             L.check(lib.m1_conv3d_fwd(C.byref(d), _p(w), _p(b), _p(y), _p(stats), _p(ws), packed, _stream()), "m1_conv3d_fwd")
         ctx.save_for_backward(w, *srcs)
         ctx.w_param, ctx.b_param = w, b
-        ctx.gslots = [getattr(t, "_m1_gslot", None) for t in srcs]
+        ctx.gslots = [_slot_of(t) for t in srcs]
         ctx.k, ctx.s, ctx.transposed, ctx.has_bias, ctx.cout = tuple(k), tuple(s), transposed, b is not None, cout
         if want_stats:
             ctx.mark_non_differentiable(stats)
@@ -519,7 +587,7 @@ class _ConvPair(torch.autograd.Function):
                                        _stream()), "m1_conv3d_pair_fwd")
         ctx.save_for_backward(w1, w4, *srcs)
         ctx.w1_param, ctx.b1_param, ctx.w4_param = w1, b1, w4
-        ctx.gslots = [getattr(t, "_m1_gslot", None) for t in srcs]
+        ctx.gslots = [_slot_of(t) for t in srcs]
         ctx.k, ctx.s, ctx.c1, ctx.c4 = tuple(k), tuple(s), c1, c4
         ctx.mark_non_differentiable(s1, s4)
         ctx.set_materialize_grads(False)
@@ -593,7 +661,7 @@ class _PairGraft(torch.autograd.Function):
     def forward(ctx, y1, y4, w1, b1, w4, k, s, *srcs):
         ctx.save_for_backward(w1, w4, *srcs)
         ctx.w1_param, ctx.b1_param, ctx.w4_param = w1, b1, w4
-        ctx.gslots = [getattr(t, "_m1_gslot", None) for t in srcs]
+        ctx.gslots = [_slot_of(t) for t in srcs]
         ctx.k, ctx.s, ctx.c1, ctx.c4 = tuple(k), tuple(s), int(w1.shape[4]), int(w4.shape[4])
         ctx.idx_w1, ctx.idx_src = 2, 7
         ctx.set_materialize_grads(False)
@@ -876,7 +944,7 @@ class _MulSigma(torch.autograd.Function):
                                           _stream()), "m1_mul_sigma_fwd")
         ctx.save_for_backward(x, sigma)
         ctx.ss = tuple(int(v) for v in ss)
-        ctx.gslot = getattr(x, "_m1_gslot", None)
+        ctx.gslot = _slot_of(x)
         return y
 
     @staticmethod

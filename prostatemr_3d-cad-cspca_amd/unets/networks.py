@@ -225,7 +225,7 @@ class M1Core(nn.Module):
         n_up = 4 if full else n_pr                     # latent-decoder levels evaluated (dec_hi + sersp)
         n_stage = 4 if full else n_pr                  # decoder concat stages evaluated (uconv3_ ... uconv0_)
         tail = int(tail_from) if (full and prob and tail_from) else None
-        T = (lambda t: t[tail:]) if tail is not None else (lambda t: t)          # batch slice of the second stacked pass
+        T = (lambda t: ops.batch_tail(t, tail)) if tail is not None else (lambda t: t)   # batch slice of the second stacked pass
         tl = lambda k: tail is not None and k >= n_pr                              # stage / level k runs on the slice
         # X(t, from_k, to_k): tensor produced at stage from_k, consumed at stage to_k
         X = lambda t, a, b: T(t) if (tl(b) and not tl(a)) else t
