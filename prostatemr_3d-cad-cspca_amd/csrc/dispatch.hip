@@ -229,6 +229,9 @@ static size_t wgrad_rx_bytes(const m1_conv_desc_t* d) {
     if (b < 2 * stride * sizeof(float)) b = 2 * stride * sizeof(float);
     return align256(b);
 }
+// every concat member has a region of its own (wgrad_rx_bytes each): with deferred folds (m1_wgrad_defer) the copies of
+// member i must survive the kernels of member i+1
+static size_t wgrad_rx_total(const m1_conv_desc_t* d) { return wgrad_rx_bytes(d) * (size_t)(d->nsrc > 0 ? d->nsrc : 1); }
 
 // ---- workspace query ---------------------------------------------------------------------------------------------
 extern "C" size_t m1_conv_ws_bytes(const m1_conv_desc_t* d, int transposed, int role) {
@@ -254,7 +257,7 @@ extern "C" size_t m1_conv_ws_bytes(const m1_conv_desc_t* d, int transposed, int 
     }
     Geo q = T ? convT_geo(d) : conv_geo(d);
     return align256(m1_reduce_ws_floats(d->N, (long long)q.OD * q.OH * q.OW, d->Cout, 1) * sizeof(float)) + 256 + stem_ws_bytes(d, T) +
-           wgrad_rx_bytes(d);
+           wgrad_rx_total(d);
 }
 
 // ---- packed-weight panel records ----------------------------------------------------------------------------------
@@ -474,7 +477,9 @@ static int wgrad_common(const m1_conv_desc_t* d, bool T, const void* dy, float* 
         g.RT = (long long)8 * d->Cout; g.RSA = d->Cout; g.a_off = 0; g.b_off = 0;
         g.rx = rx; g.rx_floats = rx_floats;
         if (fuse_db) { g.bsum = db; g.bsum_tap = (q.pd * d->kh + q.ph) * d->kw + q.pw; }
+        const int was = m1_fold_defer_set(0);          // (stem_fold_kernel below reads the folded 8-channel gradient)
         int rc = m1_tf_wgrad(g, (long long)nw8, nbias, st);
+        m1_fold_defer_set(was);
         if (rc == M1_OK) {
             hipLaunchKernelGGL(stem_fold_kernel, dim3((taps * Cin * d->Cout + 255) / 256), dim3(256), 0, st, r8, dw, taps, Cin, d->Cout);
             return m1_check_launch();
@@ -485,7 +490,7 @@ static int wgrad_common(const m1_conv_desc_t* d, bool T, const void* dy, float* 
         WgradSpec g{};
         g.N = d->N; g.R = dw; g.kd = d->kd; g.kh = d->kh; g.kw = d->kw; g.sd = d->sd; g.sh = d->sh; g.sw = d->sw;
         g.pd = q.pd; g.ph = q.ph; g.pw = q.pw; g.dtype = d->dtype;
-        g.rx = rx; g.rx_floats = rx_floats;
+        g.rx = rx ? rx + (long long)i * rx_floats : nullptr; g.rx_floats = rx_floats;          // this member's own copy region
         if (!T) {   // dw[tap][ci][co] = sum X[v*s+tap-p][ci] * dY[v][co]
             g.A = d->src[i].ptr; g.CA = d->src[i].C; g.AD = d->D; g.AH = d->H; g.AW = d->W;
             g.B = dy; g.CB = d->Cout; g.BD = q.OD; g.BH = q.OH; g.BW = q.OW;

@@ -68,3 +68,6 @@ int m1_mfma_wgrad_ex(const WgradSpec& g, long long nw, int nb, hipStream_t st);
 bool m1_tap_wgrad_supported(const WgradSpec& g);     // per-tap kernel on the transpose read (wgrad_tap.hip), >= 64 channels
 int m1_tap_wgrad(const WgradSpec& g, long long nw, int nb, hipStream_t st);
 int m1_colsum_internal(const void* x, int N, long long V, int C, int dtype, float* out, float* ws, hipStream_t st, int accumulate);
+
+// deferred-fold switch of m1_wg_rx_finish (wgrad_tf.hip): returns the previous setting
+int m1_fold_defer_set(int on);

@@ -657,6 +657,7 @@ static int fold_launch_pending_locked(hipStream_t st) {
     g_fold_pending.clear();
     return M1_OK;
 }
+int m1_fold_defer_set(int on) { std::lock_guard<std::mutex> lk(g_fold_mu); const int was = g_fold_defer; g_fold_defer = on ? 1 : 0; return was; }
 extern "C" int m1_wgrad_defer(int on) { std::lock_guard<std::mutex> lk(g_fold_mu); g_fold_defer = on ? 1 : 0; return M1_OK; }
 extern "C" int m1_wgrad_fold_drop(void) { std::lock_guard<std::mutex> lk(g_fold_mu); g_fold_pending.clear(); return M1_OK; }
 extern "C" int m1_wgrad_fold_pending(void* stream) {

@@ -213,6 +213,57 @@ def test_train_step_reduces_loss_and_is_batch_shardable(dev):
     assert l1 < l0
 
 
+@pytest.mark.parametrize("prob,filters,dtype", [(False, (8, 16, 32, 64, 128), torch.float32), (True, (8, 16, 32, 64, 128), torch.float32),
+                                               (True, (32, 64, 128, 256, 512), torch.bfloat16)])
+def test_flat_gradient_sinks_equal_autograd_gradients(dev, prob, filters, dtype):
+    """The training path -- backward kernels ACCUMULATE into the optimiser's flat gradient buffer, weight-gradient folds are
+    queued and run in batches, SE gate backwards are batched -- must give the gradients of the plain autograd path (p.grad), which
+    is the one the oracle-parity tests check.  Same kernels, same fold order: equal up to the zero the buffer starts from."""
+    cfg = O.M1Config(input_spatial_dims=(8, 32, 32), filters=filters, strides=C1_STRIDES, probabilistic=prob,
+                     prob_latent_dims=(3, 2, 1, 0))
+    P = O.fixture_params(cfg, seed=3)
+    m = build_m1(cfg, dev)
+    load_params_into(m, P)
+    m.set_compute_dtype(dtype)
+    x = rnd((2, 8, 32, 32, 3), 2).to(dev)
+    if prob:
+        x[..., 2] = (x[..., 2] > 0.5).float()                 # label channel, like data_generators.py:82
+    rw = rnd((2, 8, 32, 32, 2), 5).to(dev)
+    eps = [rnd((2, *s), 20 + i).to(dev) for i, s in enumerate(O.latent_shapes(cfg))] if prob else None
+
+    def loss():
+        out = m(x, eps_q=eps) if prob else m(x)
+        outs = out if isinstance(out, (list, tuple)) else [out]
+        l = (outs[0] * rw).sum()
+        return l + 10.0 * outs[1].mean() if prob else l
+
+    for p in m.parameters():
+        p.grad = None
+    loss().backward()
+    ref = {n: p.grad.detach().clone() for n, p in m.named_parameters() if p.grad is not None}
+    for p in m.parameters():
+        p.grad = None
+
+    opt = PKG.optim.Adam(learning_rate=1e-3, amsgrad=True)
+    focal = PKG.losses.Focal(alpha=[0.75, 0.25], gamma=2.0).loss
+    m.compile(optimizer=opt, loss=[focal], loss_weights=[1.0])          # binds the parameters to the flat buffers
+    opt.zero_grad()
+    loss().backward()
+    opt.flatp.gather_grads()
+    torch.cuda.synchronize()
+    byid = {id(p): gv for p, gv in zip(opt.flatp.params, opt.flatp.gviews)}
+    worst = 0.0
+    for n, p in m.named_parameters():
+        g = byid[id(p)].reshape(p.shape)
+        if n not in ref:
+            assert float(g.abs().max()) == 0.0, n
+            continue
+        e = float((g - ref[n]).abs().max()) / (float(ref[n].abs().max()) + 1e-30)
+        worst = max(worst, e)
+        assert e < 1e-5, (n, e)
+    assert worst < 1e-5
+
+
 @pytest.mark.parametrize("filters,dtype", [((8, 16, 32, 64, 128), torch.float32), ((32, 64, 128, 256, 512), torch.bfloat16)])
 def test_forward_and_all_gradients_are_run_to_run_deterministic(dev, filters, dtype):
     """No floating-point atomics anywhere: split-K partial sums go to per-split slabs, weight-gradient partial sums to
