@@ -499,11 +499,14 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_mfma_kernel(MfmaP p) {
         uint4 v = *reinterpret_cast<const uint4*>(C_s + row * CP + cs * SEG);
         T* dst = (T*)o.base + (long long)orow * o.C + o.col;
         if (o.C % SEG != 0 || (p.nout == 0 && oc + SEG > p.OCn)) {       // output row not 16-byte tiled (dz: 1..3 channels; class logits)
-            const T* ve = reinterpret_cast<const T*>(&v);
-            for (int k = 0; k < SEG && oc + k < p.OCn; ++k) {
-                float a = Act<T>::ld(ve + k);
-                if (o.acc) a += Act<T>::ld(dst + k);
-                Act<T>::st(dst + k, a);
+            union { uint4 q; T e[SEG]; } ve; ve.q = v;
+#pragma unroll
+            for (int k = 0; k < SEG; ++k) {               // (constant indices: a run-time bound would put the segment in scratch memory)
+                if (oc + k < p.OCn) {
+                    float a = Act<T>::ld(&ve.e[k]);
+                    if (o.acc) a += Act<T>::ld(dst + k);
+                    Act<T>::st(dst + k, a);
+                }
             }
             continue;
         }

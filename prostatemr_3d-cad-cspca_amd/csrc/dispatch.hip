@@ -503,6 +503,21 @@ static int wgrad_common(const m1_conv_desc_t* d, bool T, const void* dy, float* 
         }
         int rc = M1_ERR_UNSUPPORTED;
         static int wlog = -1; if (wlog < 0) { const char* e = getenv("M1_WG_LOG"); wlog = e ? atoi(e) : 0; }
+        // a run of members with the same channel count on the tap-fused kernel: ONE launch (blockIdx.z = member)
+        static int multi = -1; if (multi < 0) { const char* e = getenv("M1_TF_MULTI"); multi = e ? atoi(e) : 1; }
+        if (multi && !T && !g_force_direct && rx && tf_wanted(g)) {
+            int n = 1;
+            while (i + n < d->nsrc && d->src[i + n].C == d->src[i].C) ++n;
+            if (n > 1) {
+                const void* Am[M1_MAX_SRC]; int aoffs[M1_MAX_SRC]; int o = off;
+                for (int m = 0; m < n; ++m) { Am[m] = d->src[i + m].ptr; aoffs[m] = o; o += d->src[i + m].C; }
+                rc = m1_tf_wgrad_multi(g, (long long)nw, nbias, st, n, Am, aoffs, rx_floats);
+                if (wlog) fprintf(stderr, "wgrad conv N%d B %dx%dx%d CA %d x%d CB %d -> tap-fused multi rc %d\n", g.N, g.BD, g.BH, g.BW, g.CA, n, g.CB, rc);
+                if (rc == M1_OK) { off = o; i += n - 1; continue; }
+                if (rc != M1_ERR_UNSUPPORTED && rc != M1_ERR_WORKSPACE) return rc;
+                rc = M1_ERR_UNSUPPORTED;
+            }
+        }
         if (!g_force_direct && tf_wanted(g)) rc = m1_tf_wgrad(g, (long long)nw, nbias, st);   // may decline (no launch)
         if (wlog) fprintf(stderr, "wgrad %s N%d B %dx%dx%d CA %d CB %d k%d%d%d s%d%d%d -> %s\n", T ? "convT" : "conv", g.N, g.BD, g.BH, g.BW, g.CA, g.CB,
                           g.kd, g.kh, g.kw, g.sd, g.sh, g.sw, rc == M1_OK ? "tap-fused" : (m1_tap_wgrad_supported(g) ? "tap" : "mfma"));

@@ -60,6 +60,7 @@ bool m1_tf64_wgrad_supported(const WgradSpec& g);    // its 64x64-tile kernel (b
 // nw / nb: floats of the whole weight / bias gradient the spec's R / bsum point into.  M1_ERR_WORKSPACE / UNSUPPORTED:
 // nothing was launched, the caller takes the per-tap kernel instead.
 int m1_tf_wgrad(const WgradSpec& g, long long nw, int nb, hipStream_t st);
+int m1_tf_wgrad_multi(const WgradSpec& g, long long nw, int nb, hipStream_t st, int nmem, const void* const* Am, const int* a_offs, long long rx_mem);
 // partial-copy scratch (the spec's rx region when it holds `floats`, else nullptr = take the atomic path) and the fold of
 // `ncopies` copies of stride `stride` floats into g.R / g.bsum (bias sums sit at offset nw inside a copy)
 static inline float* m1_wg_rx_get(const WgradSpec& g, long long floats) { return (g.rx && g.rx_floats >= floats) ? g.rx : nullptr; }

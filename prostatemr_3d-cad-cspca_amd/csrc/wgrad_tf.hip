@@ -53,6 +53,9 @@ struct TfP {
     float* Rx; long long rx_stride;      // per-XCD private copies of R (+ bias sums behind it): see the epilogue
     long long rx_bias;       // offset of the bias sums inside one copy
     int nks;                 // k-steps per K-tile (template TF_NKS of the kernel)
+    // several concat members of one conv in ONE launch (same geometry and channel count, blockIdx.z = member): a per-member launch
+    // of ~256 blocks leaves one block per CU; member m reads Am[m] and stores into the copies at Rx + m * rx_mem
+    int nmem; const bf16_t* Am[M1_MAX_SRC]; long long rx_mem;
 };
 
 typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
@@ -95,6 +98,13 @@ __global__ void __launch_bounds__(256) wgrad_tf_kernel(TfP p) {
     const int tile_id = wave % ntile, part = wave / ntile;
     const int ta = tile_id / ntb, tb = tile_id % ntb;
     const int a0 = (blockIdx.x / p.bTiles) * 32, b0 = (blockIdx.x % p.bTiles) * 32;
+    const int mem = p.nmem > 1 ? (int)blockIdx.z : 0;
+    const bf16_t* Abase = p.A;
+    if (p.nmem > 1) {         // (a chain of uniform selects: a dynamic index would move the whole argument struct to scratch memory)
+        Abase = p.Am[0];
+#pragma unroll
+        for (int m = 1; m < M1_MAX_SRC; ++m) if (mem == m) Abase = p.Am[m];
+    }
     const int PA = p.spra * 16, PB = p.sprb * 16;            // LDS row pitch (bytes)
     const int stage_bytes = p.a_bytes + p.b_bytes;           // [A tile][B tile] per stage
     const unsigned char* zero_pg = reinterpret_cast<const unsigned char*>(m1_zero_page_w);
@@ -149,7 +159,7 @@ __global__ void __launch_bounds__(256) wgrad_tf_kernel(TfP p) {
         const long long blin0 = (((long long)n * p.BD + bd) * p.BH + bh0) * p.BW + twi * p.KWs;
         unsigned char* As = smem + st * stage_bytes;
         unsigned char* Bs = As + p.a_bytes;
-        const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)(p.A + lin0 * p.CA), 0, live ? 0x7fffffff : 0, 0x00020000);
+        const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)(Abase + lin0 * p.CA), 0, live ? 0x7fffffff : 0, 0x00020000);
         const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)(p.B + blin0 * p.CB), 0, live ? 0x7fffffff : 0, 0x00020000);
         const bool a_inner = ad0 >= 0 && ad0 + KD - 1 < p.AD && ah0 >= 0 && ah0 + p.AHt - 1 < p.AH && aw0 >= 0 && aw0 + p.AWt - 1 < p.AW;
         if (a_inner) {                                     // uniform: no per-lane work
@@ -199,7 +209,7 @@ __global__ void __launch_bounds__(256) wgrad_tf_kernel(TfP p) {
     f32x4_t acc[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) acc[t] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-    const bool do_bsum = p.bsum != nullptr && a0 == 0 && ta == 0 && part == 0;
+    const bool do_bsum = p.bsum != nullptr && a0 == 0 && ta == 0 && part == 0 && mem == 0;
     f32x4_t accb = (f32x4_t){0.f, 0.f, 0.f, 0.f};
     const bf16x8_t ones = __builtin_bit_cast(bf16x8_t, make_uint4(0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u));
 
@@ -258,7 +268,7 @@ __global__ void __launch_bounds__(256) wgrad_tf_kernel(TfP p) {
     // Float atomics are executed at the memory side on this multi-XCD part (~7 G requests/s in total, measured), which
     // would cost more than the whole K loop.  Every block instead STORES its partial tile into its own copy of R
     // (copy = K-split index); tf_finish_kernel adds the copies.
-    float* Rx = p.Rx + (long long)blockIdx.y * p.rx_stride;
+    float* Rx = p.Rx + (long long)mem * p.rx_mem + (long long)blockIdx.y * p.rx_stride;
     const int b = b0 + tb * 16 + i;
     if (do_bsum && g == 0 && b < p.CB) Rx[p.rx_bias + b] = accb[0];
 #pragma unroll
@@ -695,8 +705,15 @@ int m1_wg_rx_finish(float* rx, long long stride, int ncopies, const WgradSpec& g
 }
 
 #define TF_MAX_COPY_BYTES (96ll << 20)
+static int tf_wgrad_launch(const WgradSpec& g, long long nw, int nb, hipStream_t st, int nmem, const void* const* Am, const int* a_offs, long long rx_mem);
+// `nmem` members of one Conv3D concat at once: member m = (Am[m], a_off a_offs[m]), all with g.CA channels; copies of member m
+// live at g.rx + m * rx_mem (rx_mem >= g.rx_floats of one member)
+int m1_tf_wgrad_multi(const WgradSpec& g, long long nw, int nb, hipStream_t st, int nmem, const void* const* Am, const int* a_offs, long long rx_mem) {
+    return tf_wgrad_launch(g, nw, nb, st, nmem, Am, a_offs, rx_mem);
+}
 // nw / nb: floats of the whole weight / bias gradient that g.R / g.bsum point into
-int m1_tf_wgrad(const WgradSpec& g, long long nw, int nb, hipStream_t st) {
+int m1_tf_wgrad(const WgradSpec& g, long long nw, int nb, hipStream_t st) { return tf_wgrad_launch(g, nw, nb, st, 1, nullptr, nullptr, 0); }
+static int tf_wgrad_launch(const WgradSpec& g, long long nw, int nb, hipStream_t st, int nmem, const void* const* Am, const int* a_offs, long long rx_mem) {
     TfP p;
     const bool big = tf64_plan(g, p);
     if (!big && !tf_plan(g, p)) return M1_ERR_UNSUPPORTED;
@@ -721,6 +738,12 @@ int m1_tf_wgrad(const WgradSpec& g, long long nw, int nb, hipStream_t st) {
     p.Rx = g.rx; p.rx_stride = stride; p.rx_bias = nloc;
     const size_t smem = (size_t)p.stages * (p.a_bytes + p.b_bytes);
     dim3 grid(ctiles, (unsigned)nsplit, big ? g.kd : 1);
+    p.nmem = 1; p.rx_mem = 0;
+    if (nmem > 1) {
+        if (big || nmem > M1_MAX_SRC) return M1_ERR_UNSUPPORTED;
+        p.nmem = nmem; p.rx_mem = rx_mem; grid.z = (unsigned)nmem;
+        for (int m = 0; m < nmem; ++m) p.Am[m] = (const bf16_t*)Am[m];
+    }
     const int kparts = 4 / ((g.CA > 16 ? 2 : 1) * (g.CB > 16 ? 2 : 1));
     void (*kern)(TfP) = nullptr;
 #define TF_PICK(KD_, KP_) if ((g.kd == KD_) && kparts == KP_ && p.nks == 2) kern = wgrad_tf_kernel<KD_, 3, 3, KP_, 2>;
@@ -740,5 +763,10 @@ int m1_tf_wgrad(const WgradSpec& g, long long nw, int nb, hipStream_t st) {
     }
     hipLaunchKernelGGL(kern, grid, dim3(256), smem, st, p);
     int rc = m1_check_launch(); if (rc) return rc;
-    return m1_wg_rx_finish(p.Rx, stride, (int)nsplit, g, nloc, st);
+    if (nmem <= 1) return m1_wg_rx_finish(p.Rx, stride, (int)nsplit, g, nloc, st);
+    for (int m = 0; m < nmem; ++m) {                      // one fold per member (its own block of R; the bias sums ride on member 0)
+        WgradSpec gm = g; gm.a_off = a_offs[m]; if (m) gm.bsum = nullptr;
+        rc = m1_wg_rx_finish(p.Rx + (long long)m * rx_mem, stride, (int)nsplit, gm, nloc, st); if (rc) return rc;
+    }
+    return M1_OK;
 }
