@@ -201,7 +201,10 @@ static bool pw_plan(const MfmaP& m, int OCpad, int BN, PwP& p) {
     int CC = 0;
     for (int i = 0; i < m.nsrc; ++i) { if (m.srcC[i] % 8) return false; CC += m.srcC[i]; }
     const int kpad = m.cls_kpad[0];
-    if (kpad % 32 || kpad / 32 > 8 || CC > kpad) return false;
+    // contractions of up to 64 channels only: measured against conv_mfma (us, forward / data gradient) 16->64 at (4,20,80,80)
+    // 40 / 18 vs 60 / 25, 32->32 at (2,20,160,160) 49 / 30 vs 62 / 47, 32->128 on par, but 128->128 42 / 42 vs 37 / 26 and
+    // 256->256 41 / 33 vs 30 / 16 -- with 4 or 8 chunks of voxel fragments in registers the waves per SIMD run out
+    if (kpad % 32 || kpad / 32 > 2 || CC > kpad) return false;
     if (!(BN == 16 || BN == 32) || OCpad % BN) return false;      // (wider slices: > 128 VGPRs of per-lane epilogue state)
     p = PwP{}; p.m = m; p.kpad = kpad; p.nseg = CC / 8;
     p.V = m.OD * m.OH * m.OW; p.Mtot = (long long)m.N * p.V;
@@ -226,14 +229,14 @@ int m1_pw_conv(const MfmaP& mp, int OCpad, int BN, hipStream_t st) {
     p.nwaves = mp.stat_partial ? mp.stat_tiles : pw_nwaves(p, OCpad, BN);
     if (p.nwaves < 4 || p.nwaves % 4) return M1_ERR_BAD_ARG;
     const int nch = p.kpad / 32;
-    const int NCH = nch <= 1 ? 1 : (nch <= 2 ? 2 : (nch <= 4 ? 4 : 8));
+    const int NCH = nch <= 1 ? 1 : 2;
     if (NCH * 32 != p.kpad) {
         // the panel rows are kpad long; chunks beyond kpad would read the next row: only exact powers of two take this path
         return M1_ERR_UNSUPPORTED;
     }
     void (*kern)(PwP) = nullptr;
 #define PK(TN_, NCH_) if (BN == TN_ * 16 && NCH == NCH_) kern = conv_pw_kernel<TN_, NCH_>;
-    PK(1, 1) PK(1, 2) PK(1, 4) PK(1, 8) PK(2, 1) PK(2, 2) PK(2, 4) PK(2, 8)
+    PK(1, 1) PK(1, 2) PK(2, 1) PK(2, 2)
 #undef PK
     if (!kern) return M1_ERR_UNSUPPORTED;
     const size_t smem = (size_t)NCH * BN * 64;
