@@ -1,4 +1,7 @@
 #!/bin/bash
+# NOTE: the M1_HALO_DBG switches are NOT in the committed kernels (they cost SGPRs in the tile loop): re-apply them locally first --
+# a `dbg` field in the launch struct read from the environment in the launcher and `if (p.dbg & bit)` around the part to switch off
+# (the commits that introduced this script show the patch in their messages / DESIGN.md section 5).
 # kernel-only durations of the halo conv with parts of it switched off (M1_HALO_DBG bits: 1 MFMA loop, 2 stores/statistics,
 # 4 input DMA, 8 whole epilogue, 16 top-of-tile wait + barrier)
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}

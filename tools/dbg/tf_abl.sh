@@ -1,4 +1,7 @@
 #!/bin/bash
+# NOTE: the M1_TF_DBG switches are NOT in the committed kernels (they cost SGPRs in the tile loop): re-apply them locally first --
+# a `dbg` field in the launch struct read from the environment in the launcher and `if (p.dbg & bit)` around the part to switch off
+# (the commits that introduced this script show the patch in their messages / DESIGN.md section 5).
 # kernel-only durations of the tap-fused weight gradient with parts switched off (M1_TF_DBG bits: 1 reads + MFMAs, 4 DMA, 16 wait + barrier)
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 cd /tmp && export TMPDIR=/tmp
