@@ -679,10 +679,16 @@ struct Plan { int BN, BM, ksplit; };
 // -> 64 rows, and if still short, split K (taps x channels, up to 13,824 deep there) over blockIdx.y.
 // (Measured: keeping 128-row tiles and splitting K harder instead is slower -- the fp32 atomics cost more than the
 // saved L2 -> LDS traffic.)
-static inline Plan make_plan(int ocn, long long maxM, int ncls, int min_nchunks) {
-    Plan pl; pl.BN = pick_bn(ocn);
+// bn160: the conv1 || conv4 pair forward (32 + 128 or 64 + 256 output columns): 160-column tiles (5 MFMA column tiles per wave)
+// instead of 128-column tiles of which the last is 75 / 50 % empty
+static inline bool want_bn160(const GatherSpec& g) {
+    static int en = -1; if (en < 0) { const char* e = getenv("M1_BN160"); en = e ? atoi(e) : 1; }
+    return en && g.dtype == M1_BF16 && g.w2 && g.oc_split > 0 && g.mode == 0 && g.OC % 160 == 0 && g.OC <= 320;
+}
+static inline Plan make_plan(int ocn, long long maxM, int ncls, int min_nchunks, bool bn160 = false) {
+    Plan pl; pl.BN = bn160 ? 160 : pick_bn(ocn);
     const int ntile = (ocn + pl.BN - 1) / pl.BN;
-    pl.BM = cdiv_ll(maxM, 128) * ncls * ntile >= 256 ? 128 : 64;
+    pl.BM = (bn160 || cdiv_ll(maxM, 128) * ncls * ntile >= 256) ? 128 : 64;      // (the 160-column tile exists with 128 rows only)
     const long long blocks = cdiv_ll(maxM, pl.BM) * ncls * ntile;
     pl.ksplit = 1;
     {   // very deep contractions (>= 200 chunks: the dense-skip concats of the full model) with a 128-wide oc tile and only
@@ -767,13 +773,20 @@ static inline size_t out_elems(const GatherSpec& g) { return (size_t)g.N * g.OD 
 size_t m1_mfma_ws_bytes(const GatherSpec& g) {
     const int SEG = seg_of(g.dtype);
     int CC = 0; for (int i = 0; i < g.nsrc; ++i) CC += g.srcC[i];
-    const Plan pl = make_plan(g.OC, spec_maxM(g), spec_ncls(g), min_class_chunks(g, CC, SEG));
-    const int BN = pl.BN, OCpad = (g.OC + BN - 1) / BN * BN;
-    long long tot = 0;
-    build_classes(g, CC, SEG, OCpad, nullptr, nullptr, &tot);
-    size_t bytes = ((size_t)tot * (g.dtype == M1_BF16 ? 2 : 4) + 255) / 256 * 256;
-    if (pl.ksplit > 1) bytes += out_elems(g) * sizeof(float) * pl.ksplit;
-    return bytes + 256 + M1_PACK_JOB_BYTES;
+    // (the workspace query does not know whether the call will be the conv1 || conv4 pair, which takes 160-column tiles and may
+    //  then split K differently: size for both plans)
+    size_t best = 0;
+    const bool maybe160 = g.dtype == M1_BF16 && g.mode == 0 && g.OC % 160 == 0 && g.OC <= 320;
+    for (int v = 0; v < (maybe160 ? 2 : 1); ++v) {
+        const Plan pl = make_plan(g.OC, spec_maxM(g), spec_ncls(g), min_class_chunks(g, CC, SEG), v == 1);
+        const int BN = pl.BN, OCpad = (g.OC + BN - 1) / BN * BN;
+        long long tot = 0;
+        build_classes(g, CC, SEG, OCpad, nullptr, nullptr, &tot);
+        size_t bytes = ((size_t)tot * (g.dtype == M1_BF16 ? 2 : 4) + 255) / 256 * 256;
+        if (pl.ksplit > 1) bytes += out_elems(g) * sizeof(float) * pl.ksplit;
+        if (bytes > best) best = bytes;
+    }
+    return best + 256 + M1_PACK_JOB_BYTES;
 }
 
 template <typename T, int BM, int BN, int WM, int WN, int KC>
@@ -819,7 +832,7 @@ static int run_mfma(const GatherSpec& g, void* ws, int ws_packed, hipStream_t st
     mp.bias2 = g.bias2; mp.bias_split = g.oc_split;
     mp.nout = g.nout; mp.outOff[0] = 0;
     for (int i = 0; i < g.nout; ++i) { mp.outs[i] = g.outs[i]; mp.outC[i] = g.outC[i]; mp.outAcc[i] = g.outAcc[i]; mp.outOff[i + 1] = mp.outOff[i] + g.outC[i]; }
-    const Plan pl = make_plan(g.OC, spec_maxM(g), spec_ncls(g), min_class_chunks(g, CC, SEG));
+    const Plan pl = make_plan(g.OC, spec_maxM(g), spec_ncls(g), min_class_chunks(g, CC, SEG), want_bn160(g));
     const int BN = pl.BN, OCpad = (g.OC + BN - 1) / BN * BN;
     long long tot = 0;
     build_classes(g, CC, SEG, OCpad, &mp, &pp, &tot);
@@ -896,6 +909,7 @@ static int run_mfma(const GatherSpec& g, void* ws, int ws_packed, hipStream_t st
     switch (BN) {
         case 128: rc2 = use8 ? launch_cfg<T, 128, 128, 2, 4>(mp, maxM, OCpad, st)
                              : (small ? launch_cfg<T, 64, 128, 1, 4>(mp, maxM, OCpad, st) : launch_cfg<T, 128, 128, 2, 2>(mp, maxM, OCpad, st)); break;
+        case 160: if constexpr (sizeof(T) == 2) { rc2 = launch_cfg<T, 128, 160, 2, 2>(mp, maxM, OCpad, st); } else rc2 = M1_ERR_UNSUPPORTED; break;
         case 64:  rc2 = small ? launch_cfg<T, 64, 64, 2, 2>(mp, maxM, OCpad, st) : launch_cfg<T, 128, 64, 4, 1>(mp, maxM, OCpad, st); break;
         case 32:  rc2 = small ? launch_cfg<T, 64, 32, 4, 1>(mp, maxM, OCpad, st) : launch_cfg<T, 128, 32, 4, 1>(mp, maxM, OCpad, st); break;
         default:  rc2 = small ? launch_cfg<T, 64, 16, 4, 1>(mp, maxM, OCpad, st) : launch_cfg<T, 128, 16, 4, 1>(mp, maxM, OCpad, st); break;

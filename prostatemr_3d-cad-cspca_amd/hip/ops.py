@@ -687,12 +687,13 @@ def conv_pair_supported(srcs, w1, w4, s) -> bool:
 
 def conv_pair_same(srcs, w1, b1, w4, b4, k, s):
     """(y1, stats1, y4, stats4, branch) of Conv3D(w1) and Conv3D(w4) applied to the same virtual concat (network_blocks.py:53,64).
-    Forward: two launches, conv4 on side stream 0 (one launch over 32 + 128 columns wastes 37 % of its second 128-column tile:
-    2.31 vs 1.21 + 0.97 ms on the 512-channel res2 layer; M1_CONV_PAIR_FWD=1 selects it).  Backward: ONE contraction over
-    [dy1 | dy4] for the data gradient (1.60 vs 1.32 + 0.61 ms there), conv4's weight gradient on a tap of y4 on the side stream.
-    The caller joins ``branch`` before it reads y4 / stats4."""
+    Forward: ONE launch over the 32 + 128 (64 + 256) output columns on 160-column tiles (conv_mfma.hip want_bn160): conv1 rides on
+    the rows conv4 gathers anyway (-1.7 % per C3 step against two launches on two streams; with 128-column tiles, the last one 75 %
+    empty, it lost: 2.31 vs 1.21 + 0.97 ms on the 512-channel res2 layer).  M1_CONV_PAIR_FWD=0: two launches.  Backward: ONE
+    contraction over [dy1 | dy4] for the data gradient (1.60 vs 1.32 + 0.61 ms there), conv4's weight gradient on a tap of y4 on
+    the side stream.  The caller joins ``branch`` before it reads y4 / stats4."""
     dev = srcs[0].device
-    if _os.environ.get("M1_CONV_PAIR_FWD", "0") == "1":
+    if _os.environ.get("M1_CONV_PAIR_FWD", "1") == "1":
         y1, s1, y4raw, s4 = _ConvPair.apply(w1, b1, w4, b4, tuple(k), tuple(s), *srcs)
     else:
         with torch.no_grad():
