@@ -128,3 +128,54 @@ def m1_det_forward(P, x, filters, strides, kernel_sizes, se_reduction, num_class
            iv(se_reduction), int(num_classes), ptrs, len(arrs), _p(out))
     assert rc == 0, "naive_m1_det_forward did not consume its parameter list exactly"
     return out
+
+
+def m1_prob_core_param_order(pre, latent_dims):
+    """The order in which one core of naive_m1_prob_train_forward consumes its parameters (documented in naive_ops.c)."""
+    names = m1_det_param_order(pre=pre)
+
+    def se(n):
+        out = []
+        for c, nm in (("conv1", "norm1"), ("conv2", "norm2"), ("conv3", "norm3"), ("conv4", "norm4")):
+            out += [f"{n}.{c}.kernel", f"{n}.{c}.bias", f"{n}.{nm}.gamma", f"{n}.{nm}.beta"]
+        return out + [f"{n}.conv6.kernel", f"{n}.conv6.bias", f"{n}.conv7.kernel", f"{n}.conv7.bias"]
+    for i, lvl in enumerate((3, 2, 1, 0)):
+        if latent_dims[i] != 0:
+            names += [f"{pre}.mu_logsig{lvl}.kernel", f"{pre}.mu_logsig{lvl}.bias"]
+        names += [f"{pre}.dec_hi{lvl}.kernel", f"{pre}.dec_hi{lvl}.bias"] + [f"{pre}.{n}" for n in se(f"sersp{lvl}")]
+    return names
+
+
+def m1_prob_train_forward(P, x, eps_q, filters, strides, kernel_sizes, se_reduction, latent_dims, num_classes=2):
+    """Train-time forward of the hierarchical probabilistic M1 in plain C loops: returns (prob_train_conv, prob_kl).
+    ``eps_q``: one (N, d, h, w, L) array of N(0,1) draws per latent level with L != 0, coarsest first."""
+    x = _c(x)
+    N, D, H, W, Cin = x.shape
+    keep = []
+
+    def plist(pre):
+        names = m1_prob_core_param_order(pre, latent_dims)
+        have = {n for n in P if n.startswith(pre + ".")}
+        assert set(names) == have, sorted(set(names) ^ have)[:6]
+        arrs = [_c(P[n]) for n in names]
+        keep.append(arrs)
+        return (ctypes.POINTER(ctypes.c_double) * len(arrs))(*[_p(a) for a in arrs]), len(arrs)
+    prior, n_prior = plist("prior")
+    post, n_post = plist("posterior")
+    eps_it = iter([_c(e) for e in eps_q])
+    eps_arr = [next(eps_it) if L != 0 else None for L in latent_dims]
+    eps_ptrs = (ctypes.POINTER(ctypes.c_double) * 4)(*[(_p(e) if e is not None else None) for e in eps_arr])
+    sw, sb = _c(P["stitch.logits.kernel"]), _c(P["stitch.logits.bias"])
+    iv = lambda v: (ctypes.c_int * len(v))(*[int(a) for a in v])
+    out = np.empty((N, D // strides[0][0], H // strides[0][1], W // strides[0][2], num_classes), dtype=np.float64)
+    kl = ctypes.c_double(0.0)
+    f = lib().naive_m1_prob_train_forward
+    PD, PPD = ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.POINTER(ctypes.c_double))
+    f.argtypes = [PD] + [ctypes.c_int] * 5 + [ctypes.POINTER(ctypes.c_int)] * 4 + [ctypes.c_int, ctypes.POINTER(ctypes.c_int), PPD,
+                  PPD, ctypes.c_int, PPD, ctypes.c_int, PD, PD, PD, PD]
+    rc = f(_p(x), N, D, H, W, Cin, iv(filters), iv([a for s in strides for a in s]), iv([a for k in kernel_sizes for a in k]),
+           iv(se_reduction), int(num_classes), iv(latent_dims), eps_ptrs, prior, n_prior, post, n_post, _p(sw), _p(sb), _p(out),
+           ctypes.byref(kl))
+    assert rc == 0, "naive_m1_prob_train_forward did not consume its parameter lists exactly"
+    return out, kl.value
+

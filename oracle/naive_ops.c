@@ -178,20 +178,20 @@ static const double *nextp(cursor_t *c) { return c->cur < c->n ? c->p[c->cur++] 
 typedef struct { double *v; int D, H, W, C; } vol_t;                  /* one NDHWC tensor of batch size N (N is global) */
 
 static size_t vox(const vol_t *t) { return (size_t)t->D * t->H * t->W; }
-static vol_t valloc(int N, int D, int H, int W, int C) {
+static vol_t vol_new(int N, int D, int H, int W, int C) {
     vol_t t = { (double *)malloc(sizeof(double) * (size_t)N * D * H * W * C), D, H, W, C };
     return t;
 }
 
 static vol_t conv_layer(cursor_t *c, int N, const vol_t *x, int Co, const int *k, const int *s) {
     const double *w = nextp(c), *b = nextp(c);
-    vol_t y = valloc(N, ceil_div(x->D, s[0]), ceil_div(x->H, s[1]), ceil_div(x->W, s[2]), Co);
+    vol_t y = vol_new(N, ceil_div(x->D, s[0]), ceil_div(x->H, s[1]), ceil_div(x->W, s[2]), Co);
     naive_conv3d_same(x->v, w, b, y.v, N, x->D, x->H, x->W, x->C, Co, k[0], k[1], k[2], s[0], s[1], s[2]);
     return y;
 }
 static vol_t convT_layer(cursor_t *c, int N, const vol_t *x, int Co, const int *k, const int *s) {
     const double *w = nextp(c), *b = nextp(c);
-    vol_t y = valloc(N, x->D * s[0], x->H * s[1], x->W * s[2], Co);
+    vol_t y = vol_new(N, x->D * s[0], x->H * s[1], x->W * s[2], Co);
     naive_conv3d_transpose_same(x->v, w, b, y.v, N, x->D, x->H, x->W, x->C, Co, k[0], k[1], k[2], s[0], s[1], s[2]);
     return y;
 }
@@ -200,7 +200,7 @@ static void norm_inplace(cursor_t *c, int N, vol_t *x, double slope) {
     naive_instance_norm(x->v, g, b, x->v, N, vox(x), x->C, 1e-3, slope);        /* element-wise after the statistics: in place is safe */
 }
 static vol_t concat2(int N, const vol_t *a, const vol_t *b) {                   /* tf.concat([a, b], axis=-1) */
-    vol_t y = valloc(N, a->D, a->H, a->W, a->C + b->C);
+    vol_t y = vol_new(N, a->D, a->H, a->W, a->C + b->C);
     size_t V = (size_t)N * vox(a);
     for (size_t v = 0; v < V; ++v) {
         memcpy(y.v + v * y.C, a->v + v * a->C, sizeof(double) * a->C);
@@ -254,7 +254,7 @@ static vol_t gate_block(cursor_t *c, int N, const vol_t *x, const vol_t *g, int 
     vol_t ph = conv_layer(c, N, g, Fi, ONE3, ONE3);                                            /* B:112 */
     int ud = th.D / ph.D, uh = th.H / ph.H, uw = th.W / ph.W;                                  /* B:113-116 nearest repeat */
     const double *wpsi = nextp(c), *bpsi = nextp(c);
-    vol_t y = valloc(N, x->D, x->H, x->W, x->C);
+    vol_t y = vol_new(N, x->D, x->H, x->W, x->C);
     for (int n = 0; n < N; ++n)
     for (int d = 0; d < th.D; ++d)
     for (int h = 0; h < th.H; ++h)
@@ -314,3 +314,128 @@ int naive_m1_det_forward(const double *x, int N, int D, int H, int W, int Cin, c
     for (size_t i = 0; i < sizeof(all) / sizeof(all[0]); ++i) free(all[i].v);
     return ok ? 0 : -1;
 }
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * The hierarchical PROBABILISTIC M1 train-time forward in plain C loops (networks.py:297-385, 631-728), again written from
+ * the reference and sharing nothing with oracle/m1_oracle.py: prior and posterior M1Core with their latent branches
+ * (1x1x1 mu/log-sigma heads, reparameterised draw, transposed-conv latent decoder dec_hi*, SE blocks sersp*), the four
+ * core passes of a train step that feed its outputs (q_sample, q_mean, p_sample_z_q, p_sample_z_q_mean), the stitching
+ * decoder and KL(Q||P).  dense_skip = deep_supervision = False, att_sub_samp = (1,1,1), dropout off.
+ *
+ * Parameter order of ONE core: the deterministic order documented above (conve0 ... sersd0, logits), then for the levels
+ * 3, 2, 1, 0:  mu_logsig{l} (kernel, bias -- only when latent_dims[3-l] != 0), dec_hi{l} (kernel, bias), sersp{l} (SE block).
+ * ------------------------------------------------------------------------------------------------------------------ */
+typedef struct { vol_t ml[4]; vol_t z[4]; int L[4]; vol_t feat; } prob_out_t;     /* index 0 = level 3 (coarsest) ... 3 = level 0 */
+
+static vol_t slice_ch(int N, const vol_t *a, int c0, int c1) {
+    vol_t y = vol_new(N, a->D, a->H, a->W, c1 - c0);
+    size_t V = (size_t)N * vox(a);
+    for (size_t v = 0; v < V; ++v) memcpy(y.v + v * y.C, a->v + v * a->C + c0, sizeof(double) * (size_t)(c1 - c0));
+    return y;
+}
+/* One M1Core.__call__(inputs, prob_mean, prob_z_q) (networks.py:568-728).  z_given[i] != NULL: the latent of level 3-i is
+ * that tensor (prob_z_q); else eps[i] != NULL: mu + exp(clip(logsigma, +-0.1)) * eps[i] (distrib.sample()); else mu. */
+static int core_prob_forward(const double **params, int nparams, int N, const vol_t *in, const int *F, const int *strides,
+                             const int *kernels, const int *se_red, int num_classes, const int *Ldims,
+                             const double *const *z_given, const double *const *eps, prob_out_t *out) {
+    cursor_t c = { params, 0, nparams };
+    #define S(i) (strides + 3 * (i))
+    #define K(i) (kernels + 3 * (i))
+    vol_t x0 = conv_layer(&c, N, in, F[0], K(0), S(0)); norm_inplace(&c, N, &x0, 0.1);        /* N:574-576 */
+    vol_t e1 = se_block(&c, N, &x0, F[1], K(1), S(1), se_red[1]);                              /* N:579-582 */
+    vol_t e2 = se_block(&c, N, &e1, F[2], K(2), S(2), se_red[2]);
+    vol_t e3 = se_block(&c, N, &e2, F[3], K(3), S(3), se_red[3]);
+    vol_t em = se_block(&c, N, &e3, F[4], K(4), S(4), se_red[4]);
+    vol_t a0 = gate_block(&c, N, &x0, &em, F[0]);                                              /* N:585-588 */
+    vol_t a1 = gate_block(&c, N, &e1, &em, F[1]);
+    vol_t a2 = gate_block(&c, N, &e2, &em, F[2]);
+    vol_t a3 = gate_block(&c, N, &e3, &em, F[3]);
+    vol_t d3 = convT_layer(&c, N, &em, F[3], K(4), S(4));   vol_t c3 = concat2(N, &d3, &a3);   /* N:591-597 */
+    vol_t u3 = se_block(&c, N, &c3, F[3], K(3), ONE3, se_red[3]);
+    vol_t d2 = convT_layer(&c, N, &u3, F[2], K(3), S(3));   vol_t c2 = concat2(N, &d2, &a2);   /* N:600-607 */
+    vol_t u2 = se_block(&c, N, &c2, F[2], K(2), ONE3, se_red[2]);
+    vol_t d1 = convT_layer(&c, N, &u2, F[1], K(2), S(2));   vol_t c1 = concat2(N, &d1, &a1);   /* N:610-616 */
+    vol_t u1 = se_block(&c, N, &c1, F[1], K(1), ONE3, se_red[1]);
+    vol_t d0 = convT_layer(&c, N, &u1, F[0], K(1), S(1));   vol_t c0 = concat2(N, &d0, &a0);   /* N:619-624 */
+    vol_t u0 = se_block(&c, N, &c0, F[0], K(0), ONE3, se_red[0]);
+    vol_t lg = conv_layer(&c, N, &u0, num_classes, ONE3, ONE3);                                /* N:627 (not an output here) */
+    /* ---- latent branch, N:632-723: level 3 reads convm, the others the running decoder features ---- */
+    const vol_t *skip[4] = { &c3, &c2, &c1, &c0 };                                             /* uconv3_ ... uconv0_ */
+    vol_t feat = em; int feat_owned = 0;
+    for (int i = 0; i < 4; ++i) {
+        const int lvl = 3 - i, L = Ldims[i];
+        out->L[i] = L; out->ml[i].v = NULL; out->z[i].v = NULL;
+        vol_t dec_in = feat; int dec_in_owned = 0;
+        if (L != 0) {
+            vol_t ml = conv_layer(&c, N, &feat, 2 * L, ONE3, ONE3);                            /* mu_logsig{lvl}: N:637, 660, 684, 708 */
+            vol_t z = vol_new(N, feat.D, feat.H, feat.W, L);
+            size_t V = (size_t)N * vox(&feat);
+            for (size_t v = 0; v < V; ++v)
+                for (int l = 0; l < L; ++l) {
+                    double mu = ml.v[v * 2 * L + l], ls = ml.v[v * 2 * L + L + l];
+                    ls = ls < -0.1 ? -0.1 : (ls > 0.1 ? 0.1 : ls);                             /* N:640 clip_by_value */
+                    if (z_given && z_given[i]) z.v[v * L + l] = z_given[i][v * L + l];         /* N:643 */
+                    else if (eps && eps[i])   z.v[v * L + l] = mu + exp(ls) * eps[i][v * L + l];   /* N:645 sample() */
+                    else                      z.v[v * L + l] = mu;                             /* N:644 .loc */
+                }
+            out->ml[i] = ml; out->z[i] = z;
+            dec_in = concat2(N, &z, &feat); dec_in_owned = 1;                                  /* N:651 tf.concat([z, features]) */
+        }
+        vol_t up = convT_layer(&c, N, &dec_in, F[lvl], K(lvl + 1), S(lvl + 1));                /* dec_hi{lvl}: N:548-555 */
+        vol_t cat = concat2(N, &up, skip[i]);                                                  /* N:650-651 */
+        vol_t nf = se_block(&c, N, &cat, F[lvl], K(lvl), ONE3, se_red[lvl]);                   /* sersp{lvl}: N:556-563 */
+        if (dec_in_owned) free(dec_in.v);
+        free(up.v); free(cat.v);
+        if (feat_owned) free(feat.v);
+        feat = nf; feat_owned = 1;
+    }
+    out->feat = feat;
+    #undef S
+    #undef K
+    int ok = (c.cur == nparams);
+    vol_t all[] = { x0, e1, e2, e3, em, a0, a1, a2, a3, d3, c3, u3, d2, c2, u2, d1, c1, u1, d0, c0, u0, lg };
+    for (size_t i = 0; i < sizeof(all) / sizeof(all[0]); ++i) free(all[i].v);
+    return ok ? 0 : -1;
+}
+static void prob_out_free(prob_out_t *o) {
+    for (int i = 0; i < 4; ++i) { free(o->ml[i].v); free(o->z[i].v); }
+    free(o->feat.v);
+}
+
+/* networks.py:297-385: train_conv = stitch(prior(image, z = posterior(image+label, mean).latents).decoder_features) and
+ * prob_kl = sum_levels mean_n sum_voxels KL(q_sample.dist || prior(image, z = q_sample.latents).dist).
+ * x: (N,D,H,W,Cin) with the label as channel Cin-(num_classes-1)-1 (the off-by-one slice of N:300-301 as written);
+ * eps_q[i]: N(0,1) draws of latent level 3-i for the sampled posterior pass (NULL where latent_dims[i] == 0). */
+int naive_m1_prob_train_forward(const double *x, int N, int D, int H, int W, int Cin, const int *filters, const int *strides,
+                                const int *kernels, const int *se_red, int num_classes, const int *latent_dims,
+                                const double *const *eps_q, const double **prior_params, int n_prior,
+                                const double **post_params, int n_post, const double *stitch_w, const double *stitch_b,
+                                double *train_conv, double *kl_out) {
+    vol_t in = { (double *)x, D, H, W, Cin };
+    const int nl = num_classes - 1;
+    vol_t image = slice_ch(N, &in, 0, Cin - nl);                                               /* N:300 inputs[..., :-(nc-1)] */
+    vol_t label = slice_ch(N, &in, Cin - nl - 1, Cin - 1);                                     /* N:301 inputs[..., -(nc-1)-1:-1] */
+    vol_t post_in = concat2(N, &image, &label);                                                /* N:348 */
+    prob_out_t qs, qm, pz, pzm;
+    int rc = 0;
+    rc |= core_prob_forward(post_params, n_post, N, &post_in, filters, strides, kernels, se_red, num_classes, latent_dims, NULL, eps_q, &qs);   /* N:348 */
+    rc |= core_prob_forward(post_params, n_post, N, &post_in, filters, strides, kernels, se_red, num_classes, latent_dims, NULL, NULL, &qm);    /* N:349 */
+    const double *zs[4], *zm[4];
+    for (int i = 0; i < 4; ++i) { zs[i] = qs.z[i].v; zm[i] = qm.z[i].v; }
+    rc |= core_prob_forward(prior_params, n_prior, N, &image, filters, strides, kernels, se_red, num_classes, latent_dims, zs, NULL, &pz);      /* N:351 */
+    rc |= core_prob_forward(prior_params, n_prior, N, &image, filters, strides, kernels, se_red, num_classes, latent_dims, zm, NULL, &pzm);     /* N:352 */
+    naive_conv3d_same(pzm.feat.v, stitch_w, stitch_b, train_conv, N, pzm.feat.D, pzm.feat.H, pzm.feat.W, pzm.feat.C, num_classes,
+                      1, 1, 1, 1, 1, 1);                                                       /* N:356, B:277 */
+    double kl = 0.0;
+    for (int i = 0; i < 4; ++i)
+        if (latent_dims[i] != 0) {                                                             /* N:373-379 */
+            double k = 0.0;
+            naive_kl_mvn_diag(qs.ml[i].v, pz.ml[i].v, &k, N, vox(&qs.ml[i]), latent_dims[i], 0.1);
+            kl += k;
+        }
+    *kl_out = kl;                                                                              /* N:385 */
+    prob_out_free(&qs); prob_out_free(&qm); prob_out_free(&pz); prob_out_free(&pzm);
+    free(image.v); free(label.v); free(post_in.v);
+    return rc;
+}
+

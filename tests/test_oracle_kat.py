@@ -283,3 +283,24 @@ def test_focal_and_l2_known_answers():
     manual = sum(1e-4 * float((v.double() ** 2).sum()) for k, v in P.items()
                  if (k.endswith(".kernel") or k.endswith(".bias")) and ".conv6." not in k and ".conv7." not in k)
     assert abs(reg - manual) < 1e-6 * manual
+
+
+def test_kat7_naive_c_whole_probabilistic_train_forward():
+    """The hierarchical probabilistic train-time forward -- posterior sample / mean passes, the two conditioned prior passes,
+    latent heads, reparameterised draw, latent decoder, stitching decoder, KL(Q||P) (networks.py:297-385, 631-728) -- in plain C
+    loops written from the reference equals the torch restatement in fp64: the second, independent implementation of the
+    probabilistic WIRING (label slice, concat orders, which pass feeds which output)."""
+    cfg = O.M1Config(input_spatial_dims=(4, 16, 16), filters=(8, 16, 32, 64, 128), strides=README_STRIDES, probabilistic=True,
+                     prob_latent_dims=(3, 2, 1, 0))
+    P = {k: v.double() for k, v in O.fixture_params(cfg, 5).items()}
+    rng = np.random.default_rng(11)
+    x = rng.standard_normal((2, 4, 16, 16, 3))
+    x[..., 2] = (x[..., 2] > 0.3).astype(np.float64)
+    eps = [rng.standard_normal((2, *s)) for s in O.latent_shapes(cfg)]
+    o = O.m1_forward(P, cfg, torch.from_numpy(x), eps_q=[torch.from_numpy(e) for e in eps])
+    tc, kl = naive.m1_prob_train_forward({k: v.numpy() for k, v in P.items()}, x, eps, cfg.filters, cfg.strides, cfg.kernel_sizes,
+                                         cfg.se_reduction, cfg.prob_latent_dims, cfg.num_classes)
+    assert np.abs(tc - o["prob_train_conv"].numpy()).max() < 1e-9
+    assert abs(kl - float(o["prob_kl"])) < 1e-9 * max(1.0, abs(float(o["prob_kl"])))
+    assert float(o["prob_kl"]) > 0
+
