@@ -108,7 +108,8 @@ static bool dgrad_fused_ok(const m1_conv_desc_t* d) {
     // the wide, shallow layers (res0/res1: <= 64 dY channels, stride 1, >= 32,768 voxels) run on the halo-tile kernel, whose blocks
     // own one 32-column weight slice each: per-member launches are faster there (192->32 at res0: 0.76 vs 1.13 ms per step fused)
     const long long vox = (long long)d->N * d->D * d->H * d->W;
-    if (d->dtype == M1_BF16 && d->Cout <= 64 && d->sd == 1 && d->sh == 1 && d->sw == 1 && vox >= 32768 && d->kd * d->kh * d->kw > 1) return false;
+    static int hf = -1; if (hf < 0) { const char* e = getenv("M1_DGRAD_FUSED_HALO"); hf = e ? atoi(e) : 0; }
+    if (!hf && d->dtype == M1_BF16 && d->Cout <= 64 && d->sd == 1 && d->sh == 1 && d->sw == 1 && vox >= 32768 && d->kd * d->kh * d->kw > 1) return false;
     return true;
 }
 static GatherSpec dgrad_fused_spec(const m1_conv_desc_t* d, bool T, const float* w, const void* dy, void* const* dx, const int* accumulate) {
