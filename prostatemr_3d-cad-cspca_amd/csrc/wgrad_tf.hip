@@ -589,10 +589,12 @@ static bool tf_plan(const WgradSpec& g, TfP& p) {
     p.RT = g.RT; p.RSA = g.RSA; p.a_off = g.a_off; p.b_off = g.b_off;
     p.sd = g.sd; p.sh = g.sh; p.sw = g.sw; p.pd = g.pd; p.ph = g.ph; p.pw = g.pw;
     p.KWs = g.BW % 32 == 0 ? 32 : (g.BW % 16 == 0 ? 16 : 8);
-    // K-tile: 64 voxels; 128 when both sides have <= 16 channels (res0 conv2, the narrow heads): those tiles are a few KB and
-    // 14 MFMAs per wave, the barrier and the DMA round trip per tile are the whole cost (M1_TF_NKS4=0: always 64)
-    static int n4 = -1; if (n4 < 0) { const char* e = getenv("M1_TF_NKS4"); n4 = e ? atoi(e) : 1; }
-    const int nks = (n4 && g.CA <= 16 && g.CB <= 16) ? 4 : 2;
+    // K-tile: 128 voxels (4 k-steps per barrier and DMA round trip) for the (1,3,3) kernels and wherever both sides have <= 16
+    // channels; 64 for the other (3,3,3) layers, whose 3-slice input tiles would leave one block per CU.  With the members of a
+    // concat in one launch (enough blocks per CU) the larger tile pays: 64 -> 32 at (2,20,160,160) 146 -> 112 us, 320 -> 64 at
+    // (2,20,80,80) 358 -> 294 us, -1.2 % per C3 step.  M1_TF_NKS4: 2 (default), 1 = only the <= 16-channel layers, 0 = always 64.
+    static int n4 = -1; if (n4 < 0) { const char* e = getenv("M1_TF_NKS4"); n4 = e ? atoi(e) : 2; }
+    const int nks = ((n4 && g.CA <= 16 && g.CB <= 16) || (n4 == 2 && g.kd == 1)) ? 4 : 2;
     p.nks = nks;
     p.TH = nks * (32 / p.KWs);
     p.AHt = (p.TH - 1) * g.sh + g.kh; p.AWt = (p.KWs - 1) * g.sw + g.kw;
@@ -750,6 +752,8 @@ static int tf_wgrad_launch(const WgradSpec& g, long long nw, int nb, hipStream_t
     TF_PICK(1, 1) TF_PICK(1, 2) TF_PICK(1, 4) TF_PICK(3, 1) TF_PICK(3, 2) TF_PICK(3, 4)
 #undef TF_PICK
     if (p.nks == 4 && kparts == 4) kern = g.kd == 1 ? wgrad_tf_kernel<1, 3, 3, 4, 4> : (g.kd == 3 ? wgrad_tf_kernel<3, 3, 3, 4, 4> : nullptr);
+    if (p.nks == 4 && g.kd == 1 && kparts == 1) kern = wgrad_tf_kernel<1, 3, 3, 1, 4>;
+    if (p.nks == 4 && g.kd == 1 && kparts == 2) kern = wgrad_tf_kernel<1, 3, 3, 2, 4>;
     if (big) kern = wgrad_tf64_kernel;
     if (!kern) return M1_ERR_UNSUPPORTED;
     {   // raise the dynamic-LDS limit once per instantiation
