@@ -130,9 +130,14 @@ def m1_det_forward(P, x, filters, strides, kernel_sizes, se_reduction, num_class
     return out
 
 
-def m1_prob_core_param_order(pre, latent_dims):
+def m1_prob_core_param_order(pre, latent_dims, dense_skip=False):
     """The order in which one core of naive_m1_prob_train_forward consumes its parameters (documented in naive_ops.c)."""
     names = m1_det_param_order(pre=pre)
+    if dense_skip:
+        for after, ups in (("convtd3", ("convtd3_up1", "convtd3_up2", "convtd3_up3")), ("convtd2", ("convtd2_up1", "convtd2_up2")),
+                           ("convtd1", ("convtd1_up1",))):
+            i = names.index(f"{pre}.{after}.bias") + 1
+            names[i:i] = [f"{pre}.{u}.{t}" for u in ups for t in ("kernel", "bias")]
 
     def se(n):
         out = []
@@ -146,7 +151,7 @@ def m1_prob_core_param_order(pre, latent_dims):
     return names
 
 
-def m1_prob_train_forward(P, x, eps_q, filters, strides, kernel_sizes, se_reduction, latent_dims, num_classes=2):
+def m1_prob_train_forward(P, x, eps_q, filters, strides, kernel_sizes, se_reduction, latent_dims, num_classes=2, dense_skip=False):
     """Train-time forward of the hierarchical probabilistic M1 in plain C loops: returns (prob_train_conv, prob_kl).
     ``eps_q``: one (N, d, h, w, L) array of N(0,1) draws per latent level with L != 0, coarsest first."""
     x = _c(x)
@@ -154,8 +159,8 @@ def m1_prob_train_forward(P, x, eps_q, filters, strides, kernel_sizes, se_reduct
     keep = []
 
     def plist(pre):
-        names = m1_prob_core_param_order(pre, latent_dims)
-        have = {n for n in P if n.startswith(pre + ".")}
+        names = m1_prob_core_param_order(pre, latent_dims, dense_skip)
+        have = {n for n in P if n.startswith(pre + ".") and ".dsy" not in n}     # (deep-supervision heads: not evaluated here)
         assert set(names) == have, sorted(set(names) ^ have)[:6]
         arrs = [_c(P[n]) for n in names]
         keep.append(arrs)
@@ -171,10 +176,10 @@ def m1_prob_train_forward(P, x, eps_q, filters, strides, kernel_sizes, se_reduct
     kl = ctypes.c_double(0.0)
     f = lib().naive_m1_prob_train_forward
     PD, PPD = ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.POINTER(ctypes.c_double))
-    f.argtypes = [PD] + [ctypes.c_int] * 5 + [ctypes.POINTER(ctypes.c_int)] * 4 + [ctypes.c_int, ctypes.POINTER(ctypes.c_int), PPD,
+    f.argtypes = [PD] + [ctypes.c_int] * 5 + [ctypes.POINTER(ctypes.c_int)] * 4 + [ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.c_int, PPD,
                   PPD, ctypes.c_int, PPD, ctypes.c_int, PD, PD, PD, PD]
     rc = f(_p(x), N, D, H, W, Cin, iv(filters), iv([a for s in strides for a in s]), iv([a for k in kernel_sizes for a in k]),
-           iv(se_reduction), int(num_classes), iv(latent_dims), eps_ptrs, prior, n_prior, post, n_post, _p(sw), _p(sb), _p(out),
+           iv(se_reduction), int(num_classes), iv(latent_dims), int(bool(dense_skip)), eps_ptrs, prior, n_prior, post, n_post, _p(sw), _p(sb), _p(out),
            ctypes.byref(kl))
     assert rc == 0, "naive_m1_prob_train_forward did not consume its parameter lists exactly"
     return out, kl.value

@@ -208,6 +208,16 @@ static vol_t concat2(int N, const vol_t *a, const vol_t *b) {                   
     }
     return y;
 }
+static vol_t concatn(int N, const vol_t *const *ts, int n) {                       /* tf.concat(ts, axis=-1) */
+    int C = 0; for (int i = 0; i < n; ++i) C += ts[i]->C;
+    vol_t y = vol_new(N, ts[0]->D, ts[0]->H, ts[0]->W, C);
+    size_t V = (size_t)N * vox(ts[0]);
+    for (size_t v = 0; v < V; ++v) {
+        int o = 0;
+        for (int i = 0; i < n; ++i) { memcpy(y.v + v * C + o, ts[i]->v + v * ts[i]->C, sizeof(double) * ts[i]->C); o += ts[i]->C; }
+    }
+    return y;
+}
 static const int ONE3[3] = { 1, 1, 1 }, K333[3] = { 3, 3, 3 };
 
 /* network_blocks.py:48-80 */
@@ -320,9 +330,11 @@ int naive_m1_det_forward(const double *x, int N, int D, int H, int W, int Cin, c
  * the reference and sharing nothing with oracle/m1_oracle.py: prior and posterior M1Core with their latent branches
  * (1x1x1 mu/log-sigma heads, reparameterised draw, transposed-conv latent decoder dec_hi*, SE blocks sersp*), the four
  * core passes of a train step that feed its outputs (q_sample, q_mean, p_sample_z_q, p_sample_z_q_mean), the stitching
- * decoder and KL(Q||P).  dense_skip = deep_supervision = False, att_sub_samp = (1,1,1), dropout off.
+ * decoder and KL(Q||P).  dense_skip optional (the nested decoder of N:591-621); deep supervision does not touch these
+ * outputs in probabilistic mode (its heads are not evaluated here); att_sub_samp = (1,1,1), dropout off.
  *
- * Parameter order of ONE core: the deterministic order documented above (conve0 ... sersd0, logits), then for the levels
+ * Parameter order of ONE core: the deterministic order documented above (conve0 ... sersd0, logits; with dense_skip
+ * convtd3 is followed by convtd3_up1, _up2, _up3, convtd2 by convtd2_up1, _up2, convtd1 by convtd1_up1), then for the levels
  * 3, 2, 1, 0:  mu_logsig{l} (kernel, bias -- only when latent_dims[3-l] != 0), dec_hi{l} (kernel, bias), sersp{l} (SE block).
  * ------------------------------------------------------------------------------------------------------------------ */
 typedef struct { vol_t ml[4]; vol_t z[4]; int L[4]; vol_t feat; } prob_out_t;     /* index 0 = level 3 (coarsest) ... 3 = level 0 */
@@ -336,7 +348,7 @@ static vol_t slice_ch(int N, const vol_t *a, int c0, int c1) {
 /* One M1Core.__call__(inputs, prob_mean, prob_z_q) (networks.py:568-728).  z_given[i] != NULL: the latent of level 3-i is
  * that tensor (prob_z_q); else eps[i] != NULL: mu + exp(clip(logsigma, +-0.1)) * eps[i] (distrib.sample()); else mu. */
 static int core_prob_forward(const double **params, int nparams, int N, const vol_t *in, const int *F, const int *strides,
-                             const int *kernels, const int *se_red, int num_classes, const int *Ldims,
+                             const int *kernels, const int *se_red, int num_classes, const int *Ldims, int dense,
                              const double *const *z_given, const double *const *eps, prob_out_t *out) {
     cursor_t c = { params, 0, nparams };
     #define S(i) (strides + 3 * (i))
@@ -350,13 +362,36 @@ static int core_prob_forward(const double **params, int nparams, int N, const vo
     vol_t a1 = gate_block(&c, N, &e1, &em, F[1]);
     vol_t a2 = gate_block(&c, N, &e2, &em, F[2]);
     vol_t a3 = gate_block(&c, N, &e3, &em, F[3]);
-    vol_t d3 = convT_layer(&c, N, &em, F[3], K(4), S(4));   vol_t c3 = concat2(N, &d3, &a3);   /* N:591-597 */
+    /* nested decoder, N:589-624; dense_skip: every transposed conv output is carried up to all finer stages (N:592-594, 601-603, 612) */
+    vol_t nil = { NULL, 0, 0, 0, 0 };
+    vol_t d3 = convT_layer(&c, N, &em, F[3], K(4), S(4));
+    vol_t d3u1 = nil, d3u2 = nil, d3u3 = nil, d2u1 = nil, d2u2 = nil, d1u1 = nil;
+    if (dense) {
+        d3u1 = convT_layer(&c, N, &d3, F[2], K(3), S(3));
+        d3u2 = convT_layer(&c, N, &d3u1, F[1], K(2), S(2));
+        d3u3 = convT_layer(&c, N, &d3u2, F[0], K(1), S(1));
+    }
+    vol_t c3 = concat2(N, &d3, &a3);                                                            /* N:595 */
     vol_t u3 = se_block(&c, N, &c3, F[3], K(3), ONE3, se_red[3]);
-    vol_t d2 = convT_layer(&c, N, &u3, F[2], K(3), S(3));   vol_t c2 = concat2(N, &d2, &a2);   /* N:600-607 */
+    vol_t d2 = convT_layer(&c, N, &u3, F[2], K(3), S(3));
+    vol_t c2;
+    if (dense) {
+        d2u1 = convT_layer(&c, N, &d2, F[1], K(2), S(2));
+        d2u2 = convT_layer(&c, N, &d2u1, F[0], K(1), S(1));
+        const vol_t *ts[] = { &d2, &d3u1, &a2 }; c2 = concatn(N, ts, 3);                        /* N:603 */
+    } else c2 = concat2(N, &d2, &a2);
     vol_t u2 = se_block(&c, N, &c2, F[2], K(2), ONE3, se_red[2]);
-    vol_t d1 = convT_layer(&c, N, &u2, F[1], K(2), S(2));   vol_t c1 = concat2(N, &d1, &a1);   /* N:610-616 */
+    vol_t d1 = convT_layer(&c, N, &u2, F[1], K(2), S(2));
+    vol_t c1;
+    if (dense) {
+        d1u1 = convT_layer(&c, N, &d1, F[0], K(1), S(1));
+        const vol_t *ts[] = { &d1, &d2u1, &d3u2, &a1 }; c1 = concatn(N, ts, 4);                 /* N:613 */
+    } else c1 = concat2(N, &d1, &a1);
     vol_t u1 = se_block(&c, N, &c1, F[1], K(1), ONE3, se_red[1]);
-    vol_t d0 = convT_layer(&c, N, &u1, F[0], K(1), S(1));   vol_t c0 = concat2(N, &d0, &a0);   /* N:619-624 */
+    vol_t d0 = convT_layer(&c, N, &u1, F[0], K(1), S(1));
+    vol_t c0;
+    if (dense) { const vol_t *ts[] = { &d0, &d1u1, &d2u2, &d3u3, &a0 }; c0 = concatn(N, ts, 5); }  /* N:621 */
+    else c0 = concat2(N, &d0, &a0);
     vol_t u0 = se_block(&c, N, &c0, F[0], K(0), ONE3, se_red[0]);
     vol_t lg = conv_layer(&c, N, &u0, num_classes, ONE3, ONE3);                                /* N:627 (not an output here) */
     /* ---- latent branch, N:632-723: level 3 reads convm, the others the running decoder features ---- */
@@ -393,7 +428,7 @@ static int core_prob_forward(const double **params, int nparams, int N, const vo
     #undef S
     #undef K
     int ok = (c.cur == nparams);
-    vol_t all[] = { x0, e1, e2, e3, em, a0, a1, a2, a3, d3, c3, u3, d2, c2, u2, d1, c1, u1, d0, c0, u0, lg };
+    vol_t all[] = { x0, e1, e2, e3, em, a0, a1, a2, a3, d3, c3, u3, d2, c2, u2, d1, c1, u1, d0, c0, u0, lg, d3u1, d3u2, d3u3, d2u1, d2u2, d1u1 };
     for (size_t i = 0; i < sizeof(all) / sizeof(all[0]); ++i) free(all[i].v);
     return ok ? 0 : -1;
 }
@@ -407,7 +442,7 @@ static void prob_out_free(prob_out_t *o) {
  * x: (N,D,H,W,Cin) with the label as channel Cin-(num_classes-1)-1 (the off-by-one slice of N:300-301 as written);
  * eps_q[i]: N(0,1) draws of latent level 3-i for the sampled posterior pass (NULL where latent_dims[i] == 0). */
 int naive_m1_prob_train_forward(const double *x, int N, int D, int H, int W, int Cin, const int *filters, const int *strides,
-                                const int *kernels, const int *se_red, int num_classes, const int *latent_dims,
+                                const int *kernels, const int *se_red, int num_classes, const int *latent_dims, int dense_skip,
                                 const double *const *eps_q, const double **prior_params, int n_prior,
                                 const double **post_params, int n_post, const double *stitch_w, const double *stitch_b,
                                 double *train_conv, double *kl_out) {
@@ -418,12 +453,12 @@ int naive_m1_prob_train_forward(const double *x, int N, int D, int H, int W, int
     vol_t post_in = concat2(N, &image, &label);                                                /* N:348 */
     prob_out_t qs, qm, pz, pzm;
     int rc = 0;
-    rc |= core_prob_forward(post_params, n_post, N, &post_in, filters, strides, kernels, se_red, num_classes, latent_dims, NULL, eps_q, &qs);   /* N:348 */
-    rc |= core_prob_forward(post_params, n_post, N, &post_in, filters, strides, kernels, se_red, num_classes, latent_dims, NULL, NULL, &qm);    /* N:349 */
+    rc |= core_prob_forward(post_params, n_post, N, &post_in, filters, strides, kernels, se_red, num_classes, latent_dims, dense_skip, NULL, eps_q, &qs);   /* N:348 */
+    rc |= core_prob_forward(post_params, n_post, N, &post_in, filters, strides, kernels, se_red, num_classes, latent_dims, dense_skip, NULL, NULL, &qm);    /* N:349 */
     const double *zs[4], *zm[4];
     for (int i = 0; i < 4; ++i) { zs[i] = qs.z[i].v; zm[i] = qm.z[i].v; }
-    rc |= core_prob_forward(prior_params, n_prior, N, &image, filters, strides, kernels, se_red, num_classes, latent_dims, zs, NULL, &pz);      /* N:351 */
-    rc |= core_prob_forward(prior_params, n_prior, N, &image, filters, strides, kernels, se_red, num_classes, latent_dims, zm, NULL, &pzm);     /* N:352 */
+    rc |= core_prob_forward(prior_params, n_prior, N, &image, filters, strides, kernels, se_red, num_classes, latent_dims, dense_skip, zs, NULL, &pz);      /* N:351 */
+    rc |= core_prob_forward(prior_params, n_prior, N, &image, filters, strides, kernels, se_red, num_classes, latent_dims, dense_skip, zm, NULL, &pzm);     /* N:352 */
     naive_conv3d_same(pzm.feat.v, stitch_w, stitch_b, train_conv, N, pzm.feat.D, pzm.feat.H, pzm.feat.W, pzm.feat.C, num_classes,
                       1, 1, 1, 1, 1, 1);                                                       /* N:356, B:277 */
     double kl = 0.0;

@@ -304,3 +304,17 @@ def test_kat7_naive_c_whole_probabilistic_train_forward():
     assert abs(kl - float(o["prob_kl"])) < 1e-9 * max(1.0, abs(float(o["prob_kl"])))
     assert float(o["prob_kl"]) > 0
 
+
+def test_kat7_naive_c_probabilistic_forward_reproduces_the_committed_golden():
+    """The plain-C probabilistic forward with the nested (dense_skip) decoder against tests/golden/c1_prob.npz (C1 filters,
+    (8,64,64), dense_skip + deep_supervision, latents (3,2,1,0)): two independent implementations of the probabilistic wiring
+    agree with the committed train logits and KL."""
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "c1_prob.npz"))
+    cfg = O.M1Config(**C1, dense_skip=True, deep_supervision=True, probabilistic=True, prob_latent_dims=(3, 2, 1, 0))
+    P = {k: v.double().numpy() for k, v in O.fixture_params(cfg, seed=int(g["seed"])).items()}
+    eps = [g["eps0"].astype(np.float64), g["eps1"].astype(np.float64), g["eps2"].astype(np.float64)]
+    tc, kl = naive.m1_prob_train_forward(P, g["x"].astype(np.float64), eps, cfg.filters, cfg.strides, cfg.kernel_sizes, cfg.se_reduction,
+                                         cfg.prob_latent_dims, cfg.num_classes, dense_skip=True)
+    assert np.abs(tc - g["train_conv"]).max() < 1e-5            # (the golden is stored in fp32)
+    assert abs(kl - float(g["kl"])) < 1e-6 * abs(float(g["kl"]))
+
