@@ -5,15 +5,18 @@
 //   out[o][oc] = bias[oc] + sum_t sum_c X[o*s - p + off_t][c] * Wp[oc][t*CC + c]       (same packed panel as conv_mfma)
 //
 // * A block owns one <= 32-wide slice of the output channels and keeps that slice of the weight panel RESIDENT in LDS
-//   ([chunk][oc][64 B], swizzled) while it walks 128-voxel output tiles (TH rows x TW columns of one (n, d) slice).
+//   ([chunk][oc][64 B], swizzled) while it walks 256-voxel output tiles (TH rows x TW columns of one (n, d) slice; 128 with
+//   256 threads).
 // * Per tile the input voxels of the tile INCLUDING the stencil halo are staged once, by LDS-DMA
 //   (global_load_lds_dwordx4), as voxel-major rows holding the whole channel concat; a tap is a row offset into
 //   that tile, so every input voxel crosses L2 -> LDS once per tile instead of once per tap.
 // * K order is [tap][member][channel] as in the panel; the per-lane fragment offsets of all K chunks are tile
 //   invariant and live in registers; fragment reads are ds_read_b128 by inline asm, one chunk ahead of the MFMAs,
 //   the tiles themselves run in a multi-stage DMA pipeline with counted vmcnt waits (as wgrad_tf.hip).
-// * Epilogue as conv_mfma: bias, bf16 rounding, tile staged in LDS, 16-byte coalesced stores, fused InstanceNorm
-//   statistics partials.
+// * Epilogue in registers: the weights are the MFMA's A operand, so a lane holds 4 consecutive output channels of one
+//   voxel -- bias, v_cvt_pk_bf16_f32, the optional out += (fetched ahead of the next tile's DMA), running InstanceNorm
+//   statistics (one partial per sample and block) and an 8-byte store; no LDS output tile, one barrier per tile.
+// * The K-chunk / DMA-piece counts of the M1 layer shapes are template parameters (straight-line tile loop, immediate vmcnt).
 #include "conv_mfma.h"
 #include "reduce.h"
 #include <stdlib.h>

@@ -3,8 +3,8 @@
 //
 //   R[tap][a][b] += sum_{n,v} A[n, v*s + tap - p][a] * B[n, v][b]            all taps of a (1,3,3)/(3,3,3) kernel at once
 //
-// * One block owns a 32(a) x 32(b) channel tile and walks K-tiles of 64 output voxels (2 k-steps of 32: KHs rows x
-//   KWs columns, KWs = 32/16/8 dividing the row length).  Per K-tile it stages, by LDS-DMA (global_load_lds_dwordx4,
+// * One block owns a 32(a) x 32(b) channel tile and walks K-tiles of 64 or 128 output voxels (2 or 4 k-steps of 32: rows x
+//   KWs columns, KWs = 32/16/8 dividing the row length; 128 for the (1,3,3) kernels, see tf_plan).  Per K-tile it stages, by LDS-DMA (global_load_lds_dwordx4,
 //   no staging registers), the 64 B rows and the A rows of the tile INCLUDING the tap halo -- every A voxel is loaded
 //   once for all taps -- in their natural voxel-major layout.
 // * The MFMA wants K(=voxel)-contiguous fragments: ds_read_b64_tr_b16 (gfx950 transpose read) takes a
@@ -13,7 +13,9 @@
 //   Probe of the instruction's lane mapping: tools/probes/tr_b16_probe.hip.
 // * wave w accumulates the 16x16 tile (w>>1, w&1) of every tap: NT x 4 accumulator registers; the B fragment of a
 //   k-step is read once and reused by all taps.
-// * K-tiles are dealt round-robin to the blocks of a channel tile; partial sums are combined with fp32 atomics.
+// * K-tiles are dealt round-robin to the blocks of a channel tile; every block stores its partial tile into its own copy of the
+//   member's gradient block and a fold (tf_finish_*, queued and run in batches: m1_wgrad_defer) adds the copies in a fixed
+//   order -- no floating-point atomics.  The equal-width members of a concat share one launch (blockIdx.z = member).
 #include "common.h"
 #include "gather.h"
 #include <stdlib.h>
