@@ -318,3 +318,12 @@ def test_kat7_naive_c_probabilistic_forward_reproduces_the_committed_golden():
     assert np.abs(tc - g["train_conv"]).max() < 1e-5            # (the golden is stored in fp32)
     assert abs(kl - float(g["kl"])) < 1e-6 * abs(float(g["kl"]))
 
+
+def test_kat7_naive_c_deterministic_forward_reproduces_the_readme_golden():
+    """The plain-C deterministic forward at README filters (32..512) against tests/golden/readme_det.npz."""
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "readme_det.npz"))
+    cfg = O.M1Config(input_spatial_dims=(8, 32, 32), filters=(32, 64, 128, 256, 512), strides=README_STRIDES)
+    P = {k: v.double().numpy() for k, v in O.fixture_params(cfg, seed=int(g["seed"])).items()}
+    lg = naive.m1_det_forward(P, g["x"].astype(np.float64), cfg.filters, cfg.strides, cfg.kernel_sizes, cfg.se_reduction, cfg.num_classes)
+    assert np.abs(lg - g["logits"]).max() < 1e-5                # (the golden is stored in fp32)
+
