@@ -305,6 +305,19 @@ def test_kat7_naive_c_whole_probabilistic_train_forward():
     assert float(o["prob_kl"]) > 0
 
 
+def test_kat7_naive_c_probabilistic_forward_reproduces_the_readme_golden():
+    """The same at README filters (32..512), (8,32,32), dense_skip + deep_supervision: tests/golden/readme_prob.npz (the C3 model)."""
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "readme_prob.npz"))
+    cfg = O.M1Config(input_spatial_dims=(8, 32, 32), filters=(32, 64, 128, 256, 512), strides=README_STRIDES, dense_skip=True,
+                     deep_supervision=True, probabilistic=True, prob_latent_dims=(3, 2, 1, 0))
+    P = {k: v.double().numpy() for k, v in O.fixture_params(cfg, seed=int(g["seed"])).items()}
+    eps = [g["eps0"].astype(np.float64), g["eps1"].astype(np.float64), g["eps2"].astype(np.float64)]
+    tc, kl = naive.m1_prob_train_forward(P, g["x"].astype(np.float64), eps, cfg.filters, cfg.strides, cfg.kernel_sizes, cfg.se_reduction,
+                                         cfg.prob_latent_dims, cfg.num_classes, dense_skip=True)
+    assert np.abs(tc - g["train_conv"]).max() < 1e-5
+    assert abs(kl - float(g["kl"])) < 1e-6 * abs(float(g["kl"]))
+
+
 def test_kat7_naive_c_probabilistic_forward_reproduces_the_committed_golden():
     """The plain-C probabilistic forward with the nested (dense_skip) decoder against tests/golden/c1_prob.npz (C1 filters,
     (8,64,64), dense_skip + deep_supervision, latents (3,2,1,0)): two independent implementations of the probabilistic wiring
