@@ -154,6 +154,39 @@ def hbm_traffic(wl, dtype, B, recs, family, prof_steps):
     return None, "family not mapped to kernels"
 
 
+def capture_with_fallback(gmode, dist_on, capture, reducer=None, sync=lambda: None):
+    """The graph-mode fallback chain: ``full`` (the whole step, collectives included, is one hipGraph) -> ``split`` (data-parallel
+    runs only: forward+backward captured without collectives, exchange + optimiser eager) -> ``off`` (eager launches).
+    ``capture(mode)`` returns the graph or raises; a failure is recorded in the returned error string and the next mode is
+    tried.  M1_BENCH_FAIL_CAPTURE=full[,split] injects a failure into the named modes (tests).  Returns (graph, mode, error)."""
+    inject = [m for m in os.environ.get("M1_BENCH_FAIL_CAPTURE", "").split(",") if m]
+    graph, err = None, None
+
+    def attempt(mode):
+        if mode in inject:
+            raise RuntimeError(f"injected capture failure ({mode})")
+        return capture(mode)
+    if gmode == "full":
+        try:
+            graph = attempt("full")
+        except Exception as e:  # noqa: BLE001 -- fall back, report it
+            graph, err = None, f"full: {type(e).__name__}: {str(e)[:200]}"
+            sync()
+            gmode = "split" if dist_on else "off"
+    if gmode == "split":
+        try:
+            if reducer is not None:
+                reducer.overlap = False                 # no collective inside the captured forward+backward
+            graph = attempt("split")
+        except Exception as e:  # noqa: BLE001
+            graph, err = None, (err or "") + f" split: {type(e).__name__}: {str(e)[:200]}"
+            sync()
+            gmode = "off"
+            if reducer is not None:
+                reducer.overlap = True
+    return graph, gmode, err
+
+
 def _dbg(msg):
     if os.environ.get("M1_BENCH_DEBUG"):
         print(f"[rank {os.environ.get('RANK', '0')}] {msg}", file=sys.stderr, flush=True)
@@ -239,8 +272,6 @@ def run_workload(a, wl, ctx, want_roofline, want_cpu):
         gmode = os.environ.get("M1_DDP_GRAPH", "full" if backend == "nccl" else "off")
     else:
         gmode = "full"
-    graph, graph_err = None, None
-
     def capture(fn, thread_local):
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
@@ -258,24 +289,9 @@ def run_workload(a, wl, ctx, want_roofline, want_cpu):
             update()
         return gr
 
-    if gmode == "full":
-        try:
-            graph = capture(step, thread_local=dist_on)
-        except Exception as e:  # noqa: BLE001 -- fall back, report it
-            graph, graph_err = None, f"full: {type(e).__name__}: {str(e)[:200]}"
-            torch.cuda.synchronize()
-            gmode = "split" if dist_on else "off"
-    if gmode == "split":
-        try:
-            if reducer is not None:
-                reducer.overlap = False                 # no collective inside the captured forward+backward
-            graph = capture(fwd_bwd, thread_local=True)
-        except Exception as e:  # noqa: BLE001
-            graph, graph_err = None, (graph_err or "") + f" split: {type(e).__name__}: {str(e)[:200]}"
-            torch.cuda.synchronize()
-            gmode = "off"
-            if reducer is not None:
-                reducer.overlap = True
+    graph, gmode, graph_err = capture_with_fallback(gmode, dist_on, lambda mode: capture(step if mode == "full" else fwd_bwd,
+                                                                                         thread_local=(dist_on or mode == "split")),
+                                                    reducer, sync=torch.cuda.synchronize)
     if graph is None:
         run = step
     elif gmode == "full":
@@ -307,8 +323,8 @@ def run_workload(a, wl, ctx, want_roofline, want_cpu):
         dt = float(tt)
         # the replicas must still hold identical parameters (same initial weights, averaged gradients): a group that was
         # sent too early / never sent shows up here
-        chk = torch.stack([opt.flatp.flat.double().sum(), opt.flatp.flat.double().abs().sum()])
-        lo, hi = chk.clone(), chk.clone()
+        # (the FULL parameter vector, element by element: min over ranks == max over ranks)
+        lo, hi = opt.flatp.flat.clone(), opt.flatp.flat.clone()
         dist.all_reduce(lo, op=dist.ReduceOp.MIN); dist.all_reduce(hi, op=dist.ReduceOp.MAX)
         st = reducer.stats
         exchange = {"backend": backend, "graph_mode": gmode, "groups": len(reducer.order), "buckets": len(reducer.order) + 1,

@@ -93,9 +93,9 @@ def conv3d_same(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor],
     _, pwb, pwa = tf_same_pads(x.shape[3], kw, strides[2])
     xc = x.permute(0, 4, 1, 2, 3)                                   # NCDHW
     xc = F.pad(xc, (pwb, pwa, phb, pha, pdb, pda))                   # explicit asymmetric pad
-    wt = w.permute(4, 3, 0, 1, 2)                                    # (Cout,Cin,kd,kh,kw)
+    wt = _stw(w).permute(4, 3, 0, 1, 2)                              # (Cout,Cin,kd,kh,kw)
     y = F.conv3d(xc, wt, b, stride=tuple(strides))                   # cross-correlation
-    return y.permute(0, 2, 3, 4, 1).contiguous()
+    return _st(y.permute(0, 2, 3, 4, 1).contiguous())
 
 
 def conv3d_transpose_same(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor],
@@ -108,7 +108,7 @@ def conv3d_transpose_same(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Te
     kd, kh, kw, cout, cin = w.shape
     assert x.shape[-1] == cin, (x.shape, w.shape)
     xc = x.permute(0, 4, 1, 2, 3)
-    wt = w.permute(4, 3, 0, 1, 2)                                    # (Cin,Cout,kd,kh,kw)
+    wt = _stw(w).permute(4, 3, 0, 1, 2)                              # (Cin,Cout,kd,kh,kw)
     full = F.conv_transpose3d(xc, wt, None, stride=tuple(strides))   # j' = i*s+k
     sl = []
     for ax, (k, s) in enumerate(zip((kd, kh, kw), strides)):
@@ -124,7 +124,7 @@ def conv3d_transpose_same(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Te
     y = full[:, :, sl[0], sl[1], sl[2]]
     if b is not None:
         y = y + b.view(1, -1, 1, 1, 1)
-    return y.permute(0, 2, 3, 4, 1).contiguous()
+    return _st(y.permute(0, 2, 3, 4, 1).contiguous())
 
 
 def instance_norm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor) -> torch.Tensor:
@@ -136,6 +136,49 @@ def instance_norm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor) -> t
 
 
 _FORCED_PATTERN = None
+_STORE_BF16 = False
+
+
+class bf16_storage:
+    """``with bf16_storage():`` -- the oracle stores what the product's benchmark mode stores in bfloat16: every conv /
+    transposed-conv output (the kernels round the fp32 accumulator once, after the bias), every InstanceNorm(+LeakyReLU)
+    output, every SE-block output, the attention product sigma*x and the sampled latent, and it feeds the convs bf16-rounded
+    kernels (the packed weight panels).  Arithmetic stays in the tensors' own dtype (fp64 in the tests): the difference to
+    the plain oracle is the error bf16 STORAGE alone causes, the yardstick the bf16 parity tests scale their tolerance by
+    ("bf16 mode gets its own (looser) tolerance").  Gradients pass straight through the rounding."""
+
+    def __enter__(self):
+        global _STORE_BF16
+        self.prev, _STORE_BF16 = _STORE_BF16, True
+        return self
+
+    def __exit__(self, *exc):
+        global _STORE_BF16
+        _STORE_BF16 = self.prev
+        return False
+
+
+class _RoundBf16(torch.autograd.Function):
+    """y = bf16(x) (round to nearest even); the gradient passes straight through and is itself stored in bf16 (the
+    product's data gradients are bf16 tensors too)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.to(torch.bfloat16).to(x.dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.to(torch.bfloat16).to(g.dtype)
+
+
+def _st(x: torch.Tensor) -> torch.Tensor:
+    """bf16 storage rounding; identity outside ``with bf16_storage():``."""
+    return _RoundBf16.apply(x) if _STORE_BF16 else x
+
+
+def _stw(w: torch.Tensor) -> torch.Tensor:
+    """bf16 weight panels: the convs multiply bf16-rounded kernels; the weight GRADIENT is an fp32 accumulator (not rounded)."""
+    return w + (w.detach().to(torch.bfloat16).to(w.dtype) - w.detach()) if _STORE_BF16 else w
 
 
 class forced_activation_pattern:
@@ -153,6 +196,10 @@ class forced_activation_pattern:
         self.masks = masks
         self.calls: Dict[str, int] = {}
         self.used = 0
+        # how far the forced pattern is from the oracle's own (sign of its own argument): elements that took the other
+        # branch / elements forced, per tag -- the tests bound this so that a sign bug cannot hide behind the mechanism
+        self.flips: Dict[str, int] = {}
+        self.total = 0
 
     def enter_core(self, pre: str) -> None:
         self.calls[pre] = self.calls.get(pre, -1) + 1
@@ -184,8 +231,13 @@ def lrelu(x: torch.Tensor, tag: Optional[str] = None) -> torch.Tensor:
         m = _FORCED_PATTERN.lookup(tag)
         if m is not None:
             assert m.shape == x.shape, (tag, m.shape, x.shape)
-            return torch.where(m, x, LRELU * x)
-    return torch.where(x >= 0, x, LRELU * x)
+            _FORCED_PATTERN.total += m.numel()
+            nf = int((m != (x.detach() >= 0)).sum())
+            if nf:
+                _FORCED_PATTERN.flips[tag] = _FORCED_PATTERN.flips.get(tag, 0) + nf
+            return _st(torch.where(m, x, LRELU * x)) if tag is not None else torch.where(m, x, LRELU * x)
+    y = torch.where(x >= 0, x, LRELU * x)
+    return _st(y) if (tag is not None and not tag.endswith(".f")) else y        # (tagged = a stored activation; the gate's f is not)
 
 
 def upsample_nearest(x: torch.Tensor, size: Sequence[int]) -> torch.Tensor:
@@ -202,7 +254,7 @@ def dropout_with_mask(x: torch.Tensor, rate: float, mask: Optional[torch.Tensor]
     if rate == 0.0:
         return x
     assert mask is not None, "oracle dropout needs an injected keep-mask"
-    return x * mask / (1.0 - rate)
+    return _st(x * mask / (1.0 - rate))
 
 
 # --------------------------------------------------------------------------------------------------
@@ -242,12 +294,12 @@ def grid_attention_block(P: Dict[str, torch.Tensor], pre: str, x: torch.Tensor, 
     phi = upsample_nearest(phi, scale)                                                        # B:116
     f = lrelu(theta + phi, pre + ".f")                                                        # B:117
     psi = conv3d_same(f, P[pre + ".psi.kernel"], P[pre + ".psi.bias"], (1, 1, 1))             # B:118
-    sig = torch.sigmoid(psi)                                                                  # B:119
+    sig = _st(torch.sigmoid(psi))                                                             # B:119
     scale = [x.shape[1 + i] // sig.shape[1 + i] for i in range(3)]                            # B:120-122
     sig = upsample_nearest(sig, scale)                                                        # B:123
-    y = sig * x                                                                               # B:124
+    y = _st(sig * x)                                                                          # B:124
     wy = conv3d_same(y, P[pre + ".W.kernel"], P[pre + ".W.bias"], (1, 1, 1))                  # B:127
-    wy = instance_norm(wy, P[pre + ".normW.gamma"], P[pre + ".normW.beta"])                   # B:128
+    wy = _st(instance_norm(wy, P[pre + ".normW.gamma"], P[pre + ".normW.beta"]))              # B:128
     return wy, sig
 
 
@@ -280,19 +332,27 @@ def m1core_forward(P: Dict[str, torch.Tensor], pre: str, cfg: M1Config, inputs: 
                    prob_mean: bool = False, prob_z_q: Optional[List[torch.Tensor]] = None,
                    eps: Optional[List[torch.Tensor]] = None,
                    drop_masks: Optional[Dict[str, torch.Tensor]] = None,
-                   deep_supervision: Optional[bool] = None) -> CoreOut:
+                   deep_supervision: Optional[bool] = None, drop_pass: int = 0) -> CoreOut:
     """M1Core.__call__ (N:568-759).  ``eps`` are the injected N(0,1) draws for distrib.sample()
-    (App. B-6: sample = mu + sigma*eps); ``drop_masks`` the injected keep-masks keyed by layer name."""
+    (App. B-6: sample = mu + sigma*eps); ``drop_masks`` the injected keep-masks keyed by layer name -- a tensor, or a
+    dict {pass index: tensor} when the passes through one core draw different masks (tf.nn.dropout draws per call);
+    ``drop_pass`` = which pass through this core this is (m1_forward: sample pass 0, mean pass 1)."""
     F_, S, K = cfg.filters, cfg.strides, cfg.kernel_sizes
     p = cfg.dropout_rate
     dm = drop_masks or {}
     if _FORCED_PATTERN is not None:
         _FORCED_PATTERN.enter_core(pre)
+    inputs = _st(inputs)
     deep_sup = cfg.deep_supervision if deep_supervision is None else deep_supervision
     o = CoreOut()
 
     def drop(name, t, rate=p):
-        return dropout_with_mask(t, rate, dm.get(pre + "." + name))
+        m = dm.get(pre + "." + name)
+        if isinstance(m, dict):
+            m = m.get(drop_pass)
+        if m is None and rate > 0.0 and dm.get("__keep_all_where_missing__"):
+            m = torch.ones_like(t)       # a layer / pass the implementation under test pruned because no output reads it
+        return dropout_with_mask(t, rate, m)
 
     def convT(name, t, k, s):
         return conv3d_transpose_same(t, P[f"{pre}.{name}.kernel"], P[f"{pre}.{name}.bias"], s)
@@ -372,7 +432,7 @@ def m1core_forward(P: Dict[str, torch.Tensor], pre: str, cfg: M1Config, inputs: 
                     z = mu
                 else:                                                               # N:647
                     e = next(eps_it)
-                    z = mu + torch.exp(logsig_c) * e
+                    z = _st(mu + torch.exp(logsig_c) * e)
                 o.prob_mu_logsigma.append(ml)
                 o.prob_mu.append(mu)
                 o.prob_logsig.append(logsig_c)
@@ -436,15 +496,15 @@ def m1_forward(P: Dict[str, torch.Tensor], cfg: M1Config, inputs: torch.Tensor,
     post_in = torch.cat([image, label], dim=-1)
     # deep_supervision is NOT forwarded to the probabilistic cores (N:304-335, App. C-4)
     q_sample = m1core_forward(P, "posterior", cfg, post_in, False, None, eps_q, drop_masks, deep_supervision=False)
-    q_mean = m1core_forward(P, "posterior", cfg, post_in, True, None, None, drop_masks, deep_supervision=False)
+    q_mean = m1core_forward(P, "posterior", cfg, post_in, True, None, None, drop_masks, deep_supervision=False, drop_pass=1)
     p_z_q = m1core_forward(P, "prior", cfg, image, False, q_sample.prob_used_latents, None, drop_masks,
                            deep_supervision=False)
     p_z_qm = m1core_forward(P, "prior", cfg, image, False, q_mean.prob_used_latents, None, drop_masks,
-                            deep_supervision=False)
+                            deep_supervision=False, drop_pass=1)
     train_conv = conv3d_same(p_z_qm.prob_decoder_features, P["stitch.logits.kernel"],
                              P["stitch.logits.bias"], (1, 1, 1))                   # N:356, B:277-278
     if with_infer:
-        p_sample = m1core_forward(P, "prior", cfg, image, False, None, eps_p, drop_masks, deep_supervision=False)
+        p_sample = m1core_forward(P, "prior", cfg, image, False, None, eps_p, drop_masks, deep_supervision=False, drop_pass=2)
         out["prob_infer_conv"] = conv3d_same(p_sample.prob_decoder_features, P["stitch.logits.kernel"],
                                              P["stitch.logits.bias"], (1, 1, 1))   # N:355
 

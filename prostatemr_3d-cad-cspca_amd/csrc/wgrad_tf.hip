@@ -695,11 +695,18 @@ int m1_wg_rx_finish(float* rx, long long stride, int ncopies, const WgradSpec& g
     {
         std::lock_guard<std::mutex> lk(g_fold_mu);
         if (g_fold_defer) {
-            // two folds into the same block of R (a parameter used by two passes) must not share a launch: run what is queued first
+            // Two folds into the same block of R (a parameter used by two passes) must not share a launch (both read-modify-write
+            // R).  The queue may hold folds whose partial copies were written on OTHER streams (SE shortcut / gate branches,
+            // weight-gradient streams) that `st` is not ordered behind, so it is NOT flushed here: this fold runs now, on its own
+            // stream, right behind the kernel that wrote its copies; the queued one follows at m1_wgrad_fold_pending, which the
+            // caller issues on a stream that has joined every stream used since (ops.join_side_streams).
+            bool dup = false;
             for (const TfPending& q : g_fold_pending)
-                if (q.f.R == f.R && q.f.a_off == f.a_off && q.f.b_off == f.b_off) { int rc = fold_launch_pending_locked(st); if (rc) return rc; break; }
-            g_fold_pending.push_back(TfPending{f, mode, (int)blocks});
-            return M1_OK;
+                if (q.f.R == f.R && q.f.a_off == f.a_off && q.f.b_off == f.b_off) { dup = true; break; }
+            if (!dup) {
+                g_fold_pending.push_back(TfPending{f, mode, (int)blocks});
+                return M1_OK;
+            }
         }
     }
     if (mode == 1) hipLaunchKernelGGL(tf_finish_vec_kernel, dim3((unsigned)blocks), dim3(256), 0, st, f);

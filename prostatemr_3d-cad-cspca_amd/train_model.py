@@ -159,6 +159,22 @@ def batches(gen: Iterator, batch_size: int, device, rank: int = 0, world: int = 
         yield bx, by
 
 
+def claim_fold_dir(fold_dir: str, resume: bool, rank: int = 0, world: int = 1) -> None:
+    """T:226-229 under one process per GPU: rank 0 alone looks at the target folder and creates it, every rank learns the
+    verdict from a broadcast and only then continues -- a rank that arrives after rank 0 has made the folder must not take it
+    for a left-over of an earlier run ("Target Folder Already Exists")."""
+    flag = [False]
+    if rank == 0:
+        flag[0] = (not resume) and os.path.exists(fold_dir)
+        if not flag[0]:
+            os.makedirs(fold_dir, exist_ok=True)
+    if world > 1:
+        import torch.distributed as dist
+        dist.broadcast_object_list(flag, src=0)      # (also the barrier: nobody passes before rank 0 has decided)
+    if flag[0]:
+        raise Exception("Target Folder Already Exists! Either Remove It or Enable 'RESUME_TRAIN'.")
+
+
 # ---- one fold ---------------------------------------------------------------------------------------------------
 def train_fold(args, f: int, device, rank: int = 0, world: int = 1):
     fold_dir = os.path.join(args.WEIGHTS_DIR + args.NAME, 'F' + str(f + 1))
@@ -230,30 +246,36 @@ def train_fold(args, f: int, device, rank: int = 0, world: int = 1):
                                    kernel_initializer=initializers.Orthogonal(gain=1.0),
                                    kernel_regularizer=initializers.l2(args.UNET_KERNEL_REGULARIZER_L2)).to(device)
     dtype = torch.bfloat16 if args.COMPUTE_DTYPE == "bf16" else torch.float32
-    unet_model.set_compute_dtype(dtype)
-    unet_model.seed_dropout(args.SEED + 2 + rank)
+
+    def configure(model):
+        """Per-run state that lives outside the weight file: storage type, this rank's dropout stream, frozen layers (T:210-215).
+        Applied again whenever the model object is replaced by a loaded one (pre-trained weights, resume)."""
+        model.set_compute_dtype(dtype)
+        model.seed_dropout(args.SEED + 2 + rank)
+        if args.FREEZE_LAYERS != 9999:
+            for layer in model.layers[:args.FREEZE_LAYERS]:
+                for p in layer.parameters():
+                    p.requires_grad_(False)
+        return model
+    configure(unet_model)
 
     # Load pre-trained weights (T:218-219)
     if str(args.USE_PRETRAINED_WEIGHTS) != 'False':
-        unet_model = unets.networks.M1.load(path=args.USE_PRETRAINED_WEIGHTS).to(device)
-        unet_model.set_compute_dtype(dtype)
+        unet_model = configure(unets.networks.M1.load(path=args.USE_PRETRAINED_WEIGHTS).to(device))
     # Number of layers / frozen layers (T:210-215)
     print("Number of Model Layers: ", len(unet_model.layers), flush=True)
     if args.FREEZE_LAYERS != 9999:
-        for layer in unet_model.layers[:args.FREEZE_LAYERS]:
-            for p in layer.parameters():
-                p.requires_grad_(False)
         print("Trainable Layers: ", len(unet_model.layers) - args.FREEZE_LAYERS, flush=True)
 
-    # Restart / resume (T:222-229)
+    # Restart / resume (T:222-229).  The resumed optimiser starts from zero moments (the reference's weight files hold no
+    # optimiser state either, callbacks.py:62,209); the learning-rate schedule continues at init_epoch * steps_per_epoch.
     if bool(args.RESUME_TRAIN):
-        unet_model, init_epoch = cbs.ResumeTraining(model=unet_model, weights_dir=fold_dir)
+        loaded, init_epoch = cbs.ResumeTraining(model=unet_model, weights_dir=fold_dir)
+        if loaded is not unet_model:
+            unet_model = configure(loaded)
     else:
         init_epoch = 0
-        if os.path.exists(fold_dir):
-            raise Exception("Target Folder Already Exists! Either Remove It or Enable 'RESUME_TRAIN'.")
-        if rank == 0:
-            os.makedirs(fold_dir)
+    claim_fold_dir(fold_dir, bool(args.RESUME_TRAIN), rank, world)
 
     # Compile (T:231); the schedule continues where the resumed run stopped
     OPTIMIZER_SET.iterations = init_epoch * steps_per_epoch
@@ -286,9 +308,11 @@ def main(argv: Optional[Sequence[str]] = None):
     out = []
     for f in args.FOLDS:
         out.append(train_fold(args, f, device, rank, world))
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()               # the next fold's folder checks must see this fold's files from every rank's view
     if world > 1:
         import torch.distributed as dist
-        dist.barrier()
         dist.destroy_process_group()
     return out
 

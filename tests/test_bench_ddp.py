@@ -35,15 +35,30 @@ def _run(cmd, env):
     return p.returncode, out, err
 
 
-def _attempts(fn, n=2):
-    """Harness tests of a separate process group (rendezvous ports, RCCL bring-up): one retry, the first failure is reported."""
-    for k in range(n):
-        try:
-            return fn()
-        except AssertionError as e:            # pytest.fail raises Failed (not caught): a killed child fails at once
-            if k + 1 == n:
-                raise
-            print(f"[test_bench_ddp] attempt {k + 1} failed, retrying once:\n{e}", flush=True)
+# stderr of a child that never got as far as the step: rendezvous / communicator bring-up, not the code under test
+_BRINGUP = ("address already in use", "EADDRINUSE", "failed to bind", "The server socket has failed to listen",
+            "ncclSystemError", "ncclUnhandledCudaError", "NCCL error", "RendezvousConnectionError", "Connection refused",
+            "timed out waiting for", "DistNetworkError")
+
+
+def _run_retrying_bringup(cmd, env, port_arg=None):
+    """One retry, ONLY when the child died in process-group bring-up (non-zero exit and a rendezvous / RCCL-init message on
+    stderr), on a fresh port; the first failure is printed.  Everything the child reports about the step itself -- replicas in
+    sync, exchange counters -- is asserted by the caller on the single run that got that far: a nondeterministic exchange bug
+    must fail the test, not be retried away."""
+    rc, out, err = _run(cmd, env)
+    if rc != 0 and any(m.lower() in err.lower() for m in _BRINGUP):
+        print(f"[test_bench_ddp] bring-up failure (rc={rc}), retrying once on another port:\n{err[-2000:]}", flush=True)
+        import warnings
+        warnings.warn(f"bench.py child failed in process-group bring-up (rc={rc}); retried once")
+        cmd2, env2 = list(cmd), dict(env)
+        if port_arg is not None and port_arg in cmd2:
+            i = cmd2.index(port_arg) + 1
+            cmd2[i] = str(int(cmd2[i]) + 17)
+        if "MASTER_PORT" in env2:
+            env2["MASTER_PORT"] = str(int(env2["MASTER_PORT"]) + 17)
+        rc, out, err = _run(cmd2, env2)
+    return rc, out, err
 
 
 def _check_line(rc, out, err, world):
@@ -66,15 +81,13 @@ def test_bench_two_ranks_one_gpu_gloo(gmode):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", "29533", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "C1", "--steps", "3",
            "--warmup", "1", "--no-cpu-baseline"]
-    def once():
-        rc, out, err = _run(cmd, env)
-        d = _check_line(rc, out, err, 2)
-        ex = d["config"]["exchange"]
-        assert ex["graph_mode"] == gmode and ex["replicas_in_sync"] is True and ex["groups"] == 3 and ex["collectives_issued"] > 0, ex
-        assert d["config"]["hip_graph"] is (gmode == "split"), d["config"]
-        if gmode == "off":
-            assert ex["groups_sent_during_backward"] >= 2 * ex["host_steps"] - 2, ex  # groups a and b close before backward ends
-    _attempts(once)
+    rc, out, err = _run_retrying_bringup(cmd, env, "--master-port")
+    d = _check_line(rc, out, err, 2)
+    ex = d["config"]["exchange"]
+    assert ex["graph_mode"] == gmode and ex["replicas_in_sync"] is True and ex["groups"] == 3 and ex["collectives_issued"] > 0, ex
+    assert d["config"]["hip_graph"] is (gmode == "split"), d["config"]
+    if gmode == "off":
+        assert ex["groups_sent_during_backward"] >= 2 * ex["host_steps"] - 2, ex  # groups a and b close before backward ends
 
 
 @pytest.mark.timeout(2 * CHILD_TIMEOUT_S + 60)
@@ -85,10 +98,8 @@ def test_bench_rccl_world_of_one():
                M1_BENCH_FORCE_DIST="1", M1_BENCH_DEBUG="1")
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--workload", "C1", "--steps", "3", "--warmup", "1",
            "--no-cpu-baseline"]
-    def once():
-        rc, out, err = _run(cmd, env)
-        d = _check_line(rc, out, err, 1)
-        ex = d["config"]["exchange"]
-        assert ex["backend"] == "nccl" and ex["graph_mode"] == "full" and ex["replicas_in_sync"] is True, (ex, d["config"]["graph_error"])
-        assert ex["collectives_issued"] > 0 and ex["groups_sent_during_backward"] > 0, ex
-    _attempts(once)
+    rc, out, err = _run_retrying_bringup(cmd, env)
+    d = _check_line(rc, out, err, 1)
+    ex = d["config"]["exchange"]
+    assert ex["backend"] == "nccl" and ex["graph_mode"] == "full" and ex["replicas_in_sync"] is True, (ex, d["config"]["graph_error"])
+    assert ex["collectives_issued"] > 0 and ex["groups_sent_during_backward"] > 0, ex

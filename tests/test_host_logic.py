@@ -247,3 +247,155 @@ def test_two_rank_gloo_gradient_exchange_equals_global_batch_mean():
         want = np.concatenate([np.full(16, 600.0), np.full(8, 30.0), np.full(8, 3.0), np.full(8, 3.0)])
         assert np.array_equal(fg, want), fg
     assert np.array_equal(res[0][6][:16], np.full(16, 200.0)) and np.array_equal(res[1][6][:16], np.full(16, 400.0))
+
+
+# ---- N > 1 readiness without hardware -----------------------------------------------------------
+def _six_group_worker(rank, world, port, q, order_seed):
+    """The probabilistic model's 6 exchange groups (prior a, b, c, posterior a, b, c -- completion order of M1Net.exchange_groups)
+    with their marks firing in an order that is NOT the expected completion order (the same permutation on every rank, as
+    autograd's order is a function of the graph): every group must still be sent exactly once, complete, and summed."""
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import importlib
+    import random
+    pkg = importlib.import_module("prostatemr_3d-cad-cspca_amd")
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    assert pkg.ddp.init_process_group_from_env("gloo") == world
+    keys = ["prior.a", "prior.b", "prior.c", "posterior.a", "posterior.b", "posterior.c"]
+    n = 8
+    ranges = {k: (i * n, (i + 1) * n) for i, k in enumerate(keys)}
+    fg = torch.zeros(len(keys) * n + 8)
+    red = pkg.ddp.GradReducer(bucket_mb=0.00002)
+    red.bind(fg, ranges, keys, (len(keys) * n, len(keys) * n + 8))
+    log = []
+    orig = red._send
+    def send(key, early):
+        if key not in red._sent:                               # (finish() offers every group again; only real sends are logged)
+            log.append((key, early, fg[ranges[key][0]:ranges[key][1]].clone() if key in ranges else None))
+        return orig(key, early)
+    red._send = send
+    fire = keys[:]
+    random.Random(order_seed).shuffle(fire)                    # backward reaches the groups in this order
+    passes = {k: (2 if k.endswith(".a") else 1) for k in keys}      # two core passes write group a (two marks), one the others
+    unmarked = fire[-1]                                        # one group's mark never fires: finish() must still send it
+    for step in range(2):
+        fg.zero_(); red.begin_step(); log.clear()
+        x = torch.ones(2, requires_grad=True)
+        h = x * 1.0
+        for k in reversed(fire):                               # forward order = reverse of the backward order
+            lo, hi = ranges[k]
+            prev = h
+            for _ in range(passes[k]):
+                h = _WritesGrad.apply(h, fg, lo, hi, float((rank + 1) * (keys.index(k) + 1)))
+                if k != unmarked:
+                    red.mark(k, prev)                          # closing node of k = the producer of its input
+        h.sum().backward()
+        fg[len(keys) * n:] += float(rank + 1)
+        red.finish()
+    q.put((rank, fg.numpy(), [(k, e, None if v is None else v.numpy()) for k, e, v in log], fire, unmarked, dict(red.stats)))
+    dist.barrier(); dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("order_seed", [1, 7])
+def test_four_rank_gloo_six_groups_marks_in_shuffled_order(order_seed):
+    world, port = 4, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_six_group_worker, args=(r, world, port, q, order_seed)) for r in range(world)]
+    [p.start() for p in ps]
+    res = sorted([q.get(timeout=180) for _ in range(world)], key=lambda t: t[0])
+    [p.join(60) for p in ps]
+    assert all(p.exitcode == 0 for p in ps)
+    keys = ["prior.a", "prior.b", "prior.c", "posterior.a", "posterior.b", "posterior.c"]
+    ranks_sum = sum(r + 1 for r in range(world))
+    for rank, fg, log, fire, unmarked, stats in res:
+        assert fire != keys                                                        # the order really is shuffled
+        sent = [k for k, _, _ in log]
+        assert sorted(k for k in sent if k != "__tail__") == sorted(keys) and sent.count("__tail__") == 1     # exactly once each
+        early = {k: e for k, e, _ in log}
+        assert all(early[k] for k in keys if k != unmarked) and not early[unmarked] and not early["__tail__"]
+        assert [k for k in sent if early[k]] == [k for k in fire if k != unmarked]    # sent in the order backward completed them
+        for k, e, at_send in log:
+            if k == "__tail__":
+                continue
+            i = keys.index(k)
+            npass = 2 if k.endswith(".a") else 1
+            assert np.array_equal(at_send, np.full(8, float((rank + 1) * (i + 1) * npass))), (k, at_send)   # complete when sent
+            assert np.array_equal(fg[i * 8:(i + 1) * 8], np.full(8, float(ranks_sum * (i + 1) * npass)))    # summed over ranks
+        assert np.array_equal(fg[48:], np.full(8, float(ranks_sum)))
+
+
+def test_graph_mode_fallback_chain_full_split_off(monkeypatch):
+    """bench.capture_with_fallback: a capture failure in 'full' falls back to 'split' (data-parallel) or 'off' (single GPU), a
+    failure in 'split' to 'off'; the reducer's overlap flag follows; the errors are reported, nothing is swallowed."""
+    import bench
+
+    class Red:
+        overlap = True
+    calls = []
+
+    def cap(fail):
+        def capture(mode):
+            calls.append(mode)
+            if mode in fail:
+                raise RuntimeError("boom " + mode)
+            return "graph-" + mode
+        return capture
+    monkeypatch.delenv("M1_BENCH_FAIL_CAPTURE", raising=False)
+    r = Red(); assert bench.capture_with_fallback("full", True, cap(()), r) == ("graph-full", "full", None) and r.overlap
+    r = Red(); g, m, e = bench.capture_with_fallback("full", True, cap(("full",)), r)
+    assert (g, m) == ("graph-split", "split") and "full: RuntimeError: boom full" in e and r.overlap is False
+    r = Red(); g, m, e = bench.capture_with_fallback("full", True, cap(("full", "split")), r)
+    assert (g, m) == (None, "off") and "full:" in e and "split: RuntimeError: boom split" in e and r.overlap is True
+    g, m, e = bench.capture_with_fallback("full", False, cap(("full",)), None)
+    assert (g, m) == (None, "off") and "full:" in e                                      # single GPU: no split stage
+    assert bench.capture_with_fallback("off", True, cap(()), Red()) == (None, "off", None)
+    calls.clear()
+    monkeypatch.setenv("M1_BENCH_FAIL_CAPTURE", "full")                               # the injection the GPU harness test uses
+    r = Red(); g, m, e = bench.capture_with_fallback("full", True, cap(()), r)
+    assert (g, m) == ("graph-split", "split") and "injected capture failure (full)" in e and calls == ["split"]
+
+
+def _fold_dir_worker(rank, world, port, q, root):
+    sys.path.insert(0, ROOT)
+    import importlib
+    import time as _t
+    pkg = importlib.import_module("prostatemr_3d-cad-cspca_amd")
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    assert pkg.ddp.init_process_group_from_env("gloo") == world
+    tm = importlib.import_module("prostatemr_3d-cad-cspca_amd.train_model")
+    out = []
+    for f in range(3):                                          # three folds in a row, as main() runs them
+        d = os.path.join(root, f"F{f + 1}")
+        if rank == 1:
+            _t.sleep(0.3)                                       # rank 1 arrives after rank 0 has created the folder
+        try:
+            tm.claim_fold_dir(d, False, rank, world)
+            out.append("ok")
+        except Exception as e:  # noqa: BLE001
+            out.append(str(e))
+        dist.barrier()
+    try:                                                        # a folder left by an earlier run: EVERY rank must refuse
+        tm.claim_fold_dir(os.path.join(root, "F1"), False, rank, world)
+        out.append("ok")
+    except Exception as e:  # noqa: BLE001
+        out.append(str(e))
+    tm.claim_fold_dir(os.path.join(root, "F1"), True, rank, world)          # resume: fine
+    q.put((rank, out))
+    dist.barrier(); dist.destroy_process_group()
+
+
+def test_two_rank_fold_directory_is_claimed_by_rank0_and_agreed_by_all(tmp_path):
+    """every rank used to test os.path.exists(fold_dir) on its own while rank 0 created it -- the late rank aborted
+    with 'Target Folder Already Exists' and the job hung in its first collective."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_fold_dir_worker, args=(r, world, port, q, str(tmp_path))) for r in range(world)]
+    [p.start() for p in ps]
+    res = dict(q.get(timeout=60) for _ in range(world))
+    [p.join(60) for p in ps]
+    assert all(p.exitcode == 0 for p in ps)
+    for rank in range(world):
+        assert res[rank][:3] == ["ok", "ok", "ok"], res
+        assert "Target Folder Already Exists" in res[rank][3], res
+    assert all(os.path.isdir(tmp_path / f"F{f}") for f in (1, 2, 3))

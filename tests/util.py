@@ -65,6 +65,7 @@ class activation_pattern:
 
     def __init__(self, model):
         self.model, self.masks, self.handles, self.passes = model, {}, [], {}
+        self.drop = {}          # keep-masks of the dropout draws: drop[oracle layer name][pass] (see oracle_drop_masks)
 
     def _tag(self, name):
         for a, b in (("m1_model.", ""), ("m1_stage1.", "stage1."), ("m1_stage2.", "stage2.")):
@@ -82,20 +83,22 @@ class activation_pattern:
                 stacked |= {self._tag(name + ".prior"), self._tag(name + ".posterior")}
         batch = {}
 
-        def add(tag, m):
+        def add(tag, m, store=None):
+            store = self.masks if store is None else store
             core = next(c for c in sorted(cores, key=len, reverse=True) if tag.startswith(c + "."))
             m = m.cpu()
             if core in stacked and self.passes[core] == 0:
                 # one stacked pass = the oracle's passes 0 and 1: [0:B] / [B:2B]; a tensor of the tail slice belongs to pass 1
                 B2 = batch[core]
                 if m.shape[0] == B2:
-                    self.masks.setdefault(tag, {})[0] = m[:B2 // 2]
-                    self.masks[tag][1] = m[B2 // 2:]
+                    store.setdefault(tag, {})[0] = m[:B2 // 2]
+                    store[tag][1] = m[B2 // 2:]
                 else:
-                    self.masks.setdefault(tag, {})[1] = m
+                    store.setdefault(tag, {})[1] = m
                 return
             k = self.passes[core] + (1 if core in stacked else 0)      # (a later separate pass, e.g. the inference sample, is pass 2)
-            self.masks.setdefault(tag, {})[k] = m
+            store.setdefault(tag, {})[k] = m
+        drop_name = {id(mod): self._tag(name) for name, mod in self.model.named_modules() if isinstance(mod, NB._DropoutBase)}
         for name, mod in self.model.named_modules():
             tag = self._tag(name)
             if isinstance(mod, NW.M1Core):
@@ -112,7 +115,16 @@ class activation_pattern:
                         add(tag, out.detach() >= 0)
                 self.handles.append(mod.register_forward_hook(h))
             elif isinstance(mod, NB.SEResNetBottleNeck):
-                self.handles.append(mod.register_forward_hook(lambda mod, inp, out, tag=tag: add(tag + ".out", out.detach() >= 0)))
+                def hse(mod, args, kwargs, out, tag=tag):
+                    add(tag + ".out", out.detach() >= 0)
+                    dr = kwargs.get("dropout")
+                    rate = dr.effective_rate() if dr is not None else 0.0
+                    if rate > 0.0:
+                        # the keep decision is a pure function of (seed, step, layer id, element index): the stand-alone dropout
+                        # kernel on a tensor of ones reproduces the draw the fused kernel made, independently of its output
+                        keep = ops.dropout(torch.ones_like(out), rate, dr.rng, dr.layer_id) != 0
+                        add(drop_name[id(dr)], keep, self.drop)
+                self.handles.append(mod.register_forward_hook(hse, with_kwargs=True))
             elif isinstance(mod, NB.GridAttentionBlock3D):
                 st = {}
                 self.handles.append(mod.theta.register_forward_hook(lambda m_, i_, o_, st=st: st.__setitem__("theta", o_.detach())))
@@ -130,3 +142,10 @@ class activation_pattern:
         for h in self.handles:
             h.remove()
         return False
+
+    def oracle_drop_masks(self, dtype=torch.float64):
+        """``drop_masks`` argument of the oracle: the keep-masks of this run, per layer and pass; layers / passes the product
+        pruned (no output reads them) keep everything."""
+        dm = {tag: {k: m.to(dtype) for k, m in per.items()} for tag, per in self.drop.items()}
+        dm["__keep_all_where_missing__"] = True
+        return dm
