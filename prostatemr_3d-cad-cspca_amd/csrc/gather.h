@@ -68,6 +68,10 @@ int m1_wg_rx_finish(float* rx, long long stride, int ncopies, const WgradSpec& g
 int m1_mfma_wgrad_ex(const WgradSpec& g, long long nw, int nb, hipStream_t st);
 bool m1_tap_wgrad_supported(const WgradSpec& g);     // per-tap kernel on the transpose read (wgrad_tap.hip), >= 64 channels
 int m1_tap_wgrad(const WgradSpec& g, long long nw, int nb, hipStream_t st);
+// tap-fused kernel on 32x32x16 MFMAs for stride-1 layers with multiples of 64 channels on both sides (wgrad_t3.hip); nmem
+// equal-width concat members in one launch (nmem = 1: Am / a_offs unused)
+bool m1_t3_wgrad_supported(const WgradSpec& g);
+int m1_t3_wgrad(const WgradSpec& g, long long nw, int nb, hipStream_t st, int nmem, const void* const* Am, const int* a_offs, long long rx_mem);
 int m1_colsum_internal(const void* x, int N, long long V, int C, int dtype, float* out, float* ws, hipStream_t st, int accumulate);
 
 // deferred-fold switch of m1_wg_rx_finish (wgrad_tf.hip): returns the previous setting

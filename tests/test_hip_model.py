@@ -27,7 +27,9 @@ def _ball_target(shape, seed):
     return torch.from_numpy(t)
 
 
-MAX_FLIP_FRACTION = 2e-5      # fp32 product vs fp64 oracle: share of LeakyReLU elements allowed on the other branch
+# fp32 product vs fp64 oracle: share of LeakyReLU elements allowed on the other branch (measured: 1 of 4.4e5, 4 of 4.5e6, 3 of 9.1e6
+# -- elements whose fp64 pre-activation lies within the fp32 rounding error of zero)
+MAX_FLIP_FRACTION = 5e-6
 
 
 def _oracle_loss_and_grads(cfg, P, x, tgt, eps=None, masks=None, drop_masks=None, max_flip_fraction=MAX_FLIP_FRACTION,

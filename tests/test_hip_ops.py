@@ -672,6 +672,13 @@ TF_CASES = [  # (N, D, H, W), cins, cout, k, s, transposed
     ((1, 3, 8, 16), [64], 128, (3, 3, 3), (2, 2, 2), False),
     ((1, 2, 4, 8), [64], 64, (3, 3, 3), (2, 2, 2), True),
     ((1, 2, 6, 8), [64, 128], 64, (1, 3, 3), (1, 1, 1), False),
+    # wgrad_t3.hip (stride 1, multiples of 64 channels): equal-width members in one launch, row lengths 20 (whole-row tiles of
+    # 3 x 20 + 4 empty slots), 40 (8-column tiles), 12 (5 x 12 + 4 empty), 160 (32-column tiles), ragged last tile rows
+    ((2, 3, 9, 20), [128, 128, 128], 128, (3, 3, 3), (1, 1, 1), False),
+    ((1, 2, 10, 40), [64, 64], 128, (3, 3, 3), (1, 1, 1), False),
+    ((1, 4, 7, 12), [64], 64, (3, 3, 3), (1, 1, 1), False),
+    ((1, 2, 5, 160), [64, 64, 64, 64, 64], 64, (1, 3, 3), (1, 1, 1), False),
+    ((2, 3, 5, 16), [256], 192, (3, 3, 3), (1, 1, 1), False),
 ]
 
 
