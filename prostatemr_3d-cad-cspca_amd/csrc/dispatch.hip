@@ -506,13 +506,13 @@ static int wgrad_common(const m1_conv_desc_t* d, bool T, const void* dy, float* 
         static int wlog = -1; if (wlog < 0) { const char* e = getenv("M1_WG_LOG"); wlog = e ? atoi(e) : 0; }
         // >= 64 channels on both sides, stride 1: the 64x64-tile tap-fused kernel on 32x32x16 MFMAs, one launch for a run of
         // equal-width members (dY staged once per kd slice for all of them, wgrad_t3.hip)
-        if (!T && !g_force_direct && rx && m1_t3_wgrad_supported(g)) {
-            int n = 1;
-            while (i + n < d->nsrc && d->src[i + n].C == d->src[i].C) ++n;
+        if (!g_force_direct && rx && m1_t3_wgrad_supported(g)) {
+            int n = 1;                                    // (transposed conv: the members are on the dY-less side, one call each)
+            while (!T && i + n < d->nsrc && d->src[i + n].C == d->src[i].C) ++n;
             const void* Am[M1_MAX_SRC]; int aoffs[M1_MAX_SRC]; int o = off;
             for (int m = 0; m < n; ++m) { Am[m] = d->src[i + m].ptr; aoffs[m] = o; o += d->src[i + m].C; }
             rc = m1_t3_wgrad(g, (long long)nw, nbias, st, n, Am, aoffs, rx_floats);
-            if (wlog) fprintf(stderr, "wgrad conv N%d B %dx%dx%d CA %d x%d CB %d k%d%d%d -> t3 rc %d\n", g.N, g.BD, g.BH, g.BW, g.CA, n, g.CB, g.kd, g.kh, g.kw, rc);
+            if (wlog) fprintf(stderr, "wgrad %s N%d B %dx%dx%d CA %d x%d CB %d k%d%d%d s%d%d%d -> t3 rc %d\n", T ? "convT" : "conv", g.N, g.BD, g.BH, g.BW, g.CA, n, g.CB, g.kd, g.kh, g.kw, g.sd, g.sh, g.sw, rc);
             if (rc == M1_OK) { off = o; i += n - 1; continue; }
             if (rc != M1_ERR_UNSUPPORTED && rc != M1_ERR_WORKSPACE) return rc;
             rc = M1_ERR_UNSUPPORTED;

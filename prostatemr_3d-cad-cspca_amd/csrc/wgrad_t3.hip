@@ -41,7 +41,7 @@ struct T3P {
     const bf16_t* A0; const bf16_t* A1; const bf16_t* A2; const bf16_t* A3; const bf16_t* A4; const bf16_t* A5; int nmem;
     const bf16_t* B; float* Rx; long long rx_stride, rx_mem, rx_bias;
     int CA, CB, AD, AH, AW, BD, BH, BW, N;
-    int pd, ph, pw, KD;
+    int pd, ph, pw, KD, sd;
     int KWs, TH;
     int aTiles, nunits;      // 64-channel units of the concat: unit u = (member u / aTiles, channels 64 (u % aTiles) ..)
     int tiles_w, tiles_h, ntiles, nsplit, stages;
@@ -62,11 +62,11 @@ __device__ __forceinline__ bf16x8_t t3_frag(s16x4_t lo, s16x4_t hi) {
 __device__ __forceinline__ void t3_dma(i32x4_t rs, unsigned lds, unsigned voff) {
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" :: "s"(lds), "v"(voff), "s"(rs) : "memory");
 }
-// at most 4 * (S - 2) LDS-DMA pieces of this wave still in flight (every wave issues 4 pieces per stage)
-__device__ __forceinline__ void t3_wait_stages(int S) {
-    if (S == 3) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else if (S == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else if (S == 5) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+// at most P * (S - 2) LDS-DMA pieces of this wave still in flight (every wave issues P pieces per stage)
+template <int P> __device__ __forceinline__ void t3_wait_stages(int S) {
+    if (S == 3) { if (P == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); }
+    else if (S == 4) { if (P == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(14)" ::: "memory"); }
+    else if (S == 5) { if (P == 4) asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(21)" ::: "memory"); }
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 __device__ __forceinline__ float t3_sum8(bf16x8_t f) {       // sum of the 8 bf16 of a fragment
@@ -90,18 +90,26 @@ __device__ __forceinline__ const bf16_t* t3_member(const T3P& p, int m) {      /
 // KWS = columns of a K-tile: 8 / 16 / 32 (TH = 64 / KWS rows; fragment addresses = per-lane base + compile-time offsets), or
 // 0 = any multiple of 4 up to 32 (whole-row tiles of the (10,20,20) level: per-lane address table).
 // BIGB: one A tile + two B tiles (else two A tiles + one B tile).
-template <int KWS, bool BIGB>
+// STR = stride of the gather in H and W: 1, or 2 (strided convs; the transposed convs, whose dOut is the gathered side) with
+// TF-SAME pad_before 0.  The A tile is then staged DE-INTERLEAVED: 4 parity planes [row parity][column parity] of
+// (TH + 1) x (KWs + 2) rows, so that the voxels tw, tw+1, .. of a tap -- input columns 2 tw + kw -- are CONSECUTIVE rows of
+// plane (kh & 1, kw & 1) at (th + (kh >> 1), tw + (kw >> 1)): the same conflict-free transpose reads and the same compile-time
+// offsets as stride 1 (interleaved, 4 voxels would sit 256 bytes apart: one bank quarter, 2-way conflicts at best).
+template <int KWS, bool BIGB, int STR>
 __global__ void __launch_bounds__(T3_THREADS, 3) wgrad_t3_kernel(T3P p) {
 #if defined(__HIP_DEVICE_COMPILE__)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wsel = wave >= 6 ? 1 : 0, w6 = wave - 6 * wsel;
     const int wa = w6 & 1, kh = w6 >> 1;
-    const int KWs = KWS ? KWS : p.KWs, TH = KWS ? T3_KT / KWS : p.TH, AWt = KWs + 2, AHt = TH + 2;
-    const int nA = (AHt * AWt + 7) / 8;                       // 1 KB pieces of ONE A tile (rows of 128 bytes)
+    // A tile rows: stride 1 [TH + 2][KWs + 2]; stride 2 [4 planes][TH + 1][KWs + 2] (plane width KWs + 1, padded to even)
+    const int KWs = KWS ? KWS : p.KWs, TH = KWS ? T3_KT / KWS : p.TH, AWt = KWs + 2, AHt = STR == 1 ? TH + 2 : TH + 1;
+    const int PLANE = AHt * AWt, arows = (STR == 1 ? 1 : 4) * PLANE;
+    const int nA = (arows + 7) / 8;                            // 1 KB pieces of ONE A tile (rows of 128 bytes)
     constexpr int nB = T3_KT / 8;                              // ... of one B tile
     constexpr int NTA = BIGB ? 1 : 2, NTB = BIGB ? 2 : 1;      // tiles of each kind per stage
-    constexpr int A_ITS = BIGB ? 2 : 3;                        // piece slots per wave: A_ITS for A, 4 - A_ITS for B
+    constexpr int A_ITS = STR == 2 ? 5 : (BIGB ? 2 : 3);       // piece slots per wave: A_ITS for A, NP - A_ITS for B
+    constexpr int NP = STR == 2 ? 7 : 4;
     const int nAtot = NTA * nA;
     const int stage_bytes = (nAtot + NTB * nB) * 1024;
     const int kd = (int)blockIdx.z % p.KD, zu = (int)blockIdx.z / p.KD;
@@ -120,10 +128,10 @@ __global__ void __launch_bounds__(T3_THREADS, 3) wgrad_t3_kernel(T3P p) {
     //      64-byte halves swap when bit 1 of the tile column ww is set (B: of the voxel slot).  Stage = [A tiles][B tiles].
     //      Every wave issues 4 pieces (1 KB) per stage, kinds fixed per slot; a slot past the tiles fetches nothing (offset out
     //      of range) into a scratch KB behind the stages: one compile-time vmcnt for all waves, no branches. ----
-    unsigned vo[4]; int pk[4]; int dst[4]; int second[4];
+    unsigned vo[NP]; int pk[NP]; int dst[NP]; int second[NP];
     const unsigned trash = lds0 + (unsigned)(p.stages * stage_bytes);
 #pragma unroll
-    for (int it = 0; it < 4; ++it) {
+    for (int it = 0; it < NP; ++it) {
         vo[it] = OOB; pk[it] = 0;
         if (it < A_ITS) {
             const int q = wave + T3_WAVES * it;                // piece of the A tiles
@@ -131,10 +139,12 @@ __global__ void __launch_bounds__(T3_THREADS, 3) wgrad_t3_kernel(T3P p) {
             const bool real = q < nAtot;
             dst[it] = real ? q * 1024 : -1; second[it] = t1;
             const int s = ql * 64 + lane, row = s >> 3, slp = s & 7;
-            const int hh = row / AWt, ww = row - hh * AWt;
-            const int sl = slp ^ (((ww >> 1) & 1) << 2);
+            const int pl = row / PLANE, rp = row - pl * PLANE;  // (stride 1: one plane)
+            const int hp = rp / AWt, wp = rp - hp * AWt;
+            const int sl = slp ^ (((wp >> 1) & 1) << 2);
+            const int hh = STR == 1 ? hp : 2 * hp + (pl >> 1), ww = STR == 1 ? wp : 2 * wp + (pl & 1);      // input row / column of the tile
             pk[it] = hh | (ww << 8);
-            if (real && row < AHt * AWt) vo[it] = (unsigned)(((hh * p.AW + ww) * p.CA + sl * 8) * 2);
+            if (real && row < arows) vo[it] = (unsigned)(((hh * p.AW + ww) * p.CA + sl * 8) * 2);
         } else {
             const int q = wave + T3_WAVES * (it - A_ITS);      // piece of the B tiles
             const int t1 = q >= nB ? 1 : 0, ql = q - t1 * nB;
@@ -159,7 +169,7 @@ __global__ void __launch_bounds__(T3_THREADS, 3) wgrad_t3_kernel(T3P p) {
             const int twi = r % p.tiles_w; r /= p.tiles_w;
             const int thi = r % p.tiles_h; r /= p.tiles_h;
             const int bd = r % p.BD, n = r / p.BD;
-            const int ad = bd + kd - p.pd, ah0 = thi * TH - p.ph, aw0 = twi * KWs - p.pw, bh0 = thi * TH;
+            const int ad = bd * p.sd + kd - p.pd, ah0 = thi * TH * STR - p.ph, aw0 = twi * KWs * STR - p.pw, bh0 = thi * TH;
             const long long alin0 = (((long long)n * p.AD + ad) * p.AH + ah0) * p.AW + aw0;
             const long long blin0 = (((long long)n * p.BD + bd) * p.BH + bh0) * p.BW + twi * KWs;
             const unsigned long long pa = (unsigned long long)(A0base + alin0 * p.CA), pb = (unsigned long long)(p.B + blin0 * p.CB);
@@ -193,7 +203,7 @@ __global__ void __launch_bounds__(T3_THREADS, 3) wgrad_t3_kernel(T3P p) {
         const int ah0 = (ea.w << 16) >> 16, aw0 = ea.w >> 16, bh0 = eb.w;      // (vector registers: every lane read the same entry)
         const unsigned S0 = lds0 + (unsigned)(st * stage_bytes);
 #pragma unroll
-        for (int it = 0; it < 4; ++it) {
+        for (int it = 0; it < NP; ++it) {
             const unsigned d = dst[it] >= 0 ? S0 + (unsigned)dst[it] : trash;
             if (it < A_ITS) {   // halo rows / columns outside the volume fetch zeros (per-lane compares: vector work, not scalar)
                 const unsigned hh = (unsigned)(pk[it] & 0xff), ww = (unsigned)(pk[it] >> 8);
@@ -220,8 +230,12 @@ __global__ void __launch_bounds__(T3_THREADS, 3) wgrad_t3_kernel(T3P p) {
     if (KWS) {
         const int th_l = KWS == 8 ? kg : 0, tw_l = (KWS == 8 ? 0 : 8 * kg) + (i >> 2);
 #pragma unroll
-        for (int kw = 0; kw < 3; ++kw)
-            aL[kw] = At + ((th_l + kh) * AWt + tw_l + kw) * 128 + (((wa ^ ((tw_l + kw) >> 1)) & 1) << 6) + cpart;
+        for (int kw = 0; kw < 3; ++kw) {
+            // tap (kh, kw) of voxel (th, tw): stride 1 row (th + kh, tw + kw); stride 2 plane (kh & 1, kw & 1), row (th + kh / 2, tw + kw / 2)
+            const int pl = STR == 1 ? 0 : (kh & 1) * 2 + (kw & 1);
+            const int hp = th_l + (STR == 1 ? kh : kh >> 1), wp = tw_l + (STR == 1 ? kw : kw >> 1);
+            aL[kw] = At + (pl * PLANE + hp * AWt + wp) * 128 + (((wa ^ (wp >> 1)) & 1) << 6) + cpart;
+        }
     } else {
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks)
@@ -230,7 +244,8 @@ __global__ void __launch_bounds__(T3_THREADS, 3) wgrad_t3_kernel(T3P p) {
                 const int kk = ks * 16 + 8 * kg + 4 * h + (i >> 2);
                 const bool real = kk < TH * KWs;                 // (empty slots of a short tile: B is zero there, A reads any valid row)
                 const int th = real ? kk / KWs : 0, tw = real ? kk - th * KWs : (i >> 2);
-                a_tab[KWS ? 0 : ks][h] = (unsigned)(((th + kh) * AWt + tw) * 128 + (((wa ^ (tw >> 1)) & 1) << 6) + cpart);
+                const int r0 = STR == 1 ? (th + kh) * AWt + tw : ((kh & 1) * 2 * PLANE + (th + (kh >> 1)) * AWt + tw);
+                a_tab[KWS ? 0 : ks][h] = (unsigned)(r0 * 128 + (((wa ^ (tw >> 1)) & 1) << 6) + cpart);
             }
         aL[0] = aL[1] = aL[2] = At;
     }
@@ -262,7 +277,7 @@ __global__ void __launch_bounds__(T3_THREADS, 3) wgrad_t3_kernel(T3P p) {
     int st = 0;
     for (int kt = blockIdx.y; kt < p.ntiles; kt += p.nsplit) {
         fetch();
-        t3_wait_stages(S);                                     // this wave's pieces of tile kt have landed ...
+        t3_wait_stages<NP>(S);                                 // this wave's pieces of tile kt have landed ...
         __builtin_amdgcn_s_barrier();                          // ... and everybody's; everybody is also done with tile kt - nsplit
         int stn = st + S - 1; if (stn >= S) stn -= S;
         issue(stn);                                            // refill the buffer tile kt - nsplit was read from
@@ -287,8 +302,10 @@ __global__ void __launch_bounds__(T3_THREADS, 3) wgrad_t3_kernel(T3P p) {
                 unsigned aA = a_tab[KWS ? 0 : ks][0], aB = a_tab[KWS ? 0 : ks][1];
                 asm volatile("" : "+v"(aA), "+v"(aB));       // (keeps the 16 derived tap addresses out of loop-invariant registers)
                 af0 = t3_frag(t3_tr(s0 + aA), t3_tr(s0 + aB));
-                af1 = t3_frag(t3_tr(s0 + ((aA + 128u) ^ m1)), t3_tr(s0 + ((aB + 128u) ^ m1)));
-                af2 = t3_frag(t3_tr(s0 + ((aA + 256u) ^ 64u)), t3_tr(s0 + ((aB + 256u) ^ 64u)));
+                if (STR == 1) af1 = t3_frag(t3_tr(s0 + ((aA + 128u) ^ m1)), t3_tr(s0 + ((aB + 128u) ^ m1)));
+                else af1 = t3_frag(t3_tr(s0 + aA + (unsigned)(PLANE * 128)), t3_tr(s0 + aB + (unsigned)(PLANE * 128)));   // the odd-column plane, same row
+                if (STR == 1) af2 = t3_frag(t3_tr(s0 + ((aA + 256u) ^ 64u)), t3_tr(s0 + ((aB + 256u) ^ 64u)));
+                else af2 = t3_frag(t3_tr(s0 + ((aA + 128u) ^ m1)), t3_tr(s0 + ((aB + 128u) ^ m1)));                     // the even plane, next column
             }
             if (do_bsum) { accb0 += t3_sum8(bf0); accb1 += t3_sum8(bf1); }
             acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af0, bf0, acc[0][0], 0, 0, 0);
@@ -331,14 +348,16 @@ static bool t3_plan(const WgradSpec& g, T3P& p) {
     if (!en || g.dtype != M1_BF16) return false;
     if (g.CA < 64 || g.CB < 64 || g.CA % 64 || g.CB % 64) return false;
     if (!(g.kh == 3 && g.kw == 3 && (g.kd == 1 || g.kd == 3))) return false;
-    if (g.sd != 1 || g.sh != 1 || g.sw != 1) return false;
+    const bool s1 = g.sh == 1 && g.sw == 1 && g.sd == 1, s2 = g.sh == 2 && g.sw == 2 && (g.sd == 1 || g.sd == 2) && g.ph == 0 && g.pw == 0;
+    if (!s1 && !s2) return false;
+    if (s2 && g.CB % 128) return false;                        // (two de-interleaved A tiles do not fit a stage)
     if (g.BW % 4 || g.BW < 8) return false;
     // (DMA offsets are 32-bit and relative to the tile origin, which travels in the 64-bit resource base)
     if ((long long)(g.AH + 4) * g.AW * g.CA * 2 >= (1ll << 31) - 4096 || (long long)(g.BH + 4) * g.BW * g.CB * 2 >= (1ll << 31) - 4096) return false;
     p = T3P{};
     p.B = (const bf16_t*)g.B;
     p.CA = g.CA; p.CB = g.CB; p.AD = g.AD; p.AH = g.AH; p.AW = g.AW; p.BD = g.BD; p.BH = g.BH; p.BW = g.BW; p.N = g.N;
-    p.pd = g.pd; p.ph = g.ph; p.pw = g.pw; p.KD = g.kd;
+    p.pd = g.pd; p.ph = g.ph; p.pw = g.pw; p.KD = g.kd; p.sd = g.sd;
     // K-tile: TH rows x KWs columns <= 64 voxels, KWs a multiple of 4 (4-voxel transpose groups never straddle a row)
     int kws = 0;
     for (int c : {32, 16, 8}) if (g.BW % c == 0) { kws = c; break; }
@@ -346,8 +365,9 @@ static bool t3_plan(const WgradSpec& g, T3P& p) {
     if (!kws) return false;
     p.KWs = kws; p.TH = T3_KT / kws;
     if (p.TH + 2 > 255 || p.KWs + 2 > 255) return false;
-    const int nA = ((p.TH + 2) * (p.KWs + 2) + 7) / 8;
-    if (nA > 18) return false;                                 // (the kernel's fixed piece slots: 24 / 36 pieces for the A tiles)
+    const int nA = s1 ? ((p.TH + 2) * (p.KWs + 2) + 7) / 8 : (4 * (p.TH + 1) * (p.KWs + 2) + 7) / 8;
+    if (nA > (s1 ? 18 : 60)) return false;                     // (the kernel's fixed piece slots: 24 / 36 / 60 pieces for the A tiles)
+    if (2 * p.TH + 1 > 255 || 2 * p.KWs + 3 > 255) return false;
     p.tiles_w = g.BW / p.KWs; p.tiles_h = (g.BH + p.TH - 1) / p.TH;
     const long long nt = (long long)g.N * g.BD * p.tiles_h * p.tiles_w;
     if (nt >= (1ll << 30) || nt < 8) return false;
@@ -386,7 +406,8 @@ int m1_t3_wgrad(const WgradSpec& g, long long nw, int nb, hipStream_t st, int nm
     p.Rx = g.rx; p.rx_stride = stride; p.rx_bias = nloc; p.rx_mem = nmem > 1 ? rx_mem : 0;
     p.want_bsum = g.bsum != nullptr;
     // LDS: the stages, the scratch KB of the empty piece slots, the tile table (32 bytes per K-tile of a block + the padding stages)
-    const int nA = ((p.TH + 2) * (p.KWs + 2) + 7) / 8;
+    const bool s2 = g.sh == 2;
+    const int nA = !s2 ? ((p.TH + 2) * (p.KWs + 2) + 7) / 8 : (4 * (p.TH + 1) * (p.KWs + 2) + 7) / 8;
     const int stage_bytes = (bigb ? nA + 16 : 2 * nA + 8) * 1024;
     const long long tiles_per_block = (p.ntiles + nsplit - 1) / nsplit;
     int S = 4;
@@ -396,15 +417,16 @@ int m1_t3_wgrad(const WgradSpec& g, long long nw, int nb, hipStream_t st, int nm
     p.stages = S;
     const size_t smem = (size_t)S * stage_bytes + 1024 + (size_t)(tiles_per_block + S) * 32;
     void (*kern)(T3P) = nullptr;
-    if (bigb) kern = p.KWs == 8 ? wgrad_t3_kernel<8, true> : (p.KWs == 16 ? wgrad_t3_kernel<16, true> : (p.KWs == 32 ? wgrad_t3_kernel<32, true> : wgrad_t3_kernel<0, true>));
-    else kern = p.KWs == 8 ? wgrad_t3_kernel<8, false> : (p.KWs == 16 ? wgrad_t3_kernel<16, false> : (p.KWs == 32 ? wgrad_t3_kernel<32, false> : wgrad_t3_kernel<0, false>));
+    if (s2) kern = p.KWs == 8 ? wgrad_t3_kernel<8, true, 2> : (p.KWs == 16 ? wgrad_t3_kernel<16, true, 2> : (p.KWs == 32 ? wgrad_t3_kernel<32, true, 2> : wgrad_t3_kernel<0, true, 2>));
+    else if (bigb) kern = p.KWs == 8 ? wgrad_t3_kernel<8, true, 1> : (p.KWs == 16 ? wgrad_t3_kernel<16, true, 1> : (p.KWs == 32 ? wgrad_t3_kernel<32, true, 1> : wgrad_t3_kernel<0, true, 1>));
+    else kern = p.KWs == 8 ? wgrad_t3_kernel<8, false, 1> : (p.KWs == 16 ? wgrad_t3_kernel<16, false, 1> : (p.KWs == 32 ? wgrad_t3_kernel<32, false, 1> : wgrad_t3_kernel<0, false, 1>));
     {
-        static const void* done[8]; static int ndone = 0;
+        static const void* done[12]; static int ndone = 0;
         bool seen = false;
         for (int q = 0; q < ndone; ++q) seen |= done[q] == (const void*)kern;
         if (!seen) {
             if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return M1_ERR_LAUNCH;
-            if (ndone < 8) done[ndone++] = (const void*)kern;
+            if (ndone < 12) done[ndone++] = (const void*)kern;
         }
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)gx, (unsigned)nsplit, (unsigned)(gzu * g.kd)), dim3(T3_THREADS), smem, st, p);

@@ -679,6 +679,14 @@ TF_CASES = [  # (N, D, H, W), cins, cout, k, s, transposed
     ((1, 4, 7, 12), [64], 64, (3, 3, 3), (1, 1, 1), False),
     ((1, 2, 5, 160), [64, 64, 64, 64, 64], 64, (1, 3, 3), (1, 1, 1), False),
     ((2, 3, 5, 16), [256], 192, (3, 3, 3), (1, 1, 1), False),
+    # ... stride 2 in H, W (A tile staged as 4 parity planes): strided convs with C_out % 128 == 0, transposed convs (dOut is the
+    # gathered side, the members sit on the other one), stride 1 / 2 in D, tile widths 16 / 8 / 20 (generic address table)
+    ((2, 4, 16, 32), [64], 128, (3, 3, 3), (2, 2, 2), False),
+    ((2, 4, 16, 16), [64, 64], 128, (3, 3, 3), (1, 2, 2), False),
+    ((2, 2, 10, 40), [128], 256, (1, 3, 3), (1, 2, 2), False),
+    ((2, 2, 8, 16), [128], 64, (3, 3, 3), (2, 2, 2), True),
+    ((2, 3, 6, 20), [256], 128, (3, 3, 3), (2, 2, 2), True),
+    ((2, 4, 8, 8), [2, 128], 64, (3, 3, 3), (1, 2, 2), True),
 ]
 
 
