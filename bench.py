@@ -39,6 +39,8 @@ WORKLOAD_NAMES = {"C1": "C1 tiny deterministic (8,64,64,3) filters (8..128)",
                   "C5": "C5 M1 deterministic high-res (32,256,256,3)"}
 PEAK_HBM_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 PEAK_MFMA_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}
+# algorithmic train work per volume (TFLOP, GB at the config's dtype) -- C2/C3 bf16, C5 fp32
+SURVEY_8D = {"C2": (0.723, 3.48), "C3": (8.22, 25.05), "C5": (2.96, 28.53)}
 
 # volumes per GPU when --batch is not given: the reference trainer's default batch (train_model.py:83, --BATCH_SIZE 2), which is
 # also the per-GPU batch BASELINE.json names for C4; C1 is the reference's batch-1 plumbing case, C5 the single-volume stress case
@@ -79,17 +81,18 @@ def ball_targets(B, dims, seed, device):
     return torch.from_numpy(t).to(device)
 
 
-def cpu_baseline(workload, prob, dense, deep, dims, filters, kl_w, budget_s=45.0):
-    """The CPU oracle's full train step (fwd + Focal [+10 KL] + L2 + bwd, torch-CPU fp32) on ONE WHOLE VOLUME of the
-    workload when a probe predicts that fits the time budget (it does for C2 and C3 on the GPU box's host), else on the
-    largest sub-volume that does, scaled by the voxel ratio (the path is convolutional: linear in voxels)."""
+def cpu_baseline(workload, prob, dense, deep, dims, filters, kl_w, budget_s=75.0):
+    """The CPU oracle's full train step (fwd + Focal [+10 KL] + L2 + bwd + Adam-amsgrad update, torch-CPU fp32) with the protocol of
+    SURVEY.md 8(d): 1 warm-up + 3 timed steps, median -- on ONE WHOLE VOLUME of the workload when a probe predicts the four steps
+    fit the time budget (they do for C2 and C3 on the GPU box's host), else on the largest sub-volume that does, scaled by the
+    voxel ratio (the path is convolutional: linear in voxels)."""
     import torch
     from oracle import m1_oracle as O
     cores = min(os.cpu_count() or 1, 32)          # more threads than this only adds contention on these small convs
     torch.set_num_threads(cores)
     D, H, W = dims
 
-    def run(sd):
+    def make(sd):
         cfg = O.M1Config(input_spatial_dims=sd, filters=filters, strides=README_STRIDES, probabilistic=prob, dense_skip=dense,
                          deep_supervision=deep, prob_latent_dims=(3, 2, 1, 0))
         g = torch.Generator().manual_seed(0)
@@ -97,31 +100,55 @@ def cpu_baseline(workload, prob, dense, deep, dims, filters, kl_w, budget_s=45.0
         x = torch.randn(1, *sd, 3, generator=g)
         tgt = ball_targets(1, sd, 1, "cpu")
         eps = [torch.randn(1, *s, generator=g) for s in O.latent_shapes(cfg)] if prob else None
+        state = {k: [torch.zeros_like(v), torch.zeros_like(v), torch.zeros_like(v)] for k, v in P.items()}
+        return cfg, P, x, tgt, eps, state
+
+    def step(ctx, t):
+        cfg, P, x, tgt, eps, state = ctx
         t0 = time.time()
+        for v in P.values():
+            v.grad = None
         loss, _, _ = O.train_loss(P, cfg, x, tgt, eps_q=eps, kl_weight=kl_w)
         loss.backward()
+        lr_t = 1e-3 * (1 - 0.999 ** t) ** 0.5 / (1 - 0.9 ** t)                    # Keras Adam(amsgrad=True), App. B-8
+        with torch.no_grad():
+            for k, w in P.items():
+                if w.grad is None:
+                    continue
+                m, v, vh = state[k]
+                m.mul_(0.9).add_(w.grad, alpha=0.1); v.mul_(0.999).addcmul_(w.grad, w.grad, value=0.001)
+                torch.maximum(vh, v, out=vh)
+                w.addcdiv_(m, vh.sqrt().add_(1e-7), value=-lr_t)
         return time.time() - t0
 
     cands = [(D, H, W), (D, H // 2, W // 2), (D // 2 or 1, H // 2, W // 2), (D // 2 or 1, H // 4, W // 4), (4, 32, 32)]
     cands = [c for c in dict.fromkeys(cands) if c[0] >= 4 and c[1] >= 32 and c[2] >= 32 and c[0] % 4 == 0] or [(4, 32, 32)]
     vox = lambda c: c[0] * c[1] * c[2]
     probe = min(cands, key=vox)
-    run(probe)                                       # warm-up (thread pools, oneDNN primitives)
-    pick, t = probe, run(probe)
-    for c in sorted(cands, key=vox)[1:]:             # climb while the next size, predicted from the last measured one, fits
-        if t * vox(c) / vox(pick) > budget_s:        # (small volumes are less efficient: the prediction errs on the safe side)
+    pctx = make(probe)
+    step(pctx, 1)                                    # warm-up of the probe (thread pools, oneDNN primitives)
+    pick, t = probe, step(pctx, 2)
+    for c in sorted(cands, key=vox, reverse=True):   # the largest size whose 1 + 3 steps, predicted from the probe, fit the budget
+        if 4.0 * t * vox(c) / vox(probe) <= budget_s:     # (small volumes are less efficient: the prediction errs on the safe side)
+            pick = c
             break
-        pick, t = c, run(c)
+    ctx = pctx if pick == probe else make(pick)
+    del pctx
+    step(ctx, 1)                                     # 1 warm-up ...
+    times = sorted(step(ctx, 2 + i) for i in range(3))      # ... + 3 timed
+    t = times[1]
     frac = vox(pick) / float(D * H * W)
     whole = "one WHOLE volume" if frac == 1.0 else f"a ({pick[0]},{pick[1]},{pick[2]}) sub-volume = {frac:.4f} of a volume, scaled by voxel ratio"
     return {"value": frac / t, "unit": "volumes/s", "cores": cores, "kind": "port",
             "sample": f"oracle (torch-CPU fp32 restatement of the TF2.5 path, stand-in: TF cannot be installed) full train "
-                      f"step fwd+loss+bwd of {workload} on {whole}; {t:.2f} s/step on {cores} threads"}
+                      f"step fwd+loss+bwd+Adam-amsgrad of {workload} on {whole}; 1 warm-up + 3 timed steps, median {t:.2f} s/step "
+                      f"(min {times[0]:.2f}, max {times[2]:.2f}) on {cores} threads"}
 
 
 # kernel names behind each C-ABI entry-point family (the PMC pass sees kernels, the hipEvent timer sees entry points)
 _FAMILY_KERNELS = {
-    "wgrad": (("conv3d_wgrad", "convT3d_wgrad"), ("wgrad_mfma_kernel", "wgrad_tap_kernel", "wgrad_tf_kernel", "wgrad_tf64_kernel", "tf_finish_kernel")),
+    "wgrad": (("conv3d_wgrad", "convT3d_wgrad"), ("wgrad_mfma_kernel", "wgrad_tap_kernel", "wgrad_tf_kernel", "wgrad_tf64_kernel", "wgrad_t3_kernel",
+                                                  "tf_finish_kernel")),
     "conv": (("conv3d_fwd", "conv3d_dgrad", "convT3d_fwd", "convT3d_dgrad"),
              ("conv_mfma_kernel", "conv_halo_kernel", "splitk_finish_kernel")),
 }
@@ -133,7 +160,7 @@ def hbm_traffic(wl, dtype, B, recs, family, prof_steps):
     FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).  None when no committed measurement matches."""
     pdir = os.path.join(ROOT, "profiles")
     path = None
-    for rnd in ("r02", "r01"):
+    for rnd in ("r03", "r02", "r01"):
         cand = os.path.join(pdir, f"{rnd}_{wl.lower()}_{dtype}_hbm_traffic.json")
         if os.path.exists(cand):
             path = cand
@@ -150,7 +177,8 @@ def hbm_traffic(wl, dtype, B, recs, family, prof_steps):
                      for k in kernels)
             launches = sum(q["launches"] for q in recs if q["name"] in fams) / prof_steps
             return gb * 1e9 / max(launches, 1.0), ("bytes per entry-point launch, kernels " + "+".join(kernels) + " shared by " +
-                                                   "+".join(fams) + f"; rocprofv3 --pmc FETCH_SIZE(x2)/WRITE_SIZE, {os.path.basename(path)}")
+                                                   "+".join(fams) + f"; rocprofv3 --pmc FETCH_SIZE(x2)/WRITE_SIZE, {os.path.basename(path)}"
+                                                   + (f" taken at commit {pm['commit']}" if pm.get("commit") else ""))
     return None, "family not mapped to kernels"
 
 
@@ -367,6 +395,24 @@ def run_workload(a, wl, ctx, want_roofline, want_cpu):
                 roof["all_kernels_work_per_step"] = {q["name"]: [q["flops"] / a.prof_steps, q["bytes"] / a.prof_steps,
                                                                  q["launches"] / a.prof_steps] for q in recs}
             roof["traffic"], roof["traffic_note"] = hbm_traffic(wl, dtype, B, recs, r["name"], a.prof_steps)
+            # whole-step work, so that the whole-step fractions can be recomputed from this line: what the launches of one step
+            # execute (pruned latents-only passes) by the conv-like-op convention of SURVEY.md 8(d), and 8(d)'s own
+            # unpruned per-volume figures x the batch (+ the optimiser's 36 B per parameter)
+            ex_f = sum(q["flops"] for q in recs) / a.prof_steps; ex_b = sum(q["bytes"] for q in recs) / a.prof_steps
+            s8 = SURVEY_8D.get(wl)
+            step_s = dt / a.steps
+            roof["step_work"] = {
+                "executed_flops": ex_f, "executed_bytes": ex_b,
+                "executed_frac_of_mfma_peak": ex_f / step_s / 1e12 / PEAK_MFMA_TFLOPS[dtype],
+                "executed_frac_of_hbm_peak": ex_b / step_s / 1e9 / PEAK_HBM_GBS,
+                "survey_8d_flops": None if s8 is None else s8[0] * 1e12 * B,
+                "survey_8d_bytes": None if s8 is None else (s8[1] * B + 36e-9 * nparams) * 1e9 * (1.0 if dtype == "bf16" or wl == "C5" else 2.0),
+                "note": "per step of this rank; executed = sum over the entry-point records of one step (flops = 2 MAC, bytes = inputs + "
+                        "outputs of every conv-like op; norms / activations / gates count zero); survey_8d = SURVEY.md 8(d) per-volume "
+                        "figures (unpruned four passes) x batch + optimiser traffic"}
+            if s8 is not None:
+                roof["step_work"]["survey_8d_frac_of_mfma_peak"] = roof["step_work"]["survey_8d_flops"] / step_s / 1e12 / PEAK_MFMA_TFLOPS[dtype]
+                roof["step_work"]["survey_8d_frac_of_hbm_peak"] = roof["step_work"]["survey_8d_bytes"] / step_s / 1e9 / PEAK_HBM_GBS
             # The timed region runs independent branches on side streams (ops.branch): kernels share the GPU there and their
             # individual durations stretch.  Second pass with the branches in order: the same family with every kernel alone
             # on the GPU (what the per-kernel roofline means); reported next to the in-situ figure above, never instead of it.

@@ -340,3 +340,44 @@ def test_kat7_naive_c_deterministic_forward_reproduces_the_readme_golden():
     lg = naive.m1_det_forward(P, g["x"].astype(np.float64), cfg.filters, cfg.strides, cfg.kernel_sizes, cfg.se_reduction, cfg.num_classes)
     assert np.abs(lg - g["logits"]).max() < 1e-5                # (the golden is stored in fp32)
 
+
+
+def test_tf_pin_bundle_and_weight_mapping(tmp_path):
+    """tools/tf_dump_reference.py (the off-box TF 2.5 pin): the bundle it writes reproduces the oracle's outputs from its own
+    arrays, and its weight loader addresses every tensor of the bundle exactly once through the reference's attribute names
+    (gate sublayers theta/phi/psi/W/normW -> conv1..conv4/norm4, network_blocks.py:100-104) -- checked on a recording stand-in
+    for the Keras layers (TensorFlow itself is not installable here)."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("tf_dump_reference", os.path.join(os.path.dirname(os.path.dirname(__file__)), "tools", "tf_dump_reference.py"))
+    T = importlib.util.module_from_spec(spec); spec.loader.exec_module(T)
+    path = str(tmp_path / "bundle.npz")
+    T.make_bundle(path)
+    B = dict(np.load(path))
+    for case, prob in (("det", False), ("prob", True)):
+        cfg = O.M1Config(input_spatial_dims=T.DIMS, filters=T.FILTERS, strides=T.STRIDES, kernel_sizes=T.KERNELS, dense_skip=prob,
+                         probabilistic=prob, prob_latent_dims=T.LATENTS)
+        P = {k[len(case) + 3:]: torch.from_numpy(v).double() for k, v in B.items() if k.startswith(case + ".w.")}
+        assert set(P) == set(O.param_shapes(cfg)) if hasattr(O, "param_shapes") else len(P) > 100
+        eps = [torch.from_numpy(B[f"prob.eps{i}"]).double() for i in range(3)] if prob else None
+        o = O.m1_forward(P, cfg, torch.from_numpy(B[f"{case}.x"]).double(), eps_q=eps)
+        if prob:
+            assert float((o["prob_train_conv"] - torch.from_numpy(B["prob.prob_train_conv"]).double()).abs().max()) < 1e-5
+            assert abs(float(o["prob_kl"]) - float(B["prob.prob_kl"])) < 1e-8
+        else:
+            assert float((o["logits"] - torch.from_numpy(B["det.logits"]).double()).abs().max()) < 1e-5
+
+    class Rec:                                                   # attribute tree that records set_weights calls
+        def __init__(self, log, path=""):
+            self._log, self._path = log, path
+        def __getattr__(self, a):
+            return Rec(self._log, self._path + "." + a)
+        def set_weights(self, ws):
+            self._log.append((self._path, [tuple(w.shape) for w in ws]))
+    W = {k[len("prob.w."):]: v for k, v in B.items() if k.startswith("prob.w.")}
+    log = []
+    n = T._load_core(Rec(log), W, "prior") + T._load_core(Rec(log), W, "posterior")
+    assert n + 2 == len(W) and len({p for p, _ in log}) * 2 == len(log)       # every layer once per core, every tensor assigned
+    paths = {p for p, _ in log}
+    assert ".att0.conv1" in paths and ".att3.norm4" in paths and ".serse1.conv6" in paths and ".mu_logsig3" in paths
+    assert not any(s in p for p in paths for s in ("theta", "phi", "psi", "normW"))
