@@ -197,7 +197,9 @@ int m1_mul_sigma_bwd(const void* x, const void* sigma, const void* dy, void* dx,
                      int H, int W, int C, int s0, int s1, int s2, int dtype, int accumulate_dx, void* stream);
 
 /* ---- latent head : N:640-647 (x4 levels) and KL N:373-385 ----
- * ml: (N,V,2L) = [mu | logsigma]; z = mu + exp(clip(logsigma,+-0.1))*eps  (mode 0) or mu (mode 1). */
+ * ml: (N,V,2L) = [mu | logsigma]; z = mu + exp(clip(logsigma,+-0.1))*eps  (mode 0) or mu (mode 1);
+ * mode 2: N even, two passes stacked along the batch axis -- samples [0, N/2) as mode 0 with eps of N/2 samples (N:348),
+ * samples [N/2, N) as mode 1 (N:349). */
 int m1_latent_sample_fwd(const void* ml, const void* eps, void* z, int N, long long V, int L, int mode,
                          int dtype, void* stream);
 int m1_latent_sample_bwd(const void* ml, const void* eps, const void* dz, void* dml, int N, long long V, int L,

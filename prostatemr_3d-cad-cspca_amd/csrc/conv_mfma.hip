@@ -669,6 +669,62 @@ __global__ void splitk_finish_kernel(const float* __restrict__ acc32, int ksplit
     }
 }
 
+// The same finish as ONE pass with the InstanceNorm statistics of the (rounded) result: the functor of the generic per-(n,c)
+// reduction (reduce.h: a block owns a run of voxels of one sample, lanes along the channels) folds the slabs, adds the bias,
+// stores the output and returns {v, v^2} -- the stand-alone statistics pass over the finished tensor (one more read of it,
+// one more launch: 28 per C3 step on the split-K layers of the deep levels) disappears.
+template <typename T> struct FinishStatsF {
+    static constexpr int kVec = 16 / (int)sizeof(T);
+    static constexpr int kUnroll = 2;
+    const float* acc32; int ksplit; long long slab; const float* bias; const float* bias2; int bias_split;
+    T* out; long long V; int OC; FinOut fo;
+    __device__ void operator()(int n, long long v, int c, float* acc) const {      // (scalar form of the contract; the launcher gates on OC % kVec == 0)
+        const long long row = (long long)n * V + v, i = row * OC + c;
+        float a = (bias_split > 0 && c >= bias_split) ? (bias2 ? bias2[c - bias_split] : 0.f) : (bias ? bias[c] : 0.f);
+        for (int k = 0; k < ksplit; ++k) a += acc32[(long long)k * slab + i];
+        T* dst = out + i;
+        if (fo.nout > 0) {
+            int m = 0;
+            while (m + 1 < fo.nout && c >= fo.outOff[m + 1]) ++m;
+            dst = (T*)fo.outs[m] + row * fo.outC[m] + (c - fo.outOff[m]);
+        }
+        Act<T>::st(dst, a);
+        float r = a;
+        if constexpr (sizeof(T) == 2) r = bf2f(f2bf(r));
+        acc[0] += r; acc[1] += r * r;
+    }
+    __device__ void vec(int n, long long v, int c0, float (*acc)[kVec]) const {
+        const long long row = (long long)n * V + v, i = row * OC + c0;
+        float a[kVec];
+#pragma unroll
+        for (int e = 0; e < kVec; ++e) {
+            const int oc = c0 + e;
+            a[e] = (bias_split > 0 && oc >= bias_split) ? (bias2 ? bias2[oc - bias_split] : 0.f) : (bias ? bias[oc] : 0.f);
+        }
+        for (int k = 0; k < ksplit; ++k) {
+            const float* sp = acc32 + (long long)k * slab + i;
+#pragma unroll
+            for (int q = 0; q < kVec; q += 4) {
+                const float4 t = *reinterpret_cast<const float4*>(sp + q);
+                a[q] += t.x; a[q + 1] += t.y; a[q + 2] += t.z; a[q + 3] += t.w;
+            }
+        }
+        T* dst = out + i;
+        if (fo.nout > 0) {                                   // (a 16-byte group never straddles two destination tensors)
+            int m = 0;
+            while (m + 1 < fo.nout && c0 >= fo.outOff[m + 1]) ++m;
+            dst = (T*)fo.outs[m] + row * fo.outC[m] + (c0 - fo.outOff[m]);
+        }
+        VecIO<T, kVec>::st(dst, a);
+#pragma unroll
+        for (int e = 0; e < kVec; ++e) {                     // the statistics of what was STORED (rounded), as the epilogues compute them
+            float r = a[e];
+            if constexpr (sizeof(T) == 2) r = bf2f(f2bf(r));
+            acc[0][e] += r; acc[1][e] += r * r;
+        }
+    }
+};
+
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
@@ -938,6 +994,19 @@ static int run_mfma(const GatherSpec& g, void* ws, int ws_packed, hipStream_t st
     FinOut fo{}; fo.nout = mp.nout;
     for (int i = 0; i < mp.nout; ++i) { fo.outs[i] = mp.outs[i]; fo.outC[i] = mp.outC[i]; fo.outOff[i] = mp.outOff[i]; fo.outAcc[i] = mp.outAcc[i]; }
     fo.outOff[mp.nout] = mp.outOff[mp.nout];
+    {   // finish + InstanceNorm statistics in one pass (see FinishStatsF)
+        static int fs = -1; if (fs < 0) { const char* e = getenv("M1_FINISH_STATS"); fs = e ? atoi(e) : 1; }
+        constexpr int VEC = 16 / (int)sizeof(T);
+        bool ok = fs && g.stats_out && g.stats_ws && g.mode == 0 && !g.accumulate && g.OC % VEC == 0 && mp.nout <= 2;
+        for (int i = 0; i < mp.nout; ++i) ok = ok && mp.outs[i] && !mp.outAcc[i] && mp.outC[i] % VEC == 0;
+        if (mp.nout == 2 && !g.stats_out2) ok = false;          // (two output tensors: the conv1 || conv4 pair with its two statistics)
+        if (ok) {
+            FinishStatsF<T> f{mp.acc32, pl.ksplit, ne, g.bias, g.bias2, g.oc_split, (T*)g.out, Vout, g.OC, fo};
+            rc2 = m1_reduce_nc_launch<2>(f, g.N, Vout, g.OC, g.stats_ws, st); if (rc2) return rc2;
+            return m1_reduce_finalize_launch<2>(g.stats_ws, g.N, g.OC, m1_red_nchunks(Vout, g.OC, g.N), g.stats_out, Vout, g.stats_eps, st, 0,
+                                                g.stats_out2, g.stats_out2 ? g.oc_split : 0);
+        }
+    }
     hipLaunchKernelGGL(splitk_finish_kernel<T>, dim3((unsigned)fb), dim3(256), 0, st, mp.acc32, pl.ksplit, g.bias, (T*)g.out, ne, g.OC, g.accumulate, fo, g.bias2, g.oc_split);
     rc2 = m1_check_launch(); if (rc2) return rc2;
     if (g.stats_out) return stats_fallback();

@@ -15,7 +15,9 @@ __global__ void latent_sample_fwd_kernel(const T* __restrict__ ml, const T* __re
         const long long v = i / L; const int d = (int)(i % L);
         const float mu = Act<T>::ld(ml + v * 2 * L + d);
         float r = mu;
-        if (mode == 0) r = fmaf(expf(clipls(Act<T>::ld(ml + v * 2 * L + L + d))), Act<T>::ld(eps + i), mu);
+        // mode 2: two passes of the reference stacked along the batch axis -- the first half of the batch is the sampling pass
+        // (networks.py:348; eps holds N/2 samples), the second half the prob_mean pass (:349)
+        if (mode == 0 || (mode == 2 && i < tot / 2)) r = fmaf(expf(clipls(Act<T>::ld(ml + v * 2 * L + L + d))), Act<T>::ld(eps + i), mu);
         Act<T>::st(z + i, r);
     }
 }
@@ -29,7 +31,7 @@ __global__ void latent_sample_bwd_kernel(const T* __restrict__ ml, const T* __re
         const float g = Act<T>::ld(dz + i);
         Act<T>::st(dml + v * 2 * L + d, g);
         float gl = 0.f;
-        if (mode == 0) {
+        if (mode == 0 || (mode == 2 && i < tot / 2)) {
             const float ls = Act<T>::ld(ml + v * 2 * L + L + d);
             gl = g * expf(clipls(ls)) * Act<T>::ld(eps + i) * clipmask(ls);
         }
@@ -86,7 +88,7 @@ static inline int gxl(long long n) { long long b = cdiv_ll(n, 256); return (int)
 
 extern "C" int m1_latent_sample_fwd(const void* ml, const void* eps, void* z, int N, long long V, int L, int mode, int dtype,
                                     void* stream) {
-    if (!ml || !z || (mode == 0 && !eps) || N <= 0 || V <= 0 || L <= 0 || (mode != 0 && mode != 1)) return M1_ERR_BAD_ARG;
+    if (!ml || !z || (mode != 1 && !eps) || N <= 0 || V <= 0 || L <= 0 || mode < 0 || mode > 2 || (mode == 2 && (N & 1))) return M1_ERR_BAD_ARG;
     const long long NV = (long long)N * V; hipStream_t st = (hipStream_t)stream;
     if (dtype == M1_BF16) hipLaunchKernelGGL(latent_sample_fwd_kernel<bf16_t>, dim3(gxl(NV * L)), dim3(256), 0, st, (const bf16_t*)ml, (const bf16_t*)eps, (bf16_t*)z, NV, L, mode);
     else hipLaunchKernelGGL(latent_sample_fwd_kernel<float>, dim3(gxl(NV * L)), dim3(256), 0, st, (const float*)ml, (const float*)eps, (float*)z, NV, L, mode);
@@ -94,7 +96,7 @@ extern "C" int m1_latent_sample_fwd(const void* ml, const void* eps, void* z, in
 }
 extern "C" int m1_latent_sample_bwd(const void* ml, const void* eps, const void* dz, void* dml, int N, long long V, int L,
                                     int mode, int dtype, void* stream) {
-    if (!ml || !dz || !dml || (mode == 0 && !eps) || N <= 0 || V <= 0 || L <= 0) return M1_ERR_BAD_ARG;
+    if (!ml || !dz || !dml || (mode != 1 && !eps) || N <= 0 || V <= 0 || L <= 0 || mode < 0 || mode > 2 || (mode == 2 && (N & 1))) return M1_ERR_BAD_ARG;
     const long long NV = (long long)N * V; hipStream_t st = (hipStream_t)stream;
     if (dtype == M1_BF16) hipLaunchKernelGGL(latent_sample_bwd_kernel<bf16_t>, dim3(gxl(NV * L)), dim3(256), 0, st, (const bf16_t*)ml, (const bf16_t*)eps, (const bf16_t*)dz, (bf16_t*)dml, NV, L, mode);
     else hipLaunchKernelGGL(latent_sample_bwd_kernel<float>, dim3(gxl(NV * L)), dim3(256), 0, st, (const float*)ml, (const float*)eps, (const float*)dz, (float*)dml, NV, L, mode);

@@ -995,9 +995,10 @@ class _LatentSample(torch.autograd.Function):
         return dml, None, None
 
 
-def latent_sample(ml, eps, mean: bool):
-    """z = mu + exp(clip(logsigma,+-0.1))*eps, or mu when ``mean`` (networks.py:640-647)."""
-    return _LatentSample.apply(ml, eps, 1 if mean else 0)
+def latent_sample(ml, eps, mean: bool, stacked: bool = False):
+    """z = mu + exp(clip(logsigma,+-0.1))*eps, or mu when ``mean`` (networks.py:640-647).  ``stacked``: the batch holds the
+    sampling pass and the prob_mean pass of the reference one after the other; ``eps`` covers the first half only."""
+    return _LatentSample.apply(ml, eps, 2 if stacked else (1 if mean else 0))
 
 
 class _KL(torch.autograd.Function):

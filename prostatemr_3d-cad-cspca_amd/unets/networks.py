@@ -195,7 +195,7 @@ class M1Core(nn.Module):
         return [(prefix + "a", plist(dec)), (prefix + "b", plist(mid)), (prefix + "c", plist(enc))]
 
     def forward(self, inputs, prob_mean=False, prob_z_q=None, eps: Optional[List[torch.Tensor]] = None, mark=None,
-                need: str = "full", tail_from: Optional[int] = None):
+                need: str = "full", tail_from: Optional[int] = None, eps_first_half: bool = False):
         """M1Core.__call__(inputs, prob_mean, prob_z_q) (networks.py:568-759).  ``inputs`` is an NDHWC tensor or
         a list of tensors forming a virtual channel concat.  ``eps``: optional injected N(0,1) draws per level
         (MultivariateNormalDiag.sample() = mu + sigma*eps).  ``mark(group, tensor)``: data-parallel runs register the
@@ -210,7 +210,10 @@ class M1Core(nn.Module):
 
         ``tail_from=B`` (with ``need="full"``): the batch holds two passes of the reference stacked along the batch axis
         (M1Net.forward) and only the samples ``[B:]`` need the full output: the "latents" part runs on the whole batch,
-        the layers behind it on the batch slice ``[B:]`` (a contiguous view: every op of the model is per sample)."""
+        the layers behind it on the batch slice ``[B:]`` (a contiguous view: every op of the model is per sample).
+
+        ``eps_first_half``: the batch is [sampling pass; prob_mean pass] (M1Net.forward) and ``eps`` holds the draws of the
+        first half only: the latent kernel takes the mean for the second half (no zero-padded draw tensors)."""
         outputs = {}
         mark = mark if mark is not None else (lambda *_: None)
         S = self.strides
@@ -377,9 +380,12 @@ class M1Core(nn.Module):
                     elif prob_mean:                                                # networks.py:646
                         z = ops.latent_sample(ml, None, True)
                     else:                                                          # networks.py:647
-                        e = eps[zi] if eps is not None else torch.randn((*ml.shape[:-1], Ld), device=ml.device,
+                        nb = int(ml.shape[0]) // 2 if eps_first_half else int(ml.shape[0])
+                        e = eps[zi] if eps is not None else torch.randn((nb, *ml.shape[1:-1], Ld), device=ml.device,
                                                                          dtype=torch.float32)
-                        z = ops.latent_sample(ml, e.to(ml.dtype).contiguous(), False)   # draws in the activation storage type
+                        if e.dtype != ml.dtype or not e.is_contiguous():
+                            e = e.to(ml.dtype).contiguous()                              # draws in the activation storage type
+                        z = ops.latent_sample(ml, e, False, stacked=eps_first_half)
                     zi += 1
                     distributions.append(ml)
                     used_latents.append(z)
@@ -541,11 +547,16 @@ class M1Net(nn.Module):
                 dup = lambda t: torch.cat([t, t], dim=0)
                 post2 = dup(post_in) if isinstance(post_in, torch.Tensor) else [dup(t) for t in post_in]
                 lshape = self.posterior.latent_shapes(image.shape[1:4])
-                eps2 = []
-                for i, shp in enumerate(lshape):
-                    e = eps_q[i].to(torch.float32) if eps_q is not None else torch.randn((B, *shp), device=image.device, dtype=torch.float32)
-                    eps2.append(torch.cat([e, torch.zeros_like(e)], dim=0))
-                q = self.posterior(post2, prob_mean=False, prob_z_q=None, eps=eps2, mark=mq, need="latents")
+                if eps_q is not None:
+                    eps1 = [e for e in eps_q]
+                else:
+                    # ONE generator launch for the draws of all levels, in the activation storage type (views of one buffer)
+                    sizes = [B * int(np.prod(shp)) for shp in lshape]
+                    flat = torch.randn(sum(sizes), device=image.device, dtype=image.dtype)
+                    eps1, off = [], 0
+                    for n_, shp in zip(sizes, lshape):
+                        eps1.append(flat[off:off + n_].view(B, *shp)); off += n_
+                q = self.posterior(post2, prob_mean=False, prob_z_q=None, eps=eps1, mark=mq, need="latents", eps_first_half=True)
                 p = self.prior(dup(image), prob_mean=False, prob_z_q=q['prob_used_latents'], mark=mp, need="full", tail_from=B)
                 train_conv = self.stitch(p['prob_decoder_features'])                                    # networks.py:356 (p_z_qm)
                 kl = None                                                                               # networks.py:373-385

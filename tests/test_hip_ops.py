@@ -355,6 +355,13 @@ def test_latent_sample_and_kl(dev, L):
     assert rel_err(z, zo) < 1e-5 and rel_err(mqd.grad, gml) < 1e-5
     zm = ops.latent_sample(mq.to(dev), None, True)
     assert rel_err(zm, mq[..., :L]) < 1e-7
+    # stacked passes: [sampling pass; prob_mean pass] along the batch axis, draws for the first half only (networks.py:348-349)
+    mq2 = torch.cat([mq, mq], 0).to(dev).requires_grad_(True)
+    z2 = ops.latent_sample(mq2, eps.to(dev), False, stacked=True)
+    z2.backward(torch.cat([dz, dz], 0).to(dev))
+    assert torch.equal(z2[:N], z.detach()) and torch.equal(z2[N:], zm)
+    assert torch.equal(mq2.grad[:N], mqd.grad)
+    assert rel_err(mq2.grad[N:, ..., :L], dz) < 1e-7 and float(mq2.grad[N:, ..., L:].abs().max()) == 0.0
 
     def kl(q_, p_):
         return O.kl_mvn_diag(q_[..., :L], torch.clamp(q_[..., L:], -0.1, 0.1), p_[..., :L],
