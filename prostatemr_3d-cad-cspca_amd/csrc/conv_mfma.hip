@@ -959,6 +959,9 @@ static int run_mfma(const GatherSpec& g, void* ws, int ws_packed, hipStream_t st
             pw = true;
         }
     }
+    { static int lg = -1; if (lg < 0) { const char* e = getenv("M1_MFMA_LOG"); lg = e ? atoi(e) : 0; }
+      if (lg) fprintf(stderr, "mfma: mode %d N%d out %dx%dx%d CC %d OC %d k%d taps s%d%d%d nsrc %d -> %s BM %d BN %d ksplit %d korder %d stats %d\n", g.mode, g.N, g.OD, g.OH, g.OW, CC, g.OC,
+                      g.kd * g.kh * g.kw, g.sd, g.sh, g.sw, g.nsrc, halo ? "halo" : (pw ? "pw" : "mfma"), bm_eff, BN, pl.ksplit, mp.korder, fuse_stats ? 1 : 0); }
     if (halo) rc2 = m1_halo_conv(mp, OCpad, st);
     else if (pw) rc2 = m1_pw_conv(mp, OCpad, pwBN, st);
     else

@@ -4,6 +4,7 @@ both counters are in KiB."""
 import collections, csv, json, re, sys
 fetch_csv, write_csv, steps, out = sys.argv[1], sys.argv[2], int(sys.argv[3]), sys.argv[4]
 batch = int(sys.argv[5]) if len(sys.argv) > 5 else 1          # volumes per GPU of the profiled run
+commit = sys.argv[6] if len(sys.argv) > 6 and sys.argv[6] else None   # tree the passes were taken on (bench.py quotes it)
 
 
 def fam(name):
@@ -27,7 +28,7 @@ for k in set(f) | set(w):
                "fetch_GB_per_step": 2.0 * f.get(k, 0.0) * 1024 / steps / 1e9,
                "write_GB_per_step": w.get(k, 0.0) * 1024 / steps / 1e9}
 tot_f = sum(v["fetch_GB_per_step"] for v in rows.values()); tot_w = sum(v["write_GB_per_step"] for v in rows.values())
-res = {"steps": steps, "batch": batch, "note": "FETCH_SIZE x2 (gfx950 half-count of wide streams), KiB -> bytes; separate --pmc passes",
+res = {"steps": steps, "batch": batch, "commit": commit, "note": "FETCH_SIZE x2 (gfx950 half-count of wide streams), KiB -> bytes; separate --pmc passes",
        "total_fetch_GB_per_step": tot_f, "total_write_GB_per_step": tot_w, "kernels": dict(sorted(rows.items(), key=lambda kv: -(kv[1]["fetch_GB_per_step"] + kv[1]["write_GB_per_step"])))}
 json.dump(res, open(out, "w"), indent=1)
 print(f"HBM traffic per step: fetch {tot_f:.2f} GB (x2 corrected)  write {tot_w:.2f} GB")
