@@ -88,6 +88,16 @@ int m1_conv3d_fwd(const m1_conv_desc_t* d, const float* w, const float* bias, vo
  * gets its gradient summed by the kernels' own epilogues, in call order, instead of by separate add passes. */
 int m1_conv3d_dgrad(const m1_conv_desc_t* d, const float* w, const void* dy, void* const* dx, const int* accumulate,
                     void* ws, int ws_packed, void* stream);
+/* 1 when both pair entry points below accept this shape (they return M1_ERR_UNSUPPORTED otherwise): ask before building a graph. */
+int m1_conv3d_pair_supported(const m1_conv_desc_t* d, int C1);
+/* Data gradient of a single-input Conv3D whose input is a = lrelu(IN(x)) -- conv2 / conv3 of an SEResNetBottleNeck (B:54-59): `da`
+ * = d(a), and the kernel that writes it also emits the two sums the InstanceNorm backward needs (dbeta = sum dy,
+ * dgamma = sum dy*xh, dy = da*lrelu'(gamma*xh+beta)) per tile into partial [N][*nparts][Cin][2] -- no separate reduction pass over
+ * (x, da).  partial: >= N * ceil(V/64) * Cin * 2 floats.  *nparts = 0 on return: the kernel that took this shape has no such
+ * epilogue; da is complete, finish with m1_instnorm_bwd; otherwise with m1_instnorm_bwd_partials. */
+int m1_conv3d_dgrad_inbwd(const m1_conv_desc_t* d, const float* w, const void* dy, void* da, const void* x, const float* stats,
+                          const float* gamma, const float* beta, float slope, float* partial, int* nparts, void* ws,
+                          int ws_packed, void* stream);
 /* conv1 || conv4 of an SEResNetBottleNeck as ONE problem (B:53 and B:64 apply Conv3D(F/4, k, s) and Conv3D(F, k, s) to the same
  * input): d->Cout = C1 + C4; w1 (kd,kh,kw,Cin,C1), w4 (kd,kh,kw,Cin,C4) stay separate Keras tensors.  Forward writes y1 (…,C1) and
  * y4 (…,C4) and, optionally, both (N,C,2) statistics tensors; the data gradient contracts over the virtual concat [dy1 | dy4].
@@ -128,6 +138,11 @@ int m1_instnorm_apply(const void* x, const float* stats, const float* gamma, con
 int m1_instnorm_bwd(const void* x, const float* stats, const float* gamma, const float* beta, float slope,
                     const void* dy, void* dx, float* dgamma, float* dbeta, int N, long long V, int C, int dtype,
                     float* ws, int accumulate, void* stream);
+
+/* the same from the partial sums of m1_conv3d_dgrad_inbwd: partial [N][nparts][C][2]; sums: (N,C,2) floats of scratch */
+int m1_instnorm_bwd_partials(const void* x, const float* stats, const float* gamma, const float* beta, float slope,
+                             const void* dy, void* dx, float* dgamma, float* dbeta, int N, long long V, int C, int dtype,
+                             const float* partial, int nparts, float* sums, int accumulate, void* stream);
 
 /* ---- SE gate + multiplicative residual combine : B:68-78 ----
  * gate: g = sigmoid(W7 . lrelu(W6 . beta3 + b6) + b7)  (GAP(IN3(.)) == beta3 exactly).

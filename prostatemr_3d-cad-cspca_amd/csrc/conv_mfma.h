@@ -36,6 +36,8 @@ struct MfmaP {
     long long slab_elems;
     int aligned;                // every concat member is a multiple of one 64-byte K-chunk: incremental addressing
     int korder;                 // 1: K runs [64-byte chunk of the concat][tap] (needs aligned), 0: [tap][concat channel]
+    const void* ib_x;           // != nullptr: stat_partial receives the InstanceNorm-BACKWARD sums {sum dy, sum dy*xh} of the (rounded)
+    const float* ib_stats; const float* ib_gamma; const float* ib_beta; float ib_slope;   //   outputs instead (GatherSpec::ib_*)
     float* stat_partial;        // fused InstanceNorm statistics: [N][stat_tiles][OC][2] = {sum, sum of squares} of the ROUNDED
     int stat_tiles;             //   outputs, one partial per 64/128-row tile (mode 0, tiles never straddle samples) or, in the
                                 //   halo kernel, per (sample, block row)

@@ -476,6 +476,20 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_mfma_kernel(MfmaP p) {
         constexpr int G = NTHR / BN;                      // row groups
         const int col = tid % BN, rg = tid / BN;
         float s = 0.f, ss = 0.f;
+        if (p.ib_x) {              // InstanceNorm backward of the tensor this tile is the gradient of: {sum dy, sum dy * xh}
+            const int oc = oc0 + col < p.OCn ? oc0 + col : 0, n = (int)(m0 / QV);
+            const float mean = p.ib_stats[((long long)n * p.OC + oc) * 2], rstd = p.ib_stats[((long long)n * p.OC + oc) * 2 + 1];
+            const float gm = p.ib_gamma[oc], bt = p.ib_beta[oc];
+            const T* xb = (const T*)p.ib_x + oc;
+            for (int row = rg; row < BM; row += G) {
+                const int orow = outrow[row];
+                if (orow >= 0) {
+                    const float xh = (Act<T>::ld(xb + (long long)orow * p.OC) - mean) * rstd;
+                    const float dy = Act<T>::ld(C_s + row * CP + col) * lrelu_g(gm * xh + bt, p.ib_slope);
+                    s += dy; ss += dy * xh;
+                }
+            }
+        } else
         for (int row = rg; row < BM; row += G) {
             if (outrow[row] >= 0) { const float v = Act<T>::ld(C_s + row * CP + col); s += v; ss += v * v; }
         }
@@ -678,6 +692,8 @@ template <typename T> struct FinishStatsF {
     static constexpr int kUnroll = 2;
     const float* acc32; int ksplit; long long slab; const float* bias; const float* bias2; int bias_split;
     T* out; long long V; int OC; FinOut fo;
+    // ib_x != nullptr: the sums of the InstanceNorm BACKWARD of the tensor `out` is the gradient of (GatherSpec::ib_*) instead
+    const T* ib_x; const float* ib_stats; const float* ib_gamma; const float* ib_beta; float ib_slope;
     __device__ void operator()(int n, long long v, int c, float* acc) const {      // (scalar form of the contract; the launcher gates on OC % kVec == 0)
         const long long row = (long long)n * V + v, i = row * OC + c;
         float a = (bias_split > 0 && c >= bias_split) ? (bias2 ? bias2[c - bias_split] : 0.f) : (bias ? bias[c] : 0.f);
@@ -691,7 +707,11 @@ template <typename T> struct FinishStatsF {
         Act<T>::st(dst, a);
         float r = a;
         if constexpr (sizeof(T) == 2) r = bf2f(f2bf(r));
-        acc[0] += r; acc[1] += r * r;
+        if (ib_x) {
+            const float xh = (Act<T>::ld(ib_x + i) - ib_stats[((long long)n * OC + c) * 2]) * ib_stats[((long long)n * OC + c) * 2 + 1];
+            const float dy = r * lrelu_g(ib_gamma[c] * xh + ib_beta[c], ib_slope);
+            acc[0] += dy; acc[1] += dy * xh;
+        } else { acc[0] += r; acc[1] += r * r; }
     }
     __device__ void vec(int n, long long v, int c0, float (*acc)[kVec]) const {
         const long long row = (long long)n * V + v, i = row * OC + c0;
@@ -716,11 +736,18 @@ template <typename T> struct FinishStatsF {
             dst = (T*)fo.outs[m] + row * fo.outC[m] + (c0 - fo.outOff[m]);
         }
         VecIO<T, kVec>::st(dst, a);
+        float xv[kVec];
+        if (ib_x) VecIO<T, kVec>::ld(ib_x + i, xv);
 #pragma unroll
         for (int e = 0; e < kVec; ++e) {                     // the statistics of what was STORED (rounded), as the epilogues compute them
             float r = a[e];
             if constexpr (sizeof(T) == 2) r = bf2f(f2bf(r));
-            acc[0][e] += r; acc[1][e] += r * r;
+            if (ib_x) {
+                const int c = c0 + e;
+                const float xh = (xv[e] - ib_stats[((long long)n * OC + c) * 2]) * ib_stats[((long long)n * OC + c) * 2 + 1];
+                const float dy = r * lrelu_g(ib_gamma[c] * xh + ib_beta[c], ib_slope);
+                acc[0][e] += dy; acc[1][e] += dy * xh;
+            } else { acc[0][e] += r; acc[1][e] += r * r; }
         }
     }
 };
@@ -904,6 +931,16 @@ static int run_mfma(const GatherSpec& g, void* ws, int ws_packed, hipStream_t st
     bool fuse_stats = g.stats_out && g.stats_ws && g.mode == 0 && pl.ksplit == 1 && (g.N == 1 || Vout % bm_eff == 0) &&
                       !g.accumulate;           // (this kernel's statistics come from its own tile, before the add)
     if (fuse_stats) { mp.stat_partial = g.stats_ws; mp.stat_tiles = (int)cdiv_ll(Vout, bm_eff); }
+    // InstanceNorm-backward sums from the epilogue of a data gradient (GatherSpec::ib_*): one output tensor, one parity class
+    // (rows run sample-major like a forward conv's), tiles that do not straddle samples
+    const bool ib_want = g.ib_x && g.ib_partial && g.ib_nparts && !g.stats_out && !g.accumulate && g.nout <= 1 && spec_ncls(g) == 1 &&
+                         (g.nout == 0 || (g.outs[0] && !g.outAcc[0] && g.outC[0] == g.OC));
+    if (g.ib_nparts) *g.ib_nparts = 0;
+    bool ib_epi = ib_want && pl.ksplit == 1 && (g.N == 1 || Vout % bm_eff == 0);
+    if (ib_epi) {
+        mp.stat_partial = g.ib_partial; mp.stat_tiles = (int)cdiv_ll(Vout, bm_eff);
+        mp.ib_x = g.ib_x; mp.ib_stats = g.ib_stats; mp.ib_gamma = g.ib_gamma; mp.ib_beta = g.ib_beta; mp.ib_slope = g.ib_slope;
+    }
     for (int i = 0; i < g.nsrc; ++i) if (g.srcC[i] % (4 * SEG)) mp.aligned = 0;
     for (int i = 0; i < g.nsrc; ++i)          // the LDS-DMA loader addresses a member with 31-bit byte offsets
         if ((long long)g.N * g.ID * g.IH * g.IW * g.srcC[i] * (long long)sizeof(T) >= (1ll << 31) - 4096) mp.aligned = 0;
@@ -939,6 +976,7 @@ static int run_mfma(const GatherSpec& g, void* ws, int ws_packed, hipStream_t st
 
     const bool small = pl.BM == 64;
     int rc2;
+    if (halo && ib_epi) { ib_epi = false; mp.stat_partial = nullptr; mp.stat_tiles = 0; mp.ib_x = nullptr; }    // (register epilogues: not built)
     if (halo) {
         const int tps = m1_halo_conv_stat_parts(mp, OCpad);
         if (g.stats_out && g.stats_ws && g.mode == 0 && tps > 0 && tps <= (Vout + 63) / 64) {
@@ -950,6 +988,7 @@ static int run_mfma(const GatherSpec& g, void* ws, int ws_packed, hipStream_t st
     if constexpr (sizeof(T) == 2) {
         pwBN = BN > 32 ? 32 : BN;
         if (!halo && m1_pw_conv_supported(mp, OCpad, pwBN)) {
+            if (ib_epi) { ib_epi = false; mp.stat_partial = nullptr; mp.stat_tiles = 0; mp.ib_x = nullptr; }
             int parts = m1_pw_conv_stat_parts(mp, OCpad, pwBN);
             const int cap = (int)((Vout + 63) / 64) / 4 * 4;          // what the statistics workspace holds per sample
             if (parts > cap) parts = cap;
@@ -974,6 +1013,7 @@ static int run_mfma(const GatherSpec& g, void* ws, int ws_packed, hipStream_t st
         default:  rc2 = small ? launch_cfg<T, 64, 16, 4, 1>(mp, maxM, OCpad, st) : launch_cfg<T, 128, 16, 4, 1>(mp, maxM, OCpad, st); break;
     }
     if (rc2) return rc2;
+    if (ib_epi) *g.ib_nparts = mp.stat_tiles;
     // (two output tensors -- the conv1 || conv4 pair: statistics per tensor, stats_out for [0, oc_split), stats_out2 for the rest)
     auto stats_fallback = [&]() -> int {
         if (g.nout == 2 && g.stats_out2) {
@@ -1003,8 +1043,16 @@ static int run_mfma(const GatherSpec& g, void* ws, int ws_packed, hipStream_t st
         bool ok = fs && g.stats_out && g.stats_ws && g.mode == 0 && !g.accumulate && g.OC % VEC == 0 && mp.nout <= 2;
         for (int i = 0; i < mp.nout; ++i) ok = ok && mp.outs[i] && !mp.outAcc[i] && mp.outC[i] % VEC == 0;
         if (mp.nout == 2 && !g.stats_out2) ok = false;          // (two output tensors: the conv1 || conv4 pair with its two statistics)
+        constexpr int VECI = 16 / (int)sizeof(T);
+        if (ib_want && fs && g.OC % VECI == 0) {      // the same pass with the InstanceNorm-backward sums (one launch: no finalize here)
+            FinishStatsF<T> f{mp.acc32, pl.ksplit, ne, g.bias, g.bias2, g.oc_split, (T*)g.out, Vout, g.OC, fo,
+                              (const T*)g.ib_x, g.ib_stats, g.ib_gamma, g.ib_beta, g.ib_slope};
+            rc2 = m1_reduce_nc_launch<2>(f, g.N, Vout, g.OC, g.ib_partial, st); if (rc2) return rc2;
+            *g.ib_nparts = m1_red_nchunks(Vout, g.OC, g.N);
+            return M1_OK;
+        }
         if (ok) {
-            FinishStatsF<T> f{mp.acc32, pl.ksplit, ne, g.bias, g.bias2, g.oc_split, (T*)g.out, Vout, g.OC, fo};
+            FinishStatsF<T> f{mp.acc32, pl.ksplit, ne, g.bias, g.bias2, g.oc_split, (T*)g.out, Vout, g.OC, fo, nullptr, nullptr, nullptr, nullptr, 0.f};
             rc2 = m1_reduce_nc_launch<2>(f, g.N, Vout, g.OC, g.stats_ws, st); if (rc2) return rc2;
             return m1_reduce_finalize_launch<2>(g.stats_ws, g.N, g.OC, m1_red_nchunks(Vout, g.OC, g.N), g.stats_out, Vout, g.stats_eps, st, 0,
                                                 g.stats_out2, g.stats_out2 ? g.oc_split : 0);

@@ -383,6 +383,26 @@ extern "C" int m1_conv3d_pair_dgrad(const m1_conv_desc_t* d, const float* w1, co
     return any ? m1_mfma_gather(g, ws, ws_packed, (hipStream_t)stream) : M1_OK;
 }
 
+// 1 when BOTH m1_conv3d_pair_fwd and m1_conv3d_pair_dgrad take this shape (neither would return M1_ERR_UNSUPPORTED): the caller
+// decides between the pair and the two single convs BEFORE it builds its autograd graph (a refusal in the middle of a backward pass
+// has no fallback).  Mirrors every gate of the two entry points.
+extern "C" int m1_conv3d_pair_supported(const m1_conv_desc_t* d, int C1) {
+    if (!d || g_force_direct) return 0;
+    FwdGroups fg;
+    if (!pair_ok(d, C1) || fwd_groups(d, false, &fg)) return 0;
+    const int C4 = d->Cout - C1;
+    GatherSpec g = fwd_spec(d, false, nullptr, nullptr, nullptr);
+    g.oc_split = C1; g.nout = 2; g.outC[0] = C1; g.outC[1] = C4;
+    if (!m1_mfma_supported(g)) return 0;
+    GatherSpec q;
+    if (d->nsrc >= 2) {
+        if (!dgrad_fused_ok(d)) return 0;
+        q = dgrad_fused_spec(d, false, nullptr, nullptr, nullptr, nullptr);
+    } else q = dgrad_spec(d, false, nullptr, nullptr, nullptr, 0, 0);
+    q.nsrc = 2; q.srcC[0] = C1; q.srcC[1] = C4; q.c_split = C1;
+    return m1_mfma_supported(q) ? 1 : 0;
+}
+
 extern "C" int m1_convT3d_fwd(const m1_conv_desc_t* d, const float* w, const float* bias, void* y, void* ws, int ws_packed,
                               void* stream) {
     if (!desc_ok(d) || !w || !y) return M1_ERR_BAD_ARG;
@@ -416,6 +436,21 @@ extern "C" int m1_conv3d_dgrad(const m1_conv_desc_t* d, const float* w, const vo
     if (!desc_ok(d) || !w || !dy || !dx) return M1_ERR_BAD_ARG;
     M1ProfScope ps(prof_name("conv3d_dgrad", d).s, 2.0 * conv_macs(d, false), conv_bytes(d, false), (hipStream_t)stream);
     return dgrad_common(d, false, w, dy, dx, accumulate, ws, ws_packed, (hipStream_t)stream);
+}
+// Data gradient of a single-input Conv3D whose input is a = lrelu(IN(x)) (conv2 / conv3 of an SE block, network_blocks.py:54-59):
+// the kernel that writes d(a) also emits the per-tile sums the InstanceNorm backward needs ({sum dy, sum dy*xh} per sample and
+// channel) into `partial` [N][*nparts][Cin][2].  *nparts = 0: the kernel that took the shape has no such epilogue -- d(a) is
+// complete, the caller runs m1_instnorm_bwd instead of m1_instnorm_bwd_partials.
+extern "C" int m1_conv3d_dgrad_inbwd(const m1_conv_desc_t* d, const float* w, const void* dy, void* da, const void* x, const float* stats,
+                                     const float* gamma, const float* beta, float slope, float* partial, int* nparts, void* ws,
+                                     int ws_packed, void* stream) {
+    if (!desc_ok(d) || !w || !dy || !da || !x || !stats || !gamma || !beta || !partial || !nparts || d->nsrc != 1) return M1_ERR_BAD_ARG;
+    M1ProfScope ps(prof_name("conv3d_dgrad", d).s, 2.0 * conv_macs(d, false), conv_bytes(d, false), (hipStream_t)stream);
+    *nparts = 0;
+    if (g_force_direct) { void* dxs[1] = {da}; int acc0[1] = {0}; return dgrad_common(d, false, w, dy, dxs, acc0, ws, ws_packed, (hipStream_t)stream); }
+    GatherSpec g = dgrad_spec(d, false, w, dy, da, 0, 0);
+    g.ib_x = x; g.ib_stats = stats; g.ib_gamma = gamma; g.ib_beta = beta; g.ib_slope = slope; g.ib_partial = partial; g.ib_nparts = nparts;
+    return run_gather(g, ws, ws_packed, (hipStream_t)stream);
 }
 extern "C" int m1_convT3d_dgrad(const m1_conv_desc_t* d, const float* w, const void* dy, void* const* dx, const int* accumulate,
                                 void* ws, int ws_packed, void* stream) {

@@ -27,6 +27,13 @@ struct GatherSpec {
     float* stats_out;          // optional (Conv3D forward only): per-(n,oc) {mean, rstd} of the output for the InstanceNorm
     float* stats_ws;           //   that follows; fused into the epilogue when the tiling allows, else a reduction pass
     float stats_eps;
+    // optional (data gradients with ONE output tensor): the output is d(a) of a = lrelu(IN(x)) (network_blocks.py:54-58) -- the
+    // kernel that writes it also emits the two sums the InstanceNorm backward needs, per tile and (sample, channel):
+    // {sum dy, sum dy*xh}, dy = out * lrelu'(gamma*xh + beta), xh = (x - mean)*rstd, into ib_partial [N][*ib_nparts][OC][2]
+    // ("emit them as partials from the kernel that produces da").  *ib_nparts = 0 when the kernel that took
+    // the problem cannot (the caller then runs the stand-alone reduction).
+    const void* ib_x; const float* ib_stats; const float* ib_gamma; const float* ib_beta; float ib_slope;
+    float* ib_partial; int* ib_nparts;
 };
 
 int m1_stats_internal(const void* x, int N, long long V, int C, int dtype, float eps, float* stats, float* ws, hipStream_t st);

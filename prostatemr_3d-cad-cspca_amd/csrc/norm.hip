@@ -180,6 +180,37 @@ __global__ void __launch_bounds__(256) in_bwd_apply_kernel(const T* __restrict__
     }
 }
 
+// the apply half of the backward, from partial sums a data-gradient epilogue already emitted (m1_conv3d_dgrad_inbwd):
+// partial [N][nparts][C][2], sums scratch [N][C][2]
+template <typename T>
+static int bwd_from_partials(const void* x, const float* stats, const float* gamma, const float* beta, float slope, const void* dy, void* dx,
+                             float* dgamma, float* dbeta, int N, long long V, int C, const float* partial, int nparts, float* sums,
+                             hipStream_t st, int accumulate) {
+    M1ParamOut<2> po{{dbeta, dgamma}, {accumulate, accumulate}};
+    int rc = m1_reduce_finalize_params_launch<2>(partial, N, C, nparts, sums, po, st);
+    if (rc) return rc;
+    constexpr int VW = sizeof(T) == 2 ? 8 : 4;
+    if (C % VW == 0) {
+        long long per = V * (C / VW);
+        int gx = m1_grid_for(per, C / VW);
+        hipLaunchKernelGGL((in_bwd_apply_kernel<T, VW>), dim3(gx, N), dim3(256), 0, st, (const T*)x, (const T*)dy, stats, gamma, beta, slope, sums, (T*)dx, V, C);
+    } else {
+        long long per = V * C;
+        int gx = m1_grid_for(per, C);
+        hipLaunchKernelGGL((in_bwd_apply_kernel<T, 1>), dim3(gx, N), dim3(256), 0, st, (const T*)x, (const T*)dy, stats, gamma, beta, slope, sums, (T*)dx, V, C);
+    }
+    return m1_check_launch();
+}
+extern "C" int m1_instnorm_bwd_partials(const void* x, const float* stats, const float* gamma, const float* beta, float slope, const void* dy,
+                                        void* dx, float* dgamma, float* dbeta, int N, long long V, int C, int dtype, const float* partial,
+                                        int nparts, float* sums, int accumulate, void* stream) {
+    if (!x || !stats || !gamma || !beta || !dy || !dx || !dgamma || !dbeta || !partial || !sums || nparts <= 0 || N <= 0 || V <= 0 || C <= 0)
+        return M1_ERR_BAD_ARG;
+    M1ProfScope ps("instnorm_bwd", 0.0, 3.0 * N * V * C * (dtype == M1_BF16 ? 2 : 4), (hipStream_t)stream);
+    return dtype == M1_BF16 ? bwd_from_partials<bf16_t>(x, stats, gamma, beta, slope, dy, dx, dgamma, dbeta, N, V, C, partial, nparts, sums, (hipStream_t)stream, accumulate)
+                            : bwd_from_partials<float>(x, stats, gamma, beta, slope, dy, dx, dgamma, dbeta, N, V, C, partial, nparts, sums, (hipStream_t)stream, accumulate);
+}
+
 template <typename T>
 static int bwd_impl(const void* x, const float* stats, const float* gamma, const float* beta, float slope,
                     const void* dy, void* dx, float* dgamma, float* dbeta, int N, long long V, int C, float* ws,

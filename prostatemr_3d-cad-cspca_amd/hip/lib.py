@@ -68,7 +68,9 @@ SIGNATURES = {
     "m1_set_force_direct": (_i, [_i]),
     "m1_conv3d_fwd": (_i, [_desc_p, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
     "m1_conv3d_dgrad": (_i, [_desc_p, _vp, _vp, C.POINTER(_vp), C.POINTER(_i), _vp, _i, _vp]),
+    "m1_conv3d_dgrad_inbwd": (_i, [_desc_p, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, C.POINTER(_i), _vp, _i, _vp]),
     "m1_conv3d_wgrad": (_i, [_desc_p, _vp, _vp, _vp, _vp, _i, _vp]),
+    "m1_conv3d_pair_supported": (_i, [_desc_p, _i]),
     "m1_conv3d_pair_fwd": (_i, [_desc_p, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
     "m1_conv3d_pair_dgrad": (_i, [_desc_p, _vp, _vp, _i, _vp, _vp, C.POINTER(_vp), C.POINTER(_i), _vp, _i, _vp]),
     "m1_convT3d_fwd": (_i, [_desc_p, _vp, _vp, _vp, _vp, _i, _vp]),
@@ -78,6 +80,7 @@ SIGNATURES = {
     "m1_instnorm_stats": (_i, [_vp, _i, _ll, _i, _i, _f, _vp, _vp, _vp]),
     "m1_instnorm_apply": (_i, [_vp, _vp, _vp, _vp, _f, _vp, _i, _ll, _i, _i, _vp]),
     "m1_instnorm_bwd": (_i, [_vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _i, _ll, _i, _i, _vp, _i, _vp]),
+    "m1_instnorm_bwd_partials": (_i, [_vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _i, _ll, _i, _i, _vp, _i, _vp, _i, _vp]),
     "m1_se_gate_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp]),
     "m1_se_gate_fwd_batch": (_i, [C.POINTER(SeGateFwdJob), _i, _vp]),
     "m1_se_gate_bwd_batch": (_i, [C.POINTER(SeGateJob), _i, _vp]),

@@ -405,6 +405,11 @@ def same_out(size: int, s: int) -> int:
 # ---------------------------------------------------------------------------------------------------------
 # Conv3D / Conv3DTranspose (padding='same') over a virtual channel concat
 # ---------------------------------------------------------------------------------------------------------
+# InstanceNorm-backward sums from the epilogue of the data gradient that produces d(a) (m1_conv3d_dgrad_inbwd): "fused" counts the
+# data gradients that emitted them, "plain" those whose kernel has no such epilogue (the norm then runs its own reduction)
+_INBWD = {"on": _os.environ.get("M1_INBWD_FUSE", "1") != "0", "fused": 0, "plain": 0}
+
+
 class _Conv3d(torch.autograd.Function):
     @staticmethod
     def forward(ctx, w, b, k, s, transposed, want_stats, *srcs):
@@ -433,6 +438,11 @@ class _Conv3d(torch.autograd.Function):
         ctx.w_param, ctx.b_param = w, b
         ctx.gslots = [_slot_of(t) for t in srcs]
         ctx.k, ctx.s, ctx.transposed, ctx.has_bias, ctx.cout = tuple(k), tuple(s), transposed, b is not None, cout
+        # the input is a = lrelu(IN(x)) with this conv as its only reader (conv2 / conv3 of an SE block): the data gradient can
+        # emit the InstanceNorm-backward sums from its own epilogue (instnorm_act tags its output, see _InstNormAct.backward)
+        ctx.in_src = None
+        if _INBWD["on"] and len(srcs) == 1 and not transposed and ctx.gslots[0] is None:
+            ctx.in_src = getattr(srcs[0], "_m1_in_src", None)
         if want_stats:
             ctx.mark_non_differentiable(stats)
             ctx.set_materialize_grads(False)      # no zero-filled "gradient" for the statistics output
@@ -466,7 +476,23 @@ class _Conv3d(torch.autograd.Function):
             else:
                 dsrc.append(None)
                 ptrs[i] = None
-        if any_d:
+        if any_d and ctx.in_src is not None and accs[0] == 0:
+            xs, stats, gamma, beta, slope = ctx.in_src
+            da = dsrc[0]
+            N, Cn = int(xs.shape[0]), int(xs.shape[-1])
+            V = xs.numel() // (N * Cn)
+            nmax = max((V + 63) // 64, 512)
+            part = torch.empty(N * nmax * Cn * 2 + N * Cn * 2 + 64, dtype=torch.float32, device=da.device)
+            nparts = C.c_int(0)
+            ws, packed = _panel_ws(ctx.w_param, d, False, 1, (True,))
+            L.check(lib.m1_conv3d_dgrad_inbwd(C.byref(d), _p(w), _p(dy), _p(da), _p(xs), _p(stats), _p(gamma), _p(beta), float(slope),
+                                              _p(part), C.byref(nparts), _p(ws), packed, st), "m1_conv3d_dgrad_inbwd")
+            if nparts.value > 0:
+                da._m1_in_partials = (part, int(nparts.value), xs)
+                _INBWD["fused"] += 1
+            else:
+                _INBWD["plain"] += 1
+        elif any_d:
             fn = lib.m1_convT3d_dgrad if ctx.transposed else lib.m1_conv3d_dgrad
             ws, packed = _panel_ws(ctx.w_param, d, ctx.transposed, 1, tuple(bool(g is not None) for g in dsrc))
             L.check(fn(C.byref(d), _p(w), _p(dy), ptrs, accs, _p(ws), packed, st), f"m1_{name}_dgrad")
@@ -682,7 +708,11 @@ def conv_pair_supported(srcs, w1, w4, s) -> bool:
         return False
     seg = 8 if srcs[0].dtype == torch.bfloat16 else 4
     c1, c4 = int(w1.shape[4]), int(w4.shape[4])
-    return c4 >= 128 and c1 % seg == 0 and all(int(t.shape[4]) % seg == 0 for t in srcs)
+    if not (c4 >= 128 and c1 % seg == 0 and all(int(t.shape[4]) % seg == 0 for t in srcs)):
+        return False
+    # the library's own gates for the pair's forward AND data gradient (a refusal inside the backward pass would have no fallback)
+    d = _desc(srcs, c1 + c4, tuple(int(v) for v in w1.shape[:3]), s)
+    return bool(L.load().m1_conv3d_pair_supported(C.byref(d), c1))
 
 
 def conv_pair_same(srcs, w1, b1, w4, b4, k, s):
@@ -765,6 +795,14 @@ class _InstNormAct(torch.autograd.Function):
         if acc != acc2:
             gbuf, bbuf, acc = torch.empty_like(gamma), torch.empty_like(beta), 0
             dg, db = gbuf, bbuf
+        pp = getattr(dy, "_m1_in_partials", None)
+        if pp is not None and pp[2].data_ptr() == x.data_ptr() and pp[2].shape == x.shape:      # the data gradient that produced dy already emitted {sum dy, sum dy*xh} per tile
+            part, nparts, _ = pp
+            sums = part[part.numel() - N * Cn * 2 - 64:]
+            L.check(L.load().m1_instnorm_bwd_partials(_p(x), _p(stats), _p(gamma), _p(beta), ctx.slope, _p(dy), _p(dx), _p(gbuf), _p(bbuf),
+                                                      N, V, Cn, _dt(x), _p(part), nparts, _p(sums), acc, _stream()),
+                    "m1_instnorm_bwd_partials")
+            return dx, dg, db, None, None
         ws = _ws(N, V, Cn, 2, x.device)
         L.check(L.load().m1_instnorm_bwd(_p(x), _p(stats), _p(gamma), _p(beta), ctx.slope, _p(dy), _p(dx), _p(gbuf), _p(bbuf),
                                          N, V, Cn, _dt(x), _p(ws), acc, _stream()), "m1_instnorm_bwd")
@@ -774,7 +812,10 @@ class _InstNormAct(torch.autograd.Function):
 def instnorm_act(x, gamma, beta, slope: float = 1.0, stats=None):
     """tfa InstanceNormalization (eps 1e-3) followed by LeakyReLU(slope) (slope=1 -> no activation).
     ``stats``: the (N,C,2) {mean, rstd} already produced by the conv that wrote ``x`` (else computed here)."""
-    return _InstNormAct.apply(x, gamma, beta, slope, stats)
+    y = _InstNormAct.apply(x, gamma, beta, slope, stats)
+    if _INBWD["on"] and stats is not None and torch.is_grad_enabled():
+        y._m1_in_src = (x, stats, gamma, beta, float(slope))       # (read by the conv that consumes y, see _Conv3d.forward)
+    return y
 
 
 # ---------------------------------------------------------------------------------------------------------

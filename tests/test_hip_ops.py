@@ -655,6 +655,52 @@ def test_repack_all_refreshes_cached_panels(dev, transposed):
     ops.invalidate_panels()
 
 
+# ---- InstanceNorm-backward sums from the epilogue of the data gradient that produces d(a) (m1_conv3d_dgrad_inbwd) ----
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dims,c,cout,k", [((2, 4, 16, 16), 32, 32, (3, 3, 3)),      # implicit-GEMM epilogue (tile sums)
+                                           ((2, 4, 16, 16), 64, 256, (1, 1, 1)),     # pointwise conv3 of an SE block
+                                           ((4, 2, 4, 8), 64, 64, (3, 3, 3)),        # few voxels: split-K, sums from the finish pass
+                                           ((1, 3, 9, 10), 24, 16, (3, 3, 3)),       # tiles that straddle nothing (N = 1), ragged extents
+                                           ((2, 8, 32, 32), 8, 8, (3, 3, 3))])       # halo-tile kernel: no such epilogue, plain path
+def test_instnorm_backward_sums_from_the_dgrad_epilogue(dev, dtype, dims, c, cout, k):
+    """y = conv(lrelu(IN(x))): the gradients with the fused sums equal those of the stand-alone reduction (same kernels otherwise;
+    only the order of the partial sums differs) and both match the oracle."""
+    x = rnd((*dims, c), 1); g = 1.0 + 0.2 * rnd((c,), 2); bt = 0.1 * rnd((c,), 3)
+    w = rnd((*k, c, cout), 4, 1.0 / (c * k[0] * k[1] * k[2]) ** 0.5); b = rnd((cout,), 5)
+    if dtype == torch.bfloat16:
+        x = x.bfloat16().float()
+    dy = rnd((*dims, cout), 6)
+    if dtype == torch.bfloat16:
+        dy = dy.bfloat16().float()
+
+    def ref(x_, g_, b_, w_, bb_):
+        return O.conv3d_same(O.lrelu(O.instance_norm(x_, g_, b_)), w_, bb_, (1, 1, 1))
+    _, gro = _oracle_grads(ref, [x, g, bt, w, b], dy)
+
+    def run(on):
+        was = ops._INBWD["on"]; ops._INBWD["on"] = on
+        try:
+            xd = x.to(dev, dtype).requires_grad_(True)
+            ps = [t.to(dev).requires_grad_(True) for t in (g, bt, w, b)]
+            a = ops.instnorm_act(xd, ps[0], ps[1], 0.1, ops.instnorm_stats(xd))
+            y = ops.conv3d_same([a], ps[2], ps[3], k, (1, 1, 1))
+            y.backward(dy.to(dev, dtype))
+            return [xd.grad] + [p.grad for p in ps]
+        finally:
+            ops._INBWD["on"] = was
+    f0 = dict(ops._INBWD)
+    got = run(True)
+    fused = ops._INBWD["fused"] - f0["fused"], ops._INBWD["plain"] - f0["plain"]
+    assert sum(fused) == 1, fused
+    if c >= 24:
+        assert fused == (1, 0), fused                    # the implicit-GEMM / split-K paths do emit the sums
+    base = run(False)
+    tol = 2e-4 if dtype == torch.float32 else 4e-2
+    for a_, b_, o_ in zip(got, base, gro):
+        assert rel_err(a_, b_) < (2e-5 if dtype == torch.float32 else 2e-2)
+        assert rel_err(a_, o_) < tol
+
+
 # ---- tap-fused weight gradient (wgrad_tf.hip): bf16, (1,3,3)/(3,3,3) kernels, row length divisible by 8/16/32 ----
 TF_CASES = [  # (N, D, H, W), cins, cout, k, s, transposed
     ((1, 3, 6, 32), [32], 32, (1, 3, 3), (1, 1, 1), False),
