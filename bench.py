@@ -125,17 +125,15 @@ def cpu_baseline(workload, prob, dense, deep, dims, filters, kl_w, budget_s=75.0
     cands = [c for c in dict.fromkeys(cands) if c[0] >= 4 and c[1] >= 32 and c[2] >= 32 and c[0] % 4 == 0] or [(4, 32, 32)]
     vox = lambda c: c[0] * c[1] * c[2]
     probe = min(cands, key=vox)
-    pctx = make(probe)
-    step(pctx, 1)                                    # warm-up of the probe (thread pools, oneDNN primitives)
-    pick, t = probe, step(pctx, 2)
-    for c in sorted(cands, key=vox, reverse=True):   # the largest size whose 1 + 3 steps, predicted from the probe, fit the budget
-        if 4.0 * t * vox(c) / vox(probe) <= budget_s:     # (small volumes are less efficient: the prediction errs on the safe side)
-            pick = c
+    ctx = make(probe)
+    step(ctx, 1)                                     # warm-up of the probe (thread pools, oneDNN primitives)
+    pick, t = probe, step(ctx, 2)
+    for c in sorted(cands, key=vox)[1:]:             # climb while the next size's 1 + 3 steps, predicted from the last measured
+        if 4.0 * t * vox(c) / vox(pick) > budget_s:  # one, fit the budget (small volumes are less efficient: errs on the safe side)
             break
-    ctx = pctx if pick == probe else make(pick)
-    del pctx
-    step(ctx, 1)                                     # 1 warm-up ...
-    times = sorted(step(ctx, 2 + i) for i in range(3))      # ... + 3 timed
+        ctx = make(c)
+        pick, t = c, step(ctx, 1)                    # (this run is the warm-up of size c)
+    times = sorted(step(ctx, 2 + i) for i in range(3))      # 3 timed steps at the picked size
     t = times[1]
     frac = vox(pick) / float(D * H * W)
     whole = "one WHOLE volume" if frac == 1.0 else f"a ({pick[0]},{pick[1]},{pick[2]}) sub-volume = {frac:.4f} of a volume, scaled by voxel ratio"

@@ -1,14 +1,16 @@
 """GPU busy / idle structure of the steady-state train step from a rocprofv3 --kernel-trace CSV of `bench.py --steps K`:
-usage: python tools/trace_gaps.py <kernel_trace.csv> <K timed steps>
-Takes the last K steps' worth of launches (the timed graph replays), prints per step: wall time, union of kernel intervals (GPU
+usage: python tools/trace_gaps.py <kernel_trace.csv> <K timed steps> [S eager steps that FOLLOW the timed region]
+Takes the K steps in front of the last S (bench.py's roofline pass runs 2 + 2 eager steps after the timed graph replays; 0 with
+--no-roofline), prints per step: wall time, union of kernel intervals (GPU
 busy), sum of kernel durations (overlap = sum / union), number of launches, idle gaps, and the kernels behind the largest gaps."""
 import collections, csv, re, sys
 path, K = sys.argv[1], int(sys.argv[2])
+SKIP = int(sys.argv[3]) if len(sys.argv) > 3 else 0
 rows = [(int(r['Start_Timestamp']), int(r['End_Timestamp']), re.sub(r'\(.*', '', re.sub(r'^void ', '', r['Kernel_Name']))[:60]) for r in csv.DictReader(open(path))]
 rows.sort()
 # the optimiser kernel runs once per step: use it as the step delimiter
 adam = [i for i, r in enumerate(rows) if r[2].startswith('adam_amsgrad')]
-adam = adam[-(K + 1):]
+adam = adam[-(K + 1 + SKIP):len(adam) - SKIP] if SKIP else adam[-(K + 1):]
 seg = rows[adam[0] + 1: adam[-1] + 1]
 n = len(adam) - 1
 wall = seg[-1][1] - seg[0][0]
