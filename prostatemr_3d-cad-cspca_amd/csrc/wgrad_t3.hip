@@ -1,4 +1,5 @@
-// wgrad_t3.hip -- tap-fused bf16 weight gradient for the layers with >= 64 channels on both sides (stride 1), on
+// wgrad_t3.hip -- tap-fused bf16 weight gradient for the layers with >= 64 channels on both sides (stride 1; stride (1|2,2,2) and
+// transposed convs through the parity-plane staging, STR = 2), on
 // v_mfma_f32_32x32x16_bf16:
 //
 //   R[tap][a][b] += sum_{n,v} A[n, v + tap - p][a] * B[n, v][b]            the 9 (kh,kw) taps of one kd slice per block
@@ -18,8 +19,9 @@
 // * 128-byte LDS rows (64 channels); the two 64-byte halves of a row swap when bit 1 of its tile column is set, so that the 4
 //   rows x 64 bytes a 32-lane group of a transpose read touches fall on 4 different bank quarters (0 conflicts measured);
 // * the geometry of every K-tile of the block (buffer-resource words of the tile origins) is computed once into an LDS table:
-//   the CU's ONE scalar unit, on which 12 waves would repeat ~60 instructions of index arithmetic per tile, was 95 % busy
-//   in the first version; piece slots have fixed kinds and no branches for the same reason;
+//   12 waves repeating ~120 scalar instructions of 64-bit index arithmetic per tile executed 7.2 scalar instructions per
+//   MFMA on the CU's shared scalar unit (2.1 now; worth 3 % by itself, the occupancy point above was the larger one);
+//   piece slots have fixed kinds and no branches for the same reason;
 // * K-tiles are dealt round-robin to the blocks of a channel tile (blockIdx.y); every block stores its partial tiles into its
 //   own compact copy of the member's gradient block, folded in a fixed order by m1_wg_rx_finish (no float atomics);
 //   equal-width members of a concat share the launch.

@@ -399,3 +399,13 @@ def test_two_rank_fold_directory_is_claimed_by_rank0_and_agreed_by_all(tmp_path)
         assert res[rank][:3] == ["ok", "ok", "ok"], res
         assert "Target Folder Already Exists" in res[rank][3], res
     assert all(os.path.isdir(tmp_path / f"F{f}") for f in (1, 2, 3))
+
+
+def test_focal_loss_has_no_host_fallback():
+    """losses.Focal is a HIP op like the rest of the package: host tensors raise (no CPU / eager fallback)."""
+    f = PKG.losses.Focal(alpha=[0.75, 0.25], gamma=2.0)
+    y = torch.zeros(1, 2, 4, 4, 2); y[..., 0] = 1
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        f.loss(y, torch.full_like(y, 0.5))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        f.FL(y, torch.full_like(y, 0.5))
