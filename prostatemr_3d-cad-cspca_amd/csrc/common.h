@@ -118,8 +118,10 @@ __device__ __forceinline__ double wave_sum_d(double v) {
 __device__ __forceinline__ void philox_round(uint32_t& c0, uint32_t& c1, uint32_t& c2, uint32_t& c3, uint32_t k0,
                                              uint32_t k1) {
     const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u;
-    uint32_t hi0 = __umulhi(M0, c0), lo0 = M0 * c0;
-    uint32_t hi1 = __umulhi(M1, c2), lo1 = M1 * c2;
+    // (one 32x32 -> 64 multiply per product: v_mad_u64_u32 instead of a v_mul_hi_u32 + v_mul_lo_u32 pair, both quarter rate)
+    const uint64_t p0 = (uint64_t)M0 * c0, p1 = (uint64_t)M1 * c2;
+    uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0;
+    uint32_t hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
     uint32_t n0 = hi1 ^ c1 ^ k0, n1 = lo1, n2 = hi0 ^ c3 ^ k1, n3 = lo0;
     c0 = n0; c1 = n1; c2 = n2; c3 = n3;
 }
@@ -143,11 +145,12 @@ __device__ __forceinline__ bool philox_keep(uint64_t seed, uint64_t base, uint64
 }
 
 // VEC consecutive elements starting at idx0 (one Philox call per 4 consecutive stream positions when aligned)
-template <int VEC>
+// ALIGNED: the caller guarantees (base + idx0) % 4 == 0 (no code for the element-wise path)
+template <int VEC, bool ALIGNED = false>
 __device__ __forceinline__ void philox_keep_vec(uint64_t seed, uint64_t base, uint64_t idx0, float rate, bool* keep) {
     const uint64_t e0 = base + idx0;
     if constexpr (VEC % 4 == 0) {
-        if ((e0 & 3) == 0) {
+        if (ALIGNED || (e0 & 3) == 0) {
 #pragma unroll
             for (int q = 0; q < VEC / 4; ++q) {
                 const uint4 r = philox4x32_10(seed, (e0 >> 2) + q);

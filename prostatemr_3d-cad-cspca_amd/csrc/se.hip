@@ -7,6 +7,7 @@
 // GAP(IN3(.)) over D,H,W equals beta3 exactly, so g depends on parameters only.
 #include "common.h"
 #include "reduce.h"
+#include <stdlib.h>
 
 #define SE_MAX_F 1024
 #define SE_MAX_FR 256
@@ -224,28 +225,34 @@ __device__ __forceinline__ void se_rng(const SeParams& p, uint64_t& seed, uint64
 }
 
 template <typename T, int VEC>
-__global__ void __launch_bounds__(256) se_combine_fwd_kernel(const T* __restrict__ y3, const T* __restrict__ y4, SeParams p,
+__global__ void __launch_bounds__(256, 3) se_combine_fwd_kernel(const T* __restrict__ y3, const T* __restrict__ y4, SeParams p,
                                                              T* __restrict__ out) {
     const int n = blockIdx.y, F = p.F, cg = F / VEC;
     const long long per = p.V * cg;
     const size_t base = (size_t)n * p.V * F;
     uint64_t seed, rbase; se_rng(p, seed, rbase);
     const float keep_scale = p.drop_rate > 0.f ? 1.f / (1.f - p.drop_rate) : 1.f;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < per; i += (long long)gridDim.x * blockDim.x) {
-        const int c0 = (int)(i % cg) * VEC;
-        float a[VEC], b[VEC];
-        VecIO<T, VEC>::ld(y3 + base + i * VEC, a);
-        VecIO<T, VEC>::ld(y4 + base + i * VEC, b);
+    // the launch keeps gridDim.x*blockDim.x a multiple of the channel groups (m1_grid_for): a thread's channels never change and
+    // their 9 parameters live in registers (re-loaded per vector they were 72 dword loads beside 2 data loads: TA bound)
+    const long long i0 = (long long)blockIdx.x * blockDim.x + threadIdx.x, stride = (long long)gridDim.x * blockDim.x;
+    const int c0 = (int)(i0 % cg) * VEC;
+    float m3[VEC], r3[VEC], g3[VEC], b3[VEC], m4[VEC], r4[VEC], g4[VEC], b4[VEC], gt[VEC];
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) {
+        const int c = c0 + k; const size_t sc = ((size_t)n * F + c) * 2;
+        m3[k] = p.stats3[sc]; r3[k] = p.stats3[sc + 1]; g3[k] = p.gamma3[c]; b3[k] = p.beta3[c];
+        m4[k] = p.stats4[sc]; r4[k] = p.stats4[sc + 1]; g4[k] = p.gamma4[c]; b4[k] = p.beta4[c]; gt[k] = p.g[c];
+    }
+    auto body = [&](long long i, float* a, const float* b) {
 #pragma unroll
         for (int k = 0; k < VEC; ++k) {
-            const int c = c0 + k; const size_t sc = ((size_t)n * F + c) * 2;
-            const float x_ = (a[k] - p.stats3[sc]) * p.stats3[sc + 1] * p.gamma3[c] + p.beta3[c];
-            const float rho = (b[k] - p.stats4[sc]) * p.stats4[sc + 1] * p.gamma4[c] + p.beta4[c];
-            a[k] = lrelu_f(x_ * p.g[c] * rho, 0.1f);
+            const float x_ = (a[k] - m3[k]) * r3[k] * g3[k] + b3[k];
+            const float rho = (b[k] - m4[k]) * r4[k] * g4[k] + b4[k];
+            a[k] = lrelu_f(x_ * gt[k] * rho, 0.1f);
         }
         if (p.drop_rate > 0.f) {
             bool keep[VEC];
-            philox_keep_vec<VEC>(seed, rbase, base + i * VEC, p.drop_rate, keep);
+            philox_keep_vec<VEC, VEC % 4 == 0>(seed, rbase, base + i * VEC, p.drop_rate, keep);
 #pragma unroll
             for (int k = 0; k < VEC; ++k) a[k] = keep[k] ? a[k] * keep_scale : 0.f;
             if (VEC == 8 && p.mask) {                     // one byte per lane: the backward reads it instead of re-running Philox
@@ -256,6 +263,18 @@ __global__ void __launch_bounds__(256) se_combine_fwd_kernel(const T* __restrict
             }
         }
         VecIO<T, VEC>::st(out + base + i * VEC, a);
+    };
+    long long i = i0;
+    for (; i + stride < per; i += 2 * stride) {          // two vectors per tensor in flight per thread
+        float a0[VEC], b0[VEC], a1[VEC], b1[VEC];
+        VecIO<T, VEC>::ld(y3 + base + i * VEC, a0); VecIO<T, VEC>::ld(y4 + base + i * VEC, b0);
+        VecIO<T, VEC>::ld(y3 + base + (i + stride) * VEC, a1); VecIO<T, VEC>::ld(y4 + base + (i + stride) * VEC, b1);
+        body(i, a0, b0); body(i + stride, a1, b1);
+    }
+    for (; i < per; i += stride) {
+        float a0[VEC], b0[VEC];
+        VecIO<T, VEC>::ld(y3 + base + i * VEC, a0); VecIO<T, VEC>::ld(y4 + base + i * VEC, b0);
+        body(i, a0, b0);
     }
 }
 
@@ -291,7 +310,7 @@ struct SeBwdF {
             const unsigned m = p.mask[idx >> 3];
 #pragma unroll
             for (int e = 0; e < kVec; ++e) keep[e] = (m >> e) & 1u;
-        } else if (p.drop_rate > 0.f) { uint64_t seed, rbase; se_rng(p, seed, rbase); philox_keep_vec<kVec>(seed, rbase, idx, p.drop_rate, keep); }
+        } else if (p.drop_rate > 0.f) { uint64_t seed, rbase; se_rng(p, seed, rbase); philox_keep_vec<kVec, kVec % 4 == 0>(seed, rbase, idx, p.drop_rate, keep); }
         const float keep_scale = p.drop_rate > 0.f ? 1.f / (1.f - p.drop_rate) : 1.f;
 #pragma unroll
         for (int e = 0; e < kVec; ++e) {
@@ -309,8 +328,8 @@ struct SeBwdF {
     }
 };
 
-template <typename T, int VEC, bool MASKED = false>
-__global__ void __launch_bounds__(256) se_combine_bwd_apply_kernel(const T* __restrict__ y3, const T* __restrict__ y4,
+template <typename T, int VEC, bool MASKED = false, int MINW = 2>
+__global__ void __launch_bounds__(256, MINW) se_combine_bwd_apply_kernel(const T* __restrict__ y3, const T* __restrict__ y4,
                                                                    const T* __restrict__ dout, SeParams p,
                                                                    const float* __restrict__ sums /*[N][F][5]*/,
                                                                    T* __restrict__ dy3, T* __restrict__ dy4) {
@@ -320,8 +339,19 @@ __global__ void __launch_bounds__(256) se_combine_bwd_apply_kernel(const T* __re
     const float invV = 1.f / (float)p.V;
     uint64_t seed, rbase; se_rng(p, seed, rbase);
     const float keep_scale = p.drop_rate > 0.f ? 1.f / (1.f - p.drop_rate) : 1.f;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < per; i += (long long)gridDim.x * blockDim.x) {
-        const int c0 = (int)(i % cg) * VEC;
+    // channel-invariant threads (see se_combine_fwd_kernel): 13 per-channel values in registers instead of 26 loads per vector
+    const long long i0 = (long long)blockIdx.x * blockDim.x + threadIdx.x, stride = (long long)gridDim.x * blockDim.x;
+    const int c0 = (int)(i0 % cg) * VEC;
+    float m3[VEC], r3[VEC], g3[VEC], b3[VEC], m4[VEC], r4[VEC], g4[VEC], b4[VEC], gt[VEC], s0[VEC], s1[VEC], s2[VEC], s3[VEC];
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) {
+        const int c = c0 + k; const size_t sc = ((size_t)n * F + c) * 2;
+        m3[k] = p.stats3[sc]; r3[k] = p.stats3[sc + 1]; g3[k] = p.gamma3[c]; b3[k] = p.beta3[c];
+        m4[k] = p.stats4[sc]; r4[k] = p.stats4[sc + 1]; g4[k] = p.gamma4[c]; b4[k] = p.beta4[c]; gt[k] = p.g[c];
+        const float* s = sums + ((size_t)n * F + c) * 5;
+        s0[k] = s[0] * invV; s1[k] = s[1] * invV; s2[k] = s[2] * invV; s3[k] = s[3] * invV;
+    }
+    for (long long i = i0; i < per; i += stride) {
         float a[VEC], b[VEC], d[VEC];
         VecIO<T, VEC>::ld(y3 + base + i * VEC, a);
         VecIO<T, VEC>::ld(y4 + base + i * VEC, b);
@@ -331,37 +361,33 @@ __global__ void __launch_bounds__(256) se_combine_bwd_apply_kernel(const T* __re
             const unsigned m = p.mask[(base + i * VEC) >> 3];
 #pragma unroll
             for (int k = 0; k < VEC; ++k) keep[k] = (m >> k) & 1u;
-        } else if (p.drop_rate > 0.f) philox_keep_vec<VEC>(seed, rbase, base + i * VEC, p.drop_rate, keep);
+        } else if (p.drop_rate > 0.f) philox_keep_vec<VEC, VEC % 4 == 0>(seed, rbase, base + i * VEC, p.drop_rate, keep);
 #pragma unroll
         for (int k = 0; k < VEC; ++k) {
-            const int c = c0 + k; const size_t sc = ((size_t)n * F + c) * 2;
-            const float r3 = p.stats3[sc + 1], r4 = p.stats4[sc + 1];
-            const float xh3 = (a[k] - p.stats3[sc]) * r3, xh4 = (b[k] - p.stats4[sc]) * r4;
-            const float x_ = xh3 * p.gamma3[c] + p.beta3[c], rho = xh4 * p.gamma4[c] + p.beta4[c];
-            const float g = p.g[c], u = x_ * g * rho;
+            const float xh3 = (a[k] - m3[k]) * r3[k], xh4 = (b[k] - m4[k]) * r4[k];
+            const float x_ = xh3 * g3[k] + b3[k], rho = xh4 * g4[k] + b4[k];
+            const float g = gt[k], u = x_ * g * rho;
             float dd = d[k];
             if (p.drop_rate > 0.f) dd = keep[k] ? dd * keep_scale : 0.f;
             const float du = dd * lrelu_g(u, 0.1f);
             const float dx_ = du * g * rho, drho = du * g * x_;
-            const float* s = sums + ((size_t)n * F + c) * 5;
-            a[k] = p.gamma3[c] * r3 * (dx_ - s[0] * invV - xh3 * s[1] * invV);
-            b[k] = p.gamma4[c] * r4 * (drho - s[2] * invV - xh4 * s[3] * invV);
+            a[k] = g3[k] * r3[k] * (dx_ - s0[k] - xh3 * s1[k]);
+            b[k] = g4[k] * r4[k] * (drho - s2[k] - xh4 * s3[k]);
         }
         VecIO<T, VEC>::st(dy3 + base + i * VEC, a);
         VecIO<T, VEC>::st(dy4 + base + i * VEC, b);
     }
 }
 
-static inline int grid_x(long long per) { long long g = cdiv_ll(per, 256); return (int)(g > 4096 ? 4096 : (g < 1 ? 1 : g)); }
 
 template <typename T>
 static int se_fwd_impl(const void* y3, const void* y4, const SeParams& p, void* out, int N, hipStream_t st) {
     constexpr int VW = sizeof(T) == 2 ? 8 : 4;
     if (p.F % VW == 0)
-        hipLaunchKernelGGL((se_combine_fwd_kernel<T, VW>), dim3(grid_x(p.V * (p.F / VW)), N), dim3(256), 0, st, (const T*)y3,
+        hipLaunchKernelGGL((se_combine_fwd_kernel<T, VW>), dim3(m1_grid_for(p.V * (p.F / VW), p.F / VW), N), dim3(256), 0, st, (const T*)y3,
                            (const T*)y4, p, (T*)out);
     else
-        hipLaunchKernelGGL((se_combine_fwd_kernel<T, 1>), dim3(grid_x(p.V * p.F), N), dim3(256), 0, st, (const T*)y3,
+        hipLaunchKernelGGL((se_combine_fwd_kernel<T, 1>), dim3(m1_grid_for(p.V * p.F, p.F), N), dim3(256), 0, st, (const T*)y3,
                            (const T*)y4, p, (T*)out);
     return m1_check_launch();
 }
@@ -382,14 +408,18 @@ static int se_bwd_impl(const void* y3, const void* y4, const void* dout, const S
     M1ParamOut<5> po{{dbeta3, dgamma3, dbeta4, dgamma4, dg}, {acc, acc, acc, acc, 0}};
     rc = m1_reduce_finalize_params_launch<5>(ws, N, p.F, nchunks, sums, po, st);
     if (rc) return rc;
-    if (masked)
-        hipLaunchKernelGGL((se_combine_bwd_apply_kernel<T, VW, true>), dim3(grid_x(p.V * (p.F / VW)), N), dim3(256), 0, st,
+    static int w3 = -1; if (w3 < 0) { const char* e = getenv("M1_SE_BWD_W3"); w3 = e ? atoi(e) : 0; }
+    if (masked && w3)       // 3 waves per SIMD at the price of 4 spilled registers (measured: see DESIGN 5)
+        hipLaunchKernelGGL((se_combine_bwd_apply_kernel<T, VW, true, 3>), dim3(m1_grid_for(p.V * (p.F / VW), p.F / VW), N), dim3(256), 0, st,
+                           (const T*)y3, (const T*)y4, (const T*)dout, p, sums, (T*)dy3, (T*)dy4);
+    else if (masked)
+        hipLaunchKernelGGL((se_combine_bwd_apply_kernel<T, VW, true>), dim3(m1_grid_for(p.V * (p.F / VW), p.F / VW), N), dim3(256), 0, st,
                            (const T*)y3, (const T*)y4, (const T*)dout, p, sums, (T*)dy3, (T*)dy4);
     else if (p.F % VW == 0)
-        hipLaunchKernelGGL((se_combine_bwd_apply_kernel<T, VW>), dim3(grid_x(p.V * (p.F / VW)), N), dim3(256), 0, st,
+        hipLaunchKernelGGL((se_combine_bwd_apply_kernel<T, VW>), dim3(m1_grid_for(p.V * (p.F / VW), p.F / VW), N), dim3(256), 0, st,
                            (const T*)y3, (const T*)y4, (const T*)dout, p, sums, (T*)dy3, (T*)dy4);
     else
-        hipLaunchKernelGGL((se_combine_bwd_apply_kernel<T, 1>), dim3(grid_x(p.V * p.F), N), dim3(256), 0, st, (const T*)y3,
+        hipLaunchKernelGGL((se_combine_bwd_apply_kernel<T, 1>), dim3(m1_grid_for(p.V * p.F, p.F), N), dim3(256), 0, st, (const T*)y3,
                            (const T*)y4, (const T*)dout, p, sums, (T*)dy3, (T*)dy4);
     return m1_check_launch();
 }

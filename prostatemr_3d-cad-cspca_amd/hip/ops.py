@@ -158,7 +158,7 @@ def _slot_written(slot) -> None:
 # ---------------------------------------------------------------------------------------------------------
 # independent branches on side streams
 # ---------------------------------------------------------------------------------------------------------
-_BRANCH = {"on": _os.environ.get("M1_STREAMS", "1") != "0", "streams": {}, "used": set()}
+_BRANCH = {"on": _os.environ.get("M1_STREAMS", "1") != "0", "streams": {}, "used": set(), "depth": 0}
 
 
 # Deferred folds of the weight-gradient partial copies (m1_wgrad_defer): with gradients going to the flat buffer nothing reads a
@@ -219,7 +219,9 @@ class branch:
     Tensors handed to the branch must stay referenced until ``join`` (they are read on the side stream)."""
 
     def __init__(self, device, k: int = 0):
-        self.on = _BRANCH["on"] and device.type == "cuda"
+        # a branch opened INSIDE another branch runs in line on its parent's stream: forks of forks segfault the HIP graph
+        # capture of this ROCm release (and every fork then starts from the capture's origin stream)
+        self.on = _BRANCH["on"] and device.type == "cuda" and _BRANCH["depth"] == 0
         if self.on:
             key = (device, k)
             if key not in _BRANCH["streams"]:
@@ -233,10 +235,12 @@ class branch:
             self.side.wait_stream(self.cur)
             _BRANCH["used"].add(self.side)
             self.ctx.__enter__()
+            _BRANCH["depth"] += 1
         return self
 
     def __exit__(self, *exc):
         if self.on:
+            _BRANCH["depth"] -= 1
             self.ctx.__exit__(*exc)
         return False
 

@@ -21,6 +21,8 @@ import numpy as np
 import torch
 import torch.nn as nn
 
+import os as _os
+
 from .. import initializers as init
 from ..hip import ops
 from .modelio import LoadableModel, store_config_args
@@ -195,7 +197,7 @@ class M1Core(nn.Module):
         return [(prefix + "a", plist(dec)), (prefix + "b", plist(mid)), (prefix + "c", plist(enc))]
 
     def forward(self, inputs, prob_mean=False, prob_z_q=None, eps: Optional[List[torch.Tensor]] = None, mark=None,
-                need: str = "full", tail_from: Optional[int] = None, eps_first_half: bool = False):
+                need: str = "full", tail_from: Optional[int] = None, eps_first_half: bool = False, z_ready=None):
         """M1Core.__call__(inputs, prob_mean, prob_z_q) (networks.py:568-759).  ``inputs`` is an NDHWC tensor or
         a list of tensors forming a virtual channel concat.  ``eps``: optional injected N(0,1) draws per level
         (MultivariateNormalDiag.sample() = mu + sigma*eps).  ``mark(group, tensor)``: data-parallel runs register the
@@ -213,7 +215,10 @@ class M1Core(nn.Module):
         the layers behind it on the batch slice ``[B:]`` (a contiguous view: every op of the model is per sample).
 
         ``eps_first_half``: the batch is [sampling pass; prob_mean pass] (M1Net.forward) and ``eps`` holds the draws of the
-        first half only: the latent kernel takes the mean for the second half (no zero-padded draw tensors)."""
+        first half only: the latent kernel takes the mean for the second half (no zero-padded draw tensors).
+
+        ``z_ready``: called once before the first ``prob_z_q`` entry is read (the pass that produced it may still be running on
+        another stream: M1Net.forward)."""
         outputs = {}
         mark = mark if mark is not None else (lambda *_: None)
         S = self.strides
@@ -376,6 +381,8 @@ class M1Core(nn.Module):
                 if Ld != 0:
                     ml = getattr(self, "mu_logsig" + sfx)(f_ml)                    # networks.py:639 (mu | logsigma)
                     if prob_z_q is not None:                                       # networks.py:645
+                        if z_ready is not None:
+                            z_ready(); z_ready = None
                         z = prob_z_q[lvl]
                     elif prob_mean:                                                # networks.py:646
                         z = ops.latent_sample(ml, None, True)
@@ -457,6 +464,9 @@ class M1Core(nn.Module):
 # ============================================================================================================
 # m1 (networks.py:232-392)
 # ============================================================================================================
+_PQ_LANES = _os.environ.get("M1_PQ_LANES", "1") != "0"     # posterior pass on a side stream next to the prior's U-Net (M1Net.forward)
+
+
 class M1Net(nn.Module):
     """The graph ``m1(...)`` builds: deterministic (one core) or hierarchical probabilistic (prior core,
     posterior core, StitchingProbDecoder, 4 core passes per training step + KL).  Calling it returns the
@@ -556,8 +566,18 @@ class M1Net(nn.Module):
                     eps1, off = [], 0
                     for n_, shp in zip(sizes, lshape):
                         eps1.append(flat[off:off + n_].view(B, *shp)); off += n_
-                q = self.posterior(post2, prob_mean=False, prob_z_q=None, eps=eps1, mark=mq, need="latents", eps_first_half=True)
-                p = self.prior(dup(image), prob_mean=False, prob_z_q=q['prob_used_latents'], mark=mp, need="full", tail_from=B)
+                # The prior core reads the posterior's latents only in its latent decoder (dec_hi / sersp): its U-Net -- encoder,
+                # gates, nested decoder -- is independent of the posterior pass, which therefore runs on a side stream next to
+                # it (and so do their backward passes); the prior joins where it first reads a z.
+                img2 = dup(image)
+                post_kw = dict(prob_mean=False, prob_z_q=None, eps=eps1, mark=mq, need="latents", eps_first_half=True)
+                if _PQ_LANES:
+                    with ops.branch(image.device, 8) as lane:
+                        q = self.posterior(post2, **post_kw)
+                    z_ready = lambda: lane.join(*q['prob_used_latents'], *q['prob_distributions'])
+                else:
+                    q, z_ready = self.posterior(post2, **post_kw), None
+                p = self.prior(img2, prob_mean=False, prob_z_q=q['prob_used_latents'], mark=mp, need="full", tail_from=B, z_ready=z_ready)
                 train_conv = self.stitch(p['prob_decoder_features'])                                    # networks.py:356 (p_z_qm)
                 kl = None                                                                               # networks.py:373-385
                 for lvl, (qd, pd) in enumerate(zip(q['prob_distributions'], p['prob_distributions'])):
