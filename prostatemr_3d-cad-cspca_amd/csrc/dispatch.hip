@@ -155,8 +155,35 @@ static int run_gather(const GatherSpec& g, void* ws, int ws_packed, hipStream_t 
 // gather (160->32 at res0: 470 us, bound by 9x re-reads from L2).  Split the members into groups of 8/16/32/64 channels: the
 // first group writes y (+ bias), the others add into it in their epilogue, the last one also emits the InstanceNorm statistics
 // of the sum.  Each group is an ordinary conv over its members with a channel offset into the weights (own panel, own job).
-struct FwdGroups { int n; int first[M1_MAX_SRC], count[M1_MAX_SRC], coff[M1_MAX_SRC]; };
+struct FwdGroups { int n; int first[M1_MAX_SRC], count[M1_MAX_SRC], coff[M1_MAX_SRC]; bool T; };
+// A concat of wide members plus a tiny one that is not a whole 16-byte segment per voxel (the latent z of 1..3 channels in front of
+// the feature map: networks.py:652-653, dec_hi = Conv3DTranspose([z, f])): as ONE problem the odd member takes the whole contraction
+// off the LDS-DMA loader (515 -> 256 at res4: 144 us against 69 us for 512 -> 256).  Split: the run of 64-byte-aligned members is one
+// conv that writes y (+ bias) on the fast path, the odd members follow as tiny convs that add into y.  Forward and transposed forward.
+static bool odd_split(const m1_conv_desc_t* d, bool T, FwdGroups* fg) {
+    static int en = -1; if (en < 0) { const char* e = getenv("M1_ODD_SPLIT"); en = e ? atoi(e) : 1; }
+    if (!en || g_force_direct || d->nsrc < 2) return false;
+    const int seg = d->dtype == M1_BF16 ? 8 : 4, chunk = 4 * seg;
+    int a0 = -1, a1 = -1, nodd = 0, call = 0;
+    for (int i = 0; i < d->nsrc; ++i) {
+        const int c = d->src[i].C;
+        if (c % chunk == 0) { if (a0 < 0) a0 = i; a1 = i; call += c; }
+        else if (c < seg) ++nodd;
+        else return false;
+    }
+    if (!nodd || a0 < 0 || call < 64) return false;
+    for (int i = a0; i <= a1; ++i) if (d->src[i].C % chunk) return false;        // the aligned members must be one run
+    fg->n = 0; fg->T = T;
+    int off = 0, offs[M1_MAX_SRC];
+    for (int i = 0; i < d->nsrc; ++i) { offs[i] = off; off += d->src[i].C; }
+    fg->first[0] = a0; fg->count[0] = a1 - a0 + 1; fg->coff[0] = offs[a0]; fg->n = 1;
+    if (a0 > 0) { fg->first[fg->n] = 0; fg->count[fg->n] = a0; fg->coff[fg->n] = 0; fg->n++; }
+    if (a1 + 1 < d->nsrc) { fg->first[fg->n] = a1 + 1; fg->count[fg->n] = d->nsrc - a1 - 1; fg->coff[fg->n] = offs[a1 + 1]; fg->n++; }
+    return true;
+}
 static bool fwd_groups(const m1_conv_desc_t* d, bool T, FwdGroups* fg) {
+    if (odd_split(d, T, fg)) return true;
+    fg->T = T;
     static int en = -1; if (en < 0) { const char* e = getenv("M1_HALO_GROUPS"); en = e ? atoi(e) : 1; }
     if (!en || T || g_force_direct || d->dtype != M1_BF16 || d->nsrc < 2 || d->Cin <= 64) return false;
     if (d->kd * d->kh * d->kw < 2) return false;
@@ -174,7 +201,7 @@ static bool fwd_groups(const m1_conv_desc_t* d, bool T, FwdGroups* fg) {
     return fg->n >= 2;
 }
 static GatherSpec fwd_group_spec(const m1_conv_desc_t* d, const FwdGroups& fg, int gi, const float* w, const float* bias, void* y) {
-    GatherSpec g = fwd_spec(d, false, w, gi == 0 ? bias : nullptr, y);
+    GatherSpec g = fwd_spec(d, fg.T, w, gi == 0 ? bias : nullptr, y);
     g.nsrc = fg.count[gi];
     for (int i = 0; i < g.nsrc; ++i) { g.src[i] = d->src[fg.first[gi] + i].ptr; g.srcC[i] = d->src[fg.first[gi] + i].C; }
     g.cc_off = fg.coff[gi];
@@ -407,6 +434,16 @@ extern "C" int m1_convT3d_fwd(const m1_conv_desc_t* d, const float* w, const flo
                               void* stream) {
     if (!desc_ok(d) || !w || !y) return M1_ERR_BAD_ARG;
     M1ProfScope ps(prof_name("convT3d_fwd", d).s, 2.0 * conv_macs(d, true), conv_bytes(d, true), (hipStream_t)stream);
+    FwdGroups fg;
+    if (ws && fwd_groups(d, true, &fg)) {                 // (odd_split: the aligned run first, the tiny members add into y)
+        size_t woff = 0;
+        for (int gi = 0; gi < fg.n; ++gi) {
+            GatherSpec gg = fwd_group_spec(d, fg, gi, w, bias, y);
+            int rc = run_gather(gg, (unsigned char*)ws + woff, ws_packed, (hipStream_t)stream); if (rc) return rc;
+            woff += gather_ws_bytes(gg);
+        }
+        return M1_OK;
+    }
     return run_gather(fwd_spec(d, true, w, bias, y), ws, ws_packed, (hipStream_t)stream);
 }
 static int dgrad_common(const m1_conv_desc_t* d, bool T, const float* w, const void* dy, void* const* dx, const int* accumulate,
