@@ -49,7 +49,7 @@ __device__ __forceinline__ void wait_vmh(int n) {
     }
 }
 
-#define HL_MAX_XIT 8         // LDS-DMA pieces per thread for one input tile
+#define HL_MAX_XIT 10        // LDS-DMA pieces per thread for one input tile
 #define HL_MAX_CH 20         // K chunks (of 32) whose fragment offsets live in registers
 
 struct HaloP {
@@ -396,9 +396,18 @@ __global__ void __launch_bounds__(NTHR) conv_halo_kernel(HaloP p) {
 }
 
 // ------------------------------------------------------------------------------------------------
+static bool halo_plan_nthr(const MfmaP& m, int OCpad, HaloP& p, int force_nthr);
+// 256-voxel tiles on 512 threads; when those do not fit (a stride-2 layer's input tile is 4x its output tile: 32 -> 64 k133 s122 at
+// res0 needs 74 KB per stage) 128-voxel tiles on 256 threads
 static bool halo_plan(const MfmaP& m, int OCpad, HaloP& p) {
+    if (halo_plan_nthr(m, OCpad, p, 0)) return true;
+    return halo_plan_nthr(m, OCpad, p, 256);
+}
+static bool halo_plan_nthr(const MfmaP& m, int OCpad, HaloP& p, int force_nthr) {
     if (m.nclasses != 1 || m.ksplit != 1) return false;
     if (!(m.mode == 0 || (m.mode == 1 && m.sd == 1 && m.sh == 1 && m.sw == 1))) return false;
+    { static int hs = -1; if (hs < 0) { const char* e = getenv("M1_HALO_STRIDED"); hs = e ? atoi(e) : 1; }       // 0: strided layers stay on conv_mfma (A/B switch)
+      if (!hs && m.mode == 0 && (m.sd > 1 || m.sh > 1 || m.sw > 1)) return false; }
     int CC = 0;
     for (int i = 0; i < m.nsrc; ++i) { if (m.srcC[i] % 8) return false; CC += m.srcC[i]; }
     if (!(CC == 8 || CC == 16 || CC == 32 || CC == 64)) return false;
@@ -417,6 +426,7 @@ static bool halo_plan(const MfmaP& m, int OCpad, HaloP& p) {
     if (m.mode == 0) { p.sde = m.sd; p.she = m.sh; p.swe = m.sw; p.pde = m.pd; p.phe = m.ph; p.pwe = m.pw; }
     else { p.sde = p.she = p.swe = 1; p.pde = p.phe = p.pwe = 0; }
     { static int nt_ = -1; if (nt_ < 0) { const char* e = getenv("M1_HALO_THREADS"); nt_ = e ? atoi(e) : 512; } p.nthr = nt_ == 512 ? 512 : 256; }
+    if (force_nthr) p.nthr = force_nthr;
     p.TW = m.OW % 32 == 0 ? 32 : (m.OW % 16 == 0 ? 16 : 8);
     if (p.nthr == 512) {      // 256-voxel tiles unless their row padding wastes clearly more than 128-voxel tiles would
         const int th5 = 256 / p.TW, th2 = 128 / p.TW;
@@ -482,6 +492,10 @@ int m1_halo_conv(const MfmaP& mp, int OCpad, hipStream_t st) {
     if (p.nthr == 512) {
 #define HK(NCH_, NXIT_) if (!kern && p.nchunks == NCH_ && nxit == NXIT_) kern = p.BNh == 32 ? conv_halo_kernel<2, 512, NCH_, NXIT_> : conv_halo_kernel<1, 512, NCH_, NXIT_>;
         HK(18, 6) HK(9, 3) HK(5, 2) HK(3, 1) HK(14, 4) HK(7, 2)
+#undef HK
+    } else {
+#define HK(NCH_, NXIT_) if (!kern && p.nchunks == NCH_ && nxit == NXIT_) kern = p.BNh == 32 ? conv_halo_kernel<2, 256, NCH_, NXIT_> : conv_halo_kernel<1, 256, NCH_, NXIT_>;
+        HK(9, 9)                       // 32 -> 64 / 16, k133, s122 at res0 -> res1 (the strided SE blocks' conv1 / conv4)
 #undef HK
     }
     { static int lg = -1; if (lg < 0) { const char* e = getenv("M1_HALO_LOG"); lg = e ? atoi(e) : 0; }

@@ -740,6 +740,9 @@ TF_CASES = [  # (N, D, H, W), cins, cout, k, s, transposed
     ((2, 2, 8, 16), [128], 64, (3, 3, 3), (2, 2, 2), True),
     ((2, 3, 6, 20), [256], 128, (3, 3, 3), (2, 2, 2), True),
     ((2, 4, 8, 8), [2, 128], 64, (3, 3, 3), (1, 2, 2), True),
+    # the strided SE blocks' conv1 / conv4 at res0 -> res1 (halo-tile kernel with 128-voxel tiles under M1_HALO=2)
+    ((1, 2, 32, 32), [32], 64, (1, 3, 3), (1, 2, 2), False),
+    ((2, 3, 16, 48), [32], 16, (1, 3, 3), (1, 2, 2), False),
 ]
 
 
