@@ -164,7 +164,54 @@ _BRANCH = {"on": _os.environ.get("M1_STREAMS", "1") != "0", "streams": {}, "used
 # Deferred folds of the weight-gradient partial copies (m1_wgrad_defer): with gradients going to the flat buffer nothing reads a
 # weight gradient before join_side_streams, so the ~130 fold launches of a step (5-10 us each, a few dozen blocks, alone on
 # their stream) become a handful of batched ones there.  The workspaces holding the copies are kept until then.
-_FOLD = {"on": _os.environ.get("M1_WG_FOLD_BATCH", "1") != "0", "keep": []}
+_FOLD = {"on": _os.environ.get("M1_WG_FOLD_BATCH", "1") != "0", "keep": [],
+         # M1_FOLD_ASYNC = n > 0 (default 24, one batched launch): every n queued weight gradients the folds queued so far run on
+         # a stream of their own NEXT TO the backward pass (bandwidth-bound folds beside MFMA-bound convolutions) instead of
+         # all at its end, where they ran alone on the GPU (0.8 ms of the C3 step)
+         "async": int(_os.environ.get("M1_FOLD_ASYNC", "-1")), "stream": None,
+         "async_mb": int(_os.environ.get("M1_FOLD_ASYNC_MB", "0")), "bytes": 0,
+         # M1_FOLD_HEAVY = g > 0: also right before the backward kernels of a conv of >= g GFLOP (when >= 4 folds wait)
+         "heavy": float(_os.environ.get("M1_FOLD_HEAVY", "0")), "heavy_min": int(_os.environ.get("M1_FOLD_HEAVY_MIN", "4"))}
+
+
+def _fold_before_heavy(d) -> None:
+    if _FOLD["heavy"] > 0 and _BRANCH["on"] and len(_FOLD["keep"]) >= _FOLD["heavy_min"]:
+        gf = 2e-9 * d.N * d.D * d.H * d.W * d.Cin * d.Cout * d.kd * d.kh * d.kw / (d.sd * d.sh * d.sw)
+        if gf >= _FOLD["heavy"]:
+            _fold_async()
+
+
+def fold_async_default(n: int) -> None:
+    """Model-level default of the M1_FOLD_ASYNC interval (the environment variable wins).  Measured optimum, same box: 10-12 for
+    the hierarchical probabilistic model (~130 weight gradients per step: 26.7 ms against 27.3 at 24, 27.7 without, 27.6-27.9
+    at <= 8), 24 for the deterministic one (~60 per step: 7.87 ms against 8.01 at 12, 7.94 without)."""
+    if "M1_FOLD_ASYNC" not in _os.environ:
+        _FOLD["async"] = int(n)
+
+
+def _fold_async() -> None:
+    """Run the queued folds on the fold stream, ordered behind everything enqueued so far.  Only from the stream the step started
+    on (a fork of a fork breaks graph capture, see ``branch``): weight gradients of branch streams wait for the next trigger."""
+    origin = _BRANCH.get("origin")
+    cur = torch.cuda.current_stream()
+    if origin is None or cur != origin or not _FOLD["keep"]:
+        return
+    fs = _FOLD["stream"]
+    if fs is None:
+        fs = _FOLD["stream"] = torch.cuda.Stream(device=cur.device)
+    fs.wait_stream(cur)                                   # (first: the fold stream joins a capture through its origin)
+    for s in _BRANCH["used"]:
+        if s != cur and s != fs:
+            fs.wait_stream(s)
+    _BRANCH["used"].add(fs)
+    try:
+        with torch.cuda.stream(fs):
+            L.check(L.load().m1_wgrad_fold_pending(fs.cuda_stream), "m1_wgrad_fold_pending")
+        for ws, made_on in _FOLD["keep"]:
+            if made_on != fs:
+                ws.record_stream(fs)
+    finally:
+        _FOLD["keep"].clear(); _FOLD["bytes"] = 0
 
 
 def fold_pending() -> None:
@@ -177,7 +224,7 @@ def fold_pending() -> None:
                 if made_on != cur:
                     ws.record_stream(cur)             # read here, allocated on a branch stream
         finally:
-            _FOLD["keep"].clear()
+            _FOLD["keep"].clear(); _FOLD["bytes"] = 0
 
 
 def finish_queued_for_exchange() -> None:
@@ -194,7 +241,7 @@ def finish_queued_for_exchange() -> None:
 def fold_drop() -> None:
     if _FOLD["keep"]:
         L.load().m1_wgrad_fold_drop()
-        _FOLD["keep"].clear()
+        _FOLD["keep"].clear(); _FOLD["bytes"] = 0
 
 
 def join_side_streams() -> None:
@@ -223,6 +270,7 @@ class branch:
         # capture of this ROCm release (and every fork then starts from the capture's origin stream)
         self.on = _BRANCH["on"] and device.type == "cuda" and _BRANCH["depth"] == 0
         if self.on:
+            _BRANCH["origin"] = torch.cuda.current_stream(device)          # (depth 0: the stream the step runs on)
             key = (device, k)
             if key not in _BRANCH["streams"]:
                 _BRANCH["streams"][key] = torch.cuda.Stream(device=device)
@@ -465,6 +513,7 @@ class _Conv3d(torch.autograd.Function):
         st = _stream()
         name = "convT3d" if ctx.transposed else "conv3d"
         dw = db = None
+        _fold_before_heavy(d)
         if ctx.needs_input_grad[0] or (ctx.has_bias and ctx.needs_input_grad[1]):
             dw, db = _wgrad_into_sinks(lib, d, dy, ctx.w_param, ctx.b_param if ctx.has_bias else None, ctx.transposed, st, srcs)
         dsrc: List[Optional[torch.Tensor]] = []
@@ -582,6 +631,10 @@ def _wgrad_into_sinks(lib, d, dy, w_param, b_param, transposed: bool, st, srcs=(
             finally:
                 lib.m1_wgrad_defer(0)
             _FOLD["keep"].append((ws, torch.cuda.current_stream(w_param.device)))
+            _FOLD["bytes"] += ws.numel() * ws.element_size()
+            if _BRANCH["on"] and ((_FOLD["async"] > 0 and len(_FOLD["keep"]) >= _FOLD["async"]) or
+                                  (_FOLD["async_mb"] > 0 and _FOLD["bytes"] >= _FOLD["async_mb"] << 20)):
+                _fold_async()
         else:
             L.check(fn(C.byref(d), _p(dy), _p(wbuf), _p(bbuf), _p(ws), acc_w, st), "m1_conv3d_wgrad")
         return dw, db
@@ -638,6 +691,7 @@ class _ConvPair(torch.autograd.Function):
         dy1, dy4 = dy1.contiguous(), dy4.contiguous()
         st = _stream()
         dw1 = db1 = None
+        _fold_before_heavy(_desc(srcs, ctx.c1 + ctx.c4, ctx.k, ctx.s))
         iw, isrc = getattr(ctx, "idx_w1", 0), getattr(ctx, "idx_src", 6)       # positions of w1 / the first member among the inputs
         if ctx.needs_input_grad[iw] or ctx.needs_input_grad[iw + 1]:
             dw1, db1 = _wgrad_into_sinks(lib, _desc(srcs, ctx.c1, ctx.k, ctx.s), dy1, ctx.w1_param, ctx.b1_param, False, st, srcs)
