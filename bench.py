@@ -121,18 +121,25 @@ def cpu_baseline(workload, prob, dense, deep, dims, filters, kl_w, budget_s=75.0
                 w.addcdiv_(m, vh.sqrt().add_(1e-7), value=-lr_t)
         return time.time() - t0
 
-    cands = [(D, H, W), (D, H // 2, W // 2), (D // 2 or 1, H // 2, W // 2), (D // 2 or 1, H // 4, W // 4), (4, 32, 32)]
-    cands = [c for c in dict.fromkeys(cands) if c[0] >= 4 and c[1] >= 32 and c[2] >= 32 and c[0] % 4 == 0] or [(4, 32, 32)]
+    # candidate samples (extents the five strided levels divide: D % 4, H % 16, W % 16), largest first
+    r16 = lambda v: max(32, v // 16 * 16)
+    cands = [(D, H, W), (D, r16(int(H * 0.7)), r16(int(W * 0.7))), (D, r16(H // 2), r16(W // 2)), (max(4, D // 8 * 4), r16(H // 2), r16(W // 2)),
+             (8, 64, 64), (4, 32, 32)]
+    cands = sorted({c for c in cands if c[0] >= 4 and c[0] % 4 == 0 and c[0] <= D and c[1] <= H and c[2] <= W}, key=lambda c: -c[0] * c[1] * c[2])
     vox = lambda c: c[0] * c[1] * c[2]
-    probe = min(cands, key=vox)
-    ctx = make(probe)
-    step(ctx, 1)                                     # warm-up of the probe (thread pools, oneDNN primitives)
-    pick, t = probe, step(ctx, 2)
-    for c in sorted(cands, key=vox)[1:]:             # climb while the next size's 1 + 3 steps, predicted from the last measured
-        if 4.0 * t * vox(c) / vox(pick) > budget_s:  # one, fit the budget (small volumes are less efficient: errs on the safe side)
-            break
-        ctx = make(c)
-        pick, t = c, step(ctx, 1)                    # (this run is the warm-up of size c)
+    # step time = a + b * voxels: the fixed part (Adam over 67 M parameters, per-layer overheads) is ~1 s on 32 threads, so a
+    # prediction that is linear from one tiny probe never leaves the probe.  Two probes fit (a, b); the largest candidate whose
+    # 1 warm-up + 3 timed steps are predicted to fit the budget is measured.
+    p1, p2 = (4, 32, 32), (8, 64, 64) if D >= 8 and H >= 64 and W >= 64 else (4, 32, 32)
+    ctx = make(p1); step(ctx, 1); t1 = step(ctx, 2)
+    if p2 != p1:
+        ctx = make(p2); step(ctx, 1); t2 = step(ctx, 2)
+        b_ = max(0.0, (t2 - t1) / (vox(p2) - vox(p1))); a_ = max(0.0, t1 - b_ * vox(p1))
+    else:
+        a_, b_ = 0.0, t1 / vox(p1)
+    pick = next((c for c in cands if 4.0 * (a_ + b_ * vox(c)) <= budget_s), cands[-1])
+    ctx = make(pick)
+    step(ctx, 1)                                     # warm-up at the picked size
     times = sorted(step(ctx, 2 + i) for i in range(3))      # 3 timed steps at the picked size
     t = times[1]
     frac = vox(pick) / float(D * H * W)

@@ -589,6 +589,14 @@ static int wgrad_common(const m1_conv_desc_t* d, bool T, const void* dy, float* 
             if (rc != M1_ERR_UNSUPPORTED && rc != M1_ERR_WORKSPACE) return rc;
             rc = M1_ERR_UNSUPPORTED;
         }
+        // fp32 layers the 64x64-tile kernel does not take (few channels on a side): the 32x32-tile tap-fused fp32 kernel
+        if (!g_force_direct && rx && g.dtype == M1_F32 && m1_t3s_wgrad_supported(g)) {
+            rc = m1_t3s_wgrad(g, (long long)nw, nbias, st);
+            if (wlog) fprintf(stderr, "wgrad %s N%d B %dx%dx%d CA %d CB %d k%d%d%d s%d%d%d -> t3s rc %d\n", T ? "convT" : "conv", g.N, g.BD, g.BH, g.BW, g.CA, g.CB, g.kd, g.kh, g.kw, g.sd, g.sh, g.sw, rc);
+            if (rc == M1_OK) { off += d->src[i].C; continue; }
+            if (rc != M1_ERR_UNSUPPORTED && rc != M1_ERR_WORKSPACE) return rc;
+            rc = M1_ERR_UNSUPPORTED;
+        }
         // a run of members with the same channel count on the tap-fused kernel: ONE launch (blockIdx.z = member)
         static int multi = -1; if (multi < 0) { const char* e = getenv("M1_TF_MULTI"); multi = e ? atoi(e) : 1; }
         if (multi && !T && !g_force_direct && rx && tf_wanted(g)) {

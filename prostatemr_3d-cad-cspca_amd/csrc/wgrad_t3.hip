@@ -344,31 +344,227 @@ __global__ void __launch_bounds__(T3_THREADS, 3) wgrad_t3_kernel(T3P p) {
 #endif
 }
 
+// ------------------------------------------------------------------------------------------------------------------------------
+// fp32 variant (the C5 configuration, BASELINE.json configs[3]): the same block (12 waves, 9 taps of one kd slice of two 64 x 64
+// channel tiles, haloed X tile + dY tiles staged once per K-tile by LDS-DMA, tile table, fixed piece slots, per-split partial
+// copies) on v_mfma_f32_32x32x2_f32.  An fp32 MFMA does 1/16 of the work of a bf16 one per cycle, so the kernel is bound by MFMA
+// issue with room to spare everywhere else: rows are 256 bytes (64 channels), fragments are plain ds_read_b32 (lane = channel,
+// lanes 0-31 / 32-63 = two consecutive voxels: 32 consecutive dwords per half wave, conflict-free without a swizzle), two stages.
+// Stride 1, K-tile columns 8 / 16 / 32.  It replaces the register-transposing wgrad_mfma_kernel<float> (16-42 % MFMA-busy, half of
+// the C5 step) on the layers with >= 64 channels on both sides.
+template <int KWS, bool BIGB>
+__global__ void __launch_bounds__(T3_THREADS, 3) wgrad_t3f_kernel(T3P p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wsel = wave >= 6 ? 1 : 0, w6 = wave - 6 * wsel;
+    const int wa = w6 & 1, kh = w6 >> 1;
+    constexpr int KWs = KWS, TH = T3_KT / KWS, AWt = KWs + 2, AHt = TH + 2, arows = AHt * AWt;
+    constexpr int nA = (arows + 3) / 4;                        // 1 KB pieces of ONE A tile (rows of 256 bytes)
+    constexpr int nB = T3_KT / 4;                              // ... of one B tile
+    constexpr int NTA = BIGB ? 1 : 2, NTB = BIGB ? 2 : 1;
+    constexpr int nAtot = NTA * nA, nBtot = NTB * nB;
+    constexpr int A_ITS = (nAtot + T3_WAVES - 1) / T3_WAVES, B_ITS = (nBtot + T3_WAVES - 1) / T3_WAVES, NP = A_ITS + B_ITS;
+    constexpr int stage_bytes = (nAtot + nBtot) * 1024;
+    const float* const pA0 = reinterpret_cast<const float*>(p.A0);
+    const int kd = (int)blockIdx.z % p.KD, zu = (int)blockIdx.z / p.KD;
+    const int u0 = BIGB ? zu : 2 * zu, u1 = BIGB ? zu : 2 * zu + 1;
+    const int bt0 = BIGB ? 2 * (int)blockIdx.x : (int)blockIdx.x, bt1 = BIGB ? bt0 + 1 : bt0;
+    const int m0 = u0 / p.aTiles, m1u = u1 < p.nunits ? u1 / p.aTiles : m0;
+    const float* const A0base = reinterpret_cast<const float*>(t3_member(p, m0)) + (u0 - m0 * p.aTiles) * 64;
+    const float* const A1base = reinterpret_cast<const float*>(t3_member(p, m1u)) + (u1 - m1u * p.aTiles) * 64;
+    const long long dA1 = (const char*)A1base - (const char*)A0base;
+    const bool ghost1 = !BIGB && u1 >= p.nunits;
+    constexpr unsigned OOB = 0x80000000u;
+    const unsigned lds0 = (unsigned)(unsigned long long)(lptr_t)smem;
+
+    unsigned vo[NP]; int pk[NP]; int dst[NP]; int second[NP];
+    const unsigned trash = lds0 + (unsigned)(p.stages * stage_bytes);
+#pragma unroll
+    for (int it = 0; it < NP; ++it) {
+        vo[it] = OOB; pk[it] = 0;
+        if (it < A_ITS) {
+            const int q = wave + T3_WAVES * it;
+            const int t1 = q >= nA ? 1 : 0, ql = q - t1 * nA;
+            const bool real = q < nAtot;
+            dst[it] = real ? q * 1024 : -1; second[it] = t1;
+            const int s = ql * 64 + lane, row = s >> 4, sl = s & 15;           // 16 slots of 16 bytes per row
+            const int hh = row / AWt, ww = row - hh * AWt;
+            pk[it] = hh | (ww << 8);
+            if (real && row < arows) vo[it] = (unsigned)(((hh * p.AW + ww) * p.CA + sl * 4) * 4);
+        } else {
+            const int q = wave + T3_WAVES * (it - A_ITS);
+            const int t1 = q >= nB ? 1 : 0, ql = q - t1 * nB;
+            const bool real = q < nBtot;
+            dst[it] = real ? (nAtot + q) * 1024 : -1; second[it] = t1;
+            const int s = ql * 64 + lane, kk = s >> 4, sl = s & 15;
+            const int th = kk / KWs, tw = kk - th * KWs;
+            pk[it] = th;
+            if (real) vo[it] = (unsigned)(((th * p.BW + tw) * p.CB + (t1 ? bt1 : bt0) * 64 + sl * 4) * 4);
+        }
+    }
+
+    const int my_tiles = (p.ntiles - (int)blockIdx.y + p.nsplit - 1) / p.nsplit;
+    int* const tab = reinterpret_cast<int*>(smem + p.stages * stage_bytes + 1024);
+    for (int t = tid; t < my_tiles + p.stages; t += T3_THREADS) {
+        int e[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (t < my_tiles) {
+            int r = (int)blockIdx.y + t * p.nsplit;
+            const int twi = r % p.tiles_w; r /= p.tiles_w;
+            const int thi = r % p.tiles_h; r /= p.tiles_h;
+            const int bd = r % p.BD, n = r / p.BD;
+            const int ad = bd + kd - p.pd, ah0 = thi * TH - p.ph, aw0 = twi * KWs - p.pw, bh0 = thi * TH;
+            const long long alin0 = (((long long)n * p.AD + ad) * p.AH + ah0) * p.AW + aw0;
+            const long long blin0 = (((long long)n * p.BD + bd) * p.BH + bh0) * p.BW + twi * KWs;
+            const unsigned long long pa = (unsigned long long)(A0base + alin0 * p.CA);
+            const unsigned long long pb = (unsigned long long)(reinterpret_cast<const float*>(p.B) + blin0 * p.CB);
+            e[0] = (int)(unsigned)pa; e[1] = (int)((unsigned)(pa >> 32) & 0xffffu); e[2] = (unsigned)ad < (unsigned)p.AD ? 0x7fffffff : 0;
+            e[3] = (ah0 & 0xffff) | (aw0 << 16);
+            e[4] = (int)(unsigned)pb; e[5] = (int)((unsigned)(pb >> 32) & 0xffffu); e[6] = 0x7fffffff; e[7] = bh0;
+        }
+        reinterpret_cast<int4*>(tab)[2 * t] = make_int4(e[0], e[1], e[2], e[3]);
+        reinterpret_cast<int4*>(tab)[2 * t + 1] = make_int4(e[4], e[5], e[6], e[7]);
+    }
+    __syncthreads();
+    int q_e = 0;
+    int4 ea, eb;
+    auto fetch = [&]() {
+        ea = reinterpret_cast<const int4*>(tab)[2 * q_e]; eb = reinterpret_cast<const int4*>(tab)[2 * q_e + 1];
+        ++q_e;
+    };
+    const unsigned dA1lo = (unsigned)(unsigned long long)dA1; const int dA1hi = (int)(dA1 >> 32);
+    auto issue = [&](int st) {
+        i32x4_t ra0, ra1, rb;
+        ra0.x = __builtin_amdgcn_readfirstlane(ea.x); ra0.y = __builtin_amdgcn_readfirstlane(ea.y);
+        ra0.z = __builtin_amdgcn_readfirstlane(ea.z); ra0.w = 0x00020000;
+        rb.x = __builtin_amdgcn_readfirstlane(eb.x); rb.y = __builtin_amdgcn_readfirstlane(eb.y);
+        rb.z = __builtin_amdgcn_readfirstlane(eb.z); rb.w = 0x00020000;
+        ra1 = ra0;
+        if (!BIGB) {
+            const unsigned long long b1 = (((unsigned long long)(unsigned)ra0.y << 32) | (unsigned)ra0.x) + (((unsigned long long)(unsigned)dA1hi << 32) | dA1lo);
+            ra1.x = (int)(unsigned)b1; ra1.y = (int)((unsigned)(b1 >> 32) & 0xffffu);
+            ra1.z = ghost1 ? 0 : ra0.z;
+        }
+        const int ah0 = (ea.w << 16) >> 16, aw0 = ea.w >> 16, bh0 = eb.w;
+        const unsigned S0 = lds0 + (unsigned)(st * stage_bytes);
+#pragma unroll
+        for (int it = 0; it < NP; ++it) {
+            const unsigned d = dst[it] >= 0 ? S0 + (unsigned)dst[it] : trash;
+            if (it < A_ITS) {
+                const unsigned hh = (unsigned)(pk[it] & 0xff), ww = (unsigned)(pk[it] >> 8);
+                unsigned o = (hh + (unsigned)ah0) < (unsigned)p.AH ? vo[it] : OOB;
+                o = (ww + (unsigned)aw0) < (unsigned)p.AW ? o : OOB;
+                t3_dma((!BIGB && second[it]) ? ra1 : ra0, d, o);
+            } else {
+                t3_dma(rb, d, (unsigned)(pk[it] + bh0) < (unsigned)p.BH ? vo[it] : OOB);
+            }
+        }
+    };
+
+    // fragments: lane l = (voxel of the pair g = l >> 5, channel c = l & 31): one dword per operand and MFMA
+    const int g = lane >> 5, c = lane & 31;
+    const unsigned char* const At = smem + (BIGB ? 0 : wsel * nA * 1024);
+    const unsigned char* const Bt = smem + nAtot * 1024 + (BIGB ? wsel * nB * 1024 : 0);
+    const unsigned char* const aL = At + ((kh * AWt + g) * 64 + wa * 32 + c) * 4;      // tap (kh, 0) of voxel slot g
+    const unsigned char* const bL = Bt + (g * 64 + c) * 4;
+
+    f32x16_t acc[3][2];
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[t][nb][e] = 0.f;
+    const int uw = wsel ? u1 : u0, btw = wsel ? bt1 : bt0;
+    const int mw = wsel ? m1u : m0, aw = (uw - mw * p.aTiles) * 64, b0 = btw * 64;
+    const bool do_bsum = p.want_bsum && uw == 0 && kd == 0 && w6 == 0;
+    float accb0 = 0.f, accb1 = 0.f;
+
+    const int S = p.stages;                                    // 2 or 3
+    for (int s = 0; s < S - 1; ++s) { fetch(); issue(s); }
+    int st = 0;
+    for (int kt = blockIdx.y; kt < p.ntiles; kt += p.nsplit) {
+        fetch();
+        if (S == 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NP) : "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        int stn = st + S - 1; if (stn >= S) stn -= S;
+        issue(stn);
+        const unsigned char* const ap = aL + st * stage_bytes; const unsigned char* const bp = bL + st * stage_bytes;
+#pragma unroll 8
+        for (int k2 = 0; k2 < T3_KT / 2; ++k2) {               // voxel slots 2 k2 + g: row th = 2 k2 / KWs, column 2 k2 % KWs + g
+            const int th = (2 * k2) / KWs, tw0 = (2 * k2) % KWs;
+            const unsigned char* a = ap + (th * AWt + tw0) * 256;
+            const unsigned char* b = bp + (2 * k2) * 256;
+            const float bf0 = *reinterpret_cast<const float*>(b), bf1 = *reinterpret_cast<const float*>(b + 128);
+            const float af0 = *reinterpret_cast<const float*>(a), af1 = *reinterpret_cast<const float*>(a + 256),
+                        af2 = *reinterpret_cast<const float*>(a + 512);
+            if (do_bsum) { accb0 += bf0; accb1 += bf1; }
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af0, bf0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(af0, bf1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af1, bf0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(af1, bf1, acc[1][1], 0, 0, 0);
+            acc[2][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af2, bf0, acc[2][0], 0, 0, 0);
+            acc[2][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(af2, bf1, acc[2][1], 0, 0, 0);
+        }
+        if (++st == S) st = 0;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+    if (uw >= p.nunits) return;
+    float* Rx = p.Rx + (long long)mw * p.rx_mem + (long long)blockIdx.y * p.rx_stride;
+    if (do_bsum) {
+        accb0 += __shfl_xor(accb0, 32); accb1 += __shfl_xor(accb1, 32);
+        if (lane < 32) { Rx[p.rx_bias + b0 + lane] = accb0; Rx[p.rx_bias + b0 + 32 + lane] = accb1; }
+    }
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+        const long long tap = (long long)(kd * 3 + kh) * 3 + t;
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) {
+            const int b = b0 + nb * 32 + (lane & 31);
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int a = aw + wa * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+                Rx[(tap * p.CA + a) * p.CB + b] = acc[t][nb][e];
+            }
+        }
+    }
+#endif
+}
+
 // fills the tile geometry; false = shape outside this kernel
 static bool t3_plan(const WgradSpec& g, T3P& p) {
     static int en = -1; if (en < 0) { const char* e = getenv("M1_WG_T3"); en = e ? atoi(e) : 1; }
-    if (!en || g.dtype != M1_BF16) return false;
+    if (!en || (g.dtype != M1_BF16 && g.dtype != M1_F32)) return false;
+    const bool f32 = g.dtype == M1_F32;
+    { static int ef = -1; if (ef < 0) { const char* e = getenv("M1_WG_T3F"); ef = e ? atoi(e) : 1; } if (f32 && !ef) return false; }
     if (g.CA < 64 || g.CB < 64 || g.CA % 64 || g.CB % 64) return false;
     if (!(g.kh == 3 && g.kw == 3 && (g.kd == 1 || g.kd == 3))) return false;
     const bool s1 = g.sh == 1 && g.sw == 1 && g.sd == 1, s2 = g.sh == 2 && g.sw == 2 && (g.sd == 1 || g.sd == 2) && g.ph == 0 && g.pw == 0;
     if (!s1 && !s2) return false;
+    if (f32 && (!s1 || g.BW % 8)) return false;                // fp32 kernel: stride 1, K-tile columns 8 / 16 / 32
     if (s2 && g.CB % 128) return false;                        // (two de-interleaved A tiles do not fit a stage)
     if (g.BW % 4 || g.BW < 8) return false;
     // (DMA offsets are 32-bit and relative to the tile origin, which travels in the 64-bit resource base)
-    if ((long long)(g.AH + 4) * g.AW * g.CA * 2 >= (1ll << 31) - 4096 || (long long)(g.BH + 4) * g.BW * g.CB * 2 >= (1ll << 31) - 4096) return false;
+    const long long esz = f32 ? 4 : 2;
+    if ((long long)(g.AH + 4) * g.AW * g.CA * esz >= (1ll << 31) - 4096 || (long long)(g.BH + 4) * g.BW * g.CB * esz >= (1ll << 31) - 4096) return false;
     p = T3P{};
     p.B = (const bf16_t*)g.B;
     p.CA = g.CA; p.CB = g.CB; p.AD = g.AD; p.AH = g.AH; p.AW = g.AW; p.BD = g.BD; p.BH = g.BH; p.BW = g.BW; p.N = g.N;
     p.pd = g.pd; p.ph = g.ph; p.pw = g.pw; p.KD = g.kd; p.sd = g.sd;
     // K-tile: TH rows x KWs columns <= 64 voxels, KWs a multiple of 4 (4-voxel transpose groups never straddle a row)
     int kws = 0;
-    for (int c : {32, 16, 8}) if (g.BW % c == 0) { kws = c; break; }
+    for (int c : {32, 16, 8}) {
+        if (f32 && c == 32 && g.CB % 128) continue;            // (fp32, two X tiles per block: two stages of 32-column tiles exceed the LDS)
+        if (g.BW % c == 0) { kws = c; break; }
+    }
     if (!kws) { if (g.BW <= 32) kws = g.BW; else { for (int c = 28; c >= 8; c -= 4) if (g.BW % c == 0) { kws = c; break; } } }
     if (!kws) return false;
     p.KWs = kws; p.TH = T3_KT / kws;
     if (p.TH + 2 > 255 || p.KWs + 2 > 255) return false;
     const int nA = s1 ? ((p.TH + 2) * (p.KWs + 2) + 7) / 8 : (4 * (p.TH + 1) * (p.KWs + 2) + 7) / 8;
-    if (nA > (s1 ? 18 : 60)) return false;                     // (the kernel's fixed piece slots: 24 / 36 / 60 pieces for the A tiles)
+    if (!f32 && nA > (s1 ? 18 : 60)) return false;             // (the kernel's fixed piece slots: 24 / 36 / 60 pieces for the A tiles)
+    if (f32 && !(kws == 8 || kws == 16 || kws == 32)) return false;
     if (2 * p.TH + 1 > 255 || 2 * p.KWs + 3 > 255) return false;
     p.tiles_w = g.BW / p.KWs; p.tiles_h = (g.BH + p.TH - 1) / p.TH;
     const long long nt = (long long)g.N * g.BD * p.tiles_h * p.tiles_w;
@@ -408,27 +604,30 @@ int m1_t3_wgrad(const WgradSpec& g, long long nw, int nb, hipStream_t st, int nm
     p.Rx = g.rx; p.rx_stride = stride; p.rx_bias = nloc; p.rx_mem = nmem > 1 ? rx_mem : 0;
     p.want_bsum = g.bsum != nullptr;
     // LDS: the stages, the scratch KB of the empty piece slots, the tile table (32 bytes per K-tile of a block + the padding stages)
-    const bool s2 = g.sh == 2;
-    const int nA = !s2 ? ((p.TH + 2) * (p.KWs + 2) + 7) / 8 : (4 * (p.TH + 1) * (p.KWs + 2) + 7) / 8;
-    const int stage_bytes = (bigb ? nA + 16 : 2 * nA + 8) * 1024;
+    const bool s2 = g.sh == 2, f32 = g.dtype == M1_F32;
+    const int nA = f32 ? ((p.TH + 2) * (p.KWs + 2) + 3) / 4 : (!s2 ? ((p.TH + 2) * (p.KWs + 2) + 7) / 8 : (4 * (p.TH + 1) * (p.KWs + 2) + 7) / 8);
+    const int stage_bytes = f32 ? (bigb ? nA + 32 : 2 * nA + 16) * 1024 : (bigb ? nA + 16 : 2 * nA + 8) * 1024;
     const long long tiles_per_block = (p.ntiles + nsplit - 1) / nsplit;
-    int S = 4;
+    int S = f32 ? 3 : 4;
     { static int fs = -1; if (fs < 0) { const char* e = getenv("M1_T3_STAGES"); fs = e ? atoi(e) : 0; } if (fs >= 2 && fs <= 5) S = fs; }
+    if (f32 && S > 3) S = 3;
     while (S >= 2 && (size_t)S * stage_bytes + 1024 + (size_t)(tiles_per_block + S) * 32 > 160 * 1024) --S;
     if (S < 2) return M1_ERR_UNSUPPORTED;
     p.stages = S;
     const size_t smem = (size_t)S * stage_bytes + 1024 + (size_t)(tiles_per_block + S) * 32;
     void (*kern)(T3P) = nullptr;
-    if (s2) kern = p.KWs == 8 ? wgrad_t3_kernel<8, true, 2> : (p.KWs == 16 ? wgrad_t3_kernel<16, true, 2> : (p.KWs == 32 ? wgrad_t3_kernel<32, true, 2> : wgrad_t3_kernel<0, true, 2>));
+    if (f32) kern = bigb ? (p.KWs == 8 ? wgrad_t3f_kernel<8, true> : (p.KWs == 16 ? wgrad_t3f_kernel<16, true> : wgrad_t3f_kernel<32, true>))
+                         : (p.KWs == 8 ? wgrad_t3f_kernel<8, false> : (p.KWs == 16 ? wgrad_t3f_kernel<16, false> : wgrad_t3f_kernel<32, false>));
+    else if (s2) kern = p.KWs == 8 ? wgrad_t3_kernel<8, true, 2> : (p.KWs == 16 ? wgrad_t3_kernel<16, true, 2> : (p.KWs == 32 ? wgrad_t3_kernel<32, true, 2> : wgrad_t3_kernel<0, true, 2>));
     else if (bigb) kern = p.KWs == 8 ? wgrad_t3_kernel<8, true, 1> : (p.KWs == 16 ? wgrad_t3_kernel<16, true, 1> : (p.KWs == 32 ? wgrad_t3_kernel<32, true, 1> : wgrad_t3_kernel<0, true, 1>));
     else kern = p.KWs == 8 ? wgrad_t3_kernel<8, false, 1> : (p.KWs == 16 ? wgrad_t3_kernel<16, false, 1> : (p.KWs == 32 ? wgrad_t3_kernel<32, false, 1> : wgrad_t3_kernel<0, false, 1>));
     {
-        static const void* done[12]; static int ndone = 0;
+        static const void* done[20]; static int ndone = 0;
         bool seen = false;
         for (int q = 0; q < ndone; ++q) seen |= done[q] == (const void*)kern;
         if (!seen) {
             if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return M1_ERR_LAUNCH;
-            if (ndone < 12) done[ndone++] = (const void*)kern;
+            if (ndone < 20) done[ndone++] = (const void*)kern;
         }
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)gx, (unsigned)nsplit, (unsigned)(gzu * g.kd)), dim3(T3_THREADS), smem, st, p);

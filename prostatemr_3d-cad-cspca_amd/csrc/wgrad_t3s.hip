@@ -1,0 +1,284 @@
+// wgrad_t3s.hip -- tap-fused fp32 weight gradient for the layers with FEW channels (the SE bottleneck convs: 8 / 16 / 32 channels
+// on one or both sides, stride 1, (3,3,3) or (1,3,3)) on v_mfma_f32_32x32x2_f32:
+//
+//   R[tap][a][b] += sum_{n,v} A[n, v + tap - p][a] * B[n, v][b]            the 9 (kh,kw) taps of one kd slice per block
+//
+// The per-tap kernel (wgrad_mfma.hip) reads X and dY once per tap: at (32,256,256) a 32 -> 32 (1,3,3) layer moves 9 x 0.54 GB for
+// 39 GFLOP and takes 1.7 ms -- 17 ms of the 56 ms C5 step (BASELINE.json configs[3], fp32) went to these layers.  Here
+// * a block owns the 9 taps of one kd slice of ONE 32 x 32 channel tile (channels beyond CA / CB are zero rows: the LDS-DMA
+//   fetches nothing for them); per K-tile of 128 output voxels (TH rows x KWs columns of one (n,d) slice) it stages the dY rows
+//   and the X rows INCLUDING the tap halo once, by LDS-DMA (rows of 128 bytes, no swizzle: a half wave reads 32 consecutive dwords);
+// * 12 waves = one block per CU: wave = (voxel quarter vq, tap row kh) accumulates the 32 x 32 tiles of its 3 kw taps over its 32
+//   voxels of the K-tile (3 MFMAs per voxel pair from 3 + 1 dword reads); the four quarters are summed in a fixed order through
+//   LDS when the block is done;
+// * tile table, fixed DMA piece slots, per-split partial copies + fixed-order fold as in wgrad_t3.hip (no float atomics).
+#include "common.h"
+#include "gather.h"
+#include <stdlib.h>
+
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+typedef int i32x4_t __attribute__((ext_vector_type(4)));
+
+#define TS_WAVES 12
+#define TS_THREADS (TS_WAVES * 64)
+#define TS_KT 128           // voxel slots per K-tile (4 quarters of 32)
+
+struct TSP {
+    const float* A; const float* B; float* Rx; long long rx_stride, rx_bias;
+    int CA, CB, AD, AH, AW, BD, BH, BW, N;
+    int pd, ph, pw, KD;
+    int tiles_w, tiles_h, ntiles, nsplit, stages;
+    int nau;                 // 32-channel units of A (blockIdx.z = unit * KD + kd), b units on blockIdx.x
+    int want_bsum;
+};
+
+__device__ __forceinline__ void ts_dma(i32x4_t rs, unsigned lds, unsigned voff) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" :: "s"(lds), "v"(voff), "s"(rs) : "memory");
+}
+
+template <int KWS>
+__global__ void __launch_bounds__(TS_THREADS, 3) wgrad_t3s_kernel(TSP p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int vq = wave / 3, kh = wave - 3 * vq;
+    constexpr int KWs = KWS, TH = TS_KT / KWS, AWt = KWs + 2, AHt = TH + 2, arows = AHt * AWt;
+    constexpr int nA = (arows + 7) / 8, nB = TS_KT / 8;       // 1 KB pieces (8 rows of 128 bytes)
+    constexpr int A_ITS = (nA + TS_WAVES - 1) / TS_WAVES, B_ITS = (nB + TS_WAVES - 1) / TS_WAVES, NP = A_ITS + B_ITS;
+    constexpr int stage_bytes = (nA + nB) * 1024;
+    const int kd = (int)blockIdx.z % p.KD, au = (int)blockIdx.z / p.KD;
+    const int a_base = au * 32, b_base = (int)blockIdx.x * 32;
+    constexpr unsigned OOB = 0x80000000u;
+    const unsigned lds0 = (unsigned)(unsigned long long)(lptr_t)smem;
+
+    // ---- this lane's LDS-DMA pieces: tile row r = hh * AWt + ww holds 32 channels (a 16-byte slot = 4 channels) ----
+    unsigned vo[NP]; int pk[NP]; int dst[NP];
+    const unsigned trash = lds0 + (unsigned)(p.stages * stage_bytes);
+#pragma unroll
+    for (int it = 0; it < NP; ++it) {
+        vo[it] = OOB; pk[it] = 0;
+        if (it < A_ITS) {
+            const int q = wave + TS_WAVES * it;
+            const bool real = q < nA;
+            dst[it] = real ? q * 1024 : -1;
+            const int s = q * 64 + lane, row = s >> 3, sl = s & 7;
+            const int hh = row / AWt, ww = row - hh * AWt;
+            pk[it] = hh | (ww << 8);
+            if (real && row < arows && a_base + sl * 4 < p.CA) vo[it] = (unsigned)(((hh * p.AW + ww) * p.CA + a_base + sl * 4) * 4);
+        } else {
+            const int q = wave + TS_WAVES * (it - A_ITS);
+            const bool real = q < nB;
+            dst[it] = real ? (nA + q) * 1024 : -1;
+            const int s = q * 64 + lane, kk = s >> 3, sl = s & 7;
+            const int th = kk / KWs, tw = kk - th * KWs;
+            pk[it] = th;
+            if (real && b_base + sl * 4 < p.CB) vo[it] = (unsigned)(((th * p.BW + tw) * p.CB + b_base + sl * 4) * 4);
+        }
+    }
+
+    // ---- tile table (see wgrad_t3.hip) ----
+    const int my_tiles = (p.ntiles - (int)blockIdx.y + p.nsplit - 1) / p.nsplit;
+    constexpr int RED_BYTES = 9 * 48 * 64 * 4;                 // the three other quarters' accumulators at the end
+    const int pipe_bytes = p.stages * stage_bytes + 1024;
+    int* const tab = reinterpret_cast<int*>(smem + (pipe_bytes > RED_BYTES ? pipe_bytes : RED_BYTES));
+    for (int t = tid; t < my_tiles + p.stages; t += TS_THREADS) {
+        int e[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (t < my_tiles) {
+            int r = (int)blockIdx.y + t * p.nsplit;
+            const int twi = r % p.tiles_w; r /= p.tiles_w;
+            const int thi = r % p.tiles_h; r /= p.tiles_h;
+            const int bd = r % p.BD, n = r / p.BD;
+            const int ad = bd + kd - p.pd, ah0 = thi * TH - p.ph, aw0 = twi * KWs - p.pw, bh0 = thi * TH;
+            const long long alin0 = (((long long)n * p.AD + ad) * p.AH + ah0) * p.AW + aw0;
+            const long long blin0 = (((long long)n * p.BD + bd) * p.BH + bh0) * p.BW + twi * KWs;
+            const unsigned long long pa = (unsigned long long)(p.A + alin0 * p.CA), pb = (unsigned long long)(p.B + blin0 * p.CB);
+            e[0] = (int)(unsigned)pa; e[1] = (int)((unsigned)(pa >> 32) & 0xffffu); e[2] = (unsigned)ad < (unsigned)p.AD ? 0x7fffffff : 0;
+            e[3] = (ah0 & 0xffff) | (aw0 << 16);
+            e[4] = (int)(unsigned)pb; e[5] = (int)((unsigned)(pb >> 32) & 0xffffu); e[6] = 0x7fffffff; e[7] = bh0;
+        }
+        reinterpret_cast<int4*>(tab)[2 * t] = make_int4(e[0], e[1], e[2], e[3]);
+        reinterpret_cast<int4*>(tab)[2 * t + 1] = make_int4(e[4], e[5], e[6], e[7]);
+    }
+    __syncthreads();
+    int q_e = 0;
+    int4 ea, eb;
+    auto fetch = [&]() {
+        ea = reinterpret_cast<const int4*>(tab)[2 * q_e]; eb = reinterpret_cast<const int4*>(tab)[2 * q_e + 1];
+        ++q_e;
+    };
+    auto issue = [&](int st) {
+        i32x4_t ra, rb;
+        ra.x = __builtin_amdgcn_readfirstlane(ea.x); ra.y = __builtin_amdgcn_readfirstlane(ea.y);
+        ra.z = __builtin_amdgcn_readfirstlane(ea.z); ra.w = 0x00020000;
+        rb.x = __builtin_amdgcn_readfirstlane(eb.x); rb.y = __builtin_amdgcn_readfirstlane(eb.y);
+        rb.z = __builtin_amdgcn_readfirstlane(eb.z); rb.w = 0x00020000;
+        const int ah0 = (ea.w << 16) >> 16, aw0 = ea.w >> 16, bh0 = eb.w;
+        const unsigned S0 = lds0 + (unsigned)(st * stage_bytes);
+#pragma unroll
+        for (int it = 0; it < NP; ++it) {
+            const unsigned d = dst[it] >= 0 ? S0 + (unsigned)dst[it] : trash;
+            if (it < A_ITS) {
+                const unsigned hh = (unsigned)(pk[it] & 0xff), ww = (unsigned)(pk[it] >> 8);
+                unsigned o = (hh + (unsigned)ah0) < (unsigned)p.AH ? vo[it] : OOB;
+                o = (ww + (unsigned)aw0) < (unsigned)p.AW ? o : OOB;
+                ts_dma(ra, d, o);
+            } else {
+                ts_dma(rb, d, (unsigned)(pk[it] + bh0) < (unsigned)p.BH ? vo[it] : OOB);
+            }
+        }
+    };
+
+    // fragments: lane l = (voxel of the pair g = l >> 5, channel c = l & 31): one dword per operand and MFMA.  Voxel slot of step
+    // k2: 32 vq + 2 k2 + g = tile row (32 vq + 2 k2) / KWs, column (2 k2) % KWs + g  (32 and KWs are multiples of each other)
+    const int g = lane >> 5, c = lane & 31;
+    const int thq = (32 * vq) / KWs, twq = (32 * vq) % KWs;
+    const unsigned char* const aL = smem + (((thq + kh) * AWt + twq + g) * 32 + c) * 4;
+    const unsigned char* const bL = smem + nA * 1024 + ((32 * vq + g) * 32 + c) * 4;
+
+    f32x16_t acc[3];
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+    const bool do_bsum = p.want_bsum && au == 0 && kd == 0 && kh == 0;
+    float accb = 0.f;
+
+    const int S = p.stages;                                    // 2 or 3
+    for (int s = 0; s < S - 1; ++s) { fetch(); issue(s); }
+    int st = 0;
+    for (int kt = blockIdx.y; kt < p.ntiles; kt += p.nsplit) {
+        fetch();
+        if (S == 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NP) : "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        int stn = st + S - 1; if (stn >= S) stn -= S;
+        issue(stn);
+        const unsigned char* const ap = aL + st * stage_bytes; const unsigned char* const bp = bL + st * stage_bytes;
+#pragma unroll 4
+        for (int k2 = 0; k2 < 16; ++k2) {
+            const int th = (2 * k2) / KWs, tw0 = (2 * k2) % KWs;
+            const unsigned char* a = ap + (th * AWt + tw0) * 128;
+            const float bf = *reinterpret_cast<const float*>(bp + (2 * k2) * 128);
+            const float af0 = *reinterpret_cast<const float*>(a), af1 = *reinterpret_cast<const float*>(a + 128),
+                        af2 = *reinterpret_cast<const float*>(a + 256);
+            if (do_bsum) accb += bf;
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af0, bf, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(af1, bf, acc[1], 0, 0, 0);
+            acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(af2, bf, acc[2], 0, 0, 0);
+        }
+        if (++st == S) st = 0;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                                           // every wave is done reading the stages: they become the reduction buffer
+
+    // ---- quarters 1..3 hand their accumulators to quarter 0 (fixed order of additions) ----
+    float* const red = reinterpret_cast<float*>(smem);         // [quarter - 1][kh][tap][e][lane]
+    float* const redb = red + 9 * 48 * 64;                     // bias sums [quarter][lane] (kh == 0 waves)  -- inside the table area: done with it
+    if (vq > 0) {
+        float* r = red + ((vq - 1) * 3 + kh) * 48 * 64;
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) r[(t * 16 + e) * 64 + lane] = acc[t][e];
+    }
+    if (do_bsum) redb[vq * 64 + lane] = accb;
+    __syncthreads();
+    if (vq > 0) return;
+#pragma unroll 1
+    for (int q = 0; q < 3; ++q) {                              // (rolled: 48 loads in flight at a time, not 144)
+        const float* r = red + (q * 3 + kh) * 48 * 64;
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[t][e] += r[(t * 16 + e) * 64 + lane];
+    }
+    float* Rx = p.Rx + (long long)blockIdx.y * p.rx_stride;
+    if (do_bsum) {
+        float sb = redb[lane] + redb[64 + lane];               // (quarter order 0, 1, 2, 3; then the two voxels of a pair)
+        sb += redb[128 + lane]; sb += redb[192 + lane];
+        sb += __shfl_xor(sb, 32);
+        if (lane < 32 && b_base + lane < p.CB) Rx[p.rx_bias + b_base + lane] = sb;
+    }
+    // D[a][b] of a 32x32 tile: lane holds b = lane & 31, a = (e & 3) + 8 (e >> 2) + 4 (lane >> 5)
+    const int b = b_base + (lane & 31);
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+        const long long tap = (long long)(kd * 3 + kh) * 3 + t;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int a = a_base + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+            if (a < p.CA && b < p.CB) Rx[(tap * p.CA + a) * p.CB + b] = acc[t][e];
+        }
+    }
+#endif
+}
+
+static bool ts_plan(const WgradSpec& g, TSP& p, int* kws_out) {
+    static int en = -1; if (en < 0) { const char* e = getenv("M1_WG_T3S"); en = e ? atoi(e) : 1; }
+    if (!en || g.dtype != M1_F32) return false;
+    if (g.CA % 4 || g.CB % 4 || g.CA < 4 || g.CB < 4) return false;
+    if (!(g.kh == 3 && g.kw == 3 && (g.kd == 1 || g.kd == 3))) return false;
+    if (!(g.sh == 1 && g.sw == 1 && g.sd == 1)) return false;
+    if (g.BW % 8) return false;
+    const int nau = (g.CA + 31) / 32, nbu = (g.CB + 31) / 32;
+    if (nau * nbu > 32) return false;                          // (every tile pair re-reads its operands: the wide layers have wgrad_t3f / the per-tap kernel)
+    if ((long long)(g.AH + 4) * g.AW * g.CA * 4 >= (1ll << 31) - 4096 || (long long)(g.BH + 20) * g.BW * g.CB * 4 >= (1ll << 31) - 4096) return false;
+    int kws = g.BW % 32 == 0 ? 32 : (g.BW % 16 == 0 ? 16 : 8);
+    p = TSP{};
+    p.A = (const float*)g.A; p.B = (const float*)g.B;
+    p.CA = g.CA; p.CB = g.CB; p.AD = g.AD; p.AH = g.AH; p.AW = g.AW; p.BD = g.BD; p.BH = g.BH; p.BW = g.BW; p.N = g.N;
+    p.pd = g.pd; p.ph = g.ph; p.pw = g.pw; p.KD = g.kd;
+    const int TH = TS_KT / kws;
+    p.tiles_w = g.BW / kws; p.tiles_h = (g.BH + TH - 1) / TH;
+    const long long nt = (long long)g.N * g.BD * p.tiles_h * p.tiles_w;
+    if (nt >= (1ll << 30) || nt < 4) return false;
+    p.ntiles = (int)nt; p.nau = nau;
+    *kws_out = kws;
+    return true;
+}
+bool m1_t3s_wgrad_supported(const WgradSpec& g) { TSP p; int k; return ts_plan(g, p, &k); }
+
+int m1_t3s_wgrad(const WgradSpec& g, long long nw, int nb, hipStream_t st) {
+    TSP p; int kws;
+    if (!ts_plan(g, p, &kws)) return M1_ERR_UNSUPPORTED;
+    const int nbu = (g.CB + 31) / 32;
+    const long long per_split = (long long)nbu * p.nau * g.kd;
+    static int tgt = -1; if (tgt < 0) { const char* e = getenv("M1_T3S_BLOCKS"); tgt = e ? atoi(e) : 256; }
+    long long nsplit = tgt / per_split; if (nsplit < 1) nsplit = 1;
+    const long long nloc = (long long)g.kd * 9 * g.CA * g.CB;
+    const long long stride = nloc + g.CB;
+    if (!g.rx || g.rx_floats < stride) return M1_ERR_WORKSPACE;
+    if (nsplit * stride > g.rx_floats) nsplit = g.rx_floats / stride;
+    if (nsplit > p.ntiles / 4) nsplit = p.ntiles / 4;          // >= 4 K-tiles per block
+    if (nsplit > 512) nsplit = 512;
+    if (nsplit < 1) nsplit = 1;
+    p.nsplit = (int)nsplit;
+    p.Rx = g.rx; p.rx_stride = stride; p.rx_bias = nloc;
+    p.want_bsum = g.bsum != nullptr;
+    const int TH = TS_KT / kws, arows = (TH + 2) * (kws + 2), nA = (arows + 7) / 8;
+    const int stage_bytes = (nA + TS_KT / 8) * 1024;
+    const long long tiles_per_block = (p.ntiles + nsplit - 1) / nsplit;
+    const size_t red_bytes = (size_t)9 * 48 * 64 * 4;
+    int S = 3;
+    auto need = [&](int s) { const size_t pipe = (size_t)s * stage_bytes + 1024; return (pipe > red_bytes ? pipe : red_bytes) + (size_t)(tiles_per_block + s) * 32 + 1024; };
+    while (S >= 2 && need(S) > 160 * 1024) --S;
+    if (S < 2 || (size_t)(tiles_per_block + S) * 32 < 4 * 64 * 4) {
+        if (S < 2) return M1_ERR_UNSUPPORTED;
+    }
+    p.stages = S;
+    size_t smem = need(S);
+    if (smem < red_bytes + 4 * 64 * 4 + 1024) smem = red_bytes + 4 * 64 * 4 + 1024;     // the bias sums sit behind the reduction buffer
+    void (*kern)(TSP) = kws == 32 ? wgrad_t3s_kernel<32> : (kws == 16 ? wgrad_t3s_kernel<16> : wgrad_t3s_kernel<8>);
+    {
+        static const void* done[4]; static int ndone = 0;
+        bool seen = false;
+        for (int q = 0; q < ndone; ++q) seen |= done[q] == (const void*)kern;
+        if (!seen) {
+            if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return M1_ERR_LAUNCH;
+            if (ndone < 4) done[ndone++] = (const void*)kern;
+        }
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)nbu, (unsigned)nsplit, (unsigned)(p.nau * g.kd)), dim3(TS_THREADS), smem, st, p);
+    int rc = m1_check_launch(); if (rc) return rc;
+    return m1_wg_rx_finish(p.Rx, stride, (int)nsplit, g, nloc, st);
+}

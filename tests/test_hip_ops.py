@@ -746,6 +746,42 @@ TF_CASES = [  # (N, D, H, W), cins, cout, k, s, transposed
 ]
 
 
+T3F_CASES = [      # fp32 weight gradients on the 64x64-tile tap-fused kernel (wgrad_t3f_kernel): >= 64 channels on both sides, stride 1
+    ((1, 4, 8, 16), [64], 128, (3, 3, 3)),          # two dY tiles per block, 16-column K-tiles
+    ((2, 4, 8, 8), [64, 64], 64, (3, 3, 3)),        # two concat units per block, 8-column K-tiles, two members in one launch
+    ((1, 2, 8, 32), [128], 128, (1, 3, 3)),         # 32-column K-tiles, (1,3,3) kernel
+    ((1, 4, 6, 16), [64], 64 + 64, (3, 3, 3)),      # ragged tile rows (6 = 4 + 2)
+    ((1, 4, 8, 16), [64, 64, 64], 64, (3, 3, 3)),   # odd number of units: ghost tile
+]
+
+
+T3F_CASES += [     # few channels: the 32x32-tile fp32 kernel (wgrad_t3s_kernel); channel counts that are not multiples of 32 are zero-padded tiles
+    ((1, 3, 8, 32), [32], 32, (3, 3, 3)),           # 32-column K-tiles
+    ((2, 2, 12, 16), [8], 8, (3, 3, 3)),            # 16-column K-tiles, ragged rows (12 = 8 + 4), 8 of 32 channels used
+    ((1, 4, 20, 8), [16, 8], 32, (1, 3, 3)),        # 8-column K-tiles, (1,3,3), two members (one launch each)
+    ((1, 2, 8, 16), [64], 12, (3, 3, 3)),           # two a units, 12 output channels
+    ((1, 2, 16, 16), [32], 72, (1, 3, 3)),          # three b units, the last one partial
+]
+
+
+@pytest.mark.parametrize("case", T3F_CASES)
+def test_t3_fp32_wgrad(dev, case):
+    dims, cins, cout, k = case
+    s = (1, 1, 1)
+    xs = [rnd((*dims, c), 50 + i) for i, c in enumerate(cins)]
+    w = rnd((*k, sum(cins), cout), 6, 1.0 / (sum(cins) * k[0] * k[1] * k[2]) ** 0.5); b = rnd((cout,), 7)
+    yo = O.conv3d_same(torch.cat(xs, -1).double(), w.double(), b.double(), s)
+    dy = rnd(tuple(yo.shape), 8)
+    yo, (gx, gw, gb) = _oracle_grads(lambda x, w_, b_: O.conv3d_same(x, w_, b_, s), [torch.cat(xs, -1), w, b], dy)
+    xd = [x.to(dev).requires_grad_(True) for x in xs]
+    wd, bd = w.to(dev).requires_grad_(True), b.to(dev).requires_grad_(True)
+    y = ops.conv3d_same(xd, wd, bd, k, s)
+    y.backward(dy.to(dev))
+    assert rel_err(wd.grad, gw) < 1e-4, "dw"
+    assert rel_err(bd.grad, gb) < 1e-4, "db"
+    assert rel_err(y, yo) < TOL[torch.float32], "y"
+
+
 @pytest.mark.parametrize("case", TF_CASES)
 def test_tap_fused_wgrad(dev, case, monkeypatch):
     # (run the suite once more with M1_TF64=1 / M1_HALO=2 / M1_TF_MAXC=512 to force the optional kernels onto these shapes)
