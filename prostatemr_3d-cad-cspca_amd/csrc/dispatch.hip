@@ -589,6 +589,13 @@ static int wgrad_common(const m1_conv_desc_t* d, bool T, const void* dy, float* 
             if (rc != M1_ERR_UNSUPPORTED && rc != M1_ERR_WORKSPACE) return rc;
             rc = M1_ERR_UNSUPPORTED;
         }
+        if (!g_force_direct && rx && g.dtype == M1_F32 && !T && m1_pwf_wgrad_supported(g)) {
+            rc = m1_pwf_wgrad(g, (long long)nw, nbias, st);
+            if (wlog) fprintf(stderr, "wgrad conv N%d B %dx%dx%d CA %d CB %d k111 -> pwf rc %d\n", g.N, g.BD, g.BH, g.BW, g.CA, g.CB, rc);
+            if (rc == M1_OK) { off += d->src[i].C; continue; }
+            if (rc != M1_ERR_UNSUPPORTED && rc != M1_ERR_WORKSPACE) return rc;
+            rc = M1_ERR_UNSUPPORTED;
+        }
         // fp32 layers the 64x64-tile kernel does not take (few channels on a side): the 32x32-tile tap-fused fp32 kernel
         if (!g_force_direct && rx && g.dtype == M1_F32 && m1_t3s_wgrad_supported(g)) {
             rc = m1_t3s_wgrad(g, (long long)nw, nbias, st);

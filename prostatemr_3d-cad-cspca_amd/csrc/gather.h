@@ -82,6 +82,9 @@ int m1_t3_wgrad(const WgradSpec& g, long long nw, int nb, hipStream_t st, int nm
 // fp32, few channels (<= 32 on a side or up to 32 tile pairs), stride 1: tap-fused kernel on 32x32 tiles (wgrad_t3s.hip)
 bool m1_t3s_wgrad_supported(const WgradSpec& g);
 int m1_t3s_wgrad(const WgradSpec& g, long long nw, int nb, hipStream_t st);
+// fp32 pointwise (1x1x1, stride 1) weight gradient: operand-stream-bound GEMM over the voxel list (wgrad_t3s.hip)
+bool m1_pwf_wgrad_supported(const WgradSpec& g);
+int m1_pwf_wgrad(const WgradSpec& g, long long nw, int nb, hipStream_t st);
 int m1_colsum_internal(const void* x, int N, long long V, int C, int dtype, float* out, float* ws, hipStream_t st, int accumulate);
 
 // deferred-fold switch of m1_wg_rx_finish (wgrad_tf.hip): returns the previous setting

@@ -761,6 +761,10 @@ T3F_CASES += [     # few channels: the 32x32-tile fp32 kernel (wgrad_t3s_kernel)
     ((1, 4, 20, 8), [16, 8], 32, (1, 3, 3)),        # 8-column K-tiles, (1,3,3), two members (one launch each)
     ((1, 2, 8, 16), [64], 12, (3, 3, 3)),           # two a units, 12 output channels
     ((1, 2, 16, 16), [32], 72, (1, 3, 3)),          # three b units, the last one partial
+    # pointwise layers: the operand-stream GEMM (wgrad_pwf_kernel)
+    ((1, 4, 8, 16), [64], 128, (1, 1, 1)),
+    ((1, 5, 9, 16), [20], 12, (1, 1, 1)),           # partial last K-tile (720 voxels), partial channel tiles
+    ((2, 4, 8, 16), [128, 32], 96, (1, 1, 1)),      # two members, two a units / two b units
 ]
 
 
