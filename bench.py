@@ -153,7 +153,8 @@ def cpu_baseline(workload, prob, dense, deep, dims, filters, kl_w, budget_s=75.0
 # kernel names behind each C-ABI entry-point family (the PMC pass sees kernels, the hipEvent timer sees entry points)
 _FAMILY_KERNELS = {
     "wgrad": (("conv3d_wgrad", "convT3d_wgrad"), ("wgrad_mfma_kernel", "wgrad_tap_kernel", "wgrad_tf_kernel", "wgrad_tf64_kernel", "wgrad_t3_kernel",
-                                                  "tf_finish_kernel")),
+                                                  "wgrad_t3f_kernel", "wgrad_t3s_kernel", "wgrad_pwf_kernel", "tf_finish_kernel",
+                                                  "tf_finish_batch_kernel")),
     "conv": (("conv3d_fwd", "conv3d_dgrad", "convT3d_fwd", "convT3d_dgrad"),
              ("conv_mfma_kernel", "conv_halo_kernel", "splitk_finish_kernel")),
 }

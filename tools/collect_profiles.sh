@@ -12,6 +12,7 @@ for WL in ${WLS:-C3 C2 C5}; do
   t=$(ls $O/kt_$WL/*/*kernel_trace.csv | head -1)
   python3 $R/tools/prof_table.py $t 1 70 > $O/${TAG}_${wl}_${DT}_by_grid_total.txt
   python3 $R/tools/trace_gaps.py $t 10 4 > $O/${TAG}_${wl}_${DT}_graph_step_timeline.txt
+  python3 $R/tools/trace_exclusive.py $t 10 4 > $O/${TAG}_${wl}_${DT}_exclusive_time.txt
   grep "^{" $O/bench_$WL.log > $O/${TAG}_${wl}_bench_under_rocprof.json
   rm -rf $O/kt_$WL
   [ -n "$QUICK" ] && continue
