@@ -68,7 +68,7 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_mfma_kernel(MfmaP p) {
     constexpr int A_BYTES = BM * 64, B_BYTES = BN * 64;
     constexpr int A_LD = BM * 4 / NTHR;                 // 16-B loads per thread per chunk for A
     constexpr int B_LD = (BN * 4 + NTHR - 1) / NTHR;    // for B
-    static_assert((NW == 4 || NW == 8) && (BM * 4) % NTHR == 0 && BN % 16 == 0, "tile config");
+    static_assert((NW == 4 || NW == 8 || NW == 16) && (BM * 4) % NTHR == 0 && BN % 16 == 0, "tile config");
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     // tables first (they must survive the epilogue tile, which reuses the pipeline buffers)
@@ -949,7 +949,12 @@ static int run_mfma(const GatherSpec& g, void* ws, int ws_packed, hipStream_t st
     // data gradient, -1.7 % per C3 step, C2 neutral.  256x128 tiles on 8 waves (one block per CU) were slower (702 / 678 us).
     static int c8 = -1; if (c8 < 0) { const char* e = getenv("M1_CONV8"); c8 = e ? atoi(e) : 1; }
     const bool use8 = c8 && BN == 128 && pl.ksplit == 1 && cdiv_ll(spec_maxM(g), 128) * spec_ncls(g) * (OCpad / 128) >= 160;
-    const int bm_eff = use8 ? 128 : pl.BM;
+    // M1_CONV16 (bf16): 256-row tiles, ONE block per CU with the waves of two 128-row blocks (16 waves of 64x32 for 128 columns,
+    // 8 waves of 64x80 for the 160-column pair tile): the weight tile crosses L2 -> LDS once per 256 rows instead of once per 128
+    static int c16 = -1; if (c16 < 0) { const char* e = getenv("M1_CONV16"); c16 = e ? atoi(e) : 0; }
+    const bool use16 = c16 && sizeof(T) == 2 && (BN == 128 || BN == 160) && pl.ksplit == 1 && (BN == 160 || use8) &&
+                       cdiv_ll(spec_maxM(g), 256) * spec_ncls(g) * (OCpad / BN) >= (c16 > 1 ? c16 : 256);
+    const int bm_eff = use16 ? 256 : (use8 ? 128 : pl.BM);
     bool fuse_stats = g.stats_out && g.stats_ws && g.mode == 0 && pl.ksplit == 1 && (g.N == 1 || Vout % bm_eff == 0) &&
                       !g.accumulate;           // (this kernel's statistics come from its own tile, before the add)
     if (fuse_stats) { mp.stat_partial = g.stats_ws; mp.stat_tiles = (int)cdiv_ll(Vout, bm_eff); }
@@ -1026,6 +1031,11 @@ static int run_mfma(const GatherSpec& g, void* ws, int ws_packed, hipStream_t st
     if (halo) rc2 = m1_halo_conv(mp, OCpad, st);
     else if (pw) rc2 = m1_pw_conv(mp, OCpad, pwBN, st);
     else
+    if (use16) {
+        if constexpr (sizeof(T) == 2) {
+            rc2 = BN == 128 ? launch_cfg<T, 256, 128, 4, 4>(mp, maxM, OCpad, st) : launch_cfg<T, 256, 160, 4, 2>(mp, maxM, OCpad, st);
+        } else rc2 = M1_ERR_UNSUPPORTED;
+    } else
     switch (BN) {
         case 128: rc2 = use8 ? launch_cfg<T, 128, 128, 2, 4>(mp, maxM, OCpad, st)
                              : (small ? launch_cfg<T, 64, 128, 1, 4>(mp, maxM, OCpad, st) : launch_cfg<T, 128, 128, 2, 2>(mp, maxM, OCpad, st)); break;
