@@ -25,6 +25,8 @@
 // * K-tiles are dealt round-robin to the blocks of a channel tile (blockIdx.y); every block stores its partial tiles into its
 //   own compact copy of the member's gradient block, folded in a fixed order by m1_wg_rx_finish (no float atomics);
 //   equal-width members of a concat share the launch.
+// wgrad_t3f_kernel below is the fp32 variant of the same block on v_mfma_f32_32x32x2_f32 (plain dword fragment reads, two stages);
+// wgrad_t3s.hip holds the fp32 kernels for layers with few channels and for pointwise layers.
 #include "common.h"
 #include "gather.h"
 #include <stdlib.h>

@@ -262,9 +262,7 @@ int m1_t3s_wgrad(const WgradSpec& g, long long nw, int nb, hipStream_t st) {
     int S = 3;
     auto need = [&](int s) { const size_t pipe = (size_t)s * stage_bytes + 1024; return (pipe > red_bytes ? pipe : red_bytes) + (size_t)(tiles_per_block + s) * 32 + 1024; };
     while (S >= 2 && need(S) > 160 * 1024) --S;
-    if (S < 2 || (size_t)(tiles_per_block + S) * 32 < 4 * 64 * 4) {
-        if (S < 2) return M1_ERR_UNSUPPORTED;
-    }
+    if (S < 2) return M1_ERR_UNSUPPORTED;
     p.stages = S;
     size_t smem = need(S);
     if (smem < red_bytes + 4 * 64 * 4 + 1024) smem = red_bytes + 4 * 64 * 4 + 1024;     // the bias sums sit behind the reduction buffer
