@@ -1085,7 +1085,9 @@ static int run_mfma(const GatherSpec& g, void* ws, int ws_packed, hipStream_t st
         }
         if (ok) {
             FinishStatsF<T> f{mp.acc32, pl.ksplit, ne, g.bias, g.bias2, g.oc_split, (T*)g.out, Vout, g.OC, fo, nullptr, nullptr, nullptr, nullptr, 0.f};
-            rc2 = m1_reduce_nc_launch<2>(f, g.N, Vout, g.OC, g.stats_ws, st); if (rc2) return rc2;
+            M1RedFin<2> fin{}; fin.mode = 1; fin.out = g.stats_out; fin.stats_V = Vout; fin.eps = g.stats_eps;
+            fin.out2 = g.stats_out2; fin.csplit = g.stats_out2 ? g.oc_split : 0;
+            rc2 = m1_reduce_nc_launch<2>(f, g.N, Vout, g.OC, g.stats_ws, st, &fin); if (rc2 || fin.mode) return rc2;
             return m1_reduce_finalize_launch<2>(g.stats_ws, g.N, g.OC, m1_red_nchunks(Vout, g.OC, g.N), g.stats_out, Vout, g.stats_eps, st, 0,
                                                 g.stats_out2, g.stats_out2 ? g.oc_split : 0);
         }
