@@ -22,12 +22,12 @@ typedef int i32x4_t __attribute__((ext_vector_type(4)));
 
 #define TS_WAVES 12
 #define TS_THREADS (TS_WAVES * 64)
-#define TS_KT 128           // voxel slots per K-tile (4 quarters of 32)
+#define TS_KT 128           // voxel slots per K-tile (4 quarters of 32); 64 for the stride-2 variant (its X tile is 4x the dY tile)
 
 struct TSP {
     const float* A; const float* B; float* Rx; long long rx_stride, rx_bias;
     int CA, CB, AD, AH, AW, BD, BH, BW, N;
-    int pd, ph, pw, KD;
+    int pd, ph, pw, KD, sd;
     int tiles_w, tiles_h, ntiles, nsplit, stages;
     int nau;                 // 32-channel units of A (blockIdx.z = unit * KD + kd), b units on blockIdx.x
     int want_bsum;
@@ -37,14 +37,17 @@ __device__ __forceinline__ void ts_dma(i32x4_t rs, unsigned lds, unsigned voff) 
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" :: "s"(lds), "v"(voff), "s"(rs) : "memory");
 }
 
-template <int KWS>
+// STR = stride of the gather in H and W (1, or 2: strided convs and, with the roles of the two sides swapped, transposed convs;
+// TF-SAME pad_before 0).  No de-interleaving as in the bf16 kernel: a dword fragment read is conflict-free whatever the rows.
+template <int KWS, int STR>
 __global__ void __launch_bounds__(TS_THREADS, 3) wgrad_t3s_kernel(TSP p) {
 #if defined(__HIP_DEVICE_COMPILE__)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int vq = wave / 3, kh = wave - 3 * vq;
-    constexpr int KWs = KWS, TH = TS_KT / KWS, AWt = KWs + 2, AHt = TH + 2, arows = AHt * AWt;
-    constexpr int nA = (arows + 7) / 8, nB = TS_KT / 8;       // 1 KB pieces (8 rows of 128 bytes)
+    constexpr int KT = STR == 1 ? TS_KT : TS_KT / 2, VPQ = KT / 4;
+    constexpr int KWs = KWS, TH = KT / KWS, AWt = STR == 1 ? KWs + 2 : 2 * KWs + 2, AHt = STR == 1 ? TH + 2 : 2 * TH + 1, arows = AHt * AWt;
+    constexpr int nA = (arows + 7) / 8, nB = KT / 8;          // 1 KB pieces (8 rows of 128 bytes)
     constexpr int A_ITS = (nA + TS_WAVES - 1) / TS_WAVES, B_ITS = (nB + TS_WAVES - 1) / TS_WAVES, NP = A_ITS + B_ITS;
     constexpr int stage_bytes = (nA + nB) * 1024;
     const int kd = (int)blockIdx.z % p.KD, au = (int)blockIdx.z / p.KD;
@@ -89,7 +92,7 @@ __global__ void __launch_bounds__(TS_THREADS, 3) wgrad_t3s_kernel(TSP p) {
             const int twi = r % p.tiles_w; r /= p.tiles_w;
             const int thi = r % p.tiles_h; r /= p.tiles_h;
             const int bd = r % p.BD, n = r / p.BD;
-            const int ad = bd + kd - p.pd, ah0 = thi * TH - p.ph, aw0 = twi * KWs - p.pw, bh0 = thi * TH;
+            const int ad = bd * p.sd + kd - p.pd, ah0 = thi * TH * STR - p.ph, aw0 = twi * KWs * STR - p.pw, bh0 = thi * TH;
             const long long alin0 = (((long long)n * p.AD + ad) * p.AH + ah0) * p.AW + aw0;
             const long long blin0 = (((long long)n * p.BD + bd) * p.BH + bh0) * p.BW + twi * KWs;
             const unsigned long long pa = (unsigned long long)(p.A + alin0 * p.CA), pb = (unsigned long long)(p.B + blin0 * p.CB);
@@ -132,9 +135,9 @@ __global__ void __launch_bounds__(TS_THREADS, 3) wgrad_t3s_kernel(TSP p) {
     // fragments: lane l = (voxel of the pair g = l >> 5, channel c = l & 31): one dword per operand and MFMA.  Voxel slot of step
     // k2: 32 vq + 2 k2 + g = tile row (32 vq + 2 k2) / KWs, column (2 k2) % KWs + g  (32 and KWs are multiples of each other)
     const int g = lane >> 5, c = lane & 31;
-    const int thq = (32 * vq) / KWs, twq = (32 * vq) % KWs;
-    const unsigned char* const aL = smem + (((thq + kh) * AWt + twq + g) * 32 + c) * 4;
-    const unsigned char* const bL = smem + nA * 1024 + ((32 * vq + g) * 32 + c) * 4;
+    const int thq = (VPQ * vq) / KWs, twq = (VPQ * vq) % KWs;
+    const unsigned char* const aL = smem + (((STR * thq + kh) * AWt + STR * (twq + g)) * 32 + c) * 4;
+    const unsigned char* const bL = smem + nA * 1024 + ((VPQ * vq + g) * 32 + c) * 4;
 
     f32x16_t acc[3];
 #pragma unroll
@@ -155,9 +158,9 @@ __global__ void __launch_bounds__(TS_THREADS, 3) wgrad_t3s_kernel(TSP p) {
         issue(stn);
         const unsigned char* const ap = aL + st * stage_bytes; const unsigned char* const bp = bL + st * stage_bytes;
 #pragma unroll 4
-        for (int k2 = 0; k2 < 16; ++k2) {
+        for (int k2 = 0; k2 < VPQ / 2; ++k2) {
             const int th = (2 * k2) / KWs, tw0 = (2 * k2) % KWs;
-            const unsigned char* a = ap + (th * AWt + tw0) * 128;
+            const unsigned char* a = ap + STR * (th * AWt + tw0) * 128;
             const float bf = *reinterpret_cast<const float*>(bp + (2 * k2) * 128);
             const float af0 = *reinterpret_cast<const float*>(a), af1 = *reinterpret_cast<const float*>(a + 128),
                         af2 = *reinterpret_cast<const float*>(a + 256);
@@ -218,17 +221,21 @@ static bool ts_plan(const WgradSpec& g, TSP& p, int* kws_out) {
     if (!en || g.dtype != M1_F32) return false;
     if (g.CA % 4 || g.CB % 4 || g.CA < 4 || g.CB < 4) return false;
     if (!(g.kh == 3 && g.kw == 3 && (g.kd == 1 || g.kd == 3))) return false;
-    if (!(g.sh == 1 && g.sw == 1 && g.sd == 1)) return false;
+    const bool s1 = g.sh == 1 && g.sw == 1 && g.sd == 1, s2 = g.sh == 2 && g.sw == 2 && (g.sd == 1 || g.sd == 2) && g.ph == 0 && g.pw == 0;
+    if (!s1 && !s2) return false;
     if (g.BW % 8) return false;
     const int nau = (g.CA + 31) / 32, nbu = (g.CB + 31) / 32;
-    if (nau * nbu > 32) return false;                          // (every tile pair re-reads its operands: the wide layers have wgrad_t3f / the per-tap kernel)
+    // every tile pair re-reads its operands: the wide stride-1 layers have wgrad_t3f; the strided / transposed ones (small volumes
+    // at the deep levels) only this kernel
+    if (nau * nbu > (s2 ? 128 : 32)) return false;
     if ((long long)(g.AH + 4) * g.AW * g.CA * 4 >= (1ll << 31) - 4096 || (long long)(g.BH + 20) * g.BW * g.CB * 4 >= (1ll << 31) - 4096) return false;
     int kws = g.BW % 32 == 0 ? 32 : (g.BW % 16 == 0 ? 16 : 8);
+    const int KT = s2 ? TS_KT / 2 : TS_KT;
     p = TSP{};
     p.A = (const float*)g.A; p.B = (const float*)g.B;
     p.CA = g.CA; p.CB = g.CB; p.AD = g.AD; p.AH = g.AH; p.AW = g.AW; p.BD = g.BD; p.BH = g.BH; p.BW = g.BW; p.N = g.N;
-    p.pd = g.pd; p.ph = g.ph; p.pw = g.pw; p.KD = g.kd;
-    const int TH = TS_KT / kws;
+    p.pd = g.pd; p.ph = g.ph; p.pw = g.pw; p.KD = g.kd; p.sd = g.sd;
+    const int TH = KT / kws;
     p.tiles_w = g.BW / kws; p.tiles_h = (g.BH + TH - 1) / TH;
     const long long nt = (long long)g.N * g.BD * p.tiles_h * p.tiles_w;
     if (nt >= (1ll << 30) || nt < 4) return false;
@@ -255,8 +262,10 @@ int m1_t3s_wgrad(const WgradSpec& g, long long nw, int nb, hipStream_t st) {
     p.nsplit = (int)nsplit;
     p.Rx = g.rx; p.rx_stride = stride; p.rx_bias = nloc;
     p.want_bsum = g.bsum != nullptr;
-    const int TH = TS_KT / kws, arows = (TH + 2) * (kws + 2), nA = (arows + 7) / 8;
-    const int stage_bytes = (nA + TS_KT / 8) * 1024;
+    const bool s2 = g.sh == 2;
+    const int KT = s2 ? TS_KT / 2 : TS_KT;
+    const int TH = KT / kws, arows = s2 ? (2 * TH + 1) * (2 * kws + 2) : (TH + 2) * (kws + 2), nA = (arows + 7) / 8;
+    const int stage_bytes = (nA + KT / 8) * 1024;
     const long long tiles_per_block = (p.ntiles + nsplit - 1) / nsplit;
     const size_t red_bytes = (size_t)9 * 48 * 64 * 4;
     int S = 3;
@@ -266,14 +275,15 @@ int m1_t3s_wgrad(const WgradSpec& g, long long nw, int nb, hipStream_t st) {
     p.stages = S;
     size_t smem = need(S);
     if (smem < red_bytes + 4 * 64 * 4 + 1024) smem = red_bytes + 4 * 64 * 4 + 1024;     // the bias sums sit behind the reduction buffer
-    void (*kern)(TSP) = kws == 32 ? wgrad_t3s_kernel<32> : (kws == 16 ? wgrad_t3s_kernel<16> : wgrad_t3s_kernel<8>);
+    void (*kern)(TSP) = s2 ? (kws == 32 ? wgrad_t3s_kernel<32, 2> : (kws == 16 ? wgrad_t3s_kernel<16, 2> : wgrad_t3s_kernel<8, 2>))
+                           : (kws == 32 ? wgrad_t3s_kernel<32, 1> : (kws == 16 ? wgrad_t3s_kernel<16, 1> : wgrad_t3s_kernel<8, 1>));
     {
-        static const void* done[4]; static int ndone = 0;
+        static const void* done[8]; static int ndone = 0;
         bool seen = false;
         for (int q = 0; q < ndone; ++q) seen |= done[q] == (const void*)kern;
         if (!seen) {
             if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return M1_ERR_LAUNCH;
-            if (ndone < 4) done[ndone++] = (const void*)kern;
+            if (ndone < 8) done[ndone++] = (const void*)kern;
         }
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)nbu, (unsigned)nsplit, (unsigned)(p.nau * g.kd)), dim3(TS_THREADS), smem, st, p);

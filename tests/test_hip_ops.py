@@ -786,6 +786,35 @@ def test_t3_fp32_wgrad(dev, case):
     assert rel_err(y, yo) < TOL[torch.float32], "y"
 
 
+T3S2_CASES = [     # fp32 strided / transposed weight gradients on wgrad_t3s_kernel<KWS, 2> (dims = the conv INPUT)
+    ((1, 2, 32, 32), [32], 64, (1, 3, 3), (1, 2, 2), False),      # 16-column K-tiles
+    ((1, 4, 16, 64), [16], 8, (3, 3, 3), (2, 2, 2), False),       # depth stride 2, 32-column K-tiles
+    ((2, 3, 24, 16), [64], 32, (3, 3, 3), (1, 2, 2), False),      # 8-column K-tiles, ragged rows, two a units
+    ((1, 2, 16, 16), [64], 32, (1, 3, 3), (1, 2, 2), True),       # transposed: dOut is the gathered side
+    ((1, 2, 8, 8), [128], 64, (3, 3, 3), (2, 2, 2), True),
+]
+
+
+@pytest.mark.parametrize("case", T3S2_CASES)
+def test_t3s_fp32_strided_wgrad(dev, case):
+    dims, cins, cout, k, s, transposed = case
+    xs = [rnd((*dims, c), 60 + i) for i, c in enumerate(cins)]
+    wshape = (*k, cout, sum(cins)) if transposed else (*k, sum(cins), cout)
+    w = rnd(wshape, 6, 1.0 / (sum(cins) * k[0] * k[1] * k[2]) ** 0.5); b = rnd((cout,), 7)
+    fo = O.conv3d_transpose_same if transposed else O.conv3d_same
+    yo = fo(torch.cat(xs, -1).double(), w.double(), b.double(), s)
+    dy = rnd(tuple(yo.shape), 8)
+    yo, (gx, gw, gb) = _oracle_grads(lambda x, w_, b_: fo(x, w_, b_, s), [torch.cat(xs, -1), w, b], dy)
+    fh = ops.conv3d_transpose_same if transposed else ops.conv3d_same
+    xd = [x.to(dev).requires_grad_(True) for x in xs]
+    wd, bd = w.to(dev).requires_grad_(True), b.to(dev).requires_grad_(True)
+    y = fh(xd, wd, bd, k, s)
+    y.backward(dy.to(dev))
+    assert rel_err(wd.grad, gw) < 1e-4, "dw"
+    assert rel_err(bd.grad, gb) < 1e-4, "db"
+    assert rel_err(y, yo) < TOL[torch.float32], "y"
+
+
 @pytest.mark.parametrize("case", TF_CASES)
 def test_tap_fused_wgrad(dev, case, monkeypatch):
     # (run the suite once more with M1_TF64=1 / M1_HALO=2 / M1_TF_MAXC=512 to force the optional kernels onto these shapes)
