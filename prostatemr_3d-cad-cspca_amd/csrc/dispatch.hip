@@ -216,7 +216,8 @@ static GatherSpec fwd_group_spec(const m1_conv_desc_t* d, const FwdGroups& fg, i
 // tap-fused kernel on (X8, dY) into a scratch gradient with 8 input rows per tap, and a fold of its first Cin rows.
 static bool stem_wanted(const m1_conv_desc_t* d, bool T) {
     static int en = -1; if (en < 0) { const char* e = getenv("M1_STEM_TF"); en = e ? atoi(e) : 1; }
-    return en && !T && !g_force_direct && d->dtype == M1_BF16 && d->nsrc == 1 && d->src[0].C < 8 && d->Cin == d->src[0].C;
+    // (fp32: the same with 4 channels = one 16-byte segment per voxel, on the fp32 tap-fused kernel)
+    return en && !T && !g_force_direct && d->nsrc == 1 && d->src[0].C < (d->dtype == M1_BF16 ? 8 : 4) && d->Cin == d->src[0].C;
 }
 static size_t stem_ws_bytes(const m1_conv_desc_t* d, bool T) {
     if (!stem_wanted(d, T)) return 0;
@@ -232,12 +233,19 @@ __global__ void __launch_bounds__(256) stem_pad8_kernel(const unsigned short* __
         x8[v] = o;
     }
 }
-// dw[t][ci][co] += r8[t][ci][co], ci < Cin   (dw was zeroed above when accumulate == 0)
-__global__ void __launch_bounds__(256) stem_fold_kernel(const float* __restrict__ r8, float* __restrict__ dw, int taps, int Cin, int Cout) {
+__global__ void __launch_bounds__(256) stem_pad4f_kernel(const float* __restrict__ x, float4* __restrict__ x4, long long nvox, int C) {
+    for (long long v = (long long)blockIdx.x * 256 + threadIdx.x; v < nvox; v += (long long)gridDim.x * 256) {
+        float e[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int c = 0; c < C; ++c) e[c] = x[v * C + c];
+        x4[v] = make_float4(e[0], e[1], e[2], e[3]);
+    }
+}
+// dw[t][ci][co] += r8[t][ci][co], ci < Cin   (dw was zeroed above when accumulate == 0); CP = padded channels of r8 (8 / 4)
+__global__ void __launch_bounds__(256) stem_fold_kernel(const float* __restrict__ r8, float* __restrict__ dw, int taps, int Cin, int Cout, int CP) {
     const int n = taps * Cin * Cout;
     for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
         const int co = i % Cout, ci = (i / Cout) % Cin, t = i / (Cout * Cin);
-        dw[i] += r8[((size_t)t * 8 + ci) * Cout + co];
+        dw[i] += r8[((size_t)t * CP + ci) * Cout + co];
     }
 }
 
@@ -509,11 +517,12 @@ static bool tf_wanted(const WgradSpec& g) {
 }
 static bool m1_tf_wgrad_supported_stem(const m1_conv_desc_t* d, const Geo& q) {
     WgradSpec g{};
+    const int CP = d->dtype == M1_BF16 ? 8 : 4;
     g.N = d->N; g.kd = d->kd; g.kh = d->kh; g.kw = d->kw; g.sd = d->sd; g.sh = d->sh; g.sw = d->sw;
     g.pd = q.pd; g.ph = q.ph; g.pw = q.pw; g.dtype = d->dtype;
-    g.CA = 8; g.AD = d->D; g.AH = d->H; g.AW = d->W; g.CB = d->Cout; g.BD = q.OD; g.BH = q.OH; g.BW = q.OW;
-    g.RT = (long long)8 * d->Cout; g.RSA = d->Cout;
-    return m1_tf_wgrad_supported(g);
+    g.CA = CP; g.AD = d->D; g.AH = d->H; g.AW = d->W; g.CB = d->Cout; g.BD = q.OD; g.BH = q.OH; g.BW = q.OW;
+    g.RT = (long long)CP * d->Cout; g.RSA = d->Cout;
+    return d->dtype == M1_BF16 ? m1_tf_wgrad_supported(g) : m1_t3s_wgrad_supported(g);
 }
 static int wgrad_common(const m1_conv_desc_t* d, bool T, const void* dy, float* dw, float* db, void* ws, hipStream_t st,
                         int accumulate) {
@@ -536,25 +545,28 @@ static int wgrad_common(const m1_conv_desc_t* d, bool T, const void* dy, float* 
         const int taps = d->kd * d->kh * d->kw, Cin = d->Cin;
         const long long nvox = (long long)d->N * d->D * d->H * d->W;
         unsigned char* base = (unsigned char*)ws + align256(m1_reduce_ws_floats(d->N, (long long)q.OD * q.OH * q.OW, d->Cout, 1) * sizeof(float)) + 256;
+        const bool f32 = d->dtype == M1_F32;
+        const int CP = f32 ? 4 : 8;                       // padded channels: one 16-byte segment per voxel
         uint4* x8 = reinterpret_cast<uint4*>(base);
         float* r8 = reinterpret_cast<float*>(base + align256((size_t)nvox * 16));
-        const size_t nw8 = (size_t)taps * 8 * d->Cout;
+        const size_t nw8 = (size_t)taps * CP * d->Cout;
         if (hipMemsetAsync(r8, 0, nw8 * sizeof(float), st) != hipSuccess) return M1_ERR_LAUNCH;
         long long pb = (nvox + 255) / 256; if (pb > 8192) pb = 8192;
-        hipLaunchKernelGGL(stem_pad8_kernel, dim3((unsigned)pb), dim3(256), 0, st, (const unsigned short*)d->src[0].ptr, x8, nvox, Cin);
+        if (f32) hipLaunchKernelGGL(stem_pad4f_kernel, dim3((unsigned)pb), dim3(256), 0, st, (const float*)d->src[0].ptr, reinterpret_cast<float4*>(x8), nvox, Cin);
+        else hipLaunchKernelGGL(stem_pad8_kernel, dim3((unsigned)pb), dim3(256), 0, st, (const unsigned short*)d->src[0].ptr, x8, nvox, Cin);
         WgradSpec g{};
         g.N = d->N; g.R = r8; g.kd = d->kd; g.kh = d->kh; g.kw = d->kw; g.sd = d->sd; g.sh = d->sh; g.sw = d->sw;
         g.pd = q.pd; g.ph = q.ph; g.pw = q.pw; g.dtype = d->dtype;
-        g.A = x8; g.CA = 8; g.AD = d->D; g.AH = d->H; g.AW = d->W;
+        g.A = x8; g.CA = CP; g.AD = d->D; g.AH = d->H; g.AW = d->W;
         g.B = dy; g.CB = d->Cout; g.BD = q.OD; g.BH = q.OH; g.BW = q.OW;
-        g.RT = (long long)8 * d->Cout; g.RSA = d->Cout; g.a_off = 0; g.b_off = 0;
+        g.RT = (long long)CP * d->Cout; g.RSA = d->Cout; g.a_off = 0; g.b_off = 0;
         g.rx = rx; g.rx_floats = rx_floats;
         if (fuse_db) { g.bsum = db; g.bsum_tap = (q.pd * d->kh + q.ph) * d->kw + q.pw; }
         const int was = m1_fold_defer_set(0);          // (stem_fold_kernel below reads the folded 8-channel gradient)
-        int rc = m1_tf_wgrad(g, (long long)nw8, nbias, st);
+        int rc = f32 ? m1_t3s_wgrad(g, (long long)nw8, nbias, st) : m1_tf_wgrad(g, (long long)nw8, nbias, st);
         m1_fold_defer_set(was);
         if (rc == M1_OK) {
-            hipLaunchKernelGGL(stem_fold_kernel, dim3((taps * Cin * d->Cout + 255) / 256), dim3(256), 0, st, r8, dw, taps, Cin, d->Cout);
+            hipLaunchKernelGGL(stem_fold_kernel, dim3((taps * Cin * d->Cout + 255) / 256), dim3(256), 0, st, r8, dw, taps, Cin, d->Cout, CP);
             return m1_check_launch();
         }
         if (rc != M1_ERR_UNSUPPORTED && rc != M1_ERR_WORKSPACE) return rc;      // declined: nothing launched, take the generic path

@@ -17,6 +17,12 @@
 #include <stdlib.h>
 
 typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4s_t;
+template <int TL> struct TsAcc;
+template <> struct TsAcc<32> { typedef f32x16_t type; static constexpr int NE = 16, VG = 2;
+    static __device__ __forceinline__ type mfma(float a, float b, type c) { return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0); } };
+template <> struct TsAcc<16> { typedef f32x4s_t type; static constexpr int NE = 4, VG = 4;
+    static __device__ __forceinline__ type mfma(float a, float b, type c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); } };
 typedef __attribute__((address_space(3))) void* lptr_t;
 typedef int i32x4_t __attribute__((ext_vector_type(4)));
 
@@ -39,7 +45,9 @@ __device__ __forceinline__ void ts_dma(i32x4_t rs, unsigned lds, unsigned voff) 
 
 // STR = stride of the gather in H and W (1, or 2: strided convs and, with the roles of the two sides swapped, transposed convs;
 // TF-SAME pad_before 0).  No de-interleaving as in the bf16 kernel: a dword fragment read is conflict-free whatever the rows.
-template <int KWS, int STR>
+// TL = channel tile: 32 (v_mfma_f32_32x32x2_f32, a voxel pair per MFMA) or 16 (v_mfma_f32_16x16x4_f32, four voxels per MFMA) for the
+// layers with <= 16 channels on a side -- padded to 32 they did 4-16x the work (8 -> 8 at (32,256,256): 0.92 ms).
+template <int KWS, int STR, int TL>
 __global__ void __launch_bounds__(TS_THREADS, 3) wgrad_t3s_kernel(TSP p) {
 #if defined(__HIP_DEVICE_COMPILE__)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -51,7 +59,9 @@ __global__ void __launch_bounds__(TS_THREADS, 3) wgrad_t3s_kernel(TSP p) {
     constexpr int A_ITS = (nA + TS_WAVES - 1) / TS_WAVES, B_ITS = (nB + TS_WAVES - 1) / TS_WAVES, NP = A_ITS + B_ITS;
     constexpr int stage_bytes = (nA + nB) * 1024;
     const int kd = (int)blockIdx.z % p.KD, au = (int)blockIdx.z / p.KD;
-    const int a_base = au * 32, b_base = (int)blockIdx.x * 32;
+    const int a_base = au * TL, b_base = (int)blockIdx.x * TL;
+    typedef typename TsAcc<TL>::type acc_t;
+    constexpr int NE = TsAcc<TL>::NE, VG = TsAcc<TL>::VG, CL = 64 / VG;      // accumulator registers, voxels per MFMA, lanes per voxel
     constexpr unsigned OOB = 0x80000000u;
     const unsigned lds0 = (unsigned)(unsigned long long)(lptr_t)smem;
 
@@ -68,7 +78,7 @@ __global__ void __launch_bounds__(TS_THREADS, 3) wgrad_t3s_kernel(TSP p) {
             const int s = q * 64 + lane, row = s >> 3, sl = s & 7;
             const int hh = row / AWt, ww = row - hh * AWt;
             pk[it] = hh | (ww << 8);
-            if (real && row < arows && a_base + sl * 4 < p.CA) vo[it] = (unsigned)(((hh * p.AW + ww) * p.CA + a_base + sl * 4) * 4);
+            if (real && row < arows && sl * 4 < TL && a_base + sl * 4 < p.CA) vo[it] = (unsigned)(((hh * p.AW + ww) * p.CA + a_base + sl * 4) * 4);
         } else {
             const int q = wave + TS_WAVES * (it - A_ITS);
             const bool real = q < nB;
@@ -76,13 +86,13 @@ __global__ void __launch_bounds__(TS_THREADS, 3) wgrad_t3s_kernel(TSP p) {
             const int s = q * 64 + lane, kk = s >> 3, sl = s & 7;
             const int th = kk / KWs, tw = kk - th * KWs;
             pk[it] = th;
-            if (real && b_base + sl * 4 < p.CB) vo[it] = (unsigned)(((th * p.BW + tw) * p.CB + b_base + sl * 4) * 4);
+            if (real && sl * 4 < TL && b_base + sl * 4 < p.CB) vo[it] = (unsigned)(((th * p.BW + tw) * p.CB + b_base + sl * 4) * 4);
         }
     }
 
     // ---- tile table (see wgrad_t3.hip) ----
     const int my_tiles = (p.ntiles - (int)blockIdx.y + p.nsplit - 1) / p.nsplit;
-    constexpr int RED_BYTES = 9 * 48 * 64 * 4;                 // the three other quarters' accumulators at the end
+    constexpr int RED_BYTES = 9 * 3 * NE * 64 * 4;             // the three other quarters' accumulators at the end
     const int pipe_bytes = p.stages * stage_bytes + 1024;
     int* const tab = reinterpret_cast<int*>(smem + (pipe_bytes > RED_BYTES ? pipe_bytes : RED_BYTES));
     for (int t = tid; t < my_tiles + p.stages; t += TS_THREADS) {
@@ -134,16 +144,16 @@ __global__ void __launch_bounds__(TS_THREADS, 3) wgrad_t3s_kernel(TSP p) {
 
     // fragments: lane l = (voxel of the pair g = l >> 5, channel c = l & 31): one dword per operand and MFMA.  Voxel slot of step
     // k2: 32 vq + 2 k2 + g = tile row (32 vq + 2 k2) / KWs, column (2 k2) % KWs + g  (32 and KWs are multiples of each other)
-    const int g = lane >> 5, c = lane & 31;
+    const int g = lane / CL, c = lane % CL;
     const int thq = (VPQ * vq) / KWs, twq = (VPQ * vq) % KWs;
     const unsigned char* const aL = smem + (((STR * thq + kh) * AWt + STR * (twq + g)) * 32 + c) * 4;
     const unsigned char* const bL = smem + nA * 1024 + ((VPQ * vq + g) * 32 + c) * 4;
 
-    f32x16_t acc[3];
+    acc_t acc[3];
 #pragma unroll
     for (int t = 0; t < 3; ++t)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+        for (int e = 0; e < NE; ++e) acc[t][e] = 0.f;
     const bool do_bsum = p.want_bsum && au == 0 && kd == 0 && kh == 0;
     float accb = 0.f;
 
@@ -158,16 +168,16 @@ __global__ void __launch_bounds__(TS_THREADS, 3) wgrad_t3s_kernel(TSP p) {
         issue(stn);
         const unsigned char* const ap = aL + st * stage_bytes; const unsigned char* const bp = bL + st * stage_bytes;
 #pragma unroll 4
-        for (int k2 = 0; k2 < VPQ / 2; ++k2) {
-            const int th = (2 * k2) / KWs, tw0 = (2 * k2) % KWs;
+        for (int k2 = 0; k2 < VPQ / VG; ++k2) {
+            const int th = (VG * k2) / KWs, tw0 = (VG * k2) % KWs;
             const unsigned char* a = ap + STR * (th * AWt + tw0) * 128;
-            const float bf = *reinterpret_cast<const float*>(bp + (2 * k2) * 128);
+            const float bf = *reinterpret_cast<const float*>(bp + (VG * k2) * 128);
             const float af0 = *reinterpret_cast<const float*>(a), af1 = *reinterpret_cast<const float*>(a + 128),
                         af2 = *reinterpret_cast<const float*>(a + 256);
             if (do_bsum) accb += bf;
-            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af0, bf, acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(af1, bf, acc[1], 0, 0, 0);
-            acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(af2, bf, acc[2], 0, 0, 0);
+            acc[0] = TsAcc<TL>::mfma(af0, bf, acc[0]);
+            acc[1] = TsAcc<TL>::mfma(af1, bf, acc[1]);
+            acc[2] = TsAcc<TL>::mfma(af2, bf, acc[2]);
         }
         if (++st == S) st = 0;
     }
@@ -176,40 +186,41 @@ __global__ void __launch_bounds__(TS_THREADS, 3) wgrad_t3s_kernel(TSP p) {
 
     // ---- quarters 1..3 hand their accumulators to quarter 0 (fixed order of additions) ----
     float* const red = reinterpret_cast<float*>(smem);         // [quarter - 1][kh][tap][e][lane]
-    float* const redb = red + 9 * 48 * 64;                     // bias sums [quarter][lane] (kh == 0 waves)  -- inside the table area: done with it
+    float* const redb = red + 9 * 3 * NE * 64;                 // bias sums [quarter][lane] (kh == 0 waves)  -- inside the table area: done with it
     if (vq > 0) {
-        float* r = red + ((vq - 1) * 3 + kh) * 48 * 64;
+        float* r = red + ((vq - 1) * 3 + kh) * 3 * NE * 64;
 #pragma unroll
         for (int t = 0; t < 3; ++t)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) r[(t * 16 + e) * 64 + lane] = acc[t][e];
+            for (int e = 0; e < NE; ++e) r[(t * NE + e) * 64 + lane] = acc[t][e];
     }
     if (do_bsum) redb[vq * 64 + lane] = accb;
     __syncthreads();
     if (vq > 0) return;
 #pragma unroll 1
     for (int q = 0; q < 3; ++q) {                              // (rolled: 48 loads in flight at a time, not 144)
-        const float* r = red + (q * 3 + kh) * 48 * 64;
+        const float* r = red + (q * 3 + kh) * 3 * NE * 64;
 #pragma unroll
         for (int t = 0; t < 3; ++t)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) acc[t][e] += r[(t * 16 + e) * 64 + lane];
+            for (int e = 0; e < NE; ++e) acc[t][e] += r[(t * NE + e) * 64 + lane];
     }
     float* Rx = p.Rx + (long long)blockIdx.y * p.rx_stride;
     if (do_bsum) {
         float sb = redb[lane] + redb[64 + lane];               // (quarter order 0, 1, 2, 3; then the two voxels of a pair)
         sb += redb[128 + lane]; sb += redb[192 + lane];
-        sb += __shfl_xor(sb, 32);
-        if (lane < 32 && b_base + lane < p.CB) Rx[p.rx_bias + b_base + lane] = sb;
+        sb += __shfl_xor(sb, 32);                              // ... then the voxels of a group
+        if (TL == 16) sb += __shfl_xor(sb, 16);
+        if (lane < CL && b_base + lane < p.CB) Rx[p.rx_bias + b_base + lane] = sb;
     }
-    // D[a][b] of a 32x32 tile: lane holds b = lane & 31, a = (e & 3) + 8 (e >> 2) + 4 (lane >> 5)
-    const int b = b_base + (lane & 31);
+    // D[a][b]: 32x32 tile: lane holds b = lane & 31, a = (e & 3) + 8 (e >> 2) + 4 (lane >> 5); 16x16 tile: b = lane & 15, a = 4 (lane >> 4) + e
+    const int b = b_base + c;
 #pragma unroll
     for (int t = 0; t < 3; ++t) {
         const long long tap = (long long)(kd * 3 + kh) * 3 + t;
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int a = a_base + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+        for (int e = 0; e < NE; ++e) {
+            const int a = a_base + (TL == 32 ? (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5) : 4 * (lane >> 4) + e);
             if (a < p.CA && b < p.CB) Rx[(tap * p.CA + a) * p.CB + b] = acc[t][e];
         }
     }
@@ -224,7 +235,8 @@ static bool ts_plan(const WgradSpec& g, TSP& p, int* kws_out) {
     const bool s1 = g.sh == 1 && g.sw == 1 && g.sd == 1, s2 = g.sh == 2 && g.sw == 2 && (g.sd == 1 || g.sd == 2) && g.ph == 0 && g.pw == 0;
     if (!s1 && !s2) return false;
     if (g.BW % 8) return false;
-    const int nau = (g.CA + 31) / 32, nbu = (g.CB + 31) / 32;
+    const int TLh = (g.CA <= 16 || g.CB <= 16) ? 16 : 32;
+    const int nau = (g.CA + TLh - 1) / TLh, nbu = (g.CB + TLh - 1) / TLh;
     // every tile pair re-reads its operands: the wide stride-1 layers have wgrad_t3f; the strided / transposed ones (small volumes
     // at the deep levels) only this kernel
     if (nau * nbu > (s2 ? 128 : 32)) return false;
@@ -248,7 +260,8 @@ bool m1_t3s_wgrad_supported(const WgradSpec& g) { TSP p; int k; return ts_plan(g
 int m1_t3s_wgrad(const WgradSpec& g, long long nw, int nb, hipStream_t st) {
     TSP p; int kws;
     if (!ts_plan(g, p, &kws)) return M1_ERR_UNSUPPORTED;
-    const int nbu = (g.CB + 31) / 32;
+    const int TLh = (g.CA <= 16 || g.CB <= 16) ? 16 : 32;
+    const int nbu = (g.CB + TLh - 1) / TLh;
     const long long per_split = (long long)nbu * p.nau * g.kd;
     static int tgt = -1; if (tgt < 0) { const char* e = getenv("M1_T3S_BLOCKS"); tgt = e ? atoi(e) : 256; }
     long long nsplit = tgt / per_split; if (nsplit < 1) nsplit = 1;
@@ -267,7 +280,7 @@ int m1_t3s_wgrad(const WgradSpec& g, long long nw, int nb, hipStream_t st) {
     const int TH = KT / kws, arows = s2 ? (2 * TH + 1) * (2 * kws + 2) : (TH + 2) * (kws + 2), nA = (arows + 7) / 8;
     const int stage_bytes = (nA + KT / 8) * 1024;
     const long long tiles_per_block = (p.ntiles + nsplit - 1) / nsplit;
-    const size_t red_bytes = (size_t)9 * 48 * 64 * 4;
+    const size_t red_bytes = (size_t)9 * 3 * (TLh == 32 ? 16 : 4) * 64 * 4;
     int S = 3;
     auto need = [&](int s) { const size_t pipe = (size_t)s * stage_bytes + 1024; return (pipe > red_bytes ? pipe : red_bytes) + (size_t)(tiles_per_block + s) * 32 + 1024; };
     while (S >= 2 && need(S) > 160 * 1024) --S;
@@ -275,15 +288,17 @@ int m1_t3s_wgrad(const WgradSpec& g, long long nw, int nb, hipStream_t st) {
     p.stages = S;
     size_t smem = need(S);
     if (smem < red_bytes + 4 * 64 * 4 + 1024) smem = red_bytes + 4 * 64 * 4 + 1024;     // the bias sums sit behind the reduction buffer
-    void (*kern)(TSP) = s2 ? (kws == 32 ? wgrad_t3s_kernel<32, 2> : (kws == 16 ? wgrad_t3s_kernel<16, 2> : wgrad_t3s_kernel<8, 2>))
-                           : (kws == 32 ? wgrad_t3s_kernel<32, 1> : (kws == 16 ? wgrad_t3s_kernel<16, 1> : wgrad_t3s_kernel<8, 1>));
+    void (*kern)(TSP) = nullptr;
+#define TSK(K_, S_) (TLh == 32 ? wgrad_t3s_kernel<K_, S_, 32> : wgrad_t3s_kernel<K_, S_, 16>)
+    kern = s2 ? (kws == 32 ? TSK(32, 2) : (kws == 16 ? TSK(16, 2) : TSK(8, 2))) : (kws == 32 ? TSK(32, 1) : (kws == 16 ? TSK(16, 1) : TSK(8, 1)));
+#undef TSK
     {
-        static const void* done[8]; static int ndone = 0;
+        static const void* done[16]; static int ndone = 0;
         bool seen = false;
         for (int q = 0; q < ndone; ++q) seen |= done[q] == (const void*)kern;
         if (!seen) {
             if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return M1_ERR_LAUNCH;
-            if (ndone < 8) done[ndone++] = (const void*)kern;
+            if (ndone < 16) done[ndone++] = (const void*)kern;
         }
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)nbu, (unsigned)nsplit, (unsigned)(p.nau * g.kd)), dim3(TS_THREADS), smem, st, p);
