@@ -1041,15 +1041,17 @@ static int run_mfma(const GatherSpec& g, void* ws, int ws_packed, hipStream_t st
                              : (small ? launch_cfg<T, 64, 128, 1, 4>(mp, maxM, OCpad, st) : launch_cfg<T, 128, 128, 2, 2>(mp, maxM, OCpad, st)); break;
         case 160: if constexpr (sizeof(T) == 2) { rc2 = launch_cfg<T, 128, 160, 2, 2>(mp, maxM, OCpad, st); } else rc2 = M1_ERR_UNSUPPORTED; break;
         case 64: {
-            // fp32, 64 columns: 8 waves of 32x32 (M1_F32_W8): an fp32 MFMA is 1/16 of a bf16 one per cycle, the LDS has room for the
-            // extra fragment reads and two more waves per SIMD hide the operand latency (54 % MFMA-busy with 4 waves of 32x64)
-            static int w8 = -1; if (w8 < 0) { const char* e = getenv("M1_F32_W8"); w8 = e ? atoi(e) : 1; }
-            if (sizeof(T) == 4 && w8 && !small) rc2 = launch_cfg<T, 128, 64, 4, 2>(mp, maxM, OCpad, st);
+            // 64 / 32 columns on 8 waves of 32x32 / 32x16 instead of 4 waves of 32x64 / 32x32 (M1_F32_W8: bit 0 fp32, bit 1 bf16).  fp32: an
+            // MFMA is 1/16 of a bf16 one per cycle, the LDS has room for the extra fragment reads and the extra waves hide the operand
+            // latency (54 % MFMA-busy with 4 waves; C5 40.18 -> 39.95 ms).  bf16: these tiles are latency-bound (10-15 % MFMA-busy): C2
+            // 7.86 -> 7.59 ms, C3 neutral
+            static int w8 = -1; if (w8 < 0) { const char* e = getenv("M1_F32_W8"); w8 = e ? atoi(e) : 3; }
+            if (((sizeof(T) == 4 && (w8 & 1)) || (sizeof(T) == 2 && (w8 & 2))) && !small) rc2 = launch_cfg<T, 128, 64, 4, 2>(mp, maxM, OCpad, st);
             else rc2 = small ? launch_cfg<T, 64, 64, 2, 2>(mp, maxM, OCpad, st) : launch_cfg<T, 128, 64, 4, 1>(mp, maxM, OCpad, st);
             break; }
         case 32: {
-            static int w8 = -1; if (w8 < 0) { const char* e = getenv("M1_F32_W8"); w8 = e ? atoi(e) : 1; }
-            if (sizeof(T) == 4 && w8 && !small) rc2 = launch_cfg<T, 128, 32, 4, 2>(mp, maxM, OCpad, st);
+            static int w8 = -1; if (w8 < 0) { const char* e = getenv("M1_F32_W8"); w8 = e ? atoi(e) : 3; }
+            if (((sizeof(T) == 4 && (w8 & 1)) || (sizeof(T) == 2 && (w8 & 2))) && !small) rc2 = launch_cfg<T, 128, 32, 4, 2>(mp, maxM, OCpad, st);
             else rc2 = small ? launch_cfg<T, 64, 32, 4, 1>(mp, maxM, OCpad, st) : launch_cfg<T, 128, 32, 4, 1>(mp, maxM, OCpad, st);
             break; }
         default:  rc2 = small ? launch_cfg<T, 64, 16, 4, 1>(mp, maxM, OCpad, st) : launch_cfg<T, 128, 16, 4, 1>(mp, maxM, OCpad, st); break;
