@@ -948,7 +948,8 @@ static int run_mfma(const GatherSpec& g, void* ws, int ws_packed, hipStream_t st
     // its data gradient, neutral end to end; with the stacked passes (4 volumes per launch): 647 -> 624 us forward, 613 -> 557 us
     // data gradient, -1.7 % per C3 step, C2 neutral.  256x128 tiles on 8 waves (one block per CU) were slower (702 / 678 us).
     static int c8 = -1; if (c8 < 0) { const char* e = getenv("M1_CONV8"); c8 = e ? atoi(e) : 1; }
-    const bool use8 = c8 && BN == 128 && pl.ksplit == 1 && cdiv_ll(spec_maxM(g), 128) * spec_ncls(g) * (OCpad / 128) >= 160;
+    const bool use8 = c8 && BN == 128 && (pl.ksplit == 1 || (c8 >= 2 && pl.BM == 128)) &&
+                      cdiv_ll(spec_maxM(g), 128) * spec_ncls(g) * (OCpad / 128) * pl.ksplit >= 160;
     // M1_CONV16 (bf16): 256-row tiles, ONE block per CU with the waves of two 128-row blocks (16 waves of 64x32 for 128 columns,
     // 8 waves of 64x80 for the 160-column pair tile): the weight tile crosses L2 -> LDS once per 256 rows instead of once per 128
     static int c16 = -1; if (c16 < 0) { const char* e = getenv("M1_CONV16"); c16 = e ? atoi(e) : 0; }
@@ -1039,7 +1040,10 @@ static int run_mfma(const GatherSpec& g, void* ws, int ws_packed, hipStream_t st
     switch (BN) {
         case 128: rc2 = use8 ? launch_cfg<T, 128, 128, 2, 4>(mp, maxM, OCpad, st)
                              : (small ? launch_cfg<T, 64, 128, 1, 4>(mp, maxM, OCpad, st) : launch_cfg<T, 128, 128, 2, 2>(mp, maxM, OCpad, st)); break;
-        case 160: if constexpr (sizeof(T) == 2) { rc2 = launch_cfg<T, 128, 160, 2, 2>(mp, maxM, OCpad, st); } else rc2 = M1_ERR_UNSUPPORTED; break;
+        case 160: if constexpr (sizeof(T) == 2) {
+                static int w8 = -1; if (w8 < 0) { const char* e = getenv("M1_BN160_W8"); w8 = e ? atoi(e) : 0; }
+                rc2 = w8 ? launch_cfg<T, 128, 160, 4, 2>(mp, maxM, OCpad, st) : launch_cfg<T, 128, 160, 2, 2>(mp, maxM, OCpad, st);
+            } else rc2 = M1_ERR_UNSUPPORTED; break;
         case 64: {
             // 64 / 32 columns on 8 waves of 32x32 / 32x16 instead of 4 waves of 32x64 / 32x32 (M1_F32_W8: bit 0 fp32, bit 1 bf16).  fp32: an
             // MFMA is 1/16 of a bf16 one per cycle, the LDS has room for the extra fragment reads and the extra waves hide the operand
@@ -1054,7 +1058,11 @@ static int run_mfma(const GatherSpec& g, void* ws, int ws_packed, hipStream_t st
             if (((sizeof(T) == 4 && (w8 & 1)) || (sizeof(T) == 2 && (w8 & 2))) && !small) rc2 = launch_cfg<T, 128, 32, 4, 2>(mp, maxM, OCpad, st);
             else rc2 = small ? launch_cfg<T, 64, 32, 4, 1>(mp, maxM, OCpad, st) : launch_cfg<T, 128, 32, 4, 1>(mp, maxM, OCpad, st);
             break; }
-        default:  rc2 = small ? launch_cfg<T, 64, 16, 4, 1>(mp, maxM, OCpad, st) : launch_cfg<T, 128, 16, 4, 1>(mp, maxM, OCpad, st); break;
+        default: {
+            static int w8 = -1; if (w8 < 0) { const char* e = getenv("M1_N16_W8"); w8 = e ? atoi(e) : 0; }
+            if (w8 && !small) rc2 = launch_cfg<T, 128, 16, 8, 1>(mp, maxM, OCpad, st);
+            else rc2 = small ? launch_cfg<T, 64, 16, 4, 1>(mp, maxM, OCpad, st) : launch_cfg<T, 128, 16, 4, 1>(mp, maxM, OCpad, st);
+            break; }
     }
     if (rc2) return rc2;
     if (ib_epi) *g.ib_nparts = mp.stat_tiles;
