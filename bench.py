@@ -29,11 +29,13 @@ README_STRIDES = ((1, 1, 1), (1, 2, 2), (1, 2, 2), (2, 2, 2), (2, 2, 2))
 WORKLOADS = {
     # name: (spatial, filters, probabilistic, dense_skip, deep_supervision)   -- BASELINE.json configs
     "C1": ((8, 64, 64), (8, 16, 32, 64, 128), False, False, False),
+    "C1P": ((8, 64, 64), (8, 16, 32, 64, 128), True, True, True),       # C1-sized hierarchical probabilistic model (harness tests only)
     "C2": ((20, 160, 160), (32, 64, 128, 256, 512), False, False, False),
     "C3": ((20, 160, 160), (32, 64, 128, 256, 512), True, True, True),
     "C5": ((32, 256, 256), (32, 64, 128, 256, 512), False, False, False),
 }
 WORKLOAD_NAMES = {"C1": "C1 tiny deterministic (8,64,64,3) filters (8..128)",
+                  "C1P": "C1-sized hierarchical-probabilistic (8,64,64,3) filters (8..128) -- harness tests only",
                   "C2": "C2 M1 deterministic Attention-U-Net (20,160,160,3) filters (32..512)",
                   "C3": "C3 M1 full hierarchical-probabilistic dense_skip+deep_supervision latents (3,2,1,0) (20,160,160,3)",
                   "C5": "C5 M1 deterministic high-res (32,256,256,3)"}
@@ -44,7 +46,7 @@ SURVEY_8D = {"C2": (0.723, 3.48), "C3": (8.22, 25.05), "C5": (2.96, 28.53)}
 
 # volumes per GPU when --batch is not given: the reference trainer's default batch (train_model.py:83, --BATCH_SIZE 2), which is
 # also the per-GPU batch BASELINE.json names for C4; C1 is the reference's batch-1 plumbing case, C5 the single-volume stress case
-DEFAULT_BATCH = {"C1": 1, "C2": 2, "C3": 2, "C5": 1}
+DEFAULT_BATCH = {"C1": 1, "C1P": 2, "C2": 2, "C3": 2, "C5": 1}
 
 
 def parse():
@@ -81,7 +83,7 @@ def ball_targets(B, dims, seed, device):
     return torch.from_numpy(t).to(device)
 
 
-def cpu_baseline(workload, prob, dense, deep, dims, filters, kl_w, budget_s=75.0):
+def cpu_baseline(workload, prob, dense, deep, dims, filters, kl_w, budget_s=100.0):
     """The CPU oracle's full train step (fwd + Focal [+10 KL] + L2 + bwd + Adam-amsgrad update, torch-CPU fp32) with the protocol of
     SURVEY.md 8(d): 1 warm-up + 3 timed steps, median -- on ONE WHOLE VOLUME of the workload when a probe predicts the four steps
     fit the time budget (they do for C2 and C3 on the GPU box's host), else on the largest sub-volume that does, scaled by the
@@ -131,15 +133,30 @@ def cpu_baseline(workload, prob, dense, deep, dims, filters, kl_w, budget_s=75.0
     # prediction that is linear from one tiny probe never leaves the probe.  Two probes fit (a, b); the largest candidate whose
     # 1 warm-up + 3 timed steps are predicted to fit the budget is measured.
     p1, p2 = (4, 32, 32), (8, 64, 64) if D >= 8 and H >= 64 and W >= 64 else (4, 32, 32)
+    t_start = time.time()
     ctx = make(p1); step(ctx, 1); t1 = step(ctx, 2)
     if p2 != p1:
         ctx = make(p2); step(ctx, 1); t2 = step(ctx, 2)
-        b_ = max(0.0, (t2 - t1) / (vox(p2) - vox(p1))); a_ = max(0.0, t1 - b_ * vox(p1))
+        b_ = (t2 - t1) / (vox(p2) - vox(p1))
+        if b_ <= 0.0:                                # timing noise (t2 <= t1): the conservative linear estimate from the larger probe
+            a_, b_ = 0.0, t2 / vox(p2)
+        else:
+            a_ = max(0.0, t1 - b_ * vox(p1))
     else:
         a_, b_ = 0.0, t1 / vox(p1)
+    # the two small probes OVER-estimate the per-voxel cost of the large candidates (oneDNN is far from its large-problem rate on
+    # a (8,64,64) volume: round 3's driver run predicted 4 x 19 s for a whole C3 volume that takes 4 x 12 s and settled for half a
+    # volume), so the pick is re-checked against the warm-up step MEASURED at the picked size, and climbs to the largest candidate
+    # whose 1 + 3 steps fit what is left of the budget at that measured per-voxel rate
     pick = next((c for c in cands if 4.0 * (a_ + b_ * vox(c)) <= budget_s), cands[-1])
     ctx = make(pick)
-    step(ctx, 1)                                     # warm-up at the picked size
+    tw = step(ctx, 1)                                # warm-up at the picked size
+    left = budget_s - (time.time() - t_start)
+    bigger = next((c for c in cands if vox(c) > vox(pick) and 4.0 * tw * vox(c) / vox(pick) <= left), None)
+    if bigger is not None:
+        pick = bigger
+        ctx = make(pick)
+        step(ctx, 1)
     times = sorted(step(ctx, 2 + i) for i in range(3))      # 3 timed steps at the picked size
     t = times[1]
     frac = vox(pick) / float(D * H * W)
@@ -160,13 +177,24 @@ _FAMILY_KERNELS = {
 }
 
 
+def csrc_sha():
+    """sha256 over the kernel sources of this tree (same recipe as tools/pmc_traffic.py, which stamps the PMC json)."""
+    import glob
+    import hashlib
+    root = os.path.join(ROOT, "prostatemr_3d-cad-cspca_amd", "csrc")
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(root, "*.hip")) + glob.glob(os.path.join(root, "*.h"))):
+        h.update(os.path.basename(f).encode()); h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def hbm_traffic(wl, dtype, B, recs, family, prof_steps):
     """HBM bytes per launch of the dominant entry-point family, from the committed rocprofv3 --pmc FETCH_SIZE /
     WRITE_SIZE passes of this same workload (profiles/r0N_<wl>_<dtype>_hbm_traffic.json, tools/collect_profiles.sh;
     FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).  None when no committed measurement matches."""
     pdir = os.path.join(ROOT, "profiles")
     path = None
-    for rnd in ("r03", "r02", "r01"):
+    for rnd in ("r04", "r03", "r02", "r01"):
         cand = os.path.join(pdir, f"{rnd}_{wl.lower()}_{dtype}_hbm_traffic.json")
         if os.path.exists(cand):
             path = cand
@@ -182,9 +210,13 @@ def hbm_traffic(wl, dtype, B, recs, family, prof_steps):
             gb = sum(pm["kernels"].get(k, {}).get("fetch_GB_per_step", 0.0) + pm["kernels"].get(k, {}).get("write_GB_per_step", 0.0)
                      for k in kernels)
             launches = sum(q["launches"] for q in recs if q["name"] in fams) / prof_steps
+            sha = pm.get("csrc_sha")
+            fresh = ("; kernel sources identical to the benchmarked tree" if sha == csrc_sha() else
+                     "; STALE: the kernel sources of the benchmarked tree differ from the profiled ones (csrc hash "
+                     f"{csrc_sha()} vs {sha}), the figure describes the profiled tree")
             return gb * 1e9 / max(launches, 1.0), ("bytes per entry-point launch, kernels " + "+".join(kernels) + " shared by " +
                                                    "+".join(fams) + f"; rocprofv3 --pmc FETCH_SIZE(x2)/WRITE_SIZE, {os.path.basename(path)}"
-                                                   + (f" taken at commit {pm['commit']}" if pm.get("commit") else ""))
+                                                   + (f" taken at commit {pm['commit']}" if pm.get("commit") else "") + fresh)
     return None, "family not mapped to kernels"
 
 
@@ -328,6 +360,8 @@ def run_workload(a, wl, ctx, want_roofline, want_cpu):
                                                     reducer, sync=torch.cuda.synchronize)
     if graph is None:
         run = step
+        if a.no_graph:
+            step()                       # (capture() runs one eager step before it records: both modes execute the same number of steps)
     elif gmode == "full":
         run = graph.replay
     else:
@@ -368,6 +402,9 @@ def run_workload(a, wl, ctx, want_roofline, want_cpu):
                     "note": "groups are sent from the communication stream as backward completes them (ddp.py); counters "
                             "count host-side calls (in graph mode 'full' the captured collectives replay without them)"}
     final_loss = float(loss_buf)
+    if os.environ.get("M1_BENCH_DUMP") and rank == 0:          # harness tests: the state a run ends in (bit-compared between modes)
+        torch.save({"flat": opt.flatp.flat.cpu(), "grad": opt.flatp.grad.cpu(), "m": opt.m.cpu(), "vhat": opt.vhat.cpu(),
+                    "step": opt.step_dev.cpu(), "rng": model.rng_state.cpu()}, os.environ["M1_BENCH_DUMP"])
 
     # ---- per-kernel-family hipEvent timing on the launch stream (eager launches of the same step) ----
     roof = None
@@ -471,8 +508,39 @@ def run_workload(a, wl, ctx, want_roofline, want_cpu):
     return out
 
 
+def launch_plan(gpus, env):
+    """What ``python bench.py --gpus N`` must do before anything touches the GPU: ("run", None) = this process is the (or a) rank;
+    ("spawn", argv) = N > 1 and no torchrun environment: start N ranks through torch.distributed.run as a CHILD process (never an
+    exec: this interpreter may already hold GPU state) and relay rank 0's JSON line.  Round 3 measured ONE GPU and printed
+    n_gpus 1 in that case."""
+    if gpus > 1 and "WORLD_SIZE" not in env and "RANK" not in env:
+        port = env.get("MASTER_PORT", str(29500 + (os.getpid() % 400)))
+        argv = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(gpus), "--master-addr", "127.0.0.1",
+                "--master-port", port, os.path.abspath(__file__)] + sys.argv[1:]
+        return "spawn", argv
+    return "run", None
+
+
+def spawn_ranks(argv):
+    """Run the torchrun child, pass its stderr through, print exactly the JSON line(s) rank 0 wrote; non-zero when any rank failed."""
+    import subprocess
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    p = subprocess.run(argv, env=env, stdout=subprocess.PIPE, text=True)
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    for l in lines:
+        print(l, flush=True)
+    if p.returncode != 0 or not lines:
+        sys.stderr.write(p.stdout[-4000:])
+        raise SystemExit(p.returncode or 1)
+    raise SystemExit(0)
+
+
 def main():
     a = parse()
+    mode, argv = launch_plan(a.gpus, os.environ)
+    if mode == "spawn":
+        spawn_ranks(argv)
     if os.environ.get("M1_BENCH_DEBUG"):
         import faulthandler
         faulthandler.dump_traceback_later(60, repeat=False, file=sys.stderr)   # where a hung rank is standing
@@ -486,8 +554,9 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != a.gpus and world > 1:
-        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    if world != a.gpus:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch through torch.distributed.run with --nproc-per-node {a.gpus} "
+                         f"(or without any torchrun environment: bench.py then starts the ranks itself)")
     # M1_BENCH_BACKEND=gloo: functional check of the N > 1 code path with every rank on one GPU; M1_BENCH_FORCE_DIST=1: a world
     # of one takes the N > 1 path (RCCL init, collectives from the communication stream, barrier, destroy).  Never measurements.
     backend = os.environ.get("M1_BENCH_BACKEND", "nccl")
@@ -503,13 +572,23 @@ def main():
             dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    torch.manual_seed(1234 + rank)                    # the latent draws of the probabilistic model come from torch's device generator
     ctx = dict(pkg=pkg, ops=ops, dev=dev, world=world, rank=rank, backend=backend, dist_on=dist_on)
 
     out = run_workload(a, a.workload, ctx, want_roofline=not a.no_roofline, want_cpu=(not a.no_cpu_baseline and not dist_on))
     if a.workload == "C3" and not dist_on and not a.no_secondary and a.batch is None:
         # the light deterministic variant of the same volume (BASELINE.json configs[1]) next to the headline
+        keys = ("value", "unit", "ms_per_step", "dtype", "config", "roofline")
         sec = run_workload(a, "C2", ctx, want_roofline=not a.no_roofline, want_cpu=False)
-        out["secondary"] = {"C2": {k: sec[k] for k in ("value", "unit", "ms_per_step", "dtype", "config", "roofline")}}
+        out["secondary"] = {"C2": {k: sec[k] for k in keys}}
+        if a.dtype is None and os.environ.get("M1_BENCH_FP32_SECONDARY", "1") != "0":
+            # the PARITY mode's speed (fp32 is the reference's own arithmetic, train_model.py:153-161; the 1e-3 logits / KL claim is
+            # made in fp32, the headline above runs bf16) on the north-star model, and BASELINE.json's fp32 stress config C5
+            a32 = argparse.Namespace(**vars(a)); a32.dtype = "fp32"
+            sec = run_workload(a32, "C3", ctx, want_roofline=False, want_cpu=False)
+            out["secondary"]["C3_fp32"] = {k: sec[k] for k in keys}
+            sec = run_workload(a32, "C5", ctx, want_roofline=not a.no_roofline, want_cpu=False)
+            out["secondary"]["C5_fp32"] = {k: sec[k] for k in keys}
     if rank == 0:
         print(json.dumps(out), flush=True)
     if dist_on:

@@ -93,11 +93,13 @@ int m1_conv3d_pair_supported(const m1_conv_desc_t* d, int C1);
 /* Data gradient of a single-input Conv3D whose input is a = lrelu(IN(x)) -- conv2 / conv3 of an SEResNetBottleNeck (B:54-59): `da`
  * = d(a), and the kernel that writes it also emits the two sums the InstanceNorm backward needs (dbeta = sum dy,
  * dgamma = sum dy*xh, dy = da*lrelu'(gamma*xh+beta)) per tile into partial [N][*nparts][Cin][2] -- no separate reduction pass over
- * (x, da).  partial: >= N * ceil(V/64) * Cin * 2 floats.  *nparts = 0 on return: the kernel that took this shape has no such
+ * (x, da).  partial: N * partial_rows * Cin * 2 + N * Cin * 2 + 64 floats with partial_rows = m1_conv3d_dgrad_inbwd_rows(d) (a kernel
+ * that would write more rows than the caller states leaves *nparts = 0).  *nparts = 0 on return: the kernel that took this shape has no such
  * epilogue; da is complete, finish with m1_instnorm_bwd; otherwise with m1_instnorm_bwd_partials. */
+int m1_conv3d_dgrad_inbwd_rows(const m1_conv_desc_t* d);
 int m1_conv3d_dgrad_inbwd(const m1_conv_desc_t* d, const float* w, const void* dy, void* da, const void* x, const float* stats,
-                          const float* gamma, const float* beta, float slope, float* partial, int* nparts, void* ws,
-                          int ws_packed, void* stream);
+                          const float* gamma, const float* beta, float slope, float* partial, int partial_rows, int* nparts,
+                          void* ws, int ws_packed, void* stream);
 /* conv1 || conv4 of an SEResNetBottleNeck as ONE problem (B:53 and B:64 apply Conv3D(F/4, k, s) and Conv3D(F, k, s) to the same
  * input): d->Cout = C1 + C4; w1 (kd,kh,kw,Cin,C1), w4 (kd,kh,kw,Cin,C4) stay separate Keras tensors.  Forward writes y1 (…,C1) and
  * y4 (…,C4) and, optionally, both (N,C,2) statistics tensors; the data gradient contracts over the virtual concat [dy1 | dy4].
@@ -116,6 +118,13 @@ int m1_conv3d_wgrad(const m1_conv_desc_t* d, const void* dy, float* dw, float* d
                     void* stream);
 /* test hook: 1 = route every conv through the generic direct kernels (no matrix cores). */
 int m1_set_force_direct(int on);
+/* Tuning switches ("M1_..." names): one table for the whole library.  A switch's value is its built-in default, or the
+ * environment variable of the same name as the process started, or the last m1_config_set; m1_config_unset drops the override.
+ * A change takes effect at the next launch that consults the switch (there are no per-call-site caches).  m1_config_get returns
+ * M1_ERR_UNSUPPORTED for a switch nothing has consulted or set yet. */
+int m1_config_set(const char* name, int value);
+int m1_config_unset(const char* name);
+int m1_config_get(const char* name, int* value);
 
 /* ---- Conv3DTranspose(padding='same') + bias : N:496-499,505-507,513-514,520,546-553 ----
  * w: Keras layout (kd,kh,kw,Cout,Cin) fp32; y: (N, D*sd, H*sh, W*sw, Cout). */

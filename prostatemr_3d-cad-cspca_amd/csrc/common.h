@@ -87,10 +87,18 @@ template <> struct VecIO<bf16_t, 8> {
     }
 };
 
+// ---- tuning switches: ONE table for the whole library (config.hip) ----
+// M1_CFG("M1_X", default) = the switch's current value: the default, or the environment variable of the same name when the process
+// started with it, or what m1_config_set (include/m1hip.h) stored last -- a caller can change a switch between two launches and put
+// it back (tests run the same op under several settings in one process).  The call site keeps a pointer to its table entry: one load.
+struct M1CfgEntry { char name[40]; int def; int def_known; int env; int env_set; int ovr; int has_ovr; volatile int v; };
+M1CfgEntry* m1_cfg_entry(const char* name, int def);
+#define M1_CFG(NAME, DEF) ([]() -> int { static M1CfgEntry* const e_ = m1_cfg_entry(NAME, DEF); return e_->v; }())
+
 // blocks of 256 threads for `per` vector elements whose channel group is (index % cg): at most ~2048 blocks, and
 // gridDim.x*256 a multiple of cg so that a thread keeps its channel group across its grid-stride loop
 static inline int m1_grid_for(long long per, int cg) {
-    static int cap = -1; if (cap < 0) { const char* e = getenv("M1_EW_BLOCKS"); cap = e ? atoi(e) : 2048; if (cap < 1) cap = 1; }
+    int cap = M1_CFG("M1_EW_BLOCKS", 2048); { if (cap < 1) cap = 1; }
     long long g = (per + 255) / 256; if (g > cap) g = cap; if (g < 1) g = 1;
     // (g*256) % cg == 0  <=>  g is a multiple of cg / gcd(cg, 256)
     long long a = cg, b = 256; while (b) { long long t = a % b; a = b; b = t; }

@@ -406,7 +406,7 @@ static bool halo_plan(const MfmaP& m, int OCpad, HaloP& p) {
 static bool halo_plan_nthr(const MfmaP& m, int OCpad, HaloP& p, int force_nthr) {
     if (m.nclasses != 1 || m.ksplit != 1) return false;
     if (!(m.mode == 0 || (m.mode == 1 && m.sd == 1 && m.sh == 1 && m.sw == 1))) return false;
-    { static int hs = -1; if (hs < 0) { const char* e = getenv("M1_HALO_STRIDED"); hs = e ? atoi(e) : 1; }       // 0: strided layers stay on conv_mfma (A/B switch)
+    { int hs = M1_CFG("M1_HALO_STRIDED", 1);       // 0: strided layers stay on conv_mfma (A/B switch)
       if (!hs && m.mode == 0 && (m.sd > 1 || m.sh > 1 || m.sw > 1)) return false; }
     int CC = 0;
     for (int i = 0; i < m.nsrc; ++i) { if (m.srcC[i] % 8) return false; CC += m.srcC[i]; }
@@ -425,7 +425,7 @@ static bool halo_plan_nthr(const MfmaP& m, int OCpad, HaloP& p, int force_nthr) 
     p.dmin = dmin; p.hmin = hmin; p.wmin = wmin;
     if (m.mode == 0) { p.sde = m.sd; p.she = m.sh; p.swe = m.sw; p.pde = m.pd; p.phe = m.ph; p.pwe = m.pw; }
     else { p.sde = p.she = p.swe = 1; p.pde = p.phe = p.pwe = 0; }
-    { static int nt_ = -1; if (nt_ < 0) { const char* e = getenv("M1_HALO_THREADS"); nt_ = e ? atoi(e) : 512; } p.nthr = nt_ == 512 ? 512 : 256; }
+    { int nt_ = M1_CFG("M1_HALO_THREADS", 512); p.nthr = nt_ == 512 ? 512 : 256; }
     if (force_nthr) p.nthr = force_nthr;
     p.TW = m.OW % 32 == 0 ? 32 : (m.OW % 16 == 0 ? 16 : 8);
     if (p.nthr == 512) {      // 256-voxel tiles unless their row padding wastes clearly more than 128-voxel tiles would
@@ -455,10 +455,10 @@ static bool halo_plan_nthr(const MfmaP& m, int OCpad, HaloP& p, int force_nthr) 
     p.b_bytes = p.nchunks * p.BNh * 64;
     p.c_bytes = (p.nthr / 64) * p.BNh * 2 * 4;                        // statistics fold, one row per wave
     const int fixed = p.b_bytes + p.c_bytes;
-    static int kb = -1; if (kb < 0) { const char* e = getenv("M1_HALO_LDS_KB"); kb = e ? atoi(e) : 160; }
+    int kb = M1_CFG("M1_HALO_LDS_KB", 160);
     int S = (kb * 1024 - fixed) / p.x_bytes;
     if (S > 4) S = 4;
-    { static int fs = -1; if (fs < 0) { const char* e = getenv("M1_HALO_STAGES"); fs = e ? atoi(e) : 0; } if (fs >= 2 && fs < S) S = fs; }
+    { int fs = M1_CFG("M1_HALO_STAGES", 0); if (fs >= 2 && fs < S) S = fs; }
     while (S > 2 && (p.x_slots / p.nthr) * (S - 2) > 40) --S;
     if (S < 2) return false;
     p.stages = S;
@@ -469,7 +469,7 @@ static bool halo_plan_nthr(const MfmaP& m, int OCpad, HaloP& p, int force_nthr) 
 static int halo_nsplit(const HaloP& p, int OCpad) {
     const int slices = OCpad / p.BNh;
     int nsplit = 256 / slices; if (nsplit < 1) nsplit = 1;
-    { static int tg = -1; if (tg < 0) { const char* e = getenv("M1_HALO_BLOCKS"); tg = e ? atoi(e) : 0; } if (tg > 0) nsplit = tg / slices > 0 ? tg / slices : 1; }
+    { int tg = M1_CFG("M1_HALO_BLOCKS", 0); if (tg > 0) nsplit = tg / slices > 0 ? tg / slices : 1; }
     if (nsplit > p.ntiles) nsplit = p.ntiles;
     return nsplit;
 }
@@ -498,7 +498,7 @@ int m1_halo_conv(const MfmaP& mp, int OCpad, hipStream_t st) {
         HK(9, 9)                       // 32 -> 64 / 16, k133, s122 at res0 -> res1 (the strided SE blocks' conv1 / conv4)
 #undef HK
     }
-    { static int lg = -1; if (lg < 0) { const char* e = getenv("M1_HALO_LOG"); lg = e ? atoi(e) : 0; }
+    { int lg = M1_CFG("M1_HALO_LOG", 0);
       if (lg) fprintf(stderr, "halo: nthr %d BN %d nchunks %d nxit %d stages %d TW %d TH %d %s\n", p.nthr, p.BNh, p.nchunks, nxit, p.stages, p.TW, p.TH, kern ? "static" : "runtime"); }
     if (!kern) kern = p.nthr == 512 ? (p.BNh == 32 ? conv_halo_kernel<2, 512, 0, 0> : conv_halo_kernel<1, 512, 0, 0>)
                                     : (p.BNh == 32 ? conv_halo_kernel<2, 256, 0, 0> : conv_halo_kernel<1, 256, 0, 0>);

@@ -787,7 +787,7 @@ struct Plan { int BN, BM, ksplit; };
 // bn160: the conv1 || conv4 pair forward (32 + 128 or 64 + 256 output columns): 160-column tiles (5 MFMA column tiles per wave)
 // instead of 128-column tiles of which the last is 75 / 50 % empty
 static inline bool want_bn160(const GatherSpec& g) {
-    static int en = -1; if (en < 0) { const char* e = getenv("M1_BN160"); en = e ? atoi(e) : 1; }
+    int en = M1_CFG("M1_BN160", 1);
     return en && g.dtype == M1_BF16 && g.w2 && g.oc_split > 0 && g.mode == 0 && g.OC % 160 == 0 && g.OC <= 320;
 }
 static inline Plan make_plan(int ocn, long long maxM, int ncls, int min_nchunks, bool bn160 = false) {
@@ -799,7 +799,7 @@ static inline Plan make_plan(int ocn, long long maxM, int ncls, int min_nchunks,
     {   // very deep contractions (>= 200 chunks: the dense-skip concats of the full model) with a 128-wide oc tile and only
         // ~250 row tiles: 128x128 tiles (64x64 per wave: fewer fragment reads and weight re-reads per MFMA) and slab
         // split-K to get the blocks back (-19 % on the 512->128-channel res2 layer).  M1_PLAN128=<target blocks>, 0 = off
-        static int t128 = -1; if (t128 < 0) { const char* e = getenv("M1_PLAN128"); t128 = e ? atoi(e) : 768; }
+        int t128 = M1_CFG("M1_PLAN128", 768);
         const long long b128 = cdiv_ll(maxM, 128) * ncls * ntile;
         if (t128 > 0 && pl.BN == 128 && b128 >= 100 && b128 < t128 && min_nchunks >= 200) {
             pl.BM = 128;
@@ -947,12 +947,12 @@ static int run_mfma(const GatherSpec& g, void* ws, int ws_packed, hipStream_t st
     // 64x128 / 128x128 blocks with half the weight-tile re-reads.  Round 1 (2-volume launches): -8 % on the 512->128 forward, +4 % on
     // its data gradient, neutral end to end; with the stacked passes (4 volumes per launch): 647 -> 624 us forward, 613 -> 557 us
     // data gradient, -1.7 % per C3 step, C2 neutral.  256x128 tiles on 8 waves (one block per CU) were slower (702 / 678 us).
-    static int c8 = -1; if (c8 < 0) { const char* e = getenv("M1_CONV8"); c8 = e ? atoi(e) : 1; }
+    int c8 = M1_CFG("M1_CONV8", 1);
     const bool use8 = c8 && BN == 128 && (pl.ksplit == 1 || (c8 >= 2 && pl.BM == 128)) &&
                       cdiv_ll(spec_maxM(g), 128) * spec_ncls(g) * (OCpad / 128) * pl.ksplit >= 160;
     // M1_CONV16 (bf16): 256-row tiles, ONE block per CU with the waves of two 128-row blocks (16 waves of 64x32 for 128 columns,
     // 8 waves of 64x80 for the 160-column pair tile): the weight tile crosses L2 -> LDS once per 256 rows instead of once per 128
-    static int c16 = -1; if (c16 < 0) { const char* e = getenv("M1_CONV16"); c16 = e ? atoi(e) : 0; }
+    int c16 = M1_CFG("M1_CONV16", 0);
     const bool use16 = c16 && sizeof(T) == 2 && (BN == 128 || BN == 160) && pl.ksplit == 1 && (BN == 160 || use8) &&
                        cdiv_ll(spec_maxM(g), 256) * spec_ncls(g) * (OCpad / BN) >= (c16 > 1 ? c16 : 256);
     const int bm_eff = use16 ? 256 : (use8 ? 128 : pl.BM);
@@ -964,7 +964,7 @@ static int run_mfma(const GatherSpec& g, void* ws, int ws_packed, hipStream_t st
     const bool ib_want = g.ib_x && g.ib_partial && g.ib_nparts && !g.stats_out && !g.accumulate && g.nout <= 1 && spec_ncls(g) == 1 &&
                          (g.nout == 0 || (g.outs[0] && !g.outAcc[0] && g.outC[0] == g.OC));
     if (g.ib_nparts) *g.ib_nparts = 0;
-    bool ib_epi = ib_want && pl.ksplit == 1 && (g.N == 1 || Vout % bm_eff == 0);
+    bool ib_epi = ib_want && pl.ksplit == 1 && (g.N == 1 || Vout % bm_eff == 0) && cdiv_ll(Vout, bm_eff) <= g.ib_cap;
     if (ib_epi) {
         mp.stat_partial = g.ib_partial; mp.stat_tiles = (int)cdiv_ll(Vout, bm_eff);
         mp.ib_x = g.ib_x; mp.ib_stats = g.ib_stats; mp.ib_gamma = g.ib_gamma; mp.ib_beta = g.ib_beta; mp.ib_slope = g.ib_slope;
@@ -982,12 +982,12 @@ static int run_mfma(const GatherSpec& g, void* ws, int ws_packed, hipStream_t st
     const long long maxM = spec_maxM(g);
     bool halo = false;
     if constexpr (sizeof(T) == 2) {
-        static int hen = -1; if (hen < 0) { const char* e = getenv("M1_HALO"); hen = e ? atoi(e) : 1; }
+        int hen = M1_CFG("M1_HALO", 1);
         halo = hen && (maxM >= 32768 || hen == 2) && m1_halo_conv_supported(mp, OCpad);      // (M1_HALO=2: no size floor, tests)
     }
     // K order of the panel and of the LDS-DMA gather: chunk-major ([64-byte chunk][tap]) for multi-tap problems on the
     // implicit-GEMM kernel (see advance_chunk); the halo kernel and single-tap problems keep [tap][channel]
-    { static int ko = -1; if (ko < 0) { const char* e = getenv("M1_KORDER"); ko = e ? atoi(e) : 2; }     // 2: pairs of chunks when every member allows
+    { int ko = M1_CFG("M1_KORDER", 2);     // 2: pairs of chunks when every member allows
       int maxtaps = 0; for (int c = 0; c < mp.nclasses; ++c) maxtaps = mp.cls_ntaps[c] > maxtaps ? mp.cls_ntaps[c] : maxtaps;
       mp.korder = (ko && mp.aligned && !halo && maxtaps > 1) ? 1 : 0;
       if (mp.korder && ko == 2) { bool pair = true; for (int i = 0; i < g.nsrc; ++i) pair &= g.srcC[i] % (8 * SEG) == 0; if (pair) mp.korder = 2; }
@@ -1026,7 +1026,7 @@ static int run_mfma(const GatherSpec& g, void* ws, int ws_packed, hipStream_t st
             pw = true;
         }
     }
-    { static int lg = -1; if (lg < 0) { const char* e = getenv("M1_MFMA_LOG"); lg = e ? atoi(e) : 0; }
+    { int lg = M1_CFG("M1_MFMA_LOG", 0);
       if (lg) fprintf(stderr, "mfma: mode %d N%d out %dx%dx%d CC %d OC %d k%d taps s%d%d%d nsrc %d -> %s BM %d BN %d ksplit %d korder %d stats %d\n", g.mode, g.N, g.OD, g.OH, g.OW, CC, g.OC,
                       g.kd * g.kh * g.kw, g.sd, g.sh, g.sw, g.nsrc, halo ? "halo" : (pw ? "pw" : "mfma"), bm_eff, BN, pl.ksplit, mp.korder, fuse_stats ? 1 : 0); }
     if (halo) rc2 = m1_halo_conv(mp, OCpad, st);
@@ -1041,7 +1041,7 @@ static int run_mfma(const GatherSpec& g, void* ws, int ws_packed, hipStream_t st
         case 128: rc2 = use8 ? launch_cfg<T, 128, 128, 2, 4>(mp, maxM, OCpad, st)
                              : (small ? launch_cfg<T, 64, 128, 1, 4>(mp, maxM, OCpad, st) : launch_cfg<T, 128, 128, 2, 2>(mp, maxM, OCpad, st)); break;
         case 160: if constexpr (sizeof(T) == 2) {
-                static int w8 = -1; if (w8 < 0) { const char* e = getenv("M1_BN160_W8"); w8 = e ? atoi(e) : 0; }
+                int w8 = M1_CFG("M1_BN160_W8", 0);
                 rc2 = w8 ? launch_cfg<T, 128, 160, 4, 2>(mp, maxM, OCpad, st) : launch_cfg<T, 128, 160, 2, 2>(mp, maxM, OCpad, st);
             } else rc2 = M1_ERR_UNSUPPORTED; break;
         case 64: {
@@ -1049,17 +1049,17 @@ static int run_mfma(const GatherSpec& g, void* ws, int ws_packed, hipStream_t st
             // MFMA is 1/16 of a bf16 one per cycle, the LDS has room for the extra fragment reads and the extra waves hide the operand
             // latency (54 % MFMA-busy with 4 waves; C5 40.18 -> 39.95 ms).  bf16: these tiles are latency-bound (10-15 % MFMA-busy): C2
             // 7.86 -> 7.59 ms, C3 neutral
-            static int w8 = -1; if (w8 < 0) { const char* e = getenv("M1_F32_W8"); w8 = e ? atoi(e) : 3; }
+            int w8 = M1_CFG("M1_F32_W8", 3);
             if (((sizeof(T) == 4 && (w8 & 1)) || (sizeof(T) == 2 && (w8 & 2))) && !small) rc2 = launch_cfg<T, 128, 64, 4, 2>(mp, maxM, OCpad, st);
             else rc2 = small ? launch_cfg<T, 64, 64, 2, 2>(mp, maxM, OCpad, st) : launch_cfg<T, 128, 64, 4, 1>(mp, maxM, OCpad, st);
             break; }
         case 32: {
-            static int w8 = -1; if (w8 < 0) { const char* e = getenv("M1_F32_W8"); w8 = e ? atoi(e) : 3; }
+            int w8 = M1_CFG("M1_F32_W8", 3);
             if (((sizeof(T) == 4 && (w8 & 1)) || (sizeof(T) == 2 && (w8 & 2))) && !small) rc2 = launch_cfg<T, 128, 32, 4, 2>(mp, maxM, OCpad, st);
             else rc2 = small ? launch_cfg<T, 64, 32, 4, 1>(mp, maxM, OCpad, st) : launch_cfg<T, 128, 32, 4, 1>(mp, maxM, OCpad, st);
             break; }
         default: {
-            static int w8 = -1; if (w8 < 0) { const char* e = getenv("M1_N16_W8"); w8 = e ? atoi(e) : 0; }
+            int w8 = M1_CFG("M1_N16_W8", 0);
             if (w8 && !small) rc2 = launch_cfg<T, 128, 16, 8, 1>(mp, maxM, OCpad, st);
             else rc2 = small ? launch_cfg<T, 64, 16, 4, 1>(mp, maxM, OCpad, st) : launch_cfg<T, 128, 16, 4, 1>(mp, maxM, OCpad, st);
             break; }
@@ -1090,13 +1090,13 @@ static int run_mfma(const GatherSpec& g, void* ws, int ws_packed, hipStream_t st
     for (int i = 0; i < mp.nout; ++i) { fo.outs[i] = mp.outs[i]; fo.outC[i] = mp.outC[i]; fo.outOff[i] = mp.outOff[i]; fo.outAcc[i] = mp.outAcc[i]; }
     fo.outOff[mp.nout] = mp.outOff[mp.nout];
     {   // finish + InstanceNorm statistics in one pass (see FinishStatsF)
-        static int fs = -1; if (fs < 0) { const char* e = getenv("M1_FINISH_STATS"); fs = e ? atoi(e) : 1; }
+        int fs = M1_CFG("M1_FINISH_STATS", 1);
         constexpr int VEC = 16 / (int)sizeof(T);
         bool ok = fs && g.stats_out && g.stats_ws && g.mode == 0 && !g.accumulate && g.OC % VEC == 0 && mp.nout <= 2;
         for (int i = 0; i < mp.nout; ++i) ok = ok && mp.outs[i] && !mp.outAcc[i] && mp.outC[i] % VEC == 0;
         if (mp.nout == 2 && !g.stats_out2) ok = false;          // (two output tensors: the conv1 || conv4 pair with its two statistics)
         constexpr int VECI = 16 / (int)sizeof(T);
-        if (ib_want && fs && g.OC % VECI == 0) {      // the same pass with the InstanceNorm-backward sums (one launch: no finalize here)
+        if (ib_want && fs && g.OC % VECI == 0 && m1_red_nchunks(Vout, g.OC, g.N) <= g.ib_cap) {      // the same pass with the InstanceNorm-backward sums (one launch: no finalize here)
             FinishStatsF<T> f{mp.acc32, pl.ksplit, ne, g.bias, g.bias2, g.oc_split, (T*)g.out, Vout, g.OC, fo,
                               (const T*)g.ib_x, g.ib_stats, g.ib_gamma, g.ib_beta, g.ib_slope};
             rc2 = m1_reduce_nc_launch<2>(f, g.N, Vout, g.OC, g.ib_partial, st); if (rc2) return rc2;
@@ -1105,9 +1105,7 @@ static int run_mfma(const GatherSpec& g, void* ws, int ws_packed, hipStream_t st
         }
         if (ok) {
             FinishStatsF<T> f{mp.acc32, pl.ksplit, ne, g.bias, g.bias2, g.oc_split, (T*)g.out, Vout, g.OC, fo, nullptr, nullptr, nullptr, nullptr, 0.f};
-            M1RedFin<2> fin{}; fin.mode = 1; fin.out = g.stats_out; fin.stats_V = Vout; fin.eps = g.stats_eps;
-            fin.out2 = g.stats_out2; fin.csplit = g.stats_out2 ? g.oc_split : 0;
-            rc2 = m1_reduce_nc_launch<2>(f, g.N, Vout, g.OC, g.stats_ws, st, &fin); if (rc2 || fin.mode) return rc2;
+            rc2 = m1_reduce_nc_launch<2>(f, g.N, Vout, g.OC, g.stats_ws, st); if (rc2) return rc2;
             return m1_reduce_finalize_launch<2>(g.stats_ws, g.N, g.OC, m1_red_nchunks(Vout, g.OC, g.N), g.stats_out, Vout, g.stats_eps, st, 0,
                                                 g.stats_out2, g.stats_out2 ? g.oc_split : 0);
         }

@@ -192,7 +192,7 @@ __global__ void __launch_bounds__(256) conv_pw_kernel(PwP p) {
 
 // ------------------------------------------------------------------------------------------------
 static bool pw_plan(const MfmaP& m, int OCpad, int BN, PwP& p) {
-    static int en = -1; if (en < 0) { const char* e = getenv("M1_PW"); en = e ? atoi(e) : 1; }
+    int en = M1_CFG("M1_PW", 1);
     if (!en) return false;
     if (m.nclasses != 1 || m.ksplit != 1 || m.cls_ntaps[0] != 1) return false;
     if (m.tdd[0] != 0 || m.tdh[0] != 0 || m.tdw[0] != 0) return false;
@@ -213,7 +213,7 @@ static bool pw_plan(const MfmaP& m, int OCpad, int BN, PwP& p) {
 }
 static int pw_nwaves(const PwP& p, int OCpad, int BN) {
     const int slices = OCpad / BN;
-    static int tg = -1; if (tg < 0) { const char* e = getenv("M1_PW_BLOCKS"); tg = e ? atoi(e) : 2048; }
+    int tg = M1_CFG("M1_PW_BLOCKS", 2048);
     long long blocks = tg / slices; if (blocks < 1) blocks = 1;
     const long long need = (p.Mtot + 127) / 128;
     if (blocks > need) blocks = need;

@@ -5,6 +5,7 @@
 // into the same output.
 #include "common.h"
 #include "gather.h"
+#include "reduce.h"
 #include <stdio.h>
 #include <stdlib.h>
 
@@ -49,7 +50,7 @@ static inline double conv_bytes(const m1_conv_desc_t* d, bool T) {
 // M1_PROF_DETAIL=1: the profiler hooks (prof.hip) key conv records by geometry, not only by entry point
 struct ProfName { char s[48]; };
 static ProfName prof_name(const char* fam, const m1_conv_desc_t* d) {
-    static int detail = -1; if (detail < 0) { const char* e = getenv("M1_PROF_DETAIL"); detail = e ? atoi(e) : 0; }
+    int detail = M1_CFG("M1_PROF_DETAIL", 0);
     ProfName n; 
     if (!detail) { snprintf(n.s, sizeof(n.s), "%s", fam); return n; }
     snprintf(n.s, sizeof(n.s), "%s %dx%dx%d c%d>%d k%d%d%d s%d%d%d m%d", fam, d->D, d->H, d->W, d->Cin, d->Cout, d->kd, d->kh, d->kw,
@@ -101,14 +102,14 @@ static GatherSpec dgrad_spec(const m1_conv_desc_t* d, bool T, const float* w, co
 // (GatherSpec::outs).  One launch instead of one per member: dY is gathered once per tile instead of once per member, 32-channel
 // members stop running on 32-column tiles (the loader-bound shape), and a 5-member dense-skip concat costs 1 launch, not 5.
 static bool dgrad_fused_ok(const m1_conv_desc_t* d) {
-    static int en = -1; if (en < 0) { const char* e = getenv("M1_DGRAD_FUSED"); en = e ? atoi(e) : 1; }
+    int en = M1_CFG("M1_DGRAD_FUSED", 1);
     if (!en || d->nsrc < 2) return false;
     const int seg = d->dtype == M1_BF16 ? 8 : 4;
     for (int i = 0; i < d->nsrc; ++i) if (d->src[i].C % seg) return false;
     // the wide, shallow layers (res0/res1: <= 64 dY channels, stride 1, >= 32,768 voxels) run on the halo-tile kernel, whose blocks
     // own one 32-column weight slice each: per-member launches are faster there (192->32 at res0: 0.76 vs 1.13 ms per step fused)
     const long long vox = (long long)d->N * d->D * d->H * d->W;
-    static int hf = -1; if (hf < 0) { const char* e = getenv("M1_DGRAD_FUSED_HALO"); hf = e ? atoi(e) : 0; }
+    int hf = M1_CFG("M1_DGRAD_FUSED_HALO", 0);
     if (!hf && d->dtype == M1_BF16 && d->Cout <= 64 && d->sd == 1 && d->sh == 1 && d->sw == 1 && vox >= 32768 && d->kd * d->kh * d->kw > 1) return false;
     return true;
 }
@@ -161,7 +162,7 @@ struct FwdGroups { int n; int first[M1_MAX_SRC], count[M1_MAX_SRC], coff[M1_MAX_
 // off the LDS-DMA loader (515 -> 256 at res4: 144 us against 69 us for 512 -> 256).  Split: the run of 64-byte-aligned members is one
 // conv that writes y (+ bias) on the fast path, the odd members follow as tiny convs that add into y.  Forward and transposed forward.
 static bool odd_split(const m1_conv_desc_t* d, bool T, FwdGroups* fg) {
-    static int en = -1; if (en < 0) { const char* e = getenv("M1_ODD_SPLIT"); en = e ? atoi(e) : 1; }
+    int en = M1_CFG("M1_ODD_SPLIT", 1);
     if (!en || g_force_direct || d->nsrc < 2) return false;
     const int seg = d->dtype == M1_BF16 ? 8 : 4, chunk = 4 * seg;
     int a0 = -1, a1 = -1, nodd = 0, call = 0;
@@ -184,7 +185,7 @@ static bool odd_split(const m1_conv_desc_t* d, bool T, FwdGroups* fg) {
 static bool fwd_groups(const m1_conv_desc_t* d, bool T, FwdGroups* fg) {
     if (odd_split(d, T, fg)) return true;
     fg->T = T;
-    static int en = -1; if (en < 0) { const char* e = getenv("M1_HALO_GROUPS"); en = e ? atoi(e) : 1; }
+    int en = M1_CFG("M1_HALO_GROUPS", 1);
     if (!en || T || g_force_direct || d->dtype != M1_BF16 || d->nsrc < 2 || d->Cin <= 64) return false;
     if (d->kd * d->kh * d->kw < 2) return false;
     Geo q = conv_geo(d);
@@ -215,7 +216,7 @@ static GatherSpec fwd_group_spec(const m1_conv_desc_t* d, const FwdGroups& fg, i
 // 0.2 % of its flops).  Instead: X -> X8 (zero-padded to 8 channels, one 16-byte segment per voxel) in the workspace, the
 // tap-fused kernel on (X8, dY) into a scratch gradient with 8 input rows per tap, and a fold of its first Cin rows.
 static bool stem_wanted(const m1_conv_desc_t* d, bool T) {
-    static int en = -1; if (en < 0) { const char* e = getenv("M1_STEM_TF"); en = e ? atoi(e) : 1; }
+    int en = M1_CFG("M1_STEM_TF", 1);
     // (fp32: the same with 4 channels = one 16-byte segment per voxel, on the fp32 tap-fused kernel)
     return en && !T && !g_force_direct && d->nsrc == 1 && d->src[0].C < (d->dtype == M1_BF16 ? 8 : 4) && d->Cin == d->src[0].C;
 }
@@ -260,7 +261,7 @@ static size_t wgrad_rx_bytes(const m1_conv_desc_t* d) {
     const size_t other = cmax > (size_t)d->Cout ? cmax : (size_t)d->Cout;      // (transposed conv: the roles of the two sides swap)
     const size_t stride = taps * cmax * d->Cout + other;
     size_t b = 512 * stride * sizeof(float);
-    static long long cap = -1; if (cap < 0) { const char* e = getenv("M1_WG_RX_MB"); cap = (e ? atoll(e) : 64) << 20; }
+    const long long cap = (long long)M1_CFG("M1_WG_RX_MB", 64) << 20;
     if (b > (size_t)cap) b = (size_t)cap;
     if (b < 2 * stride * sizeof(float)) b = 2 * stride * sizeof(float);
     return align256(b);
@@ -486,15 +487,24 @@ extern "C" int m1_conv3d_dgrad(const m1_conv_desc_t* d, const float* w, const vo
 // the kernel that writes d(a) also emits the per-tile sums the InstanceNorm backward needs ({sum dy, sum dy*xh} per sample and
 // channel) into `partial` [N][*nparts][Cin][2].  *nparts = 0: the kernel that took the shape has no such epilogue -- d(a) is
 // complete, the caller runs m1_instnorm_bwd instead of m1_instnorm_bwd_partials.
+// rows per sample the partial buffer of m1_conv3d_dgrad_inbwd must hold (`partial` = N * rows * Cin * 2 floats): the most any kernel
+// behind it writes -- one row per epilogue tile (>= 64 voxels each) or one per chunk of the split-K finish reduction
+extern "C" int m1_conv3d_dgrad_inbwd_rows(const m1_conv_desc_t* d) {
+    if (!desc_ok(d)) return 0;
+    const long long V = (long long)d->D * d->H * d->W;
+    const long long tiles = cdiv_ll(V, 64), chunks = m1_red_nchunks(V, d->Cin, d->N);
+    const long long r = tiles > chunks ? tiles : chunks;
+    return r > 0x3fffffff ? 0x3fffffff : (int)r;
+}
 extern "C" int m1_conv3d_dgrad_inbwd(const m1_conv_desc_t* d, const float* w, const void* dy, void* da, const void* x, const float* stats,
-                                     const float* gamma, const float* beta, float slope, float* partial, int* nparts, void* ws,
-                                     int ws_packed, void* stream) {
-    if (!desc_ok(d) || !w || !dy || !da || !x || !stats || !gamma || !beta || !partial || !nparts || d->nsrc != 1) return M1_ERR_BAD_ARG;
+                                     const float* gamma, const float* beta, float slope, float* partial, int partial_rows, int* nparts,
+                                     void* ws, int ws_packed, void* stream) {
+    if (!desc_ok(d) || !w || !dy || !da || !x || !stats || !gamma || !beta || !partial || !nparts || d->nsrc != 1 || partial_rows < 0) return M1_ERR_BAD_ARG;
     M1ProfScope ps(prof_name("conv3d_dgrad", d).s, 2.0 * conv_macs(d, false), conv_bytes(d, false), (hipStream_t)stream);
     *nparts = 0;
     if (g_force_direct) { void* dxs[1] = {da}; int acc0[1] = {0}; return dgrad_common(d, false, w, dy, dxs, acc0, ws, ws_packed, (hipStream_t)stream); }
     GatherSpec g = dgrad_spec(d, false, w, dy, da, 0, 0);
-    g.ib_x = x; g.ib_stats = stats; g.ib_gamma = gamma; g.ib_beta = beta; g.ib_slope = slope; g.ib_partial = partial; g.ib_nparts = nparts;
+    g.ib_x = x; g.ib_stats = stats; g.ib_gamma = gamma; g.ib_beta = beta; g.ib_slope = slope; g.ib_partial = partial; g.ib_nparts = nparts; g.ib_cap = partial_rows;
     return run_gather(g, ws, ws_packed, (hipStream_t)stream);
 }
 extern "C" int m1_convT3d_dgrad(const m1_conv_desc_t* d, const float* w, const void* dy, void* const* dx, const int* accumulate,
@@ -507,8 +517,7 @@ extern "C" int m1_convT3d_dgrad(const m1_conv_desc_t* d, const float* w, const v
 // ---- weight gradients ------------------------------------------------------------------------------------------
 #include <stdlib.h>
 static bool tf_wanted(const WgradSpec& g) {
-    static int maxc = -1;
-    if (maxc < 0) { const char* e = getenv("M1_TF_MAXC"); maxc = e ? atoi(e) : 128; }
+    int maxc = M1_CFG("M1_TF_MAXC", 128);
     if (m1_tf64_wgrad_supported(g)) return true;
     // 32x32 channel tiles re-read dY once per 32 input channels and X once per 32 output channels: a win while the OUTPUT side
     // is narrow (conv1 of an SE block: F/4 <= 32 channels -- 512->32 at res2: 1.70 -> 1.08 ms per step), a loss beyond (512->128: 2x slower)
@@ -587,7 +596,7 @@ static int wgrad_common(const m1_conv_desc_t* d, bool T, const void* dy, float* 
             g.RT = (long long)d->Cout * d->Cin; g.RSA = d->Cin; g.a_off = 0; g.b_off = off;
         }
         int rc = M1_ERR_UNSUPPORTED;
-        static int wlog = -1; if (wlog < 0) { const char* e = getenv("M1_WG_LOG"); wlog = e ? atoi(e) : 0; }
+        int wlog = M1_CFG("M1_WG_LOG", 0);
         // >= 64 channels on both sides, stride 1: the 64x64-tile tap-fused kernel on 32x32x16 MFMAs, one launch for a run of
         // equal-width members (dY staged once per kd slice for all of them, wgrad_t3.hip)
         if (!g_force_direct && rx && m1_t3_wgrad_supported(g)) {
@@ -617,7 +626,7 @@ static int wgrad_common(const m1_conv_desc_t* d, bool T, const void* dy, float* 
             rc = M1_ERR_UNSUPPORTED;
         }
         // a run of members with the same channel count on the tap-fused kernel: ONE launch (blockIdx.z = member)
-        static int multi = -1; if (multi < 0) { const char* e = getenv("M1_TF_MULTI"); multi = e ? atoi(e) : 1; }
+        int multi = M1_CFG("M1_TF_MULTI", 1);
         if (multi && !T && !g_force_direct && rx && tf_wanted(g)) {
             int n = 1;
             while (i + n < d->nsrc && d->src[i + n].C == d->src[i].C) ++n;

@@ -34,6 +34,7 @@ struct GatherSpec {
     // the problem cannot (the caller then runs the stand-alone reduction).
     const void* ib_x; const float* ib_stats; const float* ib_gamma; const float* ib_beta; float ib_slope;
     float* ib_partial; int* ib_nparts;
+    int ib_cap;                // rows per sample `ib_partial` holds (a kernel that would write more leaves *ib_nparts = 0)
 };
 
 int m1_stats_internal(const void* x, int N, long long V, int C, int dtype, float eps, float* stats, float* ws, hipStream_t st);

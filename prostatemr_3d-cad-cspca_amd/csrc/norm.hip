@@ -31,9 +31,8 @@ struct StatsF {
 template <typename T>
 static int stats_impl(const void* x, int N, long long V, int C, float eps, float* stats, float* ws, hipStream_t st) {
     StatsF<T> f{(const T*)x, V, C};
-    M1RedFin<2> fin{}; fin.mode = 1; fin.out = stats; fin.stats_V = V; fin.eps = eps;       // {mean, rstd} by the last block of the reduction
-    int rc = m1_reduce_nc_launch<2>(f, N, V, C, ws, st, &fin);
-    if (rc || fin.mode) return rc;
+    int rc = m1_reduce_nc_launch<2>(f, N, V, C, ws, st);
+    if (rc) return rc;
     return m1_reduce_finalize_launch<2>(ws, N, C, m1_red_nchunks(V, C, N), stats, V, eps, st);
 }
 
@@ -220,10 +219,9 @@ static int bwd_impl(const void* x, const float* stats, const float* gamma, const
     const int nchunks = m1_red_nchunks(V, C, N);
     float* sums = ws + (size_t)N * nchunks * C * 2;
     M1ParamOut<2> po{{dbeta, dgamma}, {accumulate, accumulate}};      // dbeta = sum_n sums[.][0], dgamma = sum_n sums[.][1]
-    M1RedFin<2> fin{}; fin.mode = 2; fin.out = sums; fin.po = po;
-    int rc = m1_reduce_nc_launch<2>(f, N, V, C, ws, st, &fin);
+    int rc = m1_reduce_nc_launch<2>(f, N, V, C, ws, st);
     if (rc) return rc;
-    if (!fin.mode) { rc = m1_reduce_finalize_params_launch<2>(ws, N, C, nchunks, sums, po, st); if (rc) return rc; }
+    rc = m1_reduce_finalize_params_launch<2>(ws, N, C, nchunks, sums, po, st); if (rc) return rc;
     constexpr int VW = sizeof(T) == 2 ? 8 : 4;
     if (C % VW == 0) {
         long long per = V * (C / VW);
@@ -269,10 +267,9 @@ struct ColSumF {
 // Internal (used by conv wgrad): ws must hold N*nchunks*C floats.
 int m1_colsum_internal(const void* x, int N, long long V, int C, int dtype, float* out, float* ws, hipStream_t st, int accumulate) {
     int rc;
-    M1RedFin<1> fin{}; fin.mode = 1; fin.joint = 1; fin.out = out; fin.accumulate = accumulate;
-    if (dtype == M1_BF16) { ColSumF<bf16_t> f{(const bf16_t*)x, V, C}; rc = m1_reduce_nc_launch<1>(f, N, V, C, ws, st, &fin); }
-    else { ColSumF<float> f{(const float*)x, V, C}; rc = m1_reduce_nc_launch<1>(f, N, V, C, ws, st, &fin); }
-    if (rc || fin.mode) return rc;
+    if (dtype == M1_BF16) { ColSumF<bf16_t> f{(const bf16_t*)x, V, C}; rc = m1_reduce_nc_launch<1>(f, N, V, C, ws, st); }
+    else { ColSumF<float> f{(const float*)x, V, C}; rc = m1_reduce_nc_launch<1>(f, N, V, C, ws, st); }
+    if (rc) return rc;
     // partial is [N*nchunks][C][1]: fold all rows as one sample
     return m1_reduce_finalize_launch<1>(ws, 1, C, N * m1_red_nchunks(V, C, N), out, 0, 0.f, st, accumulate);
 }

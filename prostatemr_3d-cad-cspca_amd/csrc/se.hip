@@ -403,12 +403,11 @@ static int se_bwd_impl(const void* y3, const void* y4, const void* dout, const S
     float* sums = ws + (size_t)N * nchunks * p.F * 5;
     // parameter gradients ride on the fold: dg is scratch for the gate backward (always overwritten)
     M1ParamOut<5> po{{dbeta3, dgamma3, dbeta4, dgamma4, dg}, {acc, acc, acc, acc, 0}};
-    M1RedFin<5> fin{}; fin.mode = 2; fin.out = sums; fin.po = po;         // folded by the last block of the reduction
-    if (masked) { SeBwdF<T, true> f{(const T*)y3, (const T*)y4, (const T*)dout, p}; rc = m1_reduce_nc_launch<5>(f, N, p.V, p.F, ws, st, &fin); }
-    else { SeBwdF<T> f{(const T*)y3, (const T*)y4, (const T*)dout, p}; rc = m1_reduce_nc_launch<5>(f, N, p.V, p.F, ws, st, &fin); }
+    if (masked) { SeBwdF<T, true> f{(const T*)y3, (const T*)y4, (const T*)dout, p}; rc = m1_reduce_nc_launch<5>(f, N, p.V, p.F, ws, st); }
+    else { SeBwdF<T> f{(const T*)y3, (const T*)y4, (const T*)dout, p}; rc = m1_reduce_nc_launch<5>(f, N, p.V, p.F, ws, st); }
     if (rc) return rc;
-    if (!fin.mode) { rc = m1_reduce_finalize_params_launch<5>(ws, N, p.F, nchunks, sums, po, st); if (rc) return rc; }
-    static int w3 = -1; if (w3 < 0) { const char* e = getenv("M1_SE_BWD_W3"); w3 = e ? atoi(e) : 0; }
+    rc = m1_reduce_finalize_params_launch<5>(ws, N, p.F, nchunks, sums, po, st); if (rc) return rc;
+    int w3 = M1_CFG("M1_SE_BWD_W3", 0);
     if (masked && w3)       // 3 waves per SIMD at the price of 4 spilled registers (measured: see DESIGN 5)
         hipLaunchKernelGGL((se_combine_bwd_apply_kernel<T, VW, true, 3>), dim3(m1_grid_for(p.V * (p.F / VW), p.F / VW), N), dim3(256), 0, st,
                            (const T*)y3, (const T*)y4, (const T*)dout, p, sums, (T*)dy3, (T*)dy4);

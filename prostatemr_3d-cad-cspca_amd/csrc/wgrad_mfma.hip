@@ -239,8 +239,8 @@ static int launch_wg(WgP p, hipStream_t st) {
     // ~2 blocks per CU: every extra voxel split adds TA*TB float atomics per tap, and those are executed at the memory
     // side on this part (measured: 1536 -> 512 target blocks = -28 % on the 128x128x27-tap layers).  Rounded DOWN: 512 = 2 per
     // CU; one block more is a second round for its whole XCD (-8 % on the wgrad family).  M1_WG_BLOCKS overrides.
-    static int tgt = -1; if (tgt < 0) { const char* e = getenv("M1_WG_BLOCKS"); tgt = e ? atoi(e) : 512; }
-    static int rdn = -1; if (rdn < 0) { const char* e = getenv("M1_WG_FLOOR"); rdn = e ? atoi(e) : 1; }
+    int tgt = M1_CFG("M1_WG_BLOCKS", 512);
+    int rdn = M1_CFG("M1_WG_FLOOR", 1);
     long long splits = rdn ? tgt / ((long long)aTiles * bTiles * taps) : cdiv_ll(tgt, (long long)aTiles * bTiles * taps);
     const long long max_splits = cdiv_ll(TV, 4 * KS);
     if (splits > max_splits) splits = max_splits;
@@ -256,7 +256,7 @@ static int launch_wg(WgP p, hipStream_t st) {
     bool partial = false;
     const long long stride = (long long)taps * p.CA * p.CB + p.CB;
     p.rx_stride = stride; p.rx_bias = (long long)taps * p.CA * p.CB;
-    static int det = -1; if (det < 0) { const char* e = getenv("M1_WG_DET"); det = e ? atoi(e) : 1; }
+    int det = M1_CFG("M1_WG_DET", 1);
     const bool small = (long long)taps * p.CA * p.CB <= 32768 && splits >= 24;
     if (splits >= 2 && (det || small)) {
         long long fit = p.rx ? p.rx_floats / stride : 0;
@@ -266,7 +266,7 @@ static int launch_wg(WgP p, hipStream_t st) {
         } else if (det) { splits = 1; vps = cdiv_ll(TV, KS) * KS; p.vox_per_split = vps; grid.z = 1; }
     }
     if (!partial) { p.Rx = nullptr; }
-    static int xr = -1; if (xr < 0) { const char* e = getenv("M1_WG_XCD"); xr = e ? atoi(e) : 1; }
+    int xr = M1_CFG("M1_WG_XCD", 1);
     p.xcd_total = 0; p.xcd_gx = (int)grid.x; p.xcd_gy = (int)grid.y; p.xcd_gz = (int)grid.z;
     if (xr && (long long)grid.x * grid.y > 1 && splits > 1) {
         p.xcd_total = (int)(((long long)grid.x * grid.y * grid.z + 7) / 8 * 8);

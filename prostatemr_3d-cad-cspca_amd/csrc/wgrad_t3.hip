@@ -536,10 +536,10 @@ __global__ void __launch_bounds__(T3_THREADS, 3) wgrad_t3f_kernel(T3P p) {
 
 // fills the tile geometry; false = shape outside this kernel
 static bool t3_plan(const WgradSpec& g, T3P& p) {
-    static int en = -1; if (en < 0) { const char* e = getenv("M1_WG_T3"); en = e ? atoi(e) : 1; }
+    int en = M1_CFG("M1_WG_T3", 1);
     if (!en || (g.dtype != M1_BF16 && g.dtype != M1_F32)) return false;
     const bool f32 = g.dtype == M1_F32;
-    { static int ef = -1; if (ef < 0) { const char* e = getenv("M1_WG_T3F"); ef = e ? atoi(e) : 1; } if (f32 && !ef) return false; }
+    { int ef = M1_CFG("M1_WG_T3F", 1); if (f32 && !ef) return false; }
     if (g.CA < 64 || g.CB < 64 || g.CA % 64 || g.CB % 64) return false;
     if (!(g.kh == 3 && g.kw == 3 && (g.kd == 1 || g.kd == 3))) return false;
     const bool s1 = g.sh == 1 && g.sw == 1 && g.sd == 1, s2 = g.sh == 2 && g.sw == 2 && (g.sd == 1 || g.sd == 2) && g.ph == 0 && g.pw == 0;
@@ -590,7 +590,7 @@ int m1_t3_wgrad(const WgradSpec& g, long long nw, int nb, hipStream_t st, int nm
     if (!bigb && p.nunits < 2) return M1_ERR_UNSUPPORTED;      // (a single 64 -> 64 tile: the per-tap kernel)
     const int gx = bigb ? g.CB / 128 : g.CB / 64, gzu = bigb ? p.nunits : (p.nunits + 1) / 2;
     const long long per_split = (long long)gx * gzu * g.kd;    // blocks per voxel split
-    static int tgt = -1; if (tgt < 0) { const char* e = getenv("M1_T3_BLOCKS"); tgt = e ? atoi(e) : 256; }      // one block per CU
+    int tgt = M1_CFG("M1_T3_BLOCKS", 256);      // one block per CU
     long long nsplit = tgt / per_split; if (nsplit < 1) nsplit = 1;
     const long long nloc = (long long)g.kd * 9 * g.CA * g.CB;
     const long long stride = nloc + g.CB;                      // compact copy of one member's block (+ bias sums)
@@ -600,7 +600,7 @@ int m1_t3_wgrad(const WgradSpec& g, long long nw, int nb, hipStream_t st, int nm
     if (nsplit < 1) nsplit = 1;
     // too small to fill the chip at that depth (single layers of the (10,20,20) level): the per-tap kernel, with 27 x more
     // blocks per voxel split, is the better fit
-    static int minb = -1; if (minb < 0) { const char* e = getenv("M1_T3_MIN_BLOCKS"); minb = e ? atoi(e) : 128; }
+    int minb = M1_CFG("M1_T3_MIN_BLOCKS", 128);
     if (nsplit * per_split < minb) return M1_ERR_UNSUPPORTED;
     p.nsplit = (int)nsplit;
     p.Rx = g.rx; p.rx_stride = stride; p.rx_bias = nloc; p.rx_mem = nmem > 1 ? rx_mem : 0;
@@ -611,7 +611,7 @@ int m1_t3_wgrad(const WgradSpec& g, long long nw, int nb, hipStream_t st, int nm
     const int stage_bytes = f32 ? (bigb ? nA + 32 : 2 * nA + 16) * 1024 : (bigb ? nA + 16 : 2 * nA + 8) * 1024;
     const long long tiles_per_block = (p.ntiles + nsplit - 1) / nsplit;
     int S = f32 ? 3 : 4;
-    { static int fs = -1; if (fs < 0) { const char* e = getenv("M1_T3_STAGES"); fs = e ? atoi(e) : 0; } if (fs >= 2 && fs <= 5) S = fs; }
+    { int fs = M1_CFG("M1_T3_STAGES", 0); if (fs >= 2 && fs <= 5) S = fs; }
     if (f32 && S > 3) S = 3;
     while (S >= 2 && (size_t)S * stage_bytes + 1024 + (size_t)(tiles_per_block + S) * 32 > 160 * 1024) --S;
     if (S < 2) return M1_ERR_UNSUPPORTED;

@@ -228,7 +228,7 @@ __global__ void __launch_bounds__(TS_THREADS, 3) wgrad_t3s_kernel(TSP p) {
 }
 
 static bool ts_plan(const WgradSpec& g, TSP& p, int* kws_out) {
-    static int en = -1; if (en < 0) { const char* e = getenv("M1_WG_T3S"); en = e ? atoi(e) : 1; }
+    int en = M1_CFG("M1_WG_T3S", 1);
     if (!en || g.dtype != M1_F32) return false;
     if (g.CA % 4 || g.CB % 4 || g.CA < 4 || g.CB < 4) return false;
     if (!(g.kh == 3 && g.kw == 3 && (g.kd == 1 || g.kd == 3))) return false;
@@ -263,7 +263,7 @@ int m1_t3s_wgrad(const WgradSpec& g, long long nw, int nb, hipStream_t st) {
     const int TLh = (g.CA <= 16 || g.CB <= 16) ? 16 : 32;
     const int nbu = (g.CB + TLh - 1) / TLh;
     const long long per_split = (long long)nbu * p.nau * g.kd;
-    static int tgt = -1; if (tgt < 0) { const char* e = getenv("M1_T3S_BLOCKS"); tgt = e ? atoi(e) : 256; }
+    int tgt = M1_CFG("M1_T3S_BLOCKS", 256);
     long long nsplit = tgt / per_split; if (nsplit < 1) nsplit = 1;
     const long long nloc = (long long)g.kd * 9 * g.CA * g.CB;
     const long long stride = nloc + g.CB;
@@ -425,7 +425,7 @@ __global__ void __launch_bounds__(PW_THREADS, 2) wgrad_pwf_kernel(PWP p) {
 }
 
 bool m1_pwf_wgrad_supported(const WgradSpec& g) {
-    static int en = -1; if (en < 0) { const char* e = getenv("M1_WG_PWF"); en = e ? atoi(e) : 1; }
+    int en = M1_CFG("M1_WG_PWF", 1);
     if (!en || g.dtype != M1_F32) return false;
     if (g.kd != 1 || g.kh != 1 || g.kw != 1 || g.sd != 1 || g.sh != 1 || g.sw != 1) return false;
     if (g.AD != g.BD || g.AH != g.BH || g.AW != g.BW) return false;
@@ -442,7 +442,7 @@ int m1_pwf_wgrad(const WgradSpec& g, long long nw, int nb, hipStream_t st) {
     p.V = (long long)g.N * g.BD * g.BH * g.BW;
     p.ntiles = (int)((p.V + PW_KT - 1) / PW_KT);
     const int nau = (g.CA + 63) / 64, nbu = (g.CB + 63) / 64;
-    static int tgt = -1; if (tgt < 0) { const char* e = getenv("M1_PWF_BLOCKS"); tgt = e ? atoi(e) : 256; }     // one block per CU (128 KB of LDS)
+    int tgt = M1_CFG("M1_PWF_BLOCKS", 256);     // one block per CU (128 KB of LDS)
     long long nsplit = tgt / (nau * nbu); if (nsplit < 1) nsplit = 1;
     const long long nloc = (long long)g.CA * g.CB, stride = nloc + g.CB;
     if (!g.rx || g.rx_floats < stride) return M1_ERR_WORKSPACE;

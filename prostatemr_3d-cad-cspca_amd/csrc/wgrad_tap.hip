@@ -250,7 +250,7 @@ __global__ void __launch_bounds__(256) wgrad_tap_kernel(TapP p) {
 static inline int tap_side(int c) { return c > 64 ? 128 : 64; }
 
 static bool tap_plan(const WgradSpec& g, TapP& p) {
-    static int en = -1; if (en < 0) { const char* e = getenv("M1_WG_TAP"); en = e ? atoi(e) : 1; }
+    int en = M1_CFG("M1_WG_TAP", 1);
     if (!en || g.dtype != M1_BF16) return false;
     if (g.CA < 64 || g.CB < 64 || g.CA % 8 || g.CB % 8) return false;
     if (g.BW % 8 && g.BW > 32) return false;
@@ -278,18 +278,18 @@ int m1_tap_wgrad(const WgradSpec& g, long long nw, int nb, hipStream_t st) {
     if (!tap_plan(g, p)) return M1_ERR_UNSUPPORTED;
     const int TA = tap_side(g.CA), TB = tap_side(g.CB);
     const int taps = g.kd * g.kh * g.kw;
-    static int tgt = -1; if (tgt < 0) { const char* e = getenv("M1_WG_TAP_BLOCKS"); tgt = e ? atoi(e) : 512; }
+    int tgt = M1_CFG("M1_WG_TAP_BLOCKS", 512);
     const int aTiles = (g.CA + TA - 1) / TA; p.bTiles = (g.CB + TB - 1) / TB;
     const int ctiles = aTiles * p.bTiles;
     // round DOWN: 2 blocks per CU x 256 CUs = 512 slots; one block more than that is a second round for its whole XCD
-    static int rdn = -1; if (rdn < 0) { const char* e = getenv("M1_WG_FLOOR"); rdn = e ? atoi(e) : 1; }
+    int rdn = M1_CFG("M1_WG_FLOOR", 1);
     long long nsplit = rdn ? tgt / ((long long)ctiles * taps) : (tgt + (long long)ctiles * taps - 1) / ((long long)ctiles * taps);
     if (nsplit > p.ntiles / 4) nsplit = p.ntiles / 4;
     if (nsplit < 1) nsplit = 1;
     p.nsplit = (int)nsplit;
     const int stage = 64 * (TA + TB) * 2;
     int S = (76 * 1024) / stage; if (S > 4) S = 4; if (S < 2) S = 2;
-    { static int fs = -1; if (fs < 0) { const char* e = getenv("M1_WG_TAP_STAGES"); fs = e ? atoi(e) : 0; } if (fs >= 2) S = fs; }
+    { int fs = M1_CFG("M1_WG_TAP_STAGES", 0); if (fs >= 2) S = fs; }
     p.stages = S;
     const size_t smem = (size_t)S * stage;
     void (*kern)(TapP) = nullptr;
@@ -308,7 +308,7 @@ int m1_tap_wgrad(const WgradSpec& g, long long nw, int nb, hipStream_t st) {
     }
     // partial copies + fixed-order fold instead of atomics (compact per-member copies, see wgrad_mfma.hip): bit-reproducible
     // weight gradients; M1_WG_DET=0 restores the atomic path
-    static int det = -1; if (det < 0) { const char* e = getenv("M1_WG_DET"); det = e ? atoi(e) : 1; }
+    int det = M1_CFG("M1_WG_DET", 1);
     const long long stride = (long long)taps * g.CA * g.CB + g.CB;
     p.Rx = nullptr; p.rx_stride = stride; p.rx_bias = (long long)taps * g.CA * g.CB;
     if (det && nsplit >= 2) {
@@ -317,7 +317,7 @@ int m1_tap_wgrad(const WgradSpec& g, long long nw, int nb, hipStream_t st) {
         else nsplit = 1;
         p.nsplit = (int)nsplit;
     }
-    static int xr = -1; if (xr < 0) { const char* e = getenv("M1_WG_XCD"); xr = e ? atoi(e) : 1; }
+    int xr = M1_CFG("M1_WG_XCD", 1);
     p.ctiles = ctiles; p.taps = taps; p.xcd_total = 0;
     if (xr && taps > 1) {
         p.xcd_total = (int)(((long long)ctiles * nsplit * taps + 7) / 8 * 8);

@@ -595,7 +595,7 @@ static bool tf_plan(const WgradSpec& g, TfP& p) {
     // channels; 64 for the other (3,3,3) layers, whose 3-slice input tiles would leave one block per CU.  With the members of a
     // concat in one launch (enough blocks per CU) the larger tile pays: 64 -> 32 at (2,20,160,160) 146 -> 112 us, 320 -> 64 at
     // (2,20,80,80) 358 -> 294 us, -1.2 % per C3 step.  M1_TF_NKS4: 2 (default), 1 = only the <= 16-channel layers, 0 = always 64.
-    static int n4 = -1; if (n4 < 0) { const char* e = getenv("M1_TF_NKS4"); n4 = e ? atoi(e) : 2; }
+    int n4 = M1_CFG("M1_TF_NKS4", 2);
     const int nks = ((n4 && g.CA <= 16 && g.CB <= 16) || (n4 == 2 && g.kd == 1)) ? 4 : 2;
     p.nks = nks;
     p.TH = nks * (32 / p.KWs);
@@ -614,13 +614,13 @@ static bool tf_plan(const WgradSpec& g, TfP& p) {
     if (S < 3) S = 3;
     if (S > TF_MAX_STAGES) S = TF_MAX_STAGES;
     while (S > 3 && npiece * (S - 2) > 48) --S;
-    { static int fs = -1; if (fs < 0) { const char* e = getenv("M1_TF_STAGES"); fs = e ? atoi(e) : 0; } if (fs >= 3) S = fs; }
+    { int fs = M1_CFG("M1_TF_STAGES", 0); if (fs >= 3) S = fs; }
     p.stages = S;
     return npiece * (S - 2) <= 48 && (size_t)S * sb <= 160 * 1024;
 }
 // 64x64 variant: both sides multiples of 64 channels
 static bool tf64_plan(const WgradSpec& g, TfP& p) {
-    static int en = -1; if (en < 0) { const char* e = getenv("M1_TF64"); en = e ? atoi(e) : 0; }      // off by default, see the kernel header
+    int en = M1_CFG("M1_TF64", 0);      // off by default, see the kernel header
     if (!en || g.dtype != M1_BF16 || g.CA % 64 || g.CB % 64) return false;
     if (!(g.kh == 3 && g.kw == 3 && (g.kd == 1 || g.kd == 3))) return false;
     if (g.BW % 8) return false;
@@ -734,7 +734,7 @@ static int tf_wgrad_launch(const WgradSpec& g, long long nw, int nb, hipStream_t
     // blocks per launch (M1_TF_SPLIT, 0 = by size): 256 (one per CU) up to ~24k K-tiles, 512 beyond -- isolated, the 64 -> 32 layer
     // at (20,160,160) runs 102 -> 67 us with 512, but every block adds a partial copy to fold and in the captured step other
     // kernels fill the idle SIMDs: C3 (4 volumes per launch) -2 % with 512, C2 (2 volumes) +1 %
-    static int tgt_env = -1; if (tgt_env < 0) { const char* e = getenv("M1_TF_SPLIT"); tgt_env = e ? atoi(e) : 0; }
+    int tgt_env = M1_CFG("M1_TF_SPLIT", 0);
     const int tgt = tgt_env > 0 ? tgt_env : (p.ntiles >= 24576 ? 512 : 256);
     long long nsplit = (tgt + ctiles - 1) / ctiles;
     if (big) nsplit = (tgt + ctiles * g.kd - 1) / (ctiles * g.kd);

@@ -90,8 +90,8 @@ class GradReducer:
     def bind(self, flat_grad: torch.Tensor, ranges: Dict[str, Tuple[int, int]], order: Sequence[str], tail: Tuple[int, int],
              side_streams: Optional[Callable[[], Sequence]] = None, before_send: Optional[Callable[[], None]] = None) -> None:
         """``ranges[key]`` = [lo, hi) of group ``key`` inside ``flat_grad``; ``order`` = the order groups are expected to
-        complete in; ``tail`` = the range exchanged last (biases, norms, SE); ``side_streams()`` = the streams besides the
-        current one that may hold backward kernels (ops.branch)."""
+        complete in; ``tail`` = the range exchanged last (biases, norms, SE); ``side_streams()`` = the streams that may
+        hold backward kernels of the step, the stream the step started on first (ops.exchange_streams)."""
         self.flat, self.ranges, self.order, self.tail = flat_grad, dict(ranges), list(order), tuple(tail)
         if side_streams is not None:
             self._side_streams = side_streams
@@ -121,10 +121,15 @@ class GradReducer:
             self._reduce_range(lo, hi)
             return
         cur = torch.cuda.current_stream(self.flat.device)
-        self._comm.wait_stream(cur)                       # everything enqueued so far on the main stream ...
-        for s in self._side_streams():                    # ... and on the branch streams (their weight gradients land in flat too)
-            if s != cur:
-                self._comm.wait_stream(s)
+        # everything enqueued so far: the stream the step runs on FIRST (side_streams() lists it first; a hook may fire with a
+        # branch stream current -- the posterior lane -- and the communication stream must join a graph capture through the
+        # capture's origin before it takes edges from forked streams), then the branch streams (their weight gradients land in
+        # flat too), then the current stream
+        streams = list(self._side_streams())
+        if cur not in streams:
+            streams.append(cur)
+        for s in streams:
+            self._comm.wait_stream(s)
         with torch.cuda.stream(self._comm):
             self._reduce_range(lo, hi)
 

@@ -68,7 +68,11 @@ SIGNATURES = {
     "m1_set_force_direct": (_i, [_i]),
     "m1_conv3d_fwd": (_i, [_desc_p, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
     "m1_conv3d_dgrad": (_i, [_desc_p, _vp, _vp, C.POINTER(_vp), C.POINTER(_i), _vp, _i, _vp]),
-    "m1_conv3d_dgrad_inbwd": (_i, [_desc_p, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, C.POINTER(_i), _vp, _i, _vp]),
+    "m1_conv3d_dgrad_inbwd_rows": (_i, [_desc_p]),
+    "m1_conv3d_dgrad_inbwd": (_i, [_desc_p, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _i, C.POINTER(_i), _vp, _i, _vp]),
+    "m1_config_set": (_i, [C.c_char_p, _i]),
+    "m1_config_unset": (_i, [C.c_char_p]),
+    "m1_config_get": (_i, [C.c_char_p, C.POINTER(_i)]),
     "m1_conv3d_wgrad": (_i, [_desc_p, _vp, _vp, _vp, _vp, _i, _vp]),
     "m1_conv3d_pair_supported": (_i, [_desc_p, _i]),
     "m1_conv3d_pair_fwd": (_i, [_desc_p, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp]),

@@ -232,10 +232,24 @@ def finish_queued_for_exchange() -> None:
     (without retiring them) and runs the weight-gradient folds queued so far."""
     if _FOLD["keep"]:
         cur = torch.cuda.current_stream()
+        # a hook that fires on a lane (the posterior pass runs its backward on a side stream, networks.py M1_PQ_LANES) must also
+        # wait for the ORIGIN stream: the queue holds the prior's partial copies too, whose weight-gradient kernels are in flight
+        # there (``used`` only lists side streams)
+        origin = _BRANCH.get("origin")
+        if origin is not None and origin != cur:
+            cur.wait_stream(origin)
         for s in _BRANCH["used"]:
             if s != cur:
                 cur.wait_stream(s)
         fold_pending()
+
+
+def exchange_streams():
+    """Streams that may hold backward kernels of the running step, the origin stream FIRST (a communication stream must join a
+    graph capture through the stream the capture started on before it takes edges from forked streams), for ddp.GradReducer."""
+    origin = _BRANCH.get("origin")
+    out = [origin] if origin is not None else []
+    return out + [s for s in _BRANCH["used"] if s is not origin]
 
 
 def fold_drop() -> None:
@@ -493,8 +507,13 @@ class _Conv3d(torch.autograd.Function):
         # the input is a = lrelu(IN(x)) with this conv as its only reader (conv2 / conv3 of an SE block): the data gradient can
         # emit the InstanceNorm-backward sums from its own epilogue (instnorm_act tags its output, see _InstNormAct.backward)
         ctx.in_src = None
-        if _INBWD["on"] and len(srcs) == 1 and not transposed and ctx.gslots[0] is None:
-            ctx.in_src = getattr(srcs[0], "_m1_in_src", None)
+        for t in srcs:                    # every conv reading a tagged tensor counts (two readers: the norm keeps its own reduction)
+            tk = getattr(t, "_m1_in_src", None)
+            if tk is not None:
+                tk.readers += 1
+        tok = getattr(srcs[0], "_m1_in_src", None)
+        if _INBWD["on"] and len(srcs) == 1 and not transposed and ctx.gslots[0] is None and tok is not None and tok.src is not None:
+            ctx.in_src = tok
         if want_stats:
             ctx.mark_non_differentiable(stats)
             ctx.set_materialize_grads(False)      # no zero-filled "gradient" for the statistics output
@@ -530,18 +549,22 @@ class _Conv3d(torch.autograd.Function):
                 dsrc.append(None)
                 ptrs[i] = None
         if any_d and ctx.in_src is not None and accs[0] == 0:
-            xs, stats, gamma, beta, slope = ctx.in_src
+            tok = ctx.in_src
+            xs, stats, gamma, beta, slope = tok.src
             da = dsrc[0]
             N, Cn = int(xs.shape[0]), int(xs.shape[-1])
             V = xs.numel() // (N * Cn)
-            nmax = max((V + 63) // 64, 512)
+            # partial rows: the library states how many the kernel may write (its epilogue tiles or the split-K finish chunks)
+            nmax = int(lib.m1_conv3d_dgrad_inbwd_rows(C.byref(d)))
             part = torch.empty(N * nmax * Cn * 2 + N * Cn * 2 + 64, dtype=torch.float32, device=da.device)
             nparts = C.c_int(0)
             ws, packed = _panel_ws(ctx.w_param, d, False, 1, (True,))
             L.check(lib.m1_conv3d_dgrad_inbwd(C.byref(d), _p(w), _p(dy), _p(da), _p(xs), _p(stats), _p(gamma), _p(beta), float(slope),
-                                              _p(part), C.byref(nparts), _p(ws), packed, st), "m1_conv3d_dgrad_inbwd")
+                                              _p(part), nmax, C.byref(nparts), _p(ws), packed, st), "m1_conv3d_dgrad_inbwd")
             if nparts.value > 0:
-                da._m1_in_partials = (part, int(nparts.value), xs)
+                # hand-over to the norm's backward: valid for exactly this gradient tensor in exactly this state (an in-place
+                # accumulation of a second consumer's gradient bumps the version, a summed copy has another address)
+                tok.partials = (part, int(nparts.value), da.data_ptr(), da._version, tuple(da.shape))
                 _INBWD["fused"] += 1
             else:
                 _INBWD["plain"] += 1
@@ -825,9 +848,19 @@ def instnorm_stats(x: torch.Tensor) -> torch.Tensor:
     return stats
 
 
+class _InTok:
+    """Hand-over of the fused InstanceNorm-backward sums: created by instnorm_act's forward, found by the ONE conv that reads its
+    output (``_m1_in_src`` on the output tensor), filled by that conv's data gradient (``partials``), checked by the norm's backward
+    against the gradient tensor it actually receives."""
+    __slots__ = ("src", "partials", "readers")
+
+    def __init__(self):
+        self.src, self.partials, self.readers = None, None, 0
+
+
 class _InstNormAct(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, gamma, beta, slope, stats):
+    def forward(ctx, x, gamma, beta, slope, stats, tok=None):
         _req(x, gamma, beta)
         N, Cn = int(x.shape[0]), int(x.shape[-1])
         V = x.numel() // (N * Cn)
@@ -839,6 +872,7 @@ class _InstNormAct(torch.autograd.Function):
         ctx.save_for_backward(x, stats, gamma, beta)
         ctx.g_param, ctx.b_param = gamma, beta
         ctx.slope = float(slope)
+        ctx.tok = tok
         return y
 
     @staticmethod
@@ -853,27 +887,35 @@ class _InstNormAct(torch.autograd.Function):
         if acc != acc2:
             gbuf, bbuf, acc = torch.empty_like(gamma), torch.empty_like(beta), 0
             dg, db = gbuf, bbuf
-        pp = getattr(dy, "_m1_in_partials", None)
-        if pp is not None and pp[2].data_ptr() == x.data_ptr() and pp[2].shape == x.shape:      # the data gradient that produced dy already emitted {sum dy, sum dy*xh} per tile
-            part, nparts, _ = pp
+        tok = ctx.tok
+        pp = tok.partials if tok is not None else None
+        if tok is not None:
+            tok.partials = None
+        # the data gradient that produced dy already emitted {sum dy, sum dy*xh} per tile -- accepted only for the very tensor
+        # (address, shape, version) that kernel wrote, from the single reader the forward saw
+        if (pp is not None and tok.readers == 1 and pp[2] == dy.data_ptr() and pp[3] == dy._version and pp[4] == tuple(dy.shape)):
+            part, nparts = pp[0], pp[1]
             sums = part[part.numel() - N * Cn * 2 - 64:]
             L.check(L.load().m1_instnorm_bwd_partials(_p(x), _p(stats), _p(gamma), _p(beta), ctx.slope, _p(dy), _p(dx), _p(gbuf), _p(bbuf),
                                                       N, V, Cn, _dt(x), _p(part), nparts, _p(sums), acc, _stream()),
                     "m1_instnorm_bwd_partials")
-            return dx, dg, db, None, None
+            return dx, dg, db, None, None, None
         ws = _ws(N, V, Cn, 2, x.device)
         L.check(L.load().m1_instnorm_bwd(_p(x), _p(stats), _p(gamma), _p(beta), ctx.slope, _p(dy), _p(dx), _p(gbuf), _p(bbuf),
                                          N, V, Cn, _dt(x), _p(ws), acc, _stream()), "m1_instnorm_bwd")
-        return dx, dg, db, None, None
+        return dx, dg, db, None, None, None
 
 
 def instnorm_act(x, gamma, beta, slope: float = 1.0, stats=None):
     """tfa InstanceNormalization (eps 1e-3) followed by LeakyReLU(slope) (slope=1 -> no activation).
     ``stats``: the (N,C,2) {mean, rstd} already produced by the conv that wrote ``x`` (else computed here)."""
-    y = _InstNormAct.apply(x, gamma, beta, slope, stats)
     if _INBWD["on"] and stats is not None and torch.is_grad_enabled():
-        y._m1_in_src = (x, stats, gamma, beta, float(slope))       # (read by the conv that consumes y, see _Conv3d.forward)
-    return y
+        tok = _InTok()
+        y = _InstNormAct.apply(x, gamma, beta, slope, stats, tok)
+        tok.src = (x, stats, gamma, beta, float(slope))
+        y._m1_in_src = tok                                         # (found by the conv that consumes y, see _Conv3d.forward)
+        return y
+    return _InstNormAct.apply(x, gamma, beta, slope, stats)
 
 
 # ---------------------------------------------------------------------------------------------------------
@@ -1075,6 +1117,13 @@ class _LatentSample(torch.autograd.Function):
             raise RuntimeError(f"latent_sample: eps is {eps.dtype}, the head output {ml.dtype} (the kernel reads both as one type)")
         N = int(ml.shape[0]); Lc = int(ml.shape[-1]) // 2
         V = ml.numel() // (N * 2 * Lc)
+        # the kernel reads eps for every sample (modes 0 / 1 -- mode 1 ignores the values) or for the first half of the batch only
+        # (mode 2, stacked passes): a draw tensor of another size would be read out of bounds
+        need = ml.numel() // 4 if int(mode) == 2 else ml.numel() // 2
+        if int(mode) == 2 and N % 2:
+            raise RuntimeError("latent_sample: stacked mode needs an even batch")
+        if eps is not None and (int(mode) != 1) and eps.numel() != need:
+            raise RuntimeError(f"latent_sample: eps holds {eps.numel()} draws, mode {int(mode)} of a {tuple(ml.shape)} head needs {need}")
         z = torch.empty((*ml.shape[:-1], Lc), dtype=ml.dtype, device=ml.device)
         L.check(L.load().m1_latent_sample_fwd(_p(ml), _p(eps), _p(z), N, V, Lc, int(mode), _dt(ml), _stream()),
                 "m1_latent_sample_fwd")
@@ -1268,6 +1317,38 @@ def set_force_direct(on: bool):
     """Test hook: route every conv through the generic direct kernels instead of the matrix-core kernels."""
     _FORCE_DIRECT[0] = bool(on)
     L.load().m1_set_force_direct(int(on) if not isinstance(on, bool) else (1 if on else 0))
+
+
+def config_set(name: str, value: int) -> None:
+    """Set a tuning switch of libm1hip.so (m1_config_set): effective from the next launch that consults it."""
+    L.check(L.load().m1_config_set(name.encode(), int(value)), "m1_config_set")
+
+
+def config_unset(name: str) -> None:
+    L.check(L.load().m1_config_unset(name.encode()), "m1_config_unset")
+
+
+def config_get(name: str):
+    """Current value of a switch, or None when nothing has consulted or set it yet."""
+    v = C.c_int(0)
+    return int(v.value) if L.load().m1_config_get(name.encode(), C.byref(v)) == 0 else None
+
+
+class config:
+    """``with ops.config(M1_T3_MIN_BLOCKS=1): ...`` -- switches set for the block, restored after it."""
+
+    def __init__(self, **kv):
+        self.kv = kv
+
+    def __enter__(self):
+        for k, v in self.kv.items():
+            config_set(k, v)
+        return self
+
+    def __exit__(self, *exc):
+        for k in self.kv:
+            config_unset(k)
+        return False
 
 
 def prof_enable(on: bool):

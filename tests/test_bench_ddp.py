@@ -103,3 +103,46 @@ def test_bench_rccl_world_of_one():
     ex = d["config"]["exchange"]
     assert ex["backend"] == "nccl" and ex["graph_mode"] == "full" and ex["replicas_in_sync"] is True, (ex, d["config"]["graph_error"])
     assert ex["collectives_issued"] > 0 and ex["groups_sent_during_backward"] > 0, ex
+
+
+@pytest.mark.timeout(4 * CHILD_TIMEOUT_S + 60)
+def test_bench_rccl_probabilistic_lanes_match_in_order_run(tmp_path):
+    """Round-3 advisor finding: with the posterior pass on its own stream (M1_PQ_LANES) the exchange hooks of the posterior's groups
+    fire with that lane current; the queued weight-gradient folds and the collective must still be ordered behind the PRIOR's
+    weight-gradient kernels on the origin stream.  The hierarchical probabilistic model through the RCCL branch (world of one, whole
+    step captured with its collectives) with lanes and side streams on must end in exactly the state of the run with everything
+    in order on one stream."""
+    dumps = {}
+    for tag, extra in (("lanes", {}), ("inorder", {"M1_PQ_LANES": "0", "M1_STREAMS": "0"})):
+        out_pt = str(tmp_path / f"{tag}.pt")
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29537", RANK="0", LOCAL_RANK="0", WORLD_SIZE="1",
+                   M1_BENCH_FORCE_DIST="1", M1_BENCH_DEBUG="1", M1_BENCH_DUMP=out_pt, **extra)
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--workload", "C1P", "--steps", "3", "--warmup", "1",
+               "--no-cpu-baseline", "--no-roofline"]
+        rc, out, err = _run_retrying_bringup(cmd, env)
+        lines = [l for l in out.splitlines() if l.startswith("{")]
+        assert rc == 0 and len(lines) == 1, f"{tag}: rc={rc}\n--- stdout\n{out[-2000:]}\n--- stderr\n{err[-4000:]}"
+        d = json.loads(lines[0])
+        ex = d["config"]["exchange"]
+        assert ex["backend"] == "nccl" and ex["graph_mode"] == "full" and d["config"]["graph_error"] is None, (tag, ex, d["config"]["graph_error"])
+        assert ex["groups"] == 6 and ex["replicas_in_sync"] is True, (tag, ex)
+        if tag == "lanes":
+            assert ex["groups_sent_during_backward"] > 0, ex
+        import torch
+        dumps[tag] = torch.load(out_pt)
+    for k in ("flat", "grad", "m", "vhat", "step", "rng"):
+        a, b = dumps["lanes"][k], dumps["inorder"][k]
+        assert torch.equal(a, b), f"{k}: {int((a != b).sum())} of {a.numel()} elements differ between the lane run and the in-order run"
+
+
+@pytest.mark.timeout(2 * CHILD_TIMEOUT_S + 60)
+def test_bench_gpus_2_without_torchrun_starts_its_own_ranks():
+    """``python bench.py --gpus 2`` with no torchrun environment must start two ranks itself (as a child process) and report
+    n_gpus 2 -- round 3 silently measured one GPU there.  Two gloo ranks share the one GPU of this box."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    env.update(M1_BENCH_BACKEND="gloo", M1_BENCH_DEBUG="1", M1_DDP_GRAPH="off", MASTER_PORT="29541")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "C1", "--steps", "2", "--warmup", "1",
+           "--no-cpu-baseline"]
+    rc, out, err = _run_retrying_bringup(cmd, env)
+    d = _check_line(rc, out, err, 2)
+    assert d["config"]["exchange"]["replicas_in_sync"] is True and d["config"]["parallelism"] == "dp2"

@@ -254,3 +254,76 @@ def test_loss_curve_bf16_tracks_fp32_over_20_steps(dev):
     # The check is therefore a band, not a match: every step within 10 %, the same progress after 20 steps within 5 % of the descent.
     assert rel.max() < 0.10, rel
     assert abs(c16[-1] - c32[-1]) < 0.05 * (c32[0] - c32[-1])             # same progress after 20 steps
+
+
+def test_graph_replay_equals_eager_steps(dev):
+    """The artefact bench.py times is a REPLAYED hipGraph of the whole step (forward, backward, queued folds on the fold stream, the
+    posterior pass on its lane, Adam, panel re-pack, RNG / step counters).  Three replays must leave exactly the state three eager
+    steps leave from the same start: README filters, full probabilistic model, bf16, dropout 0.5, batch 2 (stacked passes) -- a
+    capture-only ordering bug (a missing graph edge between a side stream and its reader) has nowhere else to show."""
+    cfg = _cfg(True, dropout_rate=0.5, dropout_mode="monte-carlo")
+    P = O.fixture_params(cfg, seed=121)
+    x, tgt = _inputs(True, B=2, seed=122)
+    m = build_m1(cfg, dev, dtype=torch.bfloat16)
+    load_params_into(m, P)
+    m.seed_dropout(7)
+    assert m.m1_model.stack_passes and ops._BRANCH["on"]
+    opt = PKG.optim.Adam(learning_rate=1e-3, amsgrad=True)
+    focal = PKG.losses.Focal(alpha=[0.75, 0.25], gamma=2.0).loss
+    m.compile(optimizer=opt, loss=[focal, PKG.losses.EvidenceLowerBound().loss], loss_weights=[1.0, 10.0])
+    opt.set_lr_device()
+    m.train()
+    xs, ts = ops.cast(x.to(dev).contiguous(), torch.bfloat16), tgt.to(dev)
+    loss_buf = torch.zeros(1, device=dev)
+
+    def step():                                   # bench.py's step(): fwd_bwd() + update()
+        opt.zero_grad()
+        outs = m(xs)
+        total, _ = m.compute_loss(outs, {"detection": ts})
+        total.backward()
+        opt.flatp.gather_grads()
+        loss_buf.copy_(total.detach().reshape(1))
+        opt.exchange()
+        opt.apply_flat()
+        ops.step_advance(None, m.rng_state)
+
+    state = lambda: [opt.flatp.flat, opt.m, opt.v, opt.vhat, opt.step_dev, m.rng_state]
+    step(); step()                                # eager warm-up: allocator, panel registry
+    torch.cuda.synchronize()
+    start = [t.clone() for t in state()]
+    gen0 = torch.cuda.get_rng_state(dev)          # the latent draws come from torch's device generator (one launch per step)
+
+    def restore():
+        with torch.no_grad():
+            for t, s0 in zip(state(), start):
+                t.copy_(s0)
+        torch.cuda.set_rng_state(gen0, dev)
+        ops.repack_all()                          # the cached weight panels follow the restored weights
+        torch.cuda.synchronize()
+
+    losses = {"eager": [], "graph": []}
+    for _ in range(3):
+        step(); losses["eager"].append(float(loss_buf))
+    torch.cuda.synchronize()
+    eager = [t.clone() for t in state()]
+    assert not torch.equal(eager[0], start[0]) and not torch.equal(eager[-1], start[-1])      # the steps did move weights and counters
+
+    restore()
+    s = torch.cuda.Stream()                       # bench.py's capture(): one eager step on a side stream, then the capture
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        step()
+    torch.cuda.current_stream().wait_stream(s)
+    torch.cuda.synchronize()
+    gr = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(gr):
+        step()
+    torch.cuda.synchronize()
+    restore()
+    for _ in range(3):
+        gr.replay(); losses["graph"].append(float(loss_buf))
+    torch.cuda.synchronize()
+    names = ["parameters", "adam m", "adam v", "adam vhat", "step counter", "rng state"]
+    assert losses["graph"] == losses["eager"], losses
+    for n, a, b in zip(names, eager, state()):
+        assert torch.equal(a, b), f"{n}: {int((a != b).sum())} of {a.numel()} elements differ between 3 eager steps and 3 replays"

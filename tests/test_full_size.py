@@ -248,6 +248,72 @@ def test_full_size_c3_model_properties(dev):
     assert torch.equal(p1, p2) and kl1 == kl2 and l1 == l2
 
 
+def test_full_size_c3_bench_configuration_batch2_dropout(dev):
+    """The exact configuration bench.py times, at full size: C3, bf16, batch 2 (the four passes stacked into two of batch 4), Monte-Carlo
+    dropout 0.5 (0.25 behind sersd0), flat gradient buffers, drawn latents.  Properties: finite loss and gradients, KL >= 0, output
+    simplex, layers no training output reads get exactly no gradient, and the same (seed, step) gives the same step bit for bit
+    while another step counter gives another dropout draw."""
+    dims = (20, 160, 160)
+    init = PKG.initializers
+    PKG.unets.network_blocks.set_init_seed(0)
+    m = PKG.unets.networks.M1(
+        input_spatial_dims=dims, input_channels=3, num_classes=2, filters=(32, 64, 128, 256, 512),
+        strides=((1, 1, 1), (1, 2, 2), (1, 2, 2), (2, 2, 2), (2, 2, 2)),
+        kernel_sizes=((1, 3, 3), (1, 3, 3), (3, 3, 3), (3, 3, 3), (3, 3, 3)), se_reduction=(8, 8, 8, 8, 8),
+        att_sub_samp=((1, 1, 1),) * 4, dropout_rate=0.5, dropout_mode='monte-carlo', prob_latent_dims=(3, 2, 1, 0),
+        kernel_initializer=init.Orthogonal(1.0), bias_initializer=init.TruncatedNormal(0.0, 1e-3),
+        kernel_regularizer=init.l2(1e-4), bias_regularizer=init.l2(1e-4), cascaded=False, dense_skip=True,
+        deep_supervision=True, probabilistic=True, summary=False).to(dev)
+    m.set_compute_dtype(torch.bfloat16)
+    m.seed_dropout(3)
+    assert m.m1_model.stack_passes
+    tgt = torch.cat([_box_target(dims), _box_target(dims).roll(17, dims=2)], dim=0)
+    x = rnd((2, *dims, 3), 11)
+    x[..., 2] = tgt[..., 1]
+    x, tgt = ops.cast(x.to(dev).contiguous(), torch.bfloat16), tgt.to(dev)
+    lat = [(5, 10, 10, 3), (10, 20, 20, 2), (20, 40, 40, 1)]
+    eps = [rnd((2, *s), 12 + i).to(dev) for i, s in enumerate(lat)]
+    opt = PKG.optim.Adam(learning_rate=1e-3, amsgrad=True)
+    focal = PKG.losses.Focal(alpha=[0.75, 0.25], gamma=2.0).loss
+    m.compile(optimizer=opt, loss=[focal, PKG.losses.EvidenceLowerBound().loss], loss_weights=[1.0, 10.0])
+    m.train()
+    rng0 = m.rng_state.clone()
+
+    def step():
+        opt.zero_grad()
+        det, kl = m(x, eps_q=eps)
+        loss = focal(tgt, det) + 10.0 * kl.sum()
+        loss.backward()
+        opt.flatp.gather_grads()
+        torch.cuda.synchronize()
+        return det.detach().clone(), float(kl.detach()), float(loss.detach()), opt.flatp.grad.clone()
+    p1, kl1, l1, g1 = step()
+    assert tuple(p1.shape) == (2, 20, 160, 160, 2) and p1.dtype == torch.float32
+    assert float((p1.sum(dim=-1) - 1.0).abs().max()) < 1e-5 and float(p1.min()) >= 0.0
+    assert kl1 >= 0.0 and kl1 == kl1 and l1 > 0.0 and l1 == l1
+    assert bool(torch.isfinite(g1).all()) and float(g1.abs().max()) > 0.0
+    byid = {id(p): gv for p, gv in zip(opt.flatp.params, opt.flatp.gviews)}
+    dead = ("sersd0.", ".logits.")
+    dead_post = ("att0.", "att1.", "sersd2.", "sersd1.", "sersp1.", "sersp0.", "convtd1", "convtd0.", "dec_hi1.", "dec_hi0.",
+                 "convtd3_up2.", "convtd3_up3.", "convtd2_up")
+    live = 0
+    for n, p in m.named_parameters():
+        is_dead = ("stitch" not in n and any(d in n for d in dead)) or ("posterior." in n and any(d in n for d in dead_post))
+        gmax = float(byid[id(p)].abs().max())
+        if is_dead:
+            assert gmax == 0.0, n
+        else:
+            live += gmax > 0.0
+    assert live > 400
+    with torch.no_grad():
+        m.rng_state.copy_(rng0)
+    p2, kl2, l2, g2 = step()                                                  # same (seed, step): the same draw, the same step
+    assert torch.equal(p1, p2) and kl1 == kl2 and l1 == l2 and torch.equal(g1, g2)
+    ops.step_advance(None, m.rng_state)
+    p3, kl3, l3, g3 = step()                                                  # the next step draws other keep masks
+    assert not torch.equal(p1, p3)
+
+
 def test_full_size_c5_fp32_model_properties(dev):
     """C5 (BASELINE.json configs[4]): deterministic M1 at (32,256,256,3), fp32 -- App. A.1's stage shapes, parameter count,
     output simplex, finite loss and gradients, bit-identical forward run to run; the backward pass is the derivative of the

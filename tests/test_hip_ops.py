@@ -815,9 +815,21 @@ def test_t3s_fp32_strided_wgrad(dev, case):
     assert rel_err(y, yo) < TOL[torch.float32], "y"
 
 
-@pytest.mark.parametrize("case", TF_CASES)
-def test_tap_fused_wgrad(dev, case, monkeypatch):
-    # (run the suite once more with M1_TF64=1 / M1_HALO=2 / M1_TF_MAXC=512 to force the optional kernels onto these shapes)
+# every case at the suite's floor (conftest: M1_T3_MIN_BLOCKS=1 -> wgrad_t3 takes every eligible shape); the cases with >= 64 channels on
+# both sides once more at the PRODUCTION floor (128 blocks), where launches this small go to the per-tap / 32x32 tap-fused kernels
+# instead -- the kernels that serve the deep, small layers of a real step
+_TF_PARAMS = [(c, 1) for c in TF_CASES] + [(c, 128) for c in TF_CASES if min(c[1]) >= 64 and c[2] >= 64]
+
+
+@pytest.mark.parametrize("case,t3_floor", _TF_PARAMS)
+def test_tap_fused_wgrad(dev, case, t3_floor):
+    with ops.config(M1_T3_MIN_BLOCKS=t3_floor):
+        assert ops.config_get("M1_T3_MIN_BLOCKS") == t3_floor
+        _tap_fused_wgrad_case(dev, case)
+
+
+def _tap_fused_wgrad_case(dev, case):
+    # (run the suite once more with M1_HALO=2 / M1_TF_MAXC=512 to force the optional kernels onto these shapes)
     dims, cins, cout, k, s, transposed = case
     xs = [rnd((*dims, c), 40 + i).bfloat16().float() for i, c in enumerate(cins)]
     wshape = (*k, cout, sum(cins)) if transposed else (*k, sum(cins), cout)

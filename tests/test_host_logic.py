@@ -409,3 +409,44 @@ def test_focal_loss_has_no_host_fallback():
         f.loss(y, torch.full_like(y, 0.5))
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         f.FL(y, torch.full_like(y, 0.5))
+
+
+def test_bench_launch_plan_starts_ranks_only_without_a_torchrun_environment():
+    """bench.py --gpus N: inside torchrun (WORLD_SIZE / RANK set) the process is a rank; without it and N > 1 the parent must start N
+    ranks through torch.distributed.run as a child process (round 3 silently measured one GPU); N = 1 never spawns."""
+    import bench
+    assert bench.launch_plan(1, {}) == ("run", None)
+    assert bench.launch_plan(8, {"WORLD_SIZE": "8", "RANK": "3"}) == ("run", None)
+    assert bench.launch_plan(1, {"WORLD_SIZE": "1", "RANK": "0"}) == ("run", None)
+    old = sys.argv
+    sys.argv = ["bench.py", "--gpus", "4", "--steps", "7", "--warmup", "2"]
+    try:
+        mode, argv = bench.launch_plan(4, {"MASTER_PORT": "29555"})
+    finally:
+        sys.argv = old
+    assert mode == "spawn"
+    assert argv[:3] == [sys.executable, "-m", "torch.distributed.run"]
+    assert argv[argv.index("--nproc-per-node") + 1] == "4" and argv[argv.index("--master-addr") + 1] == "127.0.0.1"
+    assert argv[argv.index("--master-port") + 1] == "29555"
+    i = argv.index(os.path.abspath(bench.__file__))
+    assert argv[i + 1:] == ["--gpus", "4", "--steps", "7", "--warmup", "2"]          # the ranks get the caller's arguments unchanged
+
+
+def test_config_switches_are_set_and_restored_through_the_abi():
+    """include/m1hip.h m1_config_*: one table of tuning switches; a set value wins over the environment, unset restores it; a switch
+    nobody has consulted or set reads as unknown; names outside the M1_ namespace are rejected."""
+    ops = PKG.hip.ops
+    L = PKG.hip.lib
+    lib = L.load()
+    assert ops.config_get("M1_NO_SUCH_SWITCH_YET") is None
+    ops.config_set("M1_TEST_SWITCH", 17)
+    assert ops.config_get("M1_TEST_SWITCH") == 17
+    with ops.config(M1_TEST_SWITCH=3):
+        assert ops.config_get("M1_TEST_SWITCH") == 3
+    assert ops.config_get("M1_TEST_SWITCH") is None                     # override dropped, no default known, not in the environment
+    assert lib.m1_config_set(b"PATH", 1) == -1 and lib.m1_config_set(None, 1) == -1
+    # the suite's environment default for the wgrad_t3 floor (conftest) is visible through the same table
+    ops.config_set("M1_T3_MIN_BLOCKS", 128)
+    assert ops.config_get("M1_T3_MIN_BLOCKS") == 128
+    ops.config_unset("M1_T3_MIN_BLOCKS")
+    assert ops.config_get("M1_T3_MIN_BLOCKS") == int(os.environ["M1_T3_MIN_BLOCKS"])

@@ -7,6 +7,17 @@ batch = int(sys.argv[5]) if len(sys.argv) > 5 else 1          # volumes per GPU 
 commit = sys.argv[6] if len(sys.argv) > 6 and sys.argv[6] else None   # tree the passes were taken on (bench.py quotes it)
 
 
+def csrc_sha():
+    """sha256 over the kernel sources the passes ran (the GPU box has no .git): bench.py recomputes it and labels ``traffic``
+    stale when the benchmarked tree's kernels differ from the profiled ones."""
+    import glob, hashlib, os
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "prostatemr_3d-cad-cspca_amd", "csrc")
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(root, "*.hip")) + glob.glob(os.path.join(root, "*.h"))):
+        h.update(os.path.basename(f).encode()); h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def fam(name):
     n = re.sub(r'^void ', '', name); n = re.sub(r'\(.*', '', n); n = re.sub(r'<.*', '', n)
     return n
@@ -28,7 +39,7 @@ for k in set(f) | set(w):
                "fetch_GB_per_step": 2.0 * f.get(k, 0.0) * 1024 / steps / 1e9,
                "write_GB_per_step": w.get(k, 0.0) * 1024 / steps / 1e9}
 tot_f = sum(v["fetch_GB_per_step"] for v in rows.values()); tot_w = sum(v["write_GB_per_step"] for v in rows.values())
-res = {"steps": steps, "batch": batch, "commit": commit, "note": "FETCH_SIZE x2 (gfx950 half-count of wide streams), KiB -> bytes; separate --pmc passes",
+res = {"steps": steps, "batch": batch, "commit": commit, "csrc_sha": csrc_sha(), "note": "FETCH_SIZE x2 (gfx950 half-count of wide streams), KiB -> bytes; separate --pmc passes",
        "total_fetch_GB_per_step": tot_f, "total_write_GB_per_step": tot_w, "kernels": dict(sorted(rows.items(), key=lambda kv: -(kv[1]["fetch_GB_per_step"] + kv[1]["write_GB_per_step"])))}
 json.dump(res, open(out, "w"), indent=1)
 print(f"HBM traffic per step: fetch {tot_f:.2f} GB (x2 corrected)  write {tot_w:.2f} GB")
