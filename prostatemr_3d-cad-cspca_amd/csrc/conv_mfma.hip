@@ -18,6 +18,7 @@
 #include "reduce.h"
 
 #include "conv_mfma.h"
+#include "conv_t3.h"
 #include <stdlib.h>
 
 __device__ __forceinline__ int swz(int row, int seg) { return seg ^ ((-(row >> 2)) & 3); }
@@ -882,8 +883,12 @@ size_t m1_mfma_ws_bytes(const GatherSpec& g) {
     //  then split K differently: size for both plans)
     size_t best = 0;
     const bool maybe160 = g.dtype == M1_BF16 && g.mode == 0 && g.OC % 160 == 0 && g.OC <= 320;
-    for (int v = 0; v < (maybe160 ? 2 : 1); ++v) {
-        const Plan pl = make_plan(g.OC, spec_maxM(g), spec_ncls(g), min_class_chunks(g, CC, SEG), v == 1);
+    int t3bn = 0, t3ks = 1;
+    const bool t3 = m1_ct3_plan(g, &t3bn, &t3ks);
+    for (int v = 0; v < 3; ++v) {
+        if ((v == 1 && !maybe160) || (v == 2 && !t3)) continue;
+        Plan pl = make_plan(g.OC, spec_maxM(g), spec_ncls(g), min_class_chunks(g, CC, SEG), v == 1);
+        if (v == 2) { pl.BN = t3bn; pl.BM = 256; pl.ksplit = t3ks; }
         const int BN = pl.BN, OCpad = (g.OC + BN - 1) / BN * BN;
         long long tot = 0;
         build_classes(g, CC, SEG, OCpad, nullptr, nullptr, &tot);
@@ -937,7 +942,11 @@ static int run_mfma(const GatherSpec& g, void* ws, int ws_packed, hipStream_t st
     mp.bias2 = g.bias2; mp.bias_split = g.oc_split;
     mp.nout = g.nout; mp.outOff[0] = 0;
     for (int i = 0; i < g.nout; ++i) { mp.outs[i] = g.outs[i]; mp.outC[i] = g.outC[i]; mp.outAcc[i] = g.outAcc[i]; mp.outOff[i + 1] = mp.outOff[i] + g.outC[i]; }
-    const Plan pl = make_plan(g.OC, spec_maxM(g), spec_ncls(g), min_class_chunks(g, CC, SEG), want_bn160(g));
+    Plan pl = make_plan(g.OC, spec_maxM(g), spec_ncls(g), min_class_chunks(g, CC, SEG), want_bn160(g));
+    // stride-1 3x3x3 / 1x3x3 matrix-core layers: the staged-run kernel on 32x32x16 MFMAs (conv_t3.hip) with its own tiling
+    int t3bn = 0, t3ks = 1;
+    const bool t3 = sizeof(T) == 2 && m1_ct3_plan(g, &t3bn, &t3ks);
+    if (t3) { pl.BN = t3bn; pl.BM = 256; pl.ksplit = t3ks; }
     const int BN = pl.BN, OCpad = (g.OC + BN - 1) / BN * BN;
     long long tot = 0;
     build_classes(g, CC, SEG, OCpad, &mp, &pp, &tot);
@@ -948,25 +957,22 @@ static int run_mfma(const GatherSpec& g, void* ws, int ws_packed, hipStream_t st
     // its data gradient, neutral end to end; with the stacked passes (4 volumes per launch): 647 -> 624 us forward, 613 -> 557 us
     // data gradient, -1.7 % per C3 step, C2 neutral.  256x128 tiles on 8 waves (one block per CU) were slower (702 / 678 us).
     int c8 = M1_CFG("M1_CONV8", 1);
-    const bool use8 = c8 && BN == 128 && (pl.ksplit == 1 || (c8 >= 2 && pl.BM == 128)) &&
+    const bool use8 = !t3 && c8 && BN == 128 && (pl.ksplit == 1 || (c8 >= 2 && pl.BM == 128)) &&
                       cdiv_ll(spec_maxM(g), 128) * spec_ncls(g) * (OCpad / 128) * pl.ksplit >= 160;
-    // M1_CONV16 (bf16): 256-row tiles, ONE block per CU with the waves of two 128-row blocks (16 waves of 64x32 for 128 columns,
-    // 8 waves of 64x80 for the 160-column pair tile): the weight tile crosses L2 -> LDS once per 256 rows instead of once per 128
-    int c16 = M1_CFG("M1_CONV16", 0);
-    const bool use16 = c16 && sizeof(T) == 2 && (BN == 128 || BN == 160) && pl.ksplit == 1 && (BN == 160 || use8) &&
-                       cdiv_ll(spec_maxM(g), 256) * spec_ncls(g) * (OCpad / BN) >= (c16 > 1 ? c16 : 256);
-    const int bm_eff = use16 ? 256 : (use8 ? 128 : pl.BM);
-    bool fuse_stats = g.stats_out && g.stats_ws && g.mode == 0 && pl.ksplit == 1 && (g.N == 1 || Vout % bm_eff == 0) &&
+    const int bm_eff = t3 ? 256 : (use8 ? 128 : pl.BM);
+    // (the staged-run kernel tiles every sample on its own: its tiles never straddle samples)
+    bool fuse_stats = g.stats_out && g.stats_ws && g.mode == 0 && pl.ksplit == 1 && (g.N == 1 || Vout % bm_eff == 0 || t3) &&
                       !g.accumulate;           // (this kernel's statistics come from its own tile, before the add)
-    if (fuse_stats) { mp.stat_partial = g.stats_ws; mp.stat_tiles = (int)cdiv_ll(Vout, bm_eff); }
+    const int tiles_ps = t3 ? m1_ct3_tiles_per_sample(g.OD, g.OH, g.OW) : (int)cdiv_ll(Vout, bm_eff);      // epilogue partial rows per sample
+    if (fuse_stats) { mp.stat_partial = g.stats_ws; mp.stat_tiles = tiles_ps; }
     // InstanceNorm-backward sums from the epilogue of a data gradient (GatherSpec::ib_*): one output tensor, one parity class
     // (rows run sample-major like a forward conv's), tiles that do not straddle samples
     const bool ib_want = g.ib_x && g.ib_partial && g.ib_nparts && !g.stats_out && !g.accumulate && g.nout <= 1 && spec_ncls(g) == 1 &&
                          (g.nout == 0 || (g.outs[0] && !g.outAcc[0] && g.outC[0] == g.OC));
     if (g.ib_nparts) *g.ib_nparts = 0;
-    bool ib_epi = ib_want && pl.ksplit == 1 && (g.N == 1 || Vout % bm_eff == 0) && cdiv_ll(Vout, bm_eff) <= g.ib_cap;
+    bool ib_epi = ib_want && pl.ksplit == 1 && (g.N == 1 || Vout % bm_eff == 0 || t3) && tiles_ps <= g.ib_cap;
     if (ib_epi) {
-        mp.stat_partial = g.ib_partial; mp.stat_tiles = (int)cdiv_ll(Vout, bm_eff);
+        mp.stat_partial = g.ib_partial; mp.stat_tiles = tiles_ps;
         mp.ib_x = g.ib_x; mp.ib_stats = g.ib_stats; mp.ib_gamma = g.ib_gamma; mp.ib_beta = g.ib_beta; mp.ib_slope = g.ib_slope;
     }
     for (int i = 0; i < g.nsrc; ++i) if (g.srcC[i] % (4 * SEG)) mp.aligned = 0;
@@ -983,7 +989,7 @@ static int run_mfma(const GatherSpec& g, void* ws, int ws_packed, hipStream_t st
     bool halo = false;
     if constexpr (sizeof(T) == 2) {
         int hen = M1_CFG("M1_HALO", 1);
-        halo = hen && (maxM >= 32768 || hen == 2) && m1_halo_conv_supported(mp, OCpad);      // (M1_HALO=2: no size floor, tests)
+        halo = !t3 && hen && (maxM >= 32768 || hen == 2) && m1_halo_conv_supported(mp, OCpad);      // (M1_HALO=2: no size floor, tests)
     }
     // K order of the panel and of the LDS-DMA gather: chunk-major ([64-byte chunk][tap]) for multi-tap problems on the
     // implicit-GEMM kernel (see advance_chunk); the halo kernel and single-tap problems keep [tap][channel]
@@ -991,6 +997,7 @@ static int run_mfma(const GatherSpec& g, void* ws, int ws_packed, hipStream_t st
       int maxtaps = 0; for (int c = 0; c < mp.nclasses; ++c) maxtaps = mp.cls_ntaps[c] > maxtaps ? mp.cls_ntaps[c] : maxtaps;
       mp.korder = (ko && mp.aligned && !halo && maxtaps > 1) ? 1 : 0;
       if (mp.korder && ko == 2) { bool pair = true; for (int i = 0; i < g.nsrc; ++i) pair &= g.srcC[i] % (8 * SEG) == 0; if (pair) mp.korder = 2; }
+      if (t3) mp.korder = 1;                              // (the staged-run kernel reads [chunk][tap] panels)
       pp.korder = mp.korder; }
     pp.w = g.w; pp.wST = g.wST; pp.wSC = g.wSC; pp.wSO = g.wSO; pp.oc_off = g.oc_off; pp.cc_off = g.cc_off; pp.OCn = g.OC; pp.OCpad = OCpad; pp.CC = CC;
     pp.w2 = g.w2; pp.w2ST = g.w2ST; pp.w2SC = g.w2SC; pp.w2SO = g.w2SO; pp.oc_split = g.oc_split; pp.c_split = g.c_split;
@@ -1015,7 +1022,7 @@ static int run_mfma(const GatherSpec& g, void* ws, int ws_packed, hipStream_t st
     bool pw = false; int pwBN = 0;
     if constexpr (sizeof(T) == 2) {
         pwBN = BN > 32 ? 32 : BN;
-        if (!halo && m1_pw_conv_supported(mp, OCpad, pwBN)) {
+        if (!halo && !t3 && m1_pw_conv_supported(mp, OCpad, pwBN)) {
             if (ib_epi) { ib_epi = false; mp.stat_partial = nullptr; mp.stat_tiles = 0; mp.ib_x = nullptr; }
             int parts = m1_pw_conv_stat_parts(mp, OCpad, pwBN);
             const int cap = (int)((Vout + 63) / 64) / 4 * 4;          // what the statistics workspace holds per sample
@@ -1028,22 +1035,15 @@ static int run_mfma(const GatherSpec& g, void* ws, int ws_packed, hipStream_t st
     }
     { int lg = M1_CFG("M1_MFMA_LOG", 0);
       if (lg) fprintf(stderr, "mfma: mode %d N%d out %dx%dx%d CC %d OC %d k%d taps s%d%d%d nsrc %d -> %s BM %d BN %d ksplit %d korder %d stats %d\n", g.mode, g.N, g.OD, g.OH, g.OW, CC, g.OC,
-                      g.kd * g.kh * g.kw, g.sd, g.sh, g.sw, g.nsrc, halo ? "halo" : (pw ? "pw" : "mfma"), bm_eff, BN, pl.ksplit, mp.korder, fuse_stats ? 1 : 0); }
-    if (halo) rc2 = m1_halo_conv(mp, OCpad, st);
+                      g.kd * g.kh * g.kw, g.sd, g.sh, g.sw, g.nsrc, t3 ? "t3" : (halo ? "halo" : (pw ? "pw" : "mfma")), bm_eff, BN, pl.ksplit, mp.korder, fuse_stats ? 1 : 0); }
+    if (t3) rc2 = m1_ct3_conv(mp, BN, OCpad, st);
+    else if (halo) rc2 = m1_halo_conv(mp, OCpad, st);
     else if (pw) rc2 = m1_pw_conv(mp, OCpad, pwBN, st);
     else
-    if (use16) {
-        if constexpr (sizeof(T) == 2) {
-            rc2 = BN == 128 ? launch_cfg<T, 256, 128, 4, 4>(mp, maxM, OCpad, st) : launch_cfg<T, 256, 160, 4, 2>(mp, maxM, OCpad, st);
-        } else rc2 = M1_ERR_UNSUPPORTED;
-    } else
     switch (BN) {
         case 128: rc2 = use8 ? launch_cfg<T, 128, 128, 2, 4>(mp, maxM, OCpad, st)
                              : (small ? launch_cfg<T, 64, 128, 1, 4>(mp, maxM, OCpad, st) : launch_cfg<T, 128, 128, 2, 2>(mp, maxM, OCpad, st)); break;
-        case 160: if constexpr (sizeof(T) == 2) {
-                int w8 = M1_CFG("M1_BN160_W8", 0);
-                rc2 = w8 ? launch_cfg<T, 128, 160, 4, 2>(mp, maxM, OCpad, st) : launch_cfg<T, 128, 160, 2, 2>(mp, maxM, OCpad, st);
-            } else rc2 = M1_ERR_UNSUPPORTED; break;
+        case 160: if constexpr (sizeof(T) == 2) rc2 = launch_cfg<T, 128, 160, 2, 2>(mp, maxM, OCpad, st); else rc2 = M1_ERR_UNSUPPORTED; break;
         case 64: {
             // 64 / 32 columns on 8 waves of 32x32 / 32x16 instead of 4 waves of 32x64 / 32x32 (M1_F32_W8: bit 0 fp32, bit 1 bf16).  fp32: an
             // MFMA is 1/16 of a bf16 one per cycle, the LDS has room for the extra fragment reads and the extra waves hide the operand
@@ -1058,11 +1058,7 @@ static int run_mfma(const GatherSpec& g, void* ws, int ws_packed, hipStream_t st
             if (((sizeof(T) == 4 && (w8 & 1)) || (sizeof(T) == 2 && (w8 & 2))) && !small) rc2 = launch_cfg<T, 128, 32, 4, 2>(mp, maxM, OCpad, st);
             else rc2 = small ? launch_cfg<T, 64, 32, 4, 1>(mp, maxM, OCpad, st) : launch_cfg<T, 128, 32, 4, 1>(mp, maxM, OCpad, st);
             break; }
-        default: {
-            int w8 = M1_CFG("M1_N16_W8", 0);
-            if (w8 && !small) rc2 = launch_cfg<T, 128, 16, 8, 1>(mp, maxM, OCpad, st);
-            else rc2 = small ? launch_cfg<T, 64, 16, 4, 1>(mp, maxM, OCpad, st) : launch_cfg<T, 128, 16, 4, 1>(mp, maxM, OCpad, st);
-            break; }
+        default: rc2 = small ? launch_cfg<T, 64, 16, 4, 1>(mp, maxM, OCpad, st) : launch_cfg<T, 128, 16, 4, 1>(mp, maxM, OCpad, st); break;
     }
     if (rc2) return rc2;
     if (ib_epi) *g.ib_nparts = mp.stat_tiles;

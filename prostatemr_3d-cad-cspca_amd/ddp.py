@@ -76,6 +76,8 @@ class GradReducer:
         self._comm = None
         self._side_streams: Callable[[], Sequence] = lambda: ()
         self._before_send: Callable[[], None] = lambda: None
+        self._on_origin: Callable[[], bool] = lambda: True
+        self._deferred: List[str] = []      # groups that completed while a branch stream was current (sent from the next origin-stream hook)
         self.stats = {"buckets": 0, "early_groups": 0, "late_groups": 0, "collectives": 0}
 
     # ------------------------------------------------------------------------------------------------------
@@ -88,7 +90,8 @@ class GradReducer:
         return dist.is_initialized() and (self.world_size > 1 or self.force)
 
     def bind(self, flat_grad: torch.Tensor, ranges: Dict[str, Tuple[int, int]], order: Sequence[str], tail: Tuple[int, int],
-             side_streams: Optional[Callable[[], Sequence]] = None, before_send: Optional[Callable[[], None]] = None) -> None:
+             side_streams: Optional[Callable[[], Sequence]] = None, before_send: Optional[Callable[[], None]] = None,
+             on_origin: Optional[Callable[[], bool]] = None) -> None:
         """``ranges[key]`` = [lo, hi) of group ``key`` inside ``flat_grad``; ``order`` = the order groups are expected to
         complete in; ``tail`` = the range exchanged last (biases, norms, SE); ``side_streams()`` = the streams that may
         hold backward kernels of the step, the stream the step started on first (ops.exchange_streams)."""
@@ -97,6 +100,8 @@ class GradReducer:
             self._side_streams = side_streams
         if before_send is not None:                       # runs on the current stream before a group goes out during backward
             self._before_send = before_send
+        if on_origin is not None:                         # False while autograd runs a node on a branch stream (ops.branch)
+            self._on_origin = on_origin
         if flat_grad.is_cuda and self._comm is None:
             self._comm = torch.cuda.Stream(device=flat_grad.device)
 
@@ -139,6 +144,7 @@ class GradReducer:
         self._step += 1
         self._pending = {}
         self._sent = set()
+        self._deferred = []
 
     def mark(self, key: str, tensor: torch.Tensor) -> None:
         """The gradients of group ``key`` are complete once the autograd node that produced ``tensor`` has run (in addition
@@ -156,7 +162,17 @@ class GradReducer:
                 return
             self._pending[key] -= 1
             if self._pending[key] == 0:
-                self._send(key, early=True)
+                self._deferred.append(key)
+            # A hook may run with a BRANCH stream current: the posterior pass of the probabilistic model runs its backward on a lane of
+            # its own (networks.py M1_PQ_LANES).  Nothing is sent from there -- making the lane wait for the origin stream, folding on
+            # it and forking the communication stream off it inside a graph capture is exactly the fork-of-a-fork pattern that
+            # crashes the HIP graph capture of this ROCm release (and the queued folds would have to be ordered behind kernels of the
+            # origin stream, round-3 advisor finding).  The group goes out from the next hook that runs on the origin stream, which
+            # first waits for the branch streams, or from finish().
+            if self._deferred and self._on_origin():
+                ready, self._deferred = self._deferred, []
+                for k in ready:
+                    self._send(k, early=True)
         node.register_hook(fired)
 
     def finish(self) -> None:

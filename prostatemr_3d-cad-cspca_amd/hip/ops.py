@@ -244,6 +244,12 @@ def finish_queued_for_exchange() -> None:
         fold_pending()
 
 
+def on_origin_stream() -> bool:
+    """True unless the current stream is a branch stream of the running step (autograd runs a branch's backward nodes on it)."""
+    origin = _BRANCH.get("origin")
+    return origin is None or not torch.cuda.is_available() or torch.cuda.current_stream() == origin
+
+
 def exchange_streams():
     """Streams that may hold backward kernels of the running step, the origin stream FIRST (a communication stream must join a
     graph capture through the stream the capture started on before it takes edges from forked streams), for ddp.GradReducer."""

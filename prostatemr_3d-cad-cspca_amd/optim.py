@@ -157,7 +157,8 @@ class Adam:
         from .hip import ops as _ops
         f = self.flatp
         reducer.bind(f.grad, f.group_ranges, f.group_order, f.tail,
-                     side_streams=lambda: tuple(_ops.exchange_streams()), before_send=_ops.finish_queued_for_exchange)
+                     side_streams=lambda: tuple(_ops.exchange_streams()), before_send=_ops.finish_queued_for_exchange,
+                     on_origin=_ops.on_origin_stream)
         self.reducer, self.grad_scale = reducer, reducer.grad_scale
         if hasattr(self.model, "set_grad_marker"):
             self.model.set_grad_marker(reducer.mark)

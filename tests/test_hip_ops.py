@@ -858,3 +858,115 @@ def _tap_fused_wgrad_case(dev, case):
         yf = y2.float()
         mean = yf.mean(dim=(1, 2, 3)); var = yf.var(dim=(1, 2, 3), unbiased=False)
         assert rel_err(st[..., 0], mean) < 1e-4 and rel_err(st[..., 1], 1.0 / torch.sqrt(var + 1e-3)) < 1e-4
+
+
+# ---- staged-run conv kernel (conv_t3.hip): stride-1 3x3x3 / 1x3x3 layers on 32x32x16 MFMAs.  Production takes it from 8,192 voxels and
+#      96 channels on; the switches below lift the floors so that oracle-sized volumes reach it.  Exact-in-bf16 inputs, fp32 accumulation on
+#      both sides: forward and data gradient agree with the oracle to the rounding of the bf16 OUTPUT. ----
+CT3_LOW = dict(M1_CT3_MINM=1, M1_CT3_MINC=32, M1_CT3_MINOC=8)
+CT3_CASES = [  # dims (N, D, H, W), cins, cout, k, extra switches
+    ((2, 3, 10, 12), [64, 32], 128, (3, 3, 3), {}),                       # V = 360: a partial second tile per sample, two members
+    ((1, 4, 9, 40), [96], 160, (1, 3, 3), {}),                            # (1,3,3), row length 40 (res2), 160 output columns
+    ((1, 4, 9, 40), [96], 160, (1, 3, 3), {"M1_CT3_BN": 160}),            # ... on the 3 + 2 tile split of the pair forward
+    ((2, 2, 12, 20), [128, 128], 96, (3, 3, 3), {"M1_CT3_KSPLIT": 2}),    # split-K slabs + finish, 96 of 128 columns used
+    ((1, 5, 6, 10), [256], 192, (3, 3, 3), {"M1_CT3_BN": 192}),           # 3 + 3 tiles, row length 10 (res4), V = 300
+    ((1, 3, 8, 8), [32, 64, 32], 136, (3, 3, 3), {}),                     # 136 columns: a partial second column tile
+    ((3, 2, 7, 9), [32], 32, (3, 3, 3), {}),                              # odd extents, narrow output (conv2 of an SE block)
+]
+
+
+@pytest.mark.parametrize("case", CT3_CASES)
+def test_conv_t3_staged_run_kernel(dev, case):
+    dims, cins, cout, k, extra = case
+    s = (1, 1, 1)
+    xs = [rnd((*dims, c), 70 + i).bfloat16().float() for i, c in enumerate(cins)]
+    w = rnd((*k, sum(cins), cout), 6, 1.0 / (sum(cins) * k[0] * k[1] * k[2]) ** 0.5); b = rnd((cout,), 7)
+    yo = O.conv3d_same(torch.cat(xs, -1).double(), w.double(), b.double(), s)
+    dy = rnd(tuple(yo.shape), 8).bfloat16().float()
+    yo, (gx, gw, gb) = _oracle_grads(lambda x, w_, b_: O.conv3d_same(x, w_, b_, s), [torch.cat(xs, -1), w, b], dy)
+    res = {}
+    for tag, cfg in (("t3", dict(CT3_LOW, **extra)), ("mfma", dict(M1_CONV_T3=0))):
+        with ops.config(**cfg):
+            ops.invalidate_panels()
+            xd = [x.to(dev, torch.bfloat16).requires_grad_(True) for x in xs]
+            wd, bd = w.to(dev).requires_grad_(True), b.to(dev).requires_grad_(True)
+            y, st = ops.conv3d_same(xd, wd, bd, k, s, stats=True)
+            y.backward(dy.to(dev, torch.bfloat16))
+            torch.cuda.synchronize()
+            res[tag] = (y.detach(), st, [x.grad for x in xd], wd.grad)
+    y, st, gxd, gwd = res["t3"]
+    tol = 1e-2                                            # bf16 rounding of the stored output: 2^-9 relative to the largest element
+    assert rel_err(y, yo) < tol, "y"
+    off = 0
+    for x, g in zip(xs, gxd):
+        c = x.shape[-1]
+        assert rel_err(g, gx[..., off:off + c]) < tol, ("dx", off)
+        off += c
+    assert rel_err(gwd, gw) < 1e-4
+    yf = y.float()
+    assert rel_err(st[..., 0], yf.mean(dim=(1, 2, 3))) < 1e-4 and rel_err(st[..., 1], 1.0 / torch.sqrt(yf.var(dim=(1, 2, 3), unbiased=False) + 1e-3)) < 1e-4
+    # the implicit-GEMM kernel computes the same sums in another order: the two kernels agree far below the oracle tolerance
+    y2, st2, gx2, _ = res["mfma"]
+    assert rel_err(y, y2) < 1e-2 and float((y.float() - y2.float()).abs().mean()) < 2e-4 * float(y2.float().abs().mean()) + 1e-6
+    for a_, b_ in zip(gxd, gx2):
+        assert rel_err(a_, b_) < 1e-2
+    ops.invalidate_panels()
+
+
+def test_conv_t3_pair_forward_and_inbwd_epilogue(dev):
+    """The conv1 || conv4 pair forward (two outputs, two statistics) and the InstanceNorm-backward sums of a conv2-type data gradient
+    through the staged-run kernel's epilogues, against the implicit-GEMM kernel on the same inputs."""
+    dims, cins, c1, c4, k, s = (2, 3, 8, 10), [64, 64], 32, 128, (3, 3, 3), (1, 1, 1)
+    xs = [rnd((*dims, c), 80 + i).bfloat16().float() for i, c in enumerate(cins)]
+    cin = sum(cins)
+    sc = 1.0 / (cin * 27) ** 0.5
+    w1, b1, w4, b4 = rnd((*k, cin, c1), 3, sc), rnd((c1,), 4, 0.1), rnd((*k, cin, c4), 5, sc), rnd((c4,), 6, 0.1)
+    y1o = O.conv3d_same(torch.cat(xs, -1).double(), w1.double(), b1.double(), s)
+    y4o = O.conv3d_same(torch.cat(xs, -1).double(), w4.double(), b4.double(), s)
+    dy1, dy4 = rnd(tuple(y1o.shape), 7).bfloat16().float(), rnd(tuple(y4o.shape), 8).bfloat16().float()
+    (_, _), grads = _oracle_grads_multi(lambda x, a, b, c, d: (O.conv3d_same(x, a, b, s), O.conv3d_same(x, c, d, s)),
+                                        [torch.cat(xs, -1), w1, b1, w4, b4], (dy1, dy4))
+    with ops.config(**CT3_LOW):
+        ops.invalidate_panels()
+        xd = [x.to(dev, torch.bfloat16).requires_grad_(True) for x in xs]
+        pd = [t.to(dev).requires_grad_(True) for t in (w1, b1, w4, b4)]
+        assert ops.conv_pair_supported(xd, pd[0], pd[2], s)
+        y1, s1, y4, s4, br = ops.conv_pair_same(xd, *pd, k, s)
+        br.join(y4, s4)
+        assert rel_err(y1, y1o) < 1e-2 and rel_err(y4, y4o) < 1e-2
+        for y, st in ((y1, s1), (y4, s4)):
+            yf = y.detach().float()
+            assert rel_err(st[..., 0], yf.mean(dim=(1, 2, 3))) < 1e-4
+            assert rel_err(st[..., 1], 1 / torch.sqrt(yf.var(dim=(1, 2, 3), unbiased=False) + 1e-3)) < 1e-4
+        (y1.float() * dy1.to(dev)).sum().backward(retain_graph=True)
+        (y4.float() * dy4.to(dev)).sum().backward()
+        torch.cuda.synchronize()
+        off = 0
+        for x in xd:
+            c = x.shape[-1]
+            assert rel_err(x.grad, grads[0][..., off:off + c]) < 1e-2
+            off += c
+        # conv2-type chain: a = lrelu(IN(y)); z = conv(a): the data gradient of the conv emits the norm's backward sums
+        C2 = 32
+        yin = rnd((*dims, C2), 90).bfloat16().float()
+        g2, be2 = 1.0 + 0.1 * rnd((C2,), 91), 0.1 * rnd((C2,), 92)
+        w2 = rnd((*k, C2, C2), 93, 1.0 / (C2 * 27) ** 0.5)
+        dz = rnd((*dims, C2), 94).bfloat16().float()
+        outs = {}
+        for tag, cfg in (("t3", {}), ("mfma", dict(M1_CONV_T3=0))):
+            with ops.config(**cfg):
+                ops.invalidate_panels()
+                before = dict(ops._INBWD)
+                yd = yin.to(dev, torch.bfloat16).requires_grad_(True)
+                gd, bd_ = g2.to(dev).requires_grad_(True), be2.to(dev).requires_grad_(True)
+                wd = w2.to(dev).requires_grad_(True)
+                stats = ops.instnorm_stats(yd.detach())
+                a = ops.instnorm_act(yd, gd, bd_, 0.1, stats)
+                z = ops.conv3d_same([a], wd, None, k, s)
+                z.backward(dz.to(dev, torch.bfloat16))
+                torch.cuda.synchronize()
+                outs[tag] = (yd.grad.float(), gd.grad, bd_.grad, ops._INBWD["fused"] - before["fused"])
+        assert outs["t3"][3] == 1, "the staged-run kernel's epilogue did not emit the InstanceNorm-backward sums"
+        for a_, b_, nm in zip(outs["t3"][:3], outs["mfma"][:3], ("dy", "dgamma", "dbeta")):
+            assert rel_err(a_, b_) < 2e-2, nm
+    ops.invalidate_panels()
