@@ -80,14 +80,15 @@ __global__ void __launch_bounds__(CT3_THREADS, 2) conv_t3_kernel(MfmaP p, Ct3P q
     constexpr int NB = 3 * BN / 16;                              // its 1 KB pieces
     constexpr int NBS = (NB + 7) / 8;                            // piece slots per wave
     constexpr int NR = 2 + NJ;                                   // fragment reads per k-step
+    constexpr int RING = BN >= 256 ? 2 : 3;                      // weight stages in LDS (256 columns: 48 KB each, two fit)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     int* const s_tap = reinterpret_cast<int*>(smem);             // [27] panel tap index of (dd,dh,dw), -1 = no such tap
     int* const outrow = reinterpret_cast<int*>(smem + 128);      // [256] output voxel (global row) or -1
     unsigned char* const A_s = smem + 128 + CT3_BM * 4;
     const unsigned lds0 = (unsigned)(unsigned long long)(lptr_t)smem;
-    const unsigned ldsA = lds0 + 128 + CT3_BM * 4, ldsB = ldsA + 2 * CT3_ASTRIDE, trash = ldsB + 3 * BSTAGE;
+    const unsigned ldsA = lds0 + 128 + CT3_BM * 4, ldsB = ldsA + 2 * CT3_ASTRIDE, trash = ldsB + RING * BSTAGE;
     // descriptor tables behind the scratch KB: per stage (chunk, kd slice) the A resource + run shift, per interval the 3 panel offsets
-    int4* const tabA = reinterpret_cast<int4*>(smem + 128 + CT3_BM * 4 + 2 * CT3_ASTRIDE + 3 * BSTAGE + 1024);     // [S + 2][2]
+    int4* const tabA = reinterpret_cast<int4*>(smem + 128 + CT3_BM * 4 + 2 * CT3_ASTRIDE + RING * BSTAGE + 1024);     // [S + 2][2]
     int4* const tabB = tabA + 2 * (q.smax + 2);                                                                     // [Q + 3]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -156,13 +157,13 @@ __global__ void __launch_bounds__(CT3_THREADS, 2) conv_t3_kernel(MfmaP p, Ct3P q
         }
     }
     const int bcol0 = wn == 0 ? 0 : NJ0 * 32;
-    unsigned bad[3][NJ];
+    unsigned bad[RING][NJ];
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
         const int jj = (wn != 0 && j >= NJ1) ? NJ1 - 1 : j;          // (a tile this column wave does not have: re-read its last one)
         const int row = bcol0 + jj * 32 + (lane & 31);
 #pragma unroll
-        for (int sl = 0; sl < 3; ++sl) bad[sl][j] = ldsB + (unsigned)(sl * BSTAGE + row * 64 + ((kh8 ^ ((row >> 2) & 3)) << 4));
+        for (int sl = 0; sl < RING; ++sl) bad[sl][j] = ldsB + (unsigned)(sl * BSTAGE + row * 64 + ((kh8 ^ ((row >> 2) & 3)) << 4));
     }
 
     // ---- DMA slots of this lane.  A piece = 16 rows x 64 B of the staged run; B piece = 16 panel rows x 64 B of one tap.
@@ -231,17 +232,19 @@ __global__ void __launch_bounds__(CT3_THREADS, 2) conv_t3_kernel(MfmaP p, Ct3P q
 
     // one kh row = 6 k-steps (3 taps x 2 halves of the 32-channel chunk), each 2 A + NJ B fragments -> 2 x NJ MFMAs.  The reads of
     // k-step k + 1 are issued BEFORE the MFMAs of k-step k (two fragment sets), with a counted lgkmcnt: LDS returns in order.
-    auto compute = [&](auto parc, auto dhc) {
+    auto compute = [&](auto parc, auto dhc, auto&& pre) {
         constexpr int PAR = decltype(parc)::value, DHI = decltype(dhc)::value;
+        constexpr int SLOT = RING == 3 ? DHI : ((PAR + DHI) & 1);       // interval 3 st + dh: st = (even) + PAR
         u32x4_t fa[2][2], fb[2][NJ];
         auto reads = [&](auto kc) {                               // k-step K = 2 tap + half
             constexpr int K = decltype(kc)::value, DWI = K >> 1, KS = K & 1, BUF = K & 1;
 #pragma unroll
             for (int i = 0; i < 2; ++i) ct3_rd<PAR * CT3_ASTRIDE>(fa[BUF][i], KS ? aad[DHI * 3 + DWI][i] ^ 32u : aad[DHI * 3 + DWI][i]);
 #pragma unroll
-            for (int j = 0; j < NJ; ++j) ct3_rd<DWI * BT>(fb[BUF][j], KS ? bad[DHI][j] ^ 32u : bad[DHI][j]);
+            for (int j = 0; j < NJ; ++j) ct3_rd<DWI * BT>(fb[BUF][j], KS ? bad[SLOT][j] ^ 32u : bad[SLOT][j]);
         };
         reads(std::integral_constant<int, 0>{});
+        pre();                                                    // (the DMA issue of the interval: behind the first reads, whose latency it covers)
         ct3_for<0, 6>([&](auto kc) {
             constexpr int K = decltype(kc)::value, BUF = K & 1;
             // the wait is TIED to the fragments of this k-step (in/out operands): the compiler knows nothing of the asynchronous
@@ -249,6 +252,7 @@ __global__ void __launch_bounds__(CT3_THREADS, 2) conv_t3_kernel(MfmaP p, Ct3P q
             if constexpr (K + 1 < 6) reads(std::integral_constant<int, K + 1>{});
             constexpr int LEFT = K + 1 < 6 ? NR : 0;
             if constexpr (NJ == 2) asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(fa[BUF][0]), "+v"(fa[BUF][1]), "+v"(fb[BUF][0]), "+v"(fb[BUF][1]) : "n"(LEFT) : "memory");
+            else if constexpr (NJ == 4) asm volatile("s_waitcnt lgkmcnt(%6)" : "+v"(fa[BUF][0]), "+v"(fa[BUF][1]), "+v"(fb[BUF][0]), "+v"(fb[BUF][1]), "+v"(fb[BUF][2]), "+v"(fb[BUF][3]) : "n"(LEFT) : "memory");
             else asm volatile("s_waitcnt lgkmcnt(%5)" : "+v"(fa[BUF][0]), "+v"(fa[BUF][1]), "+v"(fb[BUF][0]), "+v"(fb[BUF][1]), "+v"(fb[BUF][2]) : "n"(LEFT) : "memory");
             // (NJ0 != NJ1, the 3 + 2 split of the 160-column tile: ONE code path -- the narrow column wave reads the fragment of its
             //  last tile a second time, so that the lgkmcnt counts stay the same, and skips the MFMAs of the tile it does not have)
@@ -268,7 +272,8 @@ __global__ void __launch_bounds__(CT3_THREADS, 2) conv_t3_kernel(MfmaP p, Ct3P q
     //      Stages go in pairs: the A buffer of a stage is a compile-time constant. ----
     if (Q > 0) {
         issue_a(0, 0, 0); issue_a(0, 0, 1);
-        issue_b(0, 0); issue_b(1, 1);
+        issue_b(0, 0);
+        if constexpr (RING == 3) issue_b(1, 1);
         for (int st0 = 0; st0 < S; st0 += 2) {
             ct3_for<0, 2>([&](auto parc) {
                 constexpr int PAR = decltype(parc)::value;
@@ -277,12 +282,15 @@ __global__ void __launch_bounds__(CT3_THREADS, 2) conv_t3_kernel(MfmaP p, Ct3P q
                     ct3_for<0, 3>([&](auto dhc) {
                         constexpr int DHI = decltype(dhc)::value;
                         const int qi = 3 * st + DHI;
-                        if constexpr (DHI == 0) ct3_vmwait<NBS>(); else ct3_vmwait<NBS + CT3_NAS>();
+                        // ring of 3: only the group issued one interval ago may be in flight; ring of 2: nothing (the weights of this
+                        // interval were issued one interval ago)
+                        if constexpr (RING == 2) ct3_vmwait<0>();
+                        else if constexpr (DHI == 0) ct3_vmwait<NBS>(); else ct3_vmwait<NBS + CT3_NAS>();
                         __builtin_amdgcn_s_barrier();
-                        issue_b(qi + 2, (DHI + 2) % 3);
-                        if constexpr (DHI < 2) issue_a(st + 1, PAR ^ 1, DHI);
-                        ct3_lgkmwait<0>();                        // (the table reads of the issue: the fragment pipeline counts from zero)
-                        compute(parc, dhc);
+                        compute(parc, dhc, [&]() {
+                            if constexpr (RING == 3) issue_b(qi + 2, (DHI + 2) % 3); else issue_b(qi + 1, (PAR + DHI + 1) & 1);
+                            if constexpr (DHI < 2) issue_a(st + 1, PAR ^ 1, DHI);
+                        });
                     });
                 }
             });
@@ -327,7 +335,7 @@ __global__ void __launch_bounds__(CT3_THREADS, 2) conv_t3_kernel(MfmaP p, Ct3P q
         }
     __syncthreads();
     if (p.stat_partial) {
-        float* red = reinterpret_cast<float*>(smem + 128 + CT3_BM * 4 + 2 * a_bytes + 3 * BSTAGE);       // the ring's scratch KB + the tables (done with both)
+        float* red = reinterpret_cast<float*>(smem + 128 + CT3_BM * 4 + 2 * a_bytes + RING * BSTAGE);       // the ring's scratch KB + the tables (done with both)
         constexpr int G = CT3_THREADS / BN;
         const int col = tid % BN, rg = tid / BN;
         float s = 0.f, ss = 0.f;
@@ -384,7 +392,7 @@ __global__ void __launch_bounds__(CT3_THREADS, 2) conv_t3_kernel(MfmaP p, Ct3P q
 static inline size_t ct3_smem(int BN, int smax) {
     size_t tab = (size_t)(smax + 2) * 32 + (size_t)(3 * smax + 3) * 16;           // descriptor tables
     if (tab < CT3_THREADS * 2 * sizeof(float)) tab = CT3_THREADS * 2 * sizeof(float);      // (the statistics scratch reuses the region)
-    return 128 + CT3_BM * 4 + 2 * (size_t)CT3_ASTRIDE + 3 * 3 * (size_t)BN * 64 + 1024 + tab;
+    return 128 + CT3_BM * 4 + 2 * (size_t)CT3_ASTRIDE + (BN >= 256 ? 2 : 3) * 3 * (size_t)BN * 64 + 1024 + tab;
 }
 
 // the shapes this kernel takes, and how: BN (columns per block), K splits.  false: conv_mfma / conv_halo keep the problem.
@@ -411,23 +419,28 @@ bool m1_ct3_plan(const GatherSpec& g, int* BN_out, int* ksplit_out) {
     const long long tiles = (long long)g.N * cdiv_ll(V, CT3_BM);
     const int nchunks = CC / 32, S = nchunks * g.kd;
     const int cus = M1_CFG("M1_CT3_CUS", 256);
+    // Cost model (us, fitted to same-box measurements of the C3 layers, profiles/r04_conv_t3_layers.txt): one block per CU, so a launch
+    // takes rounds = ceil(blocks / 256) block times; a block = a fixed part (prologue: tables, addresses, first DMA round trip;
+    // epilogue: LDS tile, statistics, stores) + its kh-row intervals, whose time grows with the tile width more slowly than the MFMA
+    // count (fewer fragment reads and less staged input per MFMA); split-K adds the slab round trip of the finish pass.
     double best = 1e30; int bBN = 0, bks = 1;
-    for (int BN : {128, 160, 192}) {
+    for (int BN : {128, 160, 192, 256}) {
         const int ntile = (g.OC + BN - 1) / BN;
+        const double t_int = BN == 128 ? 1.5 : (BN == 160 ? 1.85 : (BN == 192 ? 2.15 : 2.85)), t_fix = 10.0 + 0.03 * BN;
         for (int ks = 1; ks <= 8; ++ks) {
             if (ks > 1 && nchunks / ks < 4) break;
             if (ct3_smem(BN, (nchunks + ks - 1) / ks * g.kd) > 160 * 1024) continue;
             const long long blocks = tiles * ntile * ks;
             const long long rounds = cdiv_ll(blocks, cus);
             const int cps = (nchunks + ks - 1) / ks;
-            // time ~ rounds x (MFMA work of a block + its fixed part); split-K adds a slab write + a finish pass
-            double t = (double)rounds * ((double)BN * cps * g.kd + 0.04 * BN * S / ks + 24.0 * BN) + (ks > 1 ? 0.15 * (double)rounds * BN * S / ks + 3000.0 : 0.0);
+            double t = (double)rounds * (t_fix + 3.0 * cps * g.kd * t_int);
+            if (ks > 1) t += 6.0 + (double)g.N * V * g.OC * (4.0 * ks + 2.0) / 3.0e6;      // slabs written + read back, output written (3 TB/s)
             if (t < best) { best = t; bBN = BN; bks = ks; }
         }
     }
     if (!bBN) return false;
     const int fbn = M1_CFG("M1_CT3_BN", 0), fks = M1_CFG("M1_CT3_KSPLIT", 0);
-    if (fbn == 128 || fbn == 160 || fbn == 192) bBN = fbn;
+    if (fbn == 128 || fbn == 160 || fbn == 192 || fbn == 256) bBN = fbn;
     if (fks >= 1) bks = fks;
     if (ct3_smem(bBN, (nchunks + bks - 1) / bks * g.kd) > 160 * 1024) return false;
     *BN_out = bBN; *ksplit_out = bks;
@@ -446,7 +459,7 @@ int m1_ct3_conv(const MfmaP& mp, int BN, int OCpad, hipStream_t st) {
     q.nchunks = mp.CC / 32; q.cps = (q.nchunks + mp.ksplit - 1) / mp.ksplit; q.OCpad = OCpad; q.smax = q.cps * q.KD;
     if (mp.cls_ntaps[0] != 27 && mp.cls_ntaps[0] != 9) return M1_ERR_UNSUPPORTED;
     const size_t smem = ct3_smem(BN, q.smax);
-    void (*kern)(MfmaP, Ct3P) = BN == 128 ? conv_t3_kernel<2, 2> : (BN == 160 ? conv_t3_kernel<3, 2> : conv_t3_kernel<3, 3>);
+    void (*kern)(MfmaP, Ct3P) = BN == 128 ? conv_t3_kernel<2, 2> : (BN == 160 ? conv_t3_kernel<3, 2> : (BN == 192 ? conv_t3_kernel<3, 3> : conv_t3_kernel<4, 4>));
     {
         static const void* done[4]; static int ndone = 0;
         bool seen = false;

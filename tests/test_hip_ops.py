@@ -872,6 +872,8 @@ CT3_CASES = [  # dims (N, D, H, W), cins, cout, k, extra switches
     ((1, 5, 6, 10), [256], 192, (3, 3, 3), {"M1_CT3_BN": 192}),           # 3 + 3 tiles, row length 10 (res4), V = 300
     ((1, 3, 8, 8), [32, 64, 32], 136, (3, 3, 3), {}),                     # 136 columns: a partial second column tile
     ((3, 2, 7, 9), [32], 32, (3, 3, 3), {}),                              # odd extents, narrow output (conv2 of an SE block)
+    ((2, 3, 8, 10), [32, 128], 512, (3, 3, 3), {"M1_CT3_BN": 256}),       # 256-column blocks (4 + 4 tiles per wave pair, two weight stages in LDS)
+    ((1, 2, 6, 20), [64], 264, (1, 3, 3), {"M1_CT3_BN": 256}),            # ... with a partial second column tile, odd number of kd-less stages
 ]
 
 
