@@ -413,7 +413,7 @@ bool m1_ct3_plan(const GatherSpec& g, int* BN_out, int* ksplit_out) {
     if (nA * 1024 > CT3_ASTRIDE || nA > 2 * CT3_NAS * 8) return false;      // (W <= 46: res2 and deeper)
     if (V * 768 * 2 >= (1ll << 31) || V < 64) return false;
     const int minc = M1_CFG("M1_CT3_MINC", 96), minoc = M1_CFG("M1_CT3_MINOC", 96);
-    const long long minm = M1_CFG("M1_CT3_MINM", 8192);
+    const long long minm = M1_CFG("M1_CT3_MINM", 4096);
     if (CC < minc || g.OC < minoc || (long long)g.N * V < minm) return false;
     for (int i = 0; i < g.nsrc; ++i) if (V * g.srcC[i] * 2 >= (1ll << 31) - 4096) return false;
     const long long tiles = (long long)g.N * cdiv_ll(V, CT3_BM);
