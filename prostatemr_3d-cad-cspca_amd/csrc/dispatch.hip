@@ -518,7 +518,6 @@ extern "C" int m1_convT3d_dgrad(const m1_conv_desc_t* d, const float* w, const v
 #include <stdlib.h>
 static bool tf_wanted(const WgradSpec& g) {
     int maxc = M1_CFG("M1_TF_MAXC", 128);
-    if (m1_tf64_wgrad_supported(g)) return true;
     // 32x32 channel tiles re-read dY once per 32 input channels and X once per 32 output channels: a win while the OUTPUT side
     // is narrow (conv1 of an SE block: F/4 <= 32 channels -- 512->32 at res2: 1.70 -> 1.08 ms per step), a loss beyond (512->128: 2x slower)
     if (g.CA > 64 && g.CB > 32) return false;

@@ -64,7 +64,6 @@ int m1_pack_batch_internal(const void* const* jobs_dev, const int* prefix_dev, i
 bool m1_mfma_wgrad_supported(const WgradSpec& g);
 int m1_mfma_wgrad(const WgradSpec& g, hipStream_t st);
 bool m1_tf_wgrad_supported(const WgradSpec& g);      // tap-fused variant (wgrad_tf.hip)
-bool m1_tf64_wgrad_supported(const WgradSpec& g);    // its 64x64-tile kernel (both sides multiples of 64 channels)
 // nw / nb: floats of the whole weight / bias gradient the spec's R / bsum point into.  M1_ERR_WORKSPACE / UNSUPPORTED:
 // nothing was launched, the caller takes the per-tap kernel instead.
 int m1_tf_wgrad(const WgradSpec& g, long long nw, int nb, hipStream_t st);

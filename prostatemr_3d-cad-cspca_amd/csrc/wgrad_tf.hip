@@ -283,188 +283,6 @@ __global__ void __launch_bounds__(256) wgrad_tf_kernel(TfP p) {
 #endif
 }
 
-// ------------------------------------------------------------------------------------------------
-// 64 x 64 channel tile variant for the >= 64-channel layers: a block owns a 64x64 tile (each wave 32x32 = 2x2 MFMA tiles)
-// and the 9 taps of ONE kd slice (blockIdx.z); 128-byte LDS rows.  4x the MFMAs per staged byte and per instruction of
-// the 32x32 kernel; X and dY are read CA/64 + CB/64 times per kd instead of once per tap and channel tile.
-// EXPERIMENT, off unless M1_TF64=1: correct (tests run it), but at 404 VGPRs it runs one wave per SIMD and measured
-// 4 % slower than the per-tap kernel on the 128-channel layers (C2 wgrad 2.03 -> 2.12 ms); kept for the next round.
-// ------------------------------------------------------------------------------------------------
-#define TF64_MAX_AIT 6
-__device__ __forceinline__ int tf64_f(int col) { return ((col >> 1) & 1) | (((col >> 3) & 1) << 1); }   // 32-byte piece XOR (bank spread)
-
-__global__ void __launch_bounds__(256, 2) wgrad_tf64_kernel(TfP p) {
-    constexpr int NKS = 2, KH = 3, KW = 3, NT9 = 9;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wa = wave >> 1, wb = wave & 1;
-    const int a0 = (blockIdx.x / p.bTiles) * 64, b0 = (blockIdx.x % p.bTiles) * 64;
-    const int kd0 = blockIdx.z;
-    constexpr int PA = 128, PB = 128;
-    const int stage_bytes = p.a_bytes + p.b_bytes;
-    const unsigned char* zero_pg = reinterpret_cast<const unsigned char*>(m1_zero_page_w);
-
-    int a_rel[TF64_MAX_AIT], a_pk[TF64_MAX_AIT], a_sl[TF64_MAX_AIT];
-    const int nait = p.a_slots >> 8;
-#pragma unroll
-    for (int it = 0; it < TF64_MAX_AIT; ++it) {
-        const int q = it * 256 + tid;
-        const int row = q >> 3, slp = q & 7;
-        const int hh = row / p.AWt, ww = row - hh * p.AWt;
-        const int sl = (((slp >> 1) ^ tf64_f(ww)) << 1) | (slp & 1);
-        a_rel[it] = hh * p.AW + ww;
-        a_pk[it] = (row < p.AHt * p.AWt) ? (hh | (ww << 8)) : -1;
-        a_sl[it] = sl * 8;
-    }
-    int b_th[2], b_tw[2], b_sl[2];
-#pragma unroll
-    for (int it = 0; it < 2; ++it) {
-        const int q = it * 256 + tid;
-        const int row = q >> 3, slp = q & 7;
-        b_th[it] = row / p.KWs; b_tw[it] = row - b_th[it] * p.KWs;
-        b_sl[it] = ((((slp >> 1) ^ tf64_f(b_tw[it])) << 1) | (slp & 1)) * 8;
-    }
-
-    int q_kt = blockIdx.y, q_tw, q_th, q_bd, q_n;
-    { int r = q_kt; q_tw = r % p.tiles_w; r /= p.tiles_w; q_th = r % p.tiles_h; r /= p.tiles_h; q_bd = r % p.BD; q_n = r / p.BD; }
-    int s_tw, s_th, s_bd, s_n;
-    { int r = p.nsplit; s_tw = r % p.tiles_w; r /= p.tiles_w; s_th = r % p.tiles_h; r /= p.tiles_h; s_bd = r % p.BD; s_n = r / p.BD; }
-    auto issue = [&](int st) {
-        const bool live = q_kt < (int)p.ntiles;
-        const int twi = q_tw, thi = q_th, bd = q_bd, n = q_n;
-        q_kt += p.nsplit;
-        q_tw += s_tw; int c = q_tw >= p.tiles_w; q_tw -= c ? p.tiles_w : 0;
-        q_th += s_th + c; c = q_th >= p.tiles_h; q_th -= c ? p.tiles_h : 0;
-        q_bd += s_bd + c; c = q_bd >= p.BD; q_bd -= c ? p.BD : 0;
-        q_n += s_n + c;
-        const int ad = bd * p.sd - p.pd + kd0, ah0 = thi * p.TH * p.sh - p.ph, aw0 = twi * p.KWs * p.sw - p.pw;
-        const bool dok = live && (unsigned)ad < (unsigned)p.AD;
-        const int lin0 = ((n * p.AD + ad) * p.AH + ah0) * p.AW + aw0;
-        unsigned char* As = smem + st * stage_bytes;
-        unsigned char* Bs = As + p.a_bytes;
-#pragma unroll
-        for (int it = 0; it < TF64_MAX_AIT; ++it) {
-            if (it < nait) {
-                const int pk = a_pk[it];
-                const int hh = pk & 0xff, ww = (pk >> 8) & 0xff;
-                const bool ok = dok && pk >= 0 && (unsigned)(ah0 + hh) < (unsigned)p.AH && (unsigned)(aw0 + ww) < (unsigned)p.AW;
-                const long long real = (long long)(p.A + (long long)(lin0 + a_rel[it]) * p.CA + a0 + a_sl[it]);
-                const long long zp = (long long)zero_pg;
-                glds16w(reinterpret_cast<const unsigned char*>(zp + ((real - zp) & -(long long)ok)), As + (it * 256 + wave * 64) * 16);
-            }
-        }
-#pragma unroll
-        for (int it = 0; it < 2; ++it) {
-            const int bh = thi * p.TH + b_th[it];
-            const bool ok = live && bh < p.BH;
-            const long long lin = (((long long)n * p.BD + bd) * p.BH + bh) * p.BW + twi * p.KWs + b_tw[it];
-            const long long real = (long long)(p.B + lin * p.CB + b0 + b_sl[it]);
-            const long long zp = (long long)zero_pg;
-            glds16w(reinterpret_cast<const unsigned char*>(zp + ((real - zp) & -(long long)ok)), Bs + (it * 256 + wave * 64) * 16);
-        }
-    };
-
-    // fragment addresses of sub-tile 0 of this wave (sub-tile 1 = address ^ 32: the neighbouring 32-byte piece)
-    const int g = lane >> 4, i = lane & 15;
-    const unsigned lds0 = (unsigned)(unsigned long long)(lptr_t)smem;
-    unsigned a_ad[NKS][2][KW], b_ad[NKS][2];
-#pragma unroll
-    for (int ks = 0; ks < NKS; ++ks)
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int kk = ks * 32 + 8 * g + 4 * h + (i >> 2);
-            const int th = kk / p.KWs, tw = kk - th * p.KWs;
-#pragma unroll
-            for (int kw = 0; kw < KW; ++kw) {
-                const int ww = tw * p.sw + kw;
-                a_ad[ks][h][kw] = lds0 + ((th * p.sh) * p.AWt + ww) * PA + (((2 * wa) ^ tf64_f(ww)) * 32) + (i & 3) * 8;
-            }
-            b_ad[ks][h] = lds0 + p.a_bytes + kk * PB + (((2 * wb) ^ tf64_f(tw)) * 32) + (i & 3) * 8;
-        }
-    const int grp_pitch = p.AWt * PA;
-
-    f32x4_t acc[NT9][2][2];
-#pragma unroll
-    for (int t = 0; t < NT9; ++t)
-#pragma unroll
-        for (int x = 0; x < 4; ++x) acc[t][x >> 1][x & 1] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-    const bool do_bsum = p.bsum != nullptr && a0 == 0 && wa == 0 && kd0 == 0;
-    f32x4_t accb[2] = {(f32x4_t){0.f, 0.f, 0.f, 0.f}, (f32x4_t){0.f, 0.f, 0.f, 0.f}};
-    const bf16x8_t ones = __builtin_bit_cast(bf16x8_t, make_uint4(0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u));
-
-    const int S = p.stages, npiece = nait + 2;
-    for (int s = 0; s < S - 1; ++s) issue(s);
-    int st = 0;
-    for (long long kt = blockIdx.y; kt < p.ntiles; kt += p.nsplit) {
-        wait_vm(npiece * (S - 2));
-        __builtin_amdgcn_s_barrier();
-        int stn = st + S - 1; if (stn >= S) stn -= S;
-        issue(stn);
-        const unsigned sb = (unsigned)(st * stage_bytes);
-        constexpr int NU = NKS * KH;                           // units: one kh row of taps for one k-step
-        u32x2_t bl[2][2], bh[2][2], al[2][KW][2], ah[2][KW][2];
-        auto rd_unit = [&](int u, int set) {
-            const int ks = u / KH, kh = u % KH;
-            if (kh == 0) {
-#pragma unroll
-                for (int sbi = 0; sbi < 2; ++sbi) {
-                    bl[ks & 1][sbi] = tr_read_asm((b_ad[ks][0] + sb) ^ (sbi * 32)); bh[ks & 1][sbi] = tr_read_asm((b_ad[ks][1] + sb) ^ (sbi * 32));
-                }
-            }
-            const unsigned ro = sb + (unsigned)(kh * grp_pitch);
-#pragma unroll
-            for (int kw = 0; kw < KW; ++kw)
-#pragma unroll
-                for (int sa = 0; sa < 2; ++sa) {
-                    al[set][kw][sa] = tr_read_asm((a_ad[ks][0][kw] + ro) ^ (sa * 32));
-                    ah[set][kw][sa] = tr_read_asm((a_ad[ks][1][kw] + ro) ^ (sa * 32));
-                }
-        };
-        rd_unit(0, 0);
-#pragma unroll
-        for (int u = 0; u < NU; ++u) {
-            const int ks = u / KH, kh = u % KH, set = u & 1;
-            if (kh == 0) { lds_wait2(bl[ks & 1][0], bh[ks & 1][0]); lds_wait2(bl[ks & 1][1], bh[ks & 1][1]); }
-#pragma unroll
-            for (int kw = 0; kw < KW; ++kw) { lds_wait2(al[set][kw][0], ah[set][kw][0]); lds_wait2(al[set][kw][1], ah[set][kw][1]); }
-            if (u + 1 < NU) rd_unit(u + 1, set ^ 1);
-            __builtin_amdgcn_sched_barrier(0);
-            const bf16x8_t bf0 = frag8(bl[ks & 1][0], bh[ks & 1][0]), bf1 = frag8(bl[ks & 1][1], bh[ks & 1][1]);
-            if (do_bsum && kh == 0) {
-                accb[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, bf0, accb[0], 0, 0, 0);
-                accb[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, bf1, accb[1], 0, 0, 0);
-            }
-#pragma unroll
-            for (int kw = 0; kw < KW; ++kw)
-#pragma unroll
-                for (int sa = 0; sa < 2; ++sa) {
-                    const bf16x8_t af = frag8(al[set][kw][sa], ah[set][kw][sa]);
-                    acc[kh * KW + kw][sa][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bf0, acc[kh * KW + kw][sa][0], 0, 0, 0);
-                    acc[kh * KW + kw][sa][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bf1, acc[kh * KW + kw][sa][1], 0, 0, 0);
-                }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        if (++st == S) st = 0;
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-
-    float* Rx = p.Rx + (long long)blockIdx.y * p.rx_stride;
-#pragma unroll
-    for (int sbi = 0; sbi < 2; ++sbi) {
-        const int b = b0 + (2 * wb + sbi) * 16 + i;
-        if (do_bsum && g == 0 && b < p.CB) Rx[p.rx_bias + b] = accb[sbi][0];
-#pragma unroll
-        for (int t = 0; t < NT9; ++t)
-#pragma unroll
-            for (int sa = 0; sa < 2; ++sa)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int a = a0 + (2 * wa + sa) * 16 + g * 4 + r;
-                    if (a < p.CA && b < p.CB)
-                        Rx[((long long)(kd0 * NT9 + t) * p.CA + a) * p.CB + b] = acc[t][sa][sbi][r];
-                }
-    }
-}
 
 // R[idx(i)] += sum over the copies of Rx[copy][idx(i)] for the NT x CA x CB block of one concat member (+ its bias sums).
 // A block owns EL consecutive elements; its 256/EL lane rows stride the copies, fold through LDS, and ONE lane adds the
@@ -619,35 +437,7 @@ static bool tf_plan(const WgradSpec& g, TfP& p) {
     return npiece * (S - 2) <= 48 && (size_t)S * sb <= 160 * 1024;
 }
 // 64x64 variant: both sides multiples of 64 channels
-static bool tf64_plan(const WgradSpec& g, TfP& p) {
-    int en = M1_CFG("M1_TF64", 0);      // off by default, see the kernel header
-    if (!en || g.dtype != M1_BF16 || g.CA % 64 || g.CB % 64) return false;
-    if (!(g.kh == 3 && g.kw == 3 && (g.kd == 1 || g.kd == 3))) return false;
-    if (g.BW % 8) return false;
-    if ((long long)g.N * g.AD * g.AH * g.AW >= (1ll << 31) - (1 << 20) || (long long)g.N * g.BD * g.BH * g.BW >= (1ll << 31) - (1 << 20)) return false;
-    p = TfP{};
-    p.A = (const bf16_t*)g.A; p.B = (const bf16_t*)g.B; p.R = g.R; p.bsum = g.bsum;
-    p.CA = g.CA; p.CB = g.CB; p.AD = g.AD; p.AH = g.AH; p.AW = g.AW; p.BD = g.BD; p.BH = g.BH; p.BW = g.BW; p.N = g.N;
-    p.RT = g.RT; p.RSA = g.RSA; p.a_off = g.a_off; p.b_off = g.b_off;
-    p.sd = g.sd; p.sh = g.sh; p.sw = g.sw; p.pd = g.pd; p.ph = g.ph; p.pw = g.pw;
-    p.KWs = g.BW % 32 == 0 ? 32 : (g.BW % 16 == 0 ? 16 : 8);
-    p.TH = 2 * (32 / p.KWs);
-    p.AHt = (p.TH - 1) * g.sh + 3; p.AWt = (p.KWs - 1) * g.sw + 3;
-    p.spra = 8; p.sprb = 8;
-    p.a_slots = (p.AHt * p.AWt * 8 + 255) / 256 * 256; p.b_slots = 512;
-    if (p.a_slots > TF64_MAX_AIT * 256 || p.AHt > 255 || p.AWt > 255) return false;
-    p.a_bytes = p.a_slots * 16; p.b_bytes = 512 * 16;
-    p.tiles_w = g.BW / p.KWs; p.tiles_h = (g.BH + p.TH - 1) / p.TH;
-    p.ntiles = (long long)g.N * g.BD * p.tiles_h * p.tiles_w;
-    if (p.ntiles >= (1ll << 30)) return false;
-    const int sbytes = p.a_bytes + p.b_bytes;
-    int S = (80 * 1024) / sbytes; if (S > 4) S = 4;
-    if (S < 2) return false;
-    p.stages = S;
-    return true;
-}
-bool m1_tf_wgrad_supported(const WgradSpec& g) { TfP p; return tf_plan(g, p) || tf64_plan(g, p); }
-bool m1_tf64_wgrad_supported(const WgradSpec& g) { TfP p; return tf64_plan(g, p); }
+bool m1_tf_wgrad_supported(const WgradSpec& g) { TfP p; return tf_plan(g, p); }
 
 // ---- deferred folds: queued (process-wide, the autograd engine calls the weight gradients from its own thread) and run
 //      in a few batched launches by m1_wgrad_fold_pending ----
@@ -726,9 +516,8 @@ int m1_tf_wgrad_multi(const WgradSpec& g, long long nw, int nb, hipStream_t st, 
 int m1_tf_wgrad(const WgradSpec& g, long long nw, int nb, hipStream_t st) { return tf_wgrad_launch(g, nw, nb, st, 1, nullptr, nullptr, 0); }
 static int tf_wgrad_launch(const WgradSpec& g, long long nw, int nb, hipStream_t st, int nmem, const void* const* Am, const int* a_offs, long long rx_mem) {
     TfP p;
-    const bool big = tf64_plan(g, p);
-    if (!big && !tf_plan(g, p)) return M1_ERR_UNSUPPORTED;
-    const int TS = big ? 64 : 32;
+    if (!tf_plan(g, p)) return M1_ERR_UNSUPPORTED;
+    const int TS = 32;
     const int aTiles = (g.CA + TS - 1) / TS; p.bTiles = (g.CB + TS - 1) / TS;
     const int ctiles = aTiles * p.bTiles;
     // blocks per launch (M1_TF_SPLIT, 0 = by size): 256 (one per CU) up to ~24k K-tiles, 512 beyond -- isolated, the 64 -> 32 layer
@@ -737,7 +526,6 @@ static int tf_wgrad_launch(const WgradSpec& g, long long nw, int nb, hipStream_t
     int tgt_env = M1_CFG("M1_TF_SPLIT", 0);
     const int tgt = tgt_env > 0 ? tgt_env : (p.ntiles >= 24576 ? 512 : 256);
     long long nsplit = (tgt + ctiles - 1) / ctiles;
-    if (big) nsplit = (tgt + ctiles * g.kd - 1) / (ctiles * g.kd);
     const long long nloc = (long long)g.kd * g.kh * g.kw * g.CA * g.CB;
     const long long stride = nloc + g.CB;                      // compact copy of this member's block (+ bias sums)
     if (nsplit * stride * 4 > TF_MAX_COPY_BYTES) nsplit = TF_MAX_COPY_BYTES / (stride * 4);
@@ -748,10 +536,10 @@ static int tf_wgrad_launch(const WgradSpec& g, long long nw, int nb, hipStream_t
     p.nsplit = (int)nsplit;
     p.Rx = g.rx; p.rx_stride = stride; p.rx_bias = nloc;
     const size_t smem = (size_t)p.stages * (p.a_bytes + p.b_bytes);
-    dim3 grid(ctiles, (unsigned)nsplit, big ? g.kd : 1);
+    dim3 grid(ctiles, (unsigned)nsplit, 1);
     p.nmem = 1; p.rx_mem = 0;
     if (nmem > 1) {
-        if (big || nmem > M1_MAX_SRC) return M1_ERR_UNSUPPORTED;
+        if (nmem > M1_MAX_SRC) return M1_ERR_UNSUPPORTED;
         p.nmem = nmem; p.rx_mem = rx_mem; grid.z = (unsigned)nmem;
         for (int m = 0; m < nmem; ++m) p.Am[m] = (const bf16_t*)Am[m];
     }
@@ -763,7 +551,6 @@ static int tf_wgrad_launch(const WgradSpec& g, long long nw, int nb, hipStream_t
     if (p.nks == 4 && kparts == 4) kern = g.kd == 1 ? wgrad_tf_kernel<1, 3, 3, 4, 4> : (g.kd == 3 ? wgrad_tf_kernel<3, 3, 3, 4, 4> : nullptr);
     if (p.nks == 4 && g.kd == 1 && kparts == 1) kern = wgrad_tf_kernel<1, 3, 3, 1, 4>;
     if (p.nks == 4 && g.kd == 1 && kparts == 2) kern = wgrad_tf_kernel<1, 3, 3, 2, 4>;
-    if (big) kern = wgrad_tf64_kernel;
     if (!kern) return M1_ERR_UNSUPPORTED;
     {   // raise the dynamic-LDS limit once per instantiation
         static const void* done[8]; static int ndone = 0;

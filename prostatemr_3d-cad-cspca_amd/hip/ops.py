@@ -169,16 +169,7 @@ _FOLD = {"on": _os.environ.get("M1_WG_FOLD_BATCH", "1") != "0", "keep": [],
          # a stream of their own NEXT TO the backward pass (bandwidth-bound folds beside MFMA-bound convolutions) instead of
          # all at its end, where they ran alone on the GPU (0.8 ms of the C3 step)
          "async": int(_os.environ.get("M1_FOLD_ASYNC", "-1")), "stream": None,
-         "async_mb": int(_os.environ.get("M1_FOLD_ASYNC_MB", "0")), "bytes": 0,
-         # M1_FOLD_HEAVY = g > 0: also right before the backward kernels of a conv of >= g GFLOP (when >= 4 folds wait)
-         "heavy": float(_os.environ.get("M1_FOLD_HEAVY", "0")), "heavy_min": int(_os.environ.get("M1_FOLD_HEAVY_MIN", "4"))}
-
-
-def _fold_before_heavy(d) -> None:
-    if _FOLD["heavy"] > 0 and _BRANCH["on"] and len(_FOLD["keep"]) >= _FOLD["heavy_min"]:
-        gf = 2e-9 * d.N * d.D * d.H * d.W * d.Cin * d.Cout * d.kd * d.kh * d.kw / (d.sd * d.sh * d.sw)
-        if gf >= _FOLD["heavy"]:
-            _fold_async()
+         "async_mb": int(_os.environ.get("M1_FOLD_ASYNC_MB", "0")), "bytes": 0}
 
 
 def fold_async_default(n: int) -> None:
@@ -538,7 +529,6 @@ class _Conv3d(torch.autograd.Function):
         st = _stream()
         name = "convT3d" if ctx.transposed else "conv3d"
         dw = db = None
-        _fold_before_heavy(d)
         if ctx.needs_input_grad[0] or (ctx.has_bias and ctx.needs_input_grad[1]):
             dw, db = _wgrad_into_sinks(lib, d, dy, ctx.w_param, ctx.b_param if ctx.has_bias else None, ctx.transposed, st, srcs)
         dsrc: List[Optional[torch.Tensor]] = []
@@ -608,38 +598,12 @@ def _pair_panel_ws(w1: torch.Tensor, w4: torch.Tensor, d, role: int, need_mask=N
     return ws, 0
 
 
-_WG = {"on": _os.environ.get("M1_WGRAD_STREAMS", "0"), "next": 0}
-
-
-def _wgrad_stream(param):
-    """The weight-gradient stream of ``param`` (M1_WGRAD_STREAMS of them, 0 = launch in order on the caller's stream).  A
-    parameter keeps its stream, so the passes that share it (prior / posterior run twice when not stacked) accumulate in order."""
-    n = int(_WG["on"])
-    device = param.device
-    if n <= 0 or not _BRANCH["on"] or device.type != "cuda":
-        return None
-    k = getattr(param, "_m1_wgs", None)
-    if k is None:
-        k = _WG["next"] % n
-        _WG["next"] += 1
-        try:
-            param._m1_wgs = k
-        except Exception:  # noqa: BLE001
-            return None
-    key = (device, "wg", k)
-    if key not in _BRANCH["streams"]:
-        _BRANCH["streams"][key] = torch.cuda.Stream(device=device)
-    return _BRANCH["streams"][key]
-
-
 def _wgrad_into_sinks(lib, d, dy, w_param, b_param, transposed: bool, st, srcs=()):
     """Weight (+ bias) gradient of a conv into the parameters' sinks (or fresh tensors): returns (dw, db) for autograd.
 
-    Nothing downstream in the backward pass reads a weight gradient (the optimiser / the gradient exchange do, after
-    join_side_streams), and the data-gradient chain is the critical path: when both gradients go to the flat buffer the
-    kernels are enqueued on a weight-gradient stream that has waited for ``dy``, and run next to the data gradient of this
-    layer and the backward kernels of the following ones (the deep levels fill a fraction of the 256 CUs).  ``dy`` and the
-    saved inputs ``srcs`` are marked as in use on that stream so that the allocator does not hand their memory out early."""
+    The kernels run in order on the caller's stream (weight gradients on streams of their own next to the data-gradient chain were
+    measured twice, rounds 2 and 3: 0 ... +4 % slower -- the kernels fill the machine, they do not wait on it -- and removed).  With
+    both gradients going to the flat buffer the folds of the per-split partial copies are queued (m1_wgrad_defer) and run in batches."""
     wbuf, acc_w, dw = _sink(w_param)
     bbuf, db = None, None
     if b_param is not None:
@@ -650,31 +614,20 @@ def _wgrad_into_sinks(lib, d, dy, w_param, b_param, transposed: bool, st, srcs=(
             dw, db = wbuf, bbuf
     fn = lib.m1_convT3d_wgrad if transposed else lib.m1_conv3d_wgrad
     flat = dw is None and db is None
-    side = _wgrad_stream(w_param) if flat else None
-    if side is None:
-        ws = _conv_ws(d, transposed, 2, w_param.device)
-        if flat and _FOLD["on"]:
-            lib.m1_wgrad_defer(1)
-            try:
-                L.check(fn(C.byref(d), _p(dy), _p(wbuf), _p(bbuf), _p(ws), acc_w, st), "m1_conv3d_wgrad")
-            finally:
-                lib.m1_wgrad_defer(0)
-            _FOLD["keep"].append((ws, torch.cuda.current_stream(w_param.device)))
-            _FOLD["bytes"] += ws.numel() * ws.element_size()
-            if _BRANCH["on"] and ((_FOLD["async"] > 0 and len(_FOLD["keep"]) >= _FOLD["async"]) or
-                                  (_FOLD["async_mb"] > 0 and _FOLD["bytes"] >= _FOLD["async_mb"] << 20)):
-                _fold_async()
-        else:
+    ws = _conv_ws(d, transposed, 2, w_param.device)
+    if flat and _FOLD["on"]:
+        lib.m1_wgrad_defer(1)
+        try:
             L.check(fn(C.byref(d), _p(dy), _p(wbuf), _p(bbuf), _p(ws), acc_w, st), "m1_conv3d_wgrad")
-        return dw, db
-    side.wait_stream(torch.cuda.current_stream(w_param.device))
-    _BRANCH["used"].add(side)
-    with torch.cuda.stream(side):
-        ws = _conv_ws(d, transposed, 2, w_param.device)      # scratch from (and back to) the side stream's pool
-        L.check(fn(C.byref(d), _p(dy), _p(wbuf), _p(bbuf), _p(ws), acc_w, _stream()), "m1_conv3d_wgrad")
-    dy.record_stream(side)
-    for t in srcs:
-        t.record_stream(side)
+        finally:
+            lib.m1_wgrad_defer(0)
+        _FOLD["keep"].append((ws, torch.cuda.current_stream(w_param.device)))
+        _FOLD["bytes"] += ws.numel() * ws.element_size()
+        if _BRANCH["on"] and ((_FOLD["async"] > 0 and len(_FOLD["keep"]) >= _FOLD["async"]) or
+                              (_FOLD["async_mb"] > 0 and _FOLD["bytes"] >= _FOLD["async_mb"] << 20)):
+            _fold_async()
+    else:
+        L.check(fn(C.byref(d), _p(dy), _p(wbuf), _p(bbuf), _p(ws), acc_w, st), "m1_conv3d_wgrad")
     return dw, db
 
 
@@ -720,7 +673,6 @@ class _ConvPair(torch.autograd.Function):
         dy1, dy4 = dy1.contiguous(), dy4.contiguous()
         st = _stream()
         dw1 = db1 = None
-        _fold_before_heavy(_desc(srcs, ctx.c1 + ctx.c4, ctx.k, ctx.s))
         iw, isrc = getattr(ctx, "idx_w1", 0), getattr(ctx, "idx_src", 6)       # positions of w1 / the first member among the inputs
         if ctx.needs_input_grad[iw] or ctx.needs_input_grad[iw + 1]:
             dw1, db1 = _wgrad_into_sinks(lib, _desc(srcs, ctx.c1, ctx.k, ctx.s), dy1, ctx.w1_param, ctx.b1_param, False, st, srcs)
