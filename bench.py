@@ -169,11 +169,11 @@ def cpu_baseline(workload, prob, dense, deep, dims, filters, kl_w, budget_s=100.
 
 # kernel names behind each C-ABI entry-point family (the PMC pass sees kernels, the hipEvent timer sees entry points)
 _FAMILY_KERNELS = {
-    "wgrad": (("conv3d_wgrad", "convT3d_wgrad"), ("wgrad_mfma_kernel", "wgrad_tap_kernel", "wgrad_tf_kernel", "wgrad_tf64_kernel", "wgrad_t3_kernel",
+    "wgrad": (("conv3d_wgrad", "convT3d_wgrad"), ("wgrad_mfma_kernel", "wgrad_tap_kernel", "wgrad_tf_kernel", "wgrad_t3_kernel",
                                                   "wgrad_t3f_kernel", "wgrad_t3s_kernel", "wgrad_pwf_kernel", "tf_finish_kernel",
                                                   "tf_finish_batch_kernel")),
     "conv": (("conv3d_fwd", "conv3d_dgrad", "convT3d_fwd", "convT3d_dgrad"),
-             ("conv_mfma_kernel", "conv_halo_kernel", "splitk_finish_kernel")),
+             ("conv_mfma_kernel", "conv_t3_kernel", "conv_halo_kernel", "conv_pw_kernel", "splitk_finish_kernel")),
 }
 
 
