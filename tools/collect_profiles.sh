@@ -20,8 +20,8 @@ for WL in ${WLS:-C3 C2 C5}; do
   rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch_$WL -- $B > $O/pmc_fetch_$WL.log 2>&1
   rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write_$WL -- $B > $O/pmc_write_$WL.log 2>&1
   rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_BUSY_CYCLES SQ_WAVES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/pmc_mfma_$WL -- $B > $O/pmc_mfma_$WL.log 2>&1
-  ( cd $R; python3 tools/pmc_traffic.py $(ls $O/pmc_fetch_$WL/*/*counter_collection.csv | head -1) $(ls $O/pmc_write_$WL/*/*counter_collection.csv | head -1) 5 $O/${TAG}_${wl}_${DT}_hbm_traffic.json $BV "$COMMIT" > $O/${TAG}_${wl}_${DT}_hbm_traffic.txt
-    python3 tools/pmc_mfma.py $(ls $O/pmc_mfma_$WL/*/*counter_collection.csv | head -1) 5 > $O/${TAG}_${wl}_${DT}_mfma_busy.txt )
+  ( cd $R; python3 tools/pmc_traffic.py $(ls $O/pmc_fetch_$WL/*/*counter_collection.csv | head -1) $(ls $O/pmc_write_$WL/*/*counter_collection.csv | head -1) 6 $O/${TAG}_${wl}_${DT}_hbm_traffic.json $BV "$COMMIT" > $O/${TAG}_${wl}_${DT}_hbm_traffic.txt
+    python3 tools/pmc_mfma.py $(ls $O/pmc_mfma_$WL/*/*counter_collection.csv | head -1) 6 > $O/${TAG}_${wl}_${DT}_mfma_busy.txt )
   rm -rf $O/pmc_fetch_$WL $O/pmc_write_$WL $O/pmc_mfma_$WL
 done
 ls -la $O
