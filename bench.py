@@ -347,6 +347,13 @@ def run_workload(a, wl, ctx, want_roofline, want_cpu):
                 update()
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
+        if dist_on and backend == "nccl":
+            # The process group's watchdog thread retires finished collectives by polling their end events (every ~100 ms).  The
+            # collectives of the eager step above are finished, but may not have been polled yet -- and their events were recorded
+            # on the group's internal stream, which JOINS THE CAPTURE with the first captured collective: HIP then refuses the
+            # query ("operation not permitted on an event last recorded in a capturing stream") and the watchdog aborts the
+            # process (seen in 1 of 3 ... 1 of 8 runs of the probabilistic model).  Give the watchdog time to drain its list.
+            time.sleep(1.0)
         gr = torch.cuda.CUDAGraph()
         with torch.cuda.graph(gr, capture_error_mode="thread_local" if thread_local else "global"):
             fn()
@@ -569,6 +576,12 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend == "nccl":
+            # collectives captured into the step's hipGraph: the process group's watchdog thread must not poll their events (an event
+            # recorded in a capturing stream cannot be queried: hipErrorCapturedEvent, the watchdog then terminates the process --
+            # seen once in three runs of the probabilistic model through this path).  PyTorch's CUDA-graph notes prescribe this
+            # switch for whole-step capture with NCCL; both spellings, set before the group exists
+            os.environ.setdefault("TORCH_NCCL_ASYNC_ERROR_HANDLING", "0")
+            os.environ.setdefault("NCCL_ASYNC_ERROR_HANDLING", "0")
             dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group(backend=backend, rank=rank, world_size=world)
