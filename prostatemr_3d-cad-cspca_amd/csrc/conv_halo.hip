@@ -241,6 +241,30 @@ __global__ void __launch_bounds__(NTHR) conv_halo_kernel(HaloP p) {
     for (int j = 0; j < TN; ++j)
 #pragma unroll
         for (int r = 0; r < 4; ++r) asm volatile("" : "+v"(bias_r[j][r]));
+    // InstanceNorm-backward sums instead of statistics (MfmaP::ib_x: the output is d(a), a = lrelu(IN(x))): per lane gamma / beta of
+    // its 4 channels in registers, {mean, rstd} of every sample in LDS behind the statistics fold rows (read per tile: the sample
+    // changes along the walk), x fetched with the out += values ahead of the next tile's DMA
+    const bool ib = m.ib_x != nullptr;
+    float* const ib_ms = red + NW * BN * 2;                           // [N][BN][2]
+    float ib_g[TN][4], ib_b[TN][4];
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int oc = oc0 + j * 16 + fs * 4 + r;
+            ib_g[j][r] = (ib && oc < m.OCn) ? m.ib_gamma[oc] : 0.f; ib_b[j][r] = (ib && oc < m.OCn) ? m.ib_beta[oc] : 0.f;
+        }
+    if (ib) {
+        for (int e = tid; e < m.N * BN; e += NTHR) {
+            const int n = e / BN, c = e - n * BN, oc = oc0 + c < m.OCn ? oc0 + c : 0;
+            ib_ms[e * 2] = m.ib_stats[((long long)n * m.OC + oc) * 2]; ib_ms[e * 2 + 1] = m.ib_stats[((long long)n * m.OC + oc) * 2 + 1];
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) asm volatile("" : "+v"(ib_g[j][r]), "+v"(ib_b[j][r]));
+    if (ib) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); }
     // running {sum, sum of squares} of the ROUNDED outputs of the current sample, per lane; folded over the block and written as
     // ONE partial per (sample, block) when the walk leaves the sample: [N][nsplit][OC][2], fixed order -> deterministic
     float ssum[TN][4], ssq[TN][4];
@@ -289,7 +313,17 @@ __global__ void __launch_bounds__(NTHR) conv_halo_kernel(HaloP p) {
         // behind the DMA could only be waited for together with it
         const int oh0 = c_th * p.TH;
         const int row0 = ((c_n * m.OD + c_od) * m.OH + oh0) * m.OW + c_tw * p.TW;
-        unsigned long long oldv[TM][TN];
+        unsigned long long oldv[TM][TN], xv[TM][TN];
+        if (ib) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    xv[i][j] = 0ull;
+                    if (o_fast[j] && oh0 + e_th[i] < m.OH)
+                        xv[i][j] = gload8_untracked((const bf16_t*)m.ib_x + (long long)(row0 + e_row[i]) * m.OC + oc0 + j * 16 + fs * 4);
+                }
+        }
         if (any_acc) {
 #pragma unroll
             for (int i = 0; i < TM; ++i)
@@ -341,12 +375,12 @@ __global__ void __launch_bounds__(NTHR) conv_halo_kernel(HaloP p) {
         }
 
         // ---- epilogue in registers ----
-        if (any_acc) {            // the fetched values: everything but the DMA pieces issued behind them has landed
+        if (any_acc || ib) {      // the fetched values: everything but the DMA pieces issued behind them has landed
             if constexpr (RT) wait_vm_c<0>(); else wait_vm_c<NXIT>();
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < TN; ++j) asm volatile("" : "+v"(oldv[i][j]));
+                for (int j = 0; j < TN; ++j) { if (any_acc) asm volatile("" : "+v"(oldv[i][j])); if (ib) asm volatile("" : "+v"(xv[i][j])); }
         }
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
@@ -374,8 +408,20 @@ __global__ void __launch_bounds__(NTHR) conv_halo_kernel(HaloP p) {
                     if (want_stats) {
                         const float r0 = __uint_as_float(o.x << 16), r1 = __uint_as_float(o.x & 0xffff0000u);
                         const float r2 = __uint_as_float(o.y << 16), r3 = __uint_as_float(o.y & 0xffff0000u);
+                        if (ib) {             // {sum dy, sum dy * xh}, dy = d(a) * lrelu'(gamma xh + beta)
+                            const float4 ms0 = *reinterpret_cast<const float4*>(ib_ms + ((c_n * BN + j * 16 + fs * 4) * 2));
+                            const float4 ms1 = *reinterpret_cast<const float4*>(ib_ms + ((c_n * BN + j * 16 + fs * 4) * 2) + 4);
+                            const uint2 xw = make_uint2((unsigned)xv[i][j], (unsigned)(xv[i][j] >> 32));
+                            const float x0 = (__uint_as_float(xw.x << 16) - ms0.x) * ms0.y, x1 = (__uint_as_float(xw.x & 0xffff0000u) - ms0.z) * ms0.w;
+                            const float x2 = (__uint_as_float(xw.y << 16) - ms1.x) * ms1.y, x3 = (__uint_as_float(xw.y & 0xffff0000u) - ms1.z) * ms1.w;
+                            const float d0 = r0 * lrelu_g(ib_g[j][0] * x0 + ib_b[j][0], m.ib_slope), d1 = r1 * lrelu_g(ib_g[j][1] * x1 + ib_b[j][1], m.ib_slope);
+                            const float d2 = r2 * lrelu_g(ib_g[j][2] * x2 + ib_b[j][2], m.ib_slope), d3 = r3 * lrelu_g(ib_g[j][3] * x3 + ib_b[j][3], m.ib_slope);
+                            ssum[j][0] += d0; ssq[j][0] += d0 * x0; ssum[j][1] += d1; ssq[j][1] += d1 * x1;
+                            ssum[j][2] += d2; ssq[j][2] += d2 * x2; ssum[j][3] += d3; ssq[j][3] += d3 * x3;
+                        } else {
                         ssum[j][0] += r0; ssq[j][0] += r0 * r0; ssum[j][1] += r1; ssq[j][1] += r1 * r1;
                         ssum[j][2] += r2; ssq[j][2] += r2 * r2; ssum[j][3] += r3; ssq[j][3] += r3 * r3;
+                        }
                     }
                 } else {                      // rows that are not 8-byte tiled (1..3 channels), or a partial group
 #pragma unroll
@@ -454,6 +500,7 @@ static bool halo_plan_nthr(const MfmaP& m, int OCpad, HaloP& p, int force_nthr) 
     if (OCpad % p.BNh) return false;
     p.b_bytes = p.nchunks * p.BNh * 64;
     p.c_bytes = (p.nthr / 64) * p.BNh * 2 * 4;                        // statistics fold, one row per wave
+    if (m.ib_x) p.c_bytes += m.N * p.BNh * 2 * 4;                     // + {mean, rstd} of the block's channels, every sample (InstanceNorm-backward sums)
     const int fixed = p.b_bytes + p.c_bytes;
     int kb = M1_CFG("M1_HALO_LDS_KB", 160);
     int S = (kb * 1024 - fixed) / p.x_bytes;

@@ -1011,25 +1011,41 @@ static int run_mfma(const GatherSpec& g, void* ws, int ws_packed, hipStream_t st
 
     const bool small = pl.BM == 64;
     int rc2;
-    if (halo && ib_epi) { ib_epi = false; mp.stat_partial = nullptr; mp.stat_tiles = 0; mp.ib_x = nullptr; }    // (register epilogues: not built)
     if (halo) {
+        // InstanceNorm-backward sums from the halo kernel's register epilogue (round 4): one partial row per (sample, block row), the
+        // same rows its statistics use; whole 4-channel groups only
+        if (ib_want && !ib_epi && pl.ksplit == 1 && g.OC % 4 == 0) {
+            mp.ib_x = g.ib_x; mp.ib_stats = g.ib_stats; mp.ib_gamma = g.ib_gamma; mp.ib_beta = g.ib_beta; mp.ib_slope = g.ib_slope;
+            ib_epi = true;
+        }
         const int tps = m1_halo_conv_stat_parts(mp, OCpad);
-        if (g.stats_out && g.stats_ws && g.mode == 0 && tps > 0 && tps <= (Vout + 63) / 64) {
-            mp.stat_partial = g.stats_ws; mp.stat_tiles = tps; fuse_stats = true;
-        } else { mp.stat_partial = nullptr; mp.stat_tiles = 0; fuse_stats = false; }
+        if (ib_epi && g.OC % 4 == 0 && tps > 0 && tps <= g.ib_cap) { mp.stat_partial = g.ib_partial; mp.stat_tiles = tps; fuse_stats = false; }
+        else {
+            if (ib_epi) { ib_epi = false; mp.ib_x = nullptr; }
+            if (g.stats_out && g.stats_ws && g.mode == 0 && tps > 0 && tps <= (Vout + 63) / 64) {
+                mp.stat_partial = g.stats_ws; mp.stat_tiles = tps; fuse_stats = true;
+            } else { mp.stat_partial = nullptr; mp.stat_tiles = 0; fuse_stats = false; }
+        }
     }
     // pointwise layers: the streaming kernel (conv_pw.hip) -- no operand tiles, no barriers, epilogue in registers
     bool pw = false; int pwBN = 0;
     if constexpr (sizeof(T) == 2) {
         pwBN = BN > 32 ? 32 : BN;
         if (!halo && !t3 && m1_pw_conv_supported(mp, OCpad, pwBN)) {
-            if (ib_epi) { ib_epi = false; mp.stat_partial = nullptr; mp.stat_tiles = 0; mp.ib_x = nullptr; }
             int parts = m1_pw_conv_stat_parts(mp, OCpad, pwBN);
             const int cap = (int)((Vout + 63) / 64) / 4 * 4;          // what the statistics workspace holds per sample
             if (parts > cap) parts = cap;
-            if (g.stats_out && g.stats_ws && g.mode == 0 && !g.accumulate && parts >= 4) {
-                mp.stat_partial = g.stats_ws; mp.stat_tiles = parts; fuse_stats = true;
-            } else { mp.stat_partial = nullptr; mp.stat_tiles = 0; fuse_stats = false; }
+            // InstanceNorm-backward sums from the streaming kernel's register epilogue (round 4): one partial row per (sample, wave)
+            const bool ib_pw = ib_want && pl.ksplit == 1 && g.OC % 4 == 0 && Vout % 32 == 0 && parts >= 4 && parts <= g.ib_cap;
+            if (ib_pw) {
+                mp.ib_x = g.ib_x; mp.ib_stats = g.ib_stats; mp.ib_gamma = g.ib_gamma; mp.ib_beta = g.ib_beta; mp.ib_slope = g.ib_slope;
+                mp.stat_partial = g.ib_partial; mp.stat_tiles = parts; ib_epi = true; fuse_stats = false;
+            } else {
+                if (ib_epi) { ib_epi = false; mp.ib_x = nullptr; }
+                if (g.stats_out && g.stats_ws && g.mode == 0 && !g.accumulate && parts >= 4) {
+                    mp.stat_partial = g.stats_ws; mp.stat_tiles = parts; fuse_stats = true;
+                } else { mp.stat_partial = nullptr; mp.stat_tiles = 0; fuse_stats = false; }
+            }
             pw = true;
         }
     }

@@ -82,6 +82,16 @@ __global__ void __launch_bounds__(256) conv_pw_kernel(PwP p) {
     const unsigned char* const w_rd = smem + fr * 64 + pw_swz(fr, fs) * 16;     // fragment of oc row j*16 + fr: + (q*BN + j*16)*64
 
     const bool want_stats = m.stat_partial != nullptr;
+    // InstanceNorm-backward sums instead of statistics (MfmaP::ib_x: the output is d(a), a = lrelu(IN(x)); round 4)
+    const bool ib = m.ib_x != nullptr;
+    float ib_g[TN][4], ib_b[TN][4];
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int oc = oc0 + j * 16 + fs * 4 + r;
+            ib_g[j][r] = (ib && oc < m.OCn) ? m.ib_gamma[oc] : 0.f; ib_b[j][r] = (ib && oc < m.OCn) ? m.ib_beta[oc] : 0.f;
+        }
     float ssum[TN][4], ssq[TN][4];
 #pragma unroll
     for (int j = 0; j < TN; ++j)
@@ -167,8 +177,21 @@ __global__ void __launch_bounds__(256) conv_pw_kernel(PwP p) {
                     if (want_stats) {
                         const float r0 = __uint_as_float(o.x << 16), r1 = __uint_as_float(o.x & 0xffff0000u);
                         const float r2 = __uint_as_float(o.y << 16), r3 = __uint_as_float(o.y & 0xffff0000u);
+                        if (ib) {             // {sum dy, sum dy * xh}, dy = d(a) * lrelu'(gamma xh + beta)
+                            const int oc = oc0 + j * 16 + fs * 4, n = (int)(orow / p.V);
+                            const float* msp = m.ib_stats + ((long long)n * m.OC + oc) * 2;
+                            const float4 ms0 = *reinterpret_cast<const float4*>(msp), ms1 = *reinterpret_cast<const float4*>(msp + 4);
+                            const uint2 xw = *reinterpret_cast<const uint2*>((const bf16_t*)m.ib_x + orow * m.OC + oc);
+                            const float x0 = (__uint_as_float(xw.x << 16) - ms0.x) * ms0.y, x1 = (__uint_as_float(xw.x & 0xffff0000u) - ms0.z) * ms0.w;
+                            const float x2 = (__uint_as_float(xw.y << 16) - ms1.x) * ms1.y, x3 = (__uint_as_float(xw.y & 0xffff0000u) - ms1.z) * ms1.w;
+                            const float d0 = r0 * lrelu_g(ib_g[j][0] * x0 + ib_b[j][0], m.ib_slope), d1 = r1 * lrelu_g(ib_g[j][1] * x1 + ib_b[j][1], m.ib_slope);
+                            const float d2 = r2 * lrelu_g(ib_g[j][2] * x2 + ib_b[j][2], m.ib_slope), d3 = r3 * lrelu_g(ib_g[j][3] * x3 + ib_b[j][3], m.ib_slope);
+                            ssum[j][0] += d0; ssq[j][0] += d0 * x0; ssum[j][1] += d1; ssq[j][1] += d1 * x1;
+                            ssum[j][2] += d2; ssq[j][2] += d2 * x2; ssum[j][3] += d3; ssq[j][3] += d3 * x3;
+                        } else {
                         ssum[j][0] += r0; ssq[j][0] += r0 * r0; ssum[j][1] += r1; ssq[j][1] += r1 * r1;
                         ssum[j][2] += r2; ssq[j][2] += r2 * r2; ssum[j][3] += r3; ssq[j][3] += r3 * r3;
+                        }
                     }
                 } else {                      // rows that are not 8-byte tiled (1..3 channels), or a partial group
 #pragma unroll

@@ -661,7 +661,10 @@ def test_repack_all_refreshes_cached_panels(dev, transposed):
                                            ((2, 4, 16, 16), 64, 256, (1, 1, 1)),     # pointwise conv3 of an SE block
                                            ((4, 2, 4, 8), 64, 64, (3, 3, 3)),        # few voxels: split-K, sums from the finish pass
                                            ((1, 3, 9, 10), 24, 16, (3, 3, 3)),       # tiles that straddle nothing (N = 1), ragged extents
-                                           ((2, 8, 32, 32), 8, 8, (3, 3, 3))])       # halo-tile kernel: no such epilogue, plain path
+                                           ((2, 8, 32, 32), 8, 8, (3, 3, 3)),        # halo-tile kernel (bf16, size floor lifted): register epilogue
+                                           ((1, 6, 24, 40), 16, 16, (3, 3, 3)),      # ... 16 channels, ragged tile rows
+                                           ((2, 4, 16, 16), 16, 64, (1, 1, 1)),      # conv3 at res1: its data gradient (contraction 64) streams (conv_pw)
+                                           ((2, 8, 32, 32), 8, 32, (1, 1, 1))])      # conv3 at res0
 def test_instnorm_backward_sums_from_the_dgrad_epilogue(dev, dtype, dims, c, cout, k):
     """y = conv(lrelu(IN(x))): the gradients with the fused sums equal those of the stand-alone reduction (same kernels otherwise;
     only the order of the partial sums differs) and both match the oracle."""
@@ -689,12 +692,14 @@ def test_instnorm_backward_sums_from_the_dgrad_epilogue(dev, dtype, dims, c, cou
         finally:
             ops._INBWD["on"] = was
     f0 = dict(ops._INBWD)
-    got = run(True)
-    fused = ops._INBWD["fused"] - f0["fused"], ops._INBWD["plain"] - f0["plain"]
-    assert sum(fused) == 1, fused
-    if c >= 24:
-        assert fused == (1, 0), fused                    # the implicit-GEMM / split-K paths do emit the sums
-    base = run(False)
+    halo_case = c <= 16 and dtype == torch.bfloat16          # (the 1x1x1 cases: the pointwise streaming kernel, register epilogue as well)
+    with ops.config(**({"M1_HALO": 2} if halo_case else {})):      # (M1_HALO=2: the halo-tile kernel whatever the volume)
+        got = run(True)
+        fused = ops._INBWD["fused"] - f0["fused"], ops._INBWD["plain"] - f0["plain"]
+        assert sum(fused) == 1, fused
+        if c >= 24 or halo_case:
+            assert fused == (1, 0), fused                # the implicit-GEMM / split-K / halo-tile paths do emit the sums
+        base = run(False)
     tol = 2e-4 if dtype == torch.float32 else 4e-2
     for a_, b_, o_ in zip(got, base, gro):
         assert rel_err(a_, b_) < (2e-5 if dtype == torch.float32 else 2e-2)
