@@ -9,7 +9,8 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 # The 12-wave tap-fused weight-gradient kernel (wgrad_t3.hip) declines launches of fewer than 128 blocks in production (the per-tap
 # kernel fills the chip better there).  The parity suite runs small volumes: lift the floor so that every eligible shape of the
-# suite goes through that kernel (read once by libm1hip.so, before its first launch).
+# suite goes through that kernel -- the environment supplies the initial value of the library's switch table (config.hip); the
+# weight-gradient op tests run the >= 64-channel cases a second time at the production floor (ops.config(M1_T3_MIN_BLOCKS=128)).
 os.environ.setdefault("M1_T3_MIN_BLOCKS", "1")
 
 
