@@ -614,11 +614,20 @@ template <typename T>
 __device__ __forceinline__ void pack_class_elems(const PackP& p, int cls, T* __restrict__ out, long long first, long long stride) {
     constexpr int SEG = MT<T>::SEG;
     const int kpad = p.cls_kpad[cls], nks = kpad / SEG;
-    const long long tot = (long long)p.OCpad * nks;
-    // consecutive threads follow the contiguous axis of the SOURCE (the fp32 reads coalesce)
+    // the output-channel axis is the contiguous one of the SOURCE (forward panels) or the K axis is (data-gradient panels: a thread
+    // reads 32 contiguous bytes, consecutive threads consecutive segments).  Forward panels: a wave covers 16 output channels x 4
+    // segments -- 64-byte runs of the source per load and 64-byte runs of the panel per row (one thread per channel along the whole
+    // wave wrote 64 panel rows, 16 bytes each: 332 us for the ~120 M panel elements of C3)
     const bool oc_fast = p.wSO == 1;
+    const int ocg = p.OCpad >> 4, ksg = (nks + 3) >> 2;
+    const long long tot = oc_fast ? (long long)ocg * ksg * 64 : (long long)p.OCpad * nks;
     for (long long u = first; u < tot; u += stride) {
-        const int oc = oc_fast ? (int)(u % p.OCpad) : (int)(u / nks), kseg = oc_fast ? (int)(u / p.OCpad) : (int)(u % nks);
+        int oc, kseg;
+        if (oc_fast) {
+            const long long grp = u >> 6; const int l = (int)(u & 63);
+            oc = (int)(grp % ocg) * 16 + (l & 15); kseg = (int)(grp / ocg) * 4 + (l >> 4);
+            if (kseg >= nks) continue;
+        } else { oc = (int)(u / nks); kseg = (int)(u % nks); }
         int nvalid, wtap = 0, c = 0;
         pack_seg_pos(p, cls, kseg, &nvalid, &wtap, &c);
         if (oc >= p.OCn) nvalid = 0;
@@ -1130,5 +1139,6 @@ static int run_mfma(const GatherSpec& g, void* ws, int ws_packed, hipStream_t st
 
 int m1_mfma_gather(const GatherSpec& g, void* ws, int ws_packed, hipStream_t st) {
     if (!ws) return M1_ERR_WORKSPACE;
+    { int rc = M1_OK; if (m1_thin_conv_try(g, st, &rc)) return rc; }
     return g.dtype == M1_BF16 ? run_mfma<bf16_t>(g, ws, ws_packed, st) : run_mfma<float>(g, ws, ws_packed, st);
 }

@@ -60,6 +60,8 @@ int m1_skinny_wgrad(const WgradSpec& g, hipStream_t st);
 bool m1_mfma_supported(const GatherSpec& g);
 size_t m1_mfma_ws_bytes(const GatherSpec& g);
 int m1_mfma_gather(const GatherSpec& g, void* ws, int ws_packed, hipStream_t st);
+// layers with <= 4 (forward) / <= 8 (pointwise data gradient) channels on the thin side (conv_thin.hip): 1 = taken, *rc = result
+int m1_thin_conv_try(const GatherSpec& g, hipStream_t st, int* rc);
 int m1_pack_batch_internal(const void* const* jobs_dev, const int* prefix_dev, int njobs, int total_blocks, hipStream_t st);
 bool m1_mfma_wgrad_supported(const WgradSpec& g);
 int m1_mfma_wgrad(const WgradSpec& g, hipStream_t st);

@@ -920,6 +920,72 @@ def test_conv_t3_staged_run_kernel(dev, case):
     ops.invalidate_panels()
 
 
+# ---- thin layers (conv_thin.hip): <= 4 input channels forward (the image stem), <= 8 gradient channels pointwise data gradient (the logit
+#      heads).  Production takes them from 65,536 voxels on; M1_THIN=2 lifts the floor. ----
+THIN_FWD_CASES = [  # dims (N, D, H, W), cin, cout, k
+    ((2, 3, 16, 32), 3, 32, (1, 3, 3)),          # the C3 stem (networks.py:478): whole tiles
+    ((2, 3, 11, 40), 2, 32, (1, 3, 3)),          # partial row and column tiles
+    ((1, 4, 9, 24), 4, 16, (3, 3, 3)),           # three depth taps, 16 output channels
+    ((3, 2, 8, 8), 1, 8, (3, 3, 3)),             # one input channel, one channel group, three samples (statistics rows of idle blocks)
+]
+
+
+@pytest.mark.parametrize("case", THIN_FWD_CASES)
+def test_conv_thin_forward_kernel(dev, case):
+    dims, cin, cout, k = case
+    s = (1, 1, 1)
+    x = rnd((*dims, cin), 90).bfloat16().float()
+    w = rnd((*k, cin, cout), 6, 1.0 / (cin * k[0] * k[1] * k[2]) ** 0.5).bfloat16().float(); b = rnd((cout,), 7)
+    yo = O.conv3d_same(x.double(), w.double(), b.double(), s)
+    dy = rnd(tuple(yo.shape), 8).bfloat16().float()
+    yo, (gx, gw, gb) = _oracle_grads(lambda x_, w_, b_: O.conv3d_same(x_, w_, b_, s), [x, w, b], dy)
+    res = {}
+    for tag, cfg in (("thin", dict(M1_THIN=2)), ("mfma", dict(M1_THIN=0))):
+        with ops.config(**cfg):
+            ops.invalidate_panels()
+            xd = x.to(dev, torch.bfloat16).requires_grad_(True)
+            wd, bd = w.to(dev).requires_grad_(True), b.to(dev).requires_grad_(True)
+            y, st = ops.conv3d_same([xd], wd, bd, k, s, stats=True)
+            y.backward(dy.to(dev, torch.bfloat16))
+            torch.cuda.synchronize()
+            res[tag] = (y.detach(), st, xd.grad, wd.grad)
+    y, st, gxd, gwd = res["thin"]
+    assert rel_err(y, yo) < 1e-2, "y"                    # (bf16 rounding of the stored output)
+    assert rel_err(gxd, gx) < 1e-2 and rel_err(gwd, gw) < 1e-4
+    yf = y.float()
+    assert rel_err(st[..., 0], yf.mean(dim=(1, 2, 3))) < 1e-4 and rel_err(st[..., 1], 1.0 / torch.sqrt(yf.var(dim=(1, 2, 3), unbiased=False) + 1e-3)) < 1e-4
+    y2, st2, _, _ = res["mfma"]
+    # same bf16 weights, fp32 accumulation in another order: the stored outputs differ in a few last bits at most
+    assert rel_err(y, y2) < 1e-2 and float((y.float() - y2.float()).abs().mean()) < 2e-4 * float(y2.float().abs().mean()) + 1e-6
+    ops.invalidate_panels()
+
+
+@pytest.mark.parametrize("case", [((2, 3, 8, 10), 128, 2), ((1, 2, 5, 7), 32, 2), ((2, 2, 6, 6), 256, 4), ((1, 3, 4, 8), 512, 6)])
+def test_conv_thin_pointwise_dgrad_kernel(dev, case):
+    """Data gradient of a 1x1x1 conv onto 2..6 output channels (the logit heads, networks.py:737-751): dX = dY W^T as a streaming kernel."""
+    dims, cin, cout = case
+    k, s = (1, 1, 1), (1, 1, 1)
+    x = rnd((*dims, cin), 91).bfloat16().float()
+    w = rnd((*k, cin, cout), 6, 1.0 / cin ** 0.5).bfloat16().float(); b = rnd((cout,), 7)
+    yo = O.conv3d_same(x.double(), w.double(), b.double(), s)
+    dy = rnd(tuple(yo.shape), 8).bfloat16().float()
+    yo, (gx, gw, gb) = _oracle_grads(lambda x_, w_, b_: O.conv3d_same(x_, w_, b_, s), [x, w, b], dy)
+    res = {}
+    for tag, cfg in (("thin", dict(M1_THIN=2)), ("mfma", dict(M1_THIN=0))):
+        with ops.config(**cfg):
+            ops.invalidate_panels()
+            xd = x.to(dev, torch.bfloat16).requires_grad_(True)
+            wd, bd = w.to(dev).requires_grad_(True), b.to(dev).requires_grad_(True)
+            y = ops.conv3d_same([xd], wd, bd, k, s)
+            y.backward(dy.to(dev, torch.bfloat16))
+            torch.cuda.synchronize()
+            res[tag] = (y.detach(), xd.grad, wd.grad)
+    assert rel_err(res["thin"][0], yo) < 1e-2
+    assert rel_err(res["thin"][1], gx) < 1e-2 and rel_err(res["thin"][2], gw) < 1e-4
+    assert torch.equal(res["thin"][1], res["mfma"][1]) or rel_err(res["thin"][1], res["mfma"][1]) < 4e-3
+    ops.invalidate_panels()
+
+
 def test_conv_t3_pair_forward_and_inbwd_epilogue(dev):
     """The conv1 || conv4 pair forward (two outputs, two statistics) and the InstanceNorm-backward sums of a conv2-type data gradient
     through the staged-run kernel's epilogues, against the implicit-GEMM kernel on the same inputs."""

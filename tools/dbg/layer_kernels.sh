@@ -6,4 +6,4 @@ t=$(ls $O/kt/*/*kernel_trace.csv | head -1)
 python3 $R/tools/layer_kernels.py $t $O/log.txt > $O/layer_kernels.txt 2>&1
 python3 $R/tools/prof_table.py $t 1 400 > $O/by_grid_all.txt 2>&1
 rm -rf $O/kt
-head -50 $O/layer_kernels.txt
+head -${HEADN:-90} $O/layer_kernels.txt

@@ -7,6 +7,6 @@ for cfg in "$@"; do
 import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1])
 r=d['roofline'] or {}
-print(round(d['value'],2),'vol/s',round(d['ms_per_step'],3),'ms', {k:v for k,v in (r.get('all_kernels_ms_per_step') or {}).items() if v>0.4})
+print(round(d['value'],2),'vol/s',round(d['ms_per_step'],3),'ms', {k:v for k,v in (r.get('all_kernels_ms_per_step') or {}).items() if v>0.4 or k.startswith(('pack','adam','instnorm_apply','se_combine_fwd'))})
 "
 done

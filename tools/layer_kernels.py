@@ -6,7 +6,7 @@ trace, log = sys.argv[1], sys.argv[2]
 rows = sorted(csv.DictReader(open(trace)), key=lambda r: int(r['Dispatch_Id']))
 ks = [(re.sub(r'\(.*', '', re.sub(r'^void ', '', r['Kernel_Name'])), int(r['End_Timestamp']) - int(r['Start_Timestamp']),
        (int(r['Grid_Size_X']) // max(1, int(r['Workgroup_Size_X'])), int(r['Grid_Size_Y']), int(r['Grid_Size_Z']))) for r in rows]
-convk = [k for k in ks if k[0].startswith(('conv_mfma_kernel', 'conv_halo_kernel', 'conv_pw_kernel'))]
+convk = [k for k in ks if k[0].startswith(('conv_mfma_kernel', 'conv_halo_kernel', 'conv_pw_kernel', 'conv_t3_kernel'))]
 lines = [l.strip() for l in open(log) if l.startswith('mfma:')]
 print(f"{len(convk)} conv kernels in the trace, {len(lines)} log lines")
 n = min(len(convk), len(lines))
