@@ -411,7 +411,9 @@ def run_workload(a, wl, ctx, want_roofline, want_cpu):
     final_loss = float(loss_buf)
     if os.environ.get("M1_BENCH_DUMP") and rank == 0:          # harness tests: the state a run ends in (bit-compared between modes)
         torch.save({"flat": opt.flatp.flat.cpu(), "grad": opt.flatp.grad.cpu(), "m": opt.m.cpu(), "vhat": opt.vhat.cpu(),
-                    "step": opt.step_dev.cpu(), "rng": model.rng_state.cpu()}, os.environ["M1_BENCH_DUMP"])
+                    "step": opt.step_dev.cpu(), "rng": model.rng_state.cpu(),
+                    "layout": [({id(q): k for k, q in model.named_parameters()}.get(id(q_), "?"), q_.numel()) for q_ in opt.flatp.params]},
+                   os.environ["M1_BENCH_DUMP"])
 
     # ---- per-kernel-family hipEvent timing on the launch stream (eager launches of the same step) ----
     roof = None

@@ -17,6 +17,11 @@
 //   voxel -- bias, v_cvt_pk_bf16_f32, the optional out += (fetched ahead of the next tile's DMA), running InstanceNorm
 //   statistics (one partial per sample and block) and an 8-byte store; no LDS output tile, one barrier per tile.
 // * The K-chunk / DMA-piece counts of the M1 layer shapes are template parameters (straight-line tile loop, immediate vmcnt).
+// * Parity-class mode (template B1 > 0; round 4): the data gradient of a (1,2,2)-strided 1x3x3 conv / the forward of the matching
+//   transposed conv (res0 <-> res1) is four stride-1 problems in the q-domain (o = 2q + parity), one per (h, w) parity, with 4 / 2 /
+//   2 / 1 taps.  One block stages the dY tile (halo +-1) ONCE, keeps the weight slices of all four classes in LDS, runs the four K
+//   ranges [0,B1) [B1,B2) [B2,B3) [B3,NCH) into four accumulator sets and writes the 2x2-interleaved output rows -- conv_mfma ran the
+//   classes as separate blocks on 32-column tiles (117 TFLOP/s on 64 -> 32 at (2,20,160,160)).
 #include "conv_mfma.h"
 #include "reduce.h"
 #include <stdlib.h>
@@ -66,6 +71,8 @@ struct HaloP {
     int nthr;                        // 256 or 512 threads: the output tile is nthr/2 voxels
     int tiles_per_sample;
     int spr_sh, tw_sh;               // log2 of spr / TW
+    int ncls;                        // 1, or 4 = (h, w) parity classes (mode 1, stride (1,2,2)): tiles walk the q-domain QH x QW
+    int QH, QW;                      // extent the tiles cover (= OH, OW for one class; OH/2, OW/2 for four)
 };
 
 // physical 16-byte slot of logical slot `sl` in tile row `row` (conflict-free ds_read_b128 of 16 consecutive rows)
@@ -93,10 +100,15 @@ template <int N_> __device__ __forceinline__ void wait_vm_c() {
 
 // NCH / NXIT > 0: the number of K chunks / of LDS-DMA pieces per thread are compile-time (the common layer shapes: straight-line
 // tile loop, immediate wait counts); 0 = taken from the plan at run time (predicated unrolling up to HL_MAX_CH / HL_MAX_XIT)
-template <int TN, int NTHR, int NCH, int NXIT>
+template <int TN, int NTHR, int NCH, int NXIT, int B1 = 0, int B2 = 0, int B3 = 0>
 __global__ void __launch_bounds__(NTHR) conv_halo_kernel(HaloP p) {
     constexpr int TM = 2, BN = TN * 16, SEG = 8, NW = NTHR / 64;      // each wave owns 32 voxels x BN channels
     constexpr bool RT = NCH == 0;
+    constexpr bool CLS = B1 > 0;                                      // four parity classes: K chunks [0,B1) [B1,B2) [B2,B3) [B3,NCH)
+    constexpr int NC = CLS ? 4 : 1;
+    static_assert(!CLS || (NCH > 0 && B1 < B2 && B2 < B3 && B3 < NCH), "class boundaries");
+    auto cls_of = [](int ch) constexpr { return CLS ? (ch >= B1) + (ch >= B2) + (ch >= B3) : 0; };
+    auto cls_lo = [](int c) constexpr { return c == 0 ? 0 : (c == 1 ? B1 : (c == 2 ? B2 : B3)); };
     constexpr int CH = RT ? HL_MAX_CH : NCH, XIT = RT ? HL_MAX_XIT : NXIT;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* const Bs = smem;                                   // [nchunks][BN][64]
@@ -116,7 +128,12 @@ __global__ void __launch_bounds__(NTHR) conv_halo_kernel(HaloP p) {
         for (int q0 = 0; q0 < nslot; q0 += NTHR) {
             const int q = q0 + tid;                                   // LDS slot: chunk, oc row, physical 16-byte slot
             const int ch = q / (BN * 4), r = (q / 4) % BN, s = b_swz(r, q & 3);
-            const unsigned char* src = (q < nslot) ? reinterpret_cast<const unsigned char*>(wp + (long long)(oc0 + r) * p.kpad + (ch * 4 + s) * SEG)
+            const unsigned char* src;
+            if constexpr (CLS) {         // class c's matrix [OCpad][kpad_c] sits at cls_woff[c]
+                const int c = cls_of(ch), lo = cls_lo(c), kp = m.cls_kpad[c];
+                src = (q < nslot) ? reinterpret_cast<const unsigned char*>((const bf16_t*)m.wp + m.cls_woff[c] + (long long)(oc0 + r) * kp + ((ch - lo) * 4 + s) * SEG) : zero_pg;
+            } else
+            src = (q < nslot) ? reinterpret_cast<const unsigned char*>(wp + (long long)(oc0 + r) * p.kpad + (ch * 4 + s) * SEG)
                                                    : zero_pg;
             if (q0 + wave * 64 < nslot) glds16h(src, Bs + (q0 + wave * 64) * 16);
         }
@@ -195,8 +212,13 @@ __global__ void __launch_bounds__(NTHR) conv_halo_kernel(HaloP p) {
     unsigned a_off[CH][TM];
 #pragma unroll
     for (int q = 0; q < CH; ++q) {
-        int kseg = q * 4 + fs; if (kseg >= p.nseg) kseg = 0;          // K padding: the panel holds zeros there
-        const int t = kseg >> spt_sh, sl = kseg & (p.spr - 1);
+        int kseg = q * 4 + fs, t0 = 0;
+        if constexpr (CLS) {             // segment inside its class; the class's taps start at cls_first
+            const int c = cls_of(q);
+            kseg = (q - cls_lo(c)) * 4 + fs; t0 = m.cls_first[c];
+            if (kseg >= m.cls_ntaps[c] * p.spr) kseg = 0;
+        } else if (kseg >= p.nseg) kseg = 0;                          // K padding: the panel holds zeros there
+        const int t = t0 + (kseg >> spt_sh), sl = kseg & (p.spr - 1);
         const int ddr = m.tdd[t] - p.dmin, dhr = m.tdh[t] - p.hmin, dwr = m.tdw[t] - p.wmin;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
@@ -217,7 +239,7 @@ __global__ void __launch_bounds__(NTHR) conv_halo_kernel(HaloP p) {
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         const int mv = wave * 32 + i * 16 + fr;
-        e_th[i] = mv >> tw_sh; e_row[i] = e_th[i] * m.OW + (mv & (p.TW - 1));
+        e_th[i] = mv >> tw_sh; e_row[i] = CLS ? 2 * (e_th[i] * m.OW + (mv & (p.TW - 1))) : e_th[i] * m.OW + (mv & (p.TW - 1));
     }
     bf16_t* o_base[TN]; int o_C[TN], o_nv[TN], o_acc[TN], o_fast[TN]; float bias_r[TN][4];
 #pragma unroll
@@ -244,7 +266,7 @@ __global__ void __launch_bounds__(NTHR) conv_halo_kernel(HaloP p) {
     // InstanceNorm-backward sums instead of statistics (MfmaP::ib_x: the output is d(a), a = lrelu(IN(x))): per lane gamma / beta of
     // its 4 channels in registers, {mean, rstd} of every sample in LDS behind the statistics fold rows (read per tile: the sample
     // changes along the walk), x fetched with the out += values ahead of the next tile's DMA
-    const bool ib = m.ib_x != nullptr;
+    const bool ib = !CLS && m.ib_x != nullptr;                        // (class mode: a data gradient without statistics of any kind)
     float* const ib_ms = red + NW * BN * 2;                           // [N][BN][2]
     float ib_g[TN][4], ib_b[TN][4];
 #pragma unroll
@@ -277,7 +299,7 @@ __global__ void __launch_bounds__(NTHR) conv_halo_kernel(HaloP p) {
 #pragma unroll
     for (int j = 0; j < TN; ++j) any_acc |= o_acc[j] != 0;
     any_acc = __builtin_amdgcn_readfirstlane(__any(any_acc)) != 0;
-    const bool want_stats = m.stat_partial != nullptr;
+    const bool want_stats = !CLS && m.stat_partial != nullptr;
     auto flush = [&](int n) {
 #pragma unroll
         for (int j = 0; j < TN; ++j)
@@ -312,37 +334,42 @@ __global__ void __launch_bounds__(NTHR) conv_halo_kernel(HaloP p) {
         // out += launches: fetch what is there BEFORE the next tile's DMA is issued -- loads retire in order, so a load issued
         // behind the DMA could only be waited for together with it
         const int oh0 = c_th * p.TH;
-        const int row0 = ((c_n * m.OD + c_od) * m.OH + oh0) * m.OW + c_tw * p.TW;
-        unsigned long long oldv[TM][TN], xv[TM][TN];
+        const int row0 = CLS ? ((c_n * m.OD + c_od) * m.OH + 2 * oh0) * m.OW + 2 * c_tw * p.TW
+                             : ((c_n * m.OD + c_od) * m.OH + oh0) * m.OW + c_tw * p.TW;
+        unsigned long long oldv[NC][TM][TN], xv[TM][TN];
         if (ib) {
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
                     xv[i][j] = 0ull;
-                    if (o_fast[j] && oh0 + e_th[i] < m.OH)
+                    if (o_fast[j] && oh0 + e_th[i] < p.QH)
                         xv[i][j] = gload8_untracked((const bf16_t*)m.ib_x + (long long)(row0 + e_row[i]) * m.OC + oc0 + j * 16 + fs * 4);
                 }
         }
         if (any_acc) {
 #pragma unroll
+            for (int c = 0; c < NC; ++c)
+#pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
-                    oldv[i][j] = 0ull;
-                    if (o_acc[j] && o_fast[j] && oh0 + e_th[i] < m.OH)
-                        oldv[i][j] = gload8_untracked(o_base[j] + (long long)(row0 + e_row[i]) * o_C[j]);
+                    oldv[c][i][j] = 0ull;
+                    if (o_acc[j] && o_fast[j] && oh0 + e_th[i] < p.QH)
+                        oldv[c][i][j] = gload8_untracked(o_base[j] + (long long)(row0 + e_row[i] + (c >> 1) * m.OW + (c & 1)) * o_C[j]);
                 }
         }
         int stn = st + S - 1; if (stn >= S) stn -= S;
         issue(stn);
         const unsigned sb = (unsigned)(st * p.x_bytes);
 
-        f32x4_t acc[TM][TN];
+        f32x4_t acc[NC][TM][TN];
+#pragma unroll
+        for (int c = 0; c < NC; ++c)
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+            for (int j = 0; j < TN; ++j) acc[c][i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
         u32x4_t af[2][TM], bf[2][TN];
 #pragma unroll
         for (int i = 0; i < TM; ++i) af[0][i] = lds_read128h(a_off[0][i] + sb);
@@ -368,8 +395,8 @@ __global__ void __launch_bounds__(NTHR) conv_halo_kernel(HaloP p) {
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j)      // D[oc][voxel]: weights as A, voxels as B
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, bf[cur][j]),
-                                                                            __builtin_bit_cast(bf16x8_t, af[cur][i]), acc[i][j], 0, 0, 0);
+                        acc[cls_of(q)][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, bf[cur][j]),
+                                                                            __builtin_bit_cast(bf16x8_t, af[cur][i]), acc[cls_of(q)][i][j], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -380,22 +407,30 @@ __global__ void __launch_bounds__(NTHR) conv_halo_kernel(HaloP p) {
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < TN; ++j) { if (any_acc) asm volatile("" : "+v"(oldv[i][j])); if (ib) asm volatile("" : "+v"(xv[i][j])); }
+                for (int j = 0; j < TN; ++j) {
+                    if (any_acc) {
+#pragma unroll
+                        for (int c = 0; c < NC; ++c) asm volatile("" : "+v"(oldv[c][i][j]));
+                    }
+                    if (ib) asm volatile("" : "+v"(xv[i][j]));
+                }
         }
 #pragma unroll
+        for (int c = 0; c < NC; ++c)                      // class c = (h parity, w parity): output voxel (2 qh + c/2, 2 qw + c%2)
+#pragma unroll
         for (int i = 0; i < TM; ++i) {
-            if (oh0 + e_th[i] >= m.OH) continue;
-            const long long orow = row0 + e_row[i];
+            if (oh0 + e_th[i] >= p.QH) continue;
+            const long long orow = row0 + e_row[i] + (CLS ? (c >> 1) * m.OW + (c & 1) : 0);
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 if (o_nv[j] == 0) continue;
                 bf16_t* dst = o_base[j] + orow * o_C[j];
                 float v[4];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] + bias_r[j][r];
+                for (int r = 0; r < 4; ++r) v[r] = acc[c][i][j][r] + bias_r[j][r];
                 if (o_fast[j]) {
                     if (o_acc[j]) {           // out += : an earlier launch wrote the other concat members' share
-                        const uint2 ov = make_uint2((unsigned)oldv[i][j], (unsigned)(oldv[i][j] >> 32));
+                        const uint2 ov = make_uint2((unsigned)oldv[c][i][j], (unsigned)(oldv[c][i][j] >> 32));
                         const float b[4] = {__uint_as_float(ov.x << 16), __uint_as_float(ov.x & 0xffff0000u),
                                             __uint_as_float(ov.y << 16), __uint_as_float(ov.y & 0xffff0000u)};
                         const unsigned r01 = cvt_pk_bf16(v[0], v[1]), r23 = cvt_pk_bf16(v[2], v[3]);
@@ -442,6 +477,20 @@ __global__ void __launch_bounds__(NTHR) conv_halo_kernel(HaloP p) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// parity-class mode: the class boundaries are compile-time -- the shapes of the res0 <-> res1 transitions, both tap orders
+typedef void (*halo_kern_t)(HaloP);
+static halo_kern_t halo_cls_kernel(const MfmaP& mp, const HaloP& p) {
+    const int nxit = p.x_slots / p.nthr;
+    const int b1 = mp.cls_kpad[0] / 32, b2 = b1 + mp.cls_kpad[1] / 32, b3 = b2 + mp.cls_kpad[2] / 32;
+    halo_kern_t kern = nullptr;
+#define HC(NCH_, NXIT_, B1_, B2_, B3_) if (!kern && p.nchunks == NCH_ && nxit == NXIT_ && b1 == B1_ && b2 == B2_ && b3 == B3_) \
+        kern = p.BNh == 32 ? conv_halo_kernel<2, 512, NCH_, NXIT_, B1_, B2_, B3_> : conv_halo_kernel<1, 512, NCH_, NXIT_, B1_, B2_, B3_>;
+    HC(18, 5, 8, 12, 16) HC(18, 5, 2, 6, 10)           // 64 gradient channels: 4 / 2 / 2 / 1 taps (or reversed) x 2 chunks
+    HC(5, 2, 2, 3, 4) HC(5, 2, 1, 2, 3)                // 16 gradient channels: a tap is half a chunk
+    HC(9, 3, 4, 6, 8) HC(9, 3, 1, 3, 5)                // 32 gradient channels
+#undef HC
+    return kern;
+}
 static bool halo_plan_nthr(const MfmaP& m, int OCpad, HaloP& p, int force_nthr);
 // 256-voxel tiles on 512 threads; when those do not fit (a stride-2 layer's input tile is 4x its output tile: 32 -> 64 k133 s122 at
 // res0 needs 74 KB per stage) 128-voxel tiles on 256 threads
@@ -450,18 +499,25 @@ static bool halo_plan(const MfmaP& m, int OCpad, HaloP& p) {
     return halo_plan_nthr(m, OCpad, p, 256);
 }
 static bool halo_plan_nthr(const MfmaP& m, int OCpad, HaloP& p, int force_nthr) {
-    if (m.nclasses != 1 || m.ksplit != 1) return false;
-    if (!(m.mode == 0 || (m.mode == 1 && m.sd == 1 && m.sh == 1 && m.sw == 1))) return false;
+    if (m.ksplit != 1) return false;
+    // four (h, w) parity classes of a (1,2,2)-strided 1x3x3 layer's data gradient / transposed forward: stride-1 problems in the q-domain
+    const bool cls4 = m.mode == 1 && m.nclasses == 4 && m.sd == 1 && m.sh == 2 && m.sw == 2 && m.OH % 2 == 0 && m.OW % 2 == 0 &&
+                      m.IH == m.OH / 2 && m.IW == m.OW / 2 && m.ID == m.OD && !m.stat_partial && !m.ib_x;
+    { int hc = M1_CFG("M1_HALO_CLASSES", 1); if (cls4 && !hc) return false; }
+    if (m.nclasses != 1 && !cls4) return false;
+    if (!(m.mode == 0 || (m.mode == 1 && m.sd == 1 && m.sh == 1 && m.sw == 1) || cls4)) return false;
     { int hs = M1_CFG("M1_HALO_STRIDED", 1);       // 0: strided layers stay on conv_mfma (A/B switch)
       if (!hs && m.mode == 0 && (m.sd > 1 || m.sh > 1 || m.sw > 1)) return false; }
     int CC = 0;
     for (int i = 0; i < m.nsrc; ++i) { if (m.srcC[i] % 8) return false; CC += m.srcC[i]; }
     if (!(CC == 8 || CC == 16 || CC == 32 || CC == 64)) return false;
-    if (m.OW % 8) return false;
+    const int QH = cls4 ? m.OH / 2 : m.OH, QW = cls4 ? m.OW / 2 : m.OW;
+    if (QW % 8) return false;
     if ((long long)m.N * m.ID * m.IH * m.IW >= (1ll << 31) - (1 << 20) || (long long)m.N * m.OD * m.OH * m.OW >= (1ll << 31) - (1 << 20)) return false;
-    const int nt = m.cls_ntaps[0];
+    int nt = m.cls_ntaps[0];
+    if (cls4) { nt = 0; for (int c = 0; c < 4; ++c) { if (m.cls_first[c] != nt) return false; nt += m.cls_ntaps[c]; } }
     if (nt < 2 || m.cls_first[0] != 0) return false;                // (a 1x1x1 conv has no halo to share)
-    p = HaloP{}; p.m = m;
+    p = HaloP{}; p.m = m; p.ncls = cls4 ? 4 : 1; p.QH = QH; p.QW = QW;
     int dmin = 127, dmax = -127, hmin = 127, hmax = -127, wmin = 127, wmax = -127;
     for (int t = 0; t < nt; ++t) {
         dmin = m.tdd[t] < dmin ? m.tdd[t] : dmin; dmax = m.tdd[t] > dmax ? m.tdd[t] : dmax;
@@ -473,15 +529,16 @@ static bool halo_plan_nthr(const MfmaP& m, int OCpad, HaloP& p, int force_nthr) 
     else { p.sde = p.she = p.swe = 1; p.pde = p.phe = p.pwe = 0; }
     { int nt_ = M1_CFG("M1_HALO_THREADS", 512); p.nthr = nt_ == 512 ? 512 : 256; }
     if (force_nthr) p.nthr = force_nthr;
-    p.TW = m.OW % 32 == 0 ? 32 : (m.OW % 16 == 0 ? 16 : 8);
+    p.TW = QW % 32 == 0 ? 32 : (QW % 16 == 0 ? 16 : 8);
     if (p.nthr == 512) {      // 256-voxel tiles unless their row padding wastes clearly more than 128-voxel tiles would
         const int th5 = 256 / p.TW, th2 = 128 / p.TW;
-        const double e5 = (double)m.OH / ((m.OH + th5 - 1) / th5 * th5), e2 = (double)m.OH / ((m.OH + th2 - 1) / th2 * th2);
+        const double e5 = (double)QH / ((QH + th5 - 1) / th5 * th5), e2 = (double)QH / ((QH + th2 - 1) / th2 * th2);
         if (e5 < 0.9 * e2) p.nthr = 256;
     }
+    if (cls4 && p.nthr != 512) return false;
     const int BMh = p.nthr / 2;
     p.TH = BMh / p.TW;
-    p.tiles_w = m.OW / p.TW; p.tiles_h = (m.OH + p.TH - 1) / p.TH;
+    p.tiles_w = QW / p.TW; p.tiles_h = (QH + p.TH - 1) / p.TH;
     p.tiles_per_sample = m.OD * p.tiles_h * p.tiles_w;
     const long long nt_all = (long long)m.N * p.tiles_per_sample;
     if (nt_all >= (1ll << 30)) return false;
@@ -495,6 +552,7 @@ static bool halo_plan_nthr(const MfmaP& m, int OCpad, HaloP& p, int force_nthr) 
     if (p.x_slots > HL_MAX_XIT * p.nthr) return false;
     p.x_bytes = p.x_slots * 16 + 256;                                // (+ slack: fragment reads of K-padding segments stay inside)
     p.kpad = m.cls_kpad[0]; p.nchunks = p.kpad / 32; p.nseg = nt * p.spr;
+    if (cls4) { p.kpad = 0; for (int c = 0; c < 4; ++c) p.kpad += m.cls_kpad[c]; p.nchunks = p.kpad / 32; }
     if (p.nchunks > HL_MAX_CH) return false;
     p.BNh = (m.OCn > 16 && OCpad >= 32) ? 32 : 16;
     if (OCpad % p.BNh) return false;
@@ -509,6 +567,7 @@ static bool halo_plan_nthr(const MfmaP& m, int OCpad, HaloP& p, int force_nthr) 
     while (S > 2 && (p.x_slots / p.nthr) * (S - 2) > 40) --S;
     if (S < 2) return false;
     p.stages = S;
+    if (cls4 && !halo_cls_kernel(m, p)) return false;
     return true;
 }
 
@@ -536,6 +595,10 @@ int m1_halo_conv(const MfmaP& mp, int OCpad, hipStream_t st) {
     // compile-time (K chunks, DMA pieces per thread) for the layer shapes of the M1 configurations; anything else: run-time counts
     const int nxit = p.x_slots / p.nthr;
     void (*kern)(HaloP) = nullptr;
+    if (p.ncls == 4) {
+        kern = halo_cls_kernel(mp, p);
+        if (!kern) return M1_ERR_UNSUPPORTED;
+    } else
     if (p.nthr == 512) {
 #define HK(NCH_, NXIT_) if (!kern && p.nchunks == NCH_ && nxit == NXIT_) kern = p.BNh == 32 ? conv_halo_kernel<2, 512, NCH_, NXIT_> : conv_halo_kernel<1, 512, NCH_, NXIT_>;
         HK(18, 6) HK(9, 3) HK(5, 2) HK(3, 1) HK(14, 4) HK(7, 2)

@@ -27,6 +27,7 @@ def _dt(t: torch.Tensor) -> int:
 
 
 def _req(*ts):
+    side = None
     for t in ts:
         if t is None:
             continue
@@ -35,6 +36,27 @@ def _req(*ts):
                                "compute path of this package; there is no CPU fallback")
         if not t.is_contiguous():
             raise RuntimeError("M1 HIP ops need contiguous NDHWC tensors")
+        # An op running on a branch stream (ops.branch: SE shortcut, attention gates, the posterior lane) reads tensors that were
+        # allocated on the stream the step started on.  The caching allocator hands a freed block back to its OWN stream at once: the
+        # moment autograd drops such a tensor (its last backward node has been enqueued, not executed) a later allocation of the main
+        # stream could overwrite it under the branch's kernel.  Eager launches rarely lose that race; a replayed hipGraph, whose
+        # branches run with no host pacing, did (round 4: gradients of the deep levels off by 10-40 % in 2 of 5 runs of the captured
+        # probabilistic step).  record_stream ties the block to the branch stream as well (no-op for blocks of that stream).
+        if side is None:
+            side = _side_stream()
+        if side:
+            t.record_stream(side)
+
+
+def _side_stream():
+    """The current stream when it is a branch stream of the running step, else False."""
+    if not _BRANCH["on"]:
+        return False
+    origin = _BRANCH.get("origin")
+    if origin is None:
+        return False
+    cur = torch.cuda.current_stream()
+    return cur if cur != origin else False
 
 
 def _p(t: Optional[torch.Tensor]):
@@ -128,6 +150,7 @@ def _slot_target(slot, like: torch.Tensor):
             slot.buf, slot.tail_init = b, False
         elif slot.event is not None and slot.stream != torch.cuda.current_stream():
             torch.cuda.current_stream().wait_event(slot.event)
+            b.record_stream(torch.cuda.current_stream())
         view = b[ref.start:]
         if tuple(view.shape) != tuple(like.shape) or not view.is_contiguous():
             return torch.empty_like(like), 0
@@ -138,6 +161,7 @@ def _slot_target(slot, like: torch.Tensor):
     if b is not None and b.shape == like.shape and b.dtype == like.dtype and b.is_contiguous():
         if slot.event is not None and slot.stream != torch.cuda.current_stream():
             torch.cuda.current_stream().wait_event(slot.event)     # the previous writer ran on another stream
+            b.record_stream(torch.cuda.current_stream())           # (the buffer belongs to the stream of its first writer, see _req)
         return b, 1
     g = torch.empty_like(like)
     if b is None:
@@ -323,6 +347,11 @@ class _Fanout(torch.autograd.Function):
     def backward(ctx, *gs):
         slot = ctx.slot
         buf = slot.buf
+        if buf is not None and slot.event is not None and slot.stream != torch.cuda.current_stream():
+            # the last share was added on another stream than this node's (a gate branch, the posterior lane): the readers of the
+            # summed gradient are ordered behind THIS node by autograd, so it must wait for that write itself
+            torch.cuda.current_stream().wait_event(slot.event)
+            buf.record_stream(torch.cuda.current_stream())
         if ctx.owner:
             slot.buf, slot.tail_init = None, False
         rest = None

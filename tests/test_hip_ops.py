@@ -920,6 +920,78 @@ def test_conv_t3_staged_run_kernel(dev, case):
     ops.invalidate_panels()
 
 
+# ---- parity classes on the halo-tile kernel (conv_halo.hip, template B1 > 0): data gradient of a (1,2,2)-strided 1x3x3 conv and the forward
+#      of the matching transposed conv, res0 <-> res1.  M1_HALO=2 lifts the 32,768-voxel floor. ----
+HALO_CLS_CASES = [  # dims of the LOW-resolution side (N, D, H, W), channels low side, channels high side, transposed
+    ((2, 2, 12, 16), 64, 32, False),             # SE block conv4 32 -> 64, s122: 64 gradient channels, partial row tile
+    ((1, 3, 16, 16), 16, 32, False),             # conv1 32 -> 16: a tap is half a K chunk
+    ((2, 2, 10, 24), 64, 32, True),              # Conv3DTranspose 64 -> 32 (networks.py up path), row length 24 -> 8-column tiles
+    ((1, 2, 16, 32), 32, 32, True),              # 32 -> 32
+    ((1, 2, 8, 16), 64, 16, True),               # 16 output channels: one 16-column weight slice
+]
+
+
+@pytest.mark.parametrize("case", HALO_CLS_CASES)
+def test_conv_halo_parity_classes(dev, case):
+    dims, clo, chi, transposed = case
+    k, s = (1, 3, 3), (1, 2, 2)
+    N, D, H, W = dims
+    if transposed:
+        x = rnd((N, D, H, W, clo), 95).bfloat16().float()
+        w = rnd((*k, chi, clo), 6, 1.0 / (clo * 9) ** 0.5).bfloat16().float(); b = rnd((chi,), 7)
+        fo = lambda x_, w_, b_: O.conv3d_transpose_same(x_, w_, b_, s)
+        fd = lambda xd, wd, bd: ops.conv3d_transpose_same([xd], wd, bd, k, s)
+    else:
+        x = rnd((N, D, 2 * H, 2 * W, chi), 95).bfloat16().float()
+        w = rnd((*k, chi, clo), 6, 1.0 / (chi * 9) ** 0.5).bfloat16().float(); b = rnd((clo,), 7)
+        fo = lambda x_, w_, b_: O.conv3d_same(x_, w_, b_, s)
+        fd = lambda xd, wd, bd: ops.conv3d_same([xd], wd, bd, k, s)
+    yo = fo(x.double(), w.double(), b.double())
+    dy = rnd(tuple(yo.shape), 8).bfloat16().float()
+    yo, (gx, gw, gb) = _oracle_grads(fo, [x, w, b], dy)
+    res = {}
+    for tag, cfg in (("cls", dict(M1_HALO=2, M1_HALO_CLASSES=1)), ("mfma", dict(M1_HALO=2, M1_HALO_CLASSES=0))):
+        with ops.config(**cfg):
+            ops.invalidate_panels()
+            xd = x.to(dev, torch.bfloat16).requires_grad_(True)
+            wd, bd = w.to(dev).requires_grad_(True), b.to(dev).requires_grad_(True)
+            y = fd(xd, wd, bd)
+            y.backward(dy.to(dev, torch.bfloat16))
+            torch.cuda.synchronize()
+            res[tag] = (y.detach(), xd.grad)
+    y, gxd = res["cls"]
+    assert rel_err(y, yo) < 1e-2 and rel_err(gxd, gx) < 1e-2
+    # against the implicit-GEMM kernel (classes as separate blocks): same bf16 panels, another summation order
+    y2, gx2 = res["mfma"]
+    for a_, b_ in ((y, y2), (gxd, gx2)):
+        assert rel_err(a_, b_) < 1e-2 and float((a_.float() - b_.float()).abs().mean()) < 2e-4 * float(b_.float().abs().mean()) + 1e-6
+    ops.invalidate_panels()
+
+
+def test_conv_halo_parity_classes_accumulate(dev):
+    """conv1 || conv4 of a strided SE block read the same tensor (network_blocks.py:53,64): the second data gradient adds into the
+    first one's buffer from the class kernel's epilogue (ops.fanout)."""
+    k, s = (1, 3, 3), (1, 2, 2)
+    x = rnd((2, 2, 24, 32, 32), 96).bfloat16().float()
+    w1 = rnd((*k, 32, 16), 6, 1.0 / (32 * 9) ** 0.5).bfloat16().float(); w4 = rnd((*k, 32, 64), 7, 1.0 / (32 * 9) ** 0.5).bfloat16().float()
+    b1, b4 = rnd((16,), 8), rnd((64,), 9)
+    f = lambda x_, a, b, c, d: (O.conv3d_same(x_, a, b, s), O.conv3d_same(x_, c, d, s))
+    y1o, y4o = f(x.double(), w1.double(), b1.double(), w4.double(), b4.double())
+    dy1, dy4 = rnd(tuple(y1o.shape), 10).bfloat16().float(), rnd(tuple(y4o.shape), 11).bfloat16().float()
+    (_, _), grads = _oracle_grads_multi(f, [x, w1, b1, w4, b4], (dy1, dy4))
+    with ops.config(M1_HALO=2):
+        ops.invalidate_panels()
+        xd = x.to(dev, torch.bfloat16).requires_grad_(True)
+        pd = [t.to(dev).requires_grad_(True) for t in (w1, b1, w4, b4)]
+        z = xd * 1.0
+        za, zb = ops.fanout(z, 2)
+        y1 = ops.conv3d_same([za], pd[0], pd[1], k, s); y4 = ops.conv3d_same([zb], pd[2], pd[3], k, s)
+        torch.autograd.backward([y1, y4], [dy1.to(dev, torch.bfloat16), dy4.to(dev, torch.bfloat16)])
+        torch.cuda.synchronize()
+    assert rel_err(xd.grad, grads[0]) < 1.5e-2          # (two bf16 roundings: the first share is stored before the second is added)
+    ops.invalidate_panels()
+
+
 # ---- thin layers (conv_thin.hip): <= 4 input channels forward (the image stem), <= 8 gradient channels pointwise data gradient (the logit
 #      heads).  Production takes them from 65,536 voxels on; M1_THIN=2 lifts the floor. ----
 THIN_FWD_CASES = [  # dims (N, D, H, W), cin, cout, k
