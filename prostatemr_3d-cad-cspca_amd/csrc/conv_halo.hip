@@ -55,7 +55,7 @@ __device__ __forceinline__ void wait_vmh(int n) {
 }
 
 #define HL_MAX_XIT 10        // LDS-DMA pieces per thread for one input tile
-#define HL_MAX_CH 20         // K chunks (of 32) whose fragment offsets live in registers
+#define HL_MAX_CH 18         // K chunks (of 32) whose fragment offsets live in registers (18 = 9 taps x 64 channels; the run-time variant on 512 threads sits at the 256-VGPR limit)
 
 struct HaloP {
     MfmaP m;
@@ -107,8 +107,8 @@ __global__ void __launch_bounds__(NTHR) conv_halo_kernel(HaloP p) {
     constexpr bool CLS = B1 > 0;                                      // four parity classes: K chunks [0,B1) [B1,B2) [B2,B3) [B3,NCH)
     constexpr int NC = CLS ? 4 : 1;
     static_assert(!CLS || (NCH > 0 && B1 < B2 && B2 < B3 && B3 < NCH), "class boundaries");
-    auto cls_of = [](int ch) constexpr { return CLS ? (ch >= B1) + (ch >= B2) + (ch >= B3) : 0; };
-    auto cls_lo = [](int c) constexpr { return c == 0 ? 0 : (c == 1 ? B1 : (c == 2 ? B2 : B3)); };
+#define cls_of(ch) (CLS ? ((ch) >= B1) + ((ch) >= B2) + ((ch) >= B3) : 0)
+#define cls_lo(c) ((c) == 0 ? 0 : ((c) == 1 ? B1 : ((c) == 2 ? B2 : B3)))
     constexpr int CH = RT ? HL_MAX_CH : NCH, XIT = RT ? HL_MAX_XIT : NXIT;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* const Bs = smem;                                   // [nchunks][BN][64]
@@ -475,6 +475,8 @@ __global__ void __launch_bounds__(NTHR) conv_halo_kernel(HaloP p) {
     if (want_stats) { for (; cur_n < m.N; ++cur_n) flush(cur_n); }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
+#undef cls_of
+#undef cls_lo
 
 // ------------------------------------------------------------------------------------------------
 // parity-class mode: the class boundaries are compile-time -- the shapes of the res0 <-> res1 transitions, both tap orders
