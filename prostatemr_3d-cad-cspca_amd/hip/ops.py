@@ -26,6 +26,19 @@ def _dt(t: torch.Tensor) -> int:
     raise RuntimeError(f"unsupported activation dtype {t.dtype} (float32 / bfloat16 only)")
 
 
+if _os.environ.get("M1_DEBUG_POISON"):
+    # debug: every uninitialised allocation starts as NaN bit patterns (0xFF bytes), so that a kernel reading what no kernel wrote
+    # shows up as NaN in the results of an ordinary in-order run instead of as a run-dependent value under concurrency
+    _empty, _empty_like = torch.empty, torch.empty_like
+
+    def _poison(t):
+        if t.is_cuda and t.numel():
+            t.fill_(float("nan") if t.is_floating_point() else (255 if t.dtype == torch.uint8 else -1))
+        return t
+    torch.empty = lambda *a, **k: _poison(_empty(*a, **k))
+    torch.empty_like = lambda *a, **k: _poison(_empty_like(*a, **k))
+
+
 def _req(*ts):
     side = None
     for t in ts:

@@ -135,6 +135,48 @@ def test_bench_rccl_probabilistic_lanes_match_in_order_run(tmp_path):
         assert torch.equal(a, b), f"{k}: {int((a != b).sum())} of {a.numel()} elements differ between the lane run and the in-order run"
 
 
+def _bench_c1p(extra_env, out_pt, graph=True):
+    env = dict(os.environ, M1_BENCH_DUMP=out_pt, **extra_env)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "C1P", "--steps", "1", "--warmup", "1", "--no-cpu-baseline",
+           "--no-roofline", "--no-secondary"] + ([] if graph else ["--no-graph"])
+    rc, out, err = _run(cmd, env)
+    assert rc == 0 and any(l.startswith("{") for l in out.splitlines()), f"rc={rc}\n--- stdout\n{out[-1500:]}\n--- stderr\n{err[-3000:]}"
+    import torch
+    return torch.load(out_pt)
+
+
+@pytest.mark.timeout(8 * CHILD_TIMEOUT_S)
+def test_captured_step_with_lanes_equals_in_order_run_repeatedly(tmp_path):
+    """Round 4: with the posterior lane joined where the prior first read a z, the REPLAYED graph of the probabilistic step left
+    run-dependent gradients at the deep levels of both networks in 8-11 of 24 processes (eager launches never did; the join now sits
+    in front of the prior's first conv, M1Core.forward).  Six processes with lanes, side streams and the fold stream on must each end
+    bit-identical to the run with everything in order on one stream."""
+    ref = _bench_c1p({"M1_PQ_LANES": "0", "M1_STREAMS": "0"}, str(tmp_path / "ref.pt"))
+    import torch
+    for i in range(6):
+        d = _bench_c1p({}, str(tmp_path / f"lanes{i}.pt"))
+        for k in ("flat", "grad", "m", "vhat", "step", "rng"):
+            assert torch.equal(d[k], ref[k]), f"process {i}: {k}: {int((d[k] != ref[k]).sum())} of {ref[k].numel()} elements differ from the in-order run"
+
+
+@pytest.mark.timeout(3 * CHILD_TIMEOUT_S)
+def test_no_kernel_reads_memory_nobody_wrote(tmp_path):
+    """Every uninitialised allocation of the step (outputs, workspaces, partial rows) starts as NaN (M1_DEBUG_POISON, hip/ops.py): a
+    kernel that folds more partial rows than its producer wrote, or reads a tile edge nobody stored, turns the gradients non-finite
+    in an ordinary eager run -- instead of showing as a run-dependent value once streams overlap."""
+    import torch
+    for tag, extra in (("inorder", {"M1_PQ_LANES": "0", "M1_STREAMS": "0"}), ("streams", {})):
+        d = _bench_c1p(dict(extra, M1_DEBUG_POISON="1"), str(tmp_path / f"{tag}.pt"), graph=False)
+        off, bad = 0, []
+        for name, n in d["layout"]:
+            g = d["grad"][off:off + n]
+            if not bool(torch.isfinite(g).all()):
+                bad.append((name, int((~torch.isfinite(g)).sum()), n))
+            off += n
+        assert not bad, (tag, bad[:10])
+        assert bool(torch.isfinite(d["flat"]).all())
+
+
 @pytest.mark.timeout(2 * CHILD_TIMEOUT_S + 60)
 def test_bench_gpus_2_without_torchrun_starts_its_own_ranks():
     """``python bench.py --gpus 2`` with no torchrun environment must start two ranks itself (as a child process) and report
