@@ -125,6 +125,10 @@ int m1_set_force_direct(int on);
 int m1_config_set(const char* name, int value);
 int m1_config_unset(const char* name);
 int m1_config_get(const char* name, int* value);
+/* debug probe (tools/dbg/stress_lds.py): `blocks` workgroups fill 31 KB of static LDS with a pattern and re-read it `spins` times; *bad
+ * (device, unsigned) counts the words that changed.  Launched next to another kernel it shows whether that kernel writes LDS outside
+ * its own allocation. */
+int m1_debug_lds_canary(unsigned* bad, int blocks, int spins, void* stream);
 
 /* ---- Conv3DTranspose(padding='same') + bias : N:496-499,505-507,513-514,520,546-553 ----
  * w: Keras layout (kd,kh,kw,Cout,Cin) fp32; y: (N, D*sd, H*sh, W*sw, Cout). */

@@ -59,3 +59,22 @@ extern "C" int m1_prof_read(m1_prof_rec_t* out, int max_n) {
     }
     return n;
 }
+
+// ---- debug: LDS canary.  Blocks fill 31 KB of static LDS (the footprint of thin_fwd_kernel) with a pattern and re-read it `spins`
+// times; *bad counts words that changed.  Run next to another kernel inside a graph (tools/dbg/stress_lds.py) it shows whether that
+// kernel writes LDS outside its own allocation (LDS-DMA is not bounds-checked against the workgroup's allocation).
+__global__ void __launch_bounds__(256) m1_lds_canary_kernel(unsigned* __restrict__ bad, int spins) {
+    __shared__ unsigned buf[7936];
+    for (int i = threadIdx.x; i < 7936; i += 256) buf[i] = (unsigned)i * 2654435761u ^ blockIdx.x;
+    __syncthreads();
+    unsigned nb = 0;
+    for (int s = 0; s < spins; ++s) {
+        for (int i = threadIdx.x; i < 7936; i += 256) nb += ((volatile unsigned*)buf)[i] != ((unsigned)i * 2654435761u ^ blockIdx.x);
+        __builtin_amdgcn_s_sleep(8);
+    }
+    if (nb) atomicAdd(bad, nb);
+}
+extern "C" int m1_debug_lds_canary(unsigned* bad, int blocks, int spins, void* stream) {
+    hipLaunchKernelGGL(m1_lds_canary_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, bad, spins);
+    return m1_check_launch();
+}

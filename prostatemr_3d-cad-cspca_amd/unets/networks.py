@@ -245,12 +245,11 @@ class M1Core(nn.Module):
         else:
             used += [getattr(self, "sersp" + str(3 - lvl)) for lvl in range(n_up)]
         SEResNetBottleNeck.precompute_gates(used)
-        if z_ready is not None and _os.environ.get("M1_LANE_FWD_OVERLAP", "0") != "1":
-            # The posterior lane is joined HERE, before the first conv of this pass, not where the first z is read: with the prior's
-            # stem conv running next to the lane the replayed hipGraph of the step produced run-dependent gradients at the deep levels
-            # of both networks (round 4: 8-11 of 24 runs of the C1-sized probabilistic step differed from the in-order run, forward
-            # values intact; 0 of 48 with the join here; eager launches never differed).  The backward passes of the two networks
-            # still overlap (autograd runs the posterior's nodes on the lane).  M1_LANE_FWD_OVERLAP=1 restores the late join.
+        if z_ready is not None and _os.environ.get("M1_LANE_FWD_OVERLAP", "1") == "0":
+            # debug switch: join the posterior lane HERE, before the first conv of this pass, instead of where the first z is read (the
+            # forward passes of the two networks then do not overlap, 24.7 -> 25.7 ms per C3 step).  Round 4 shipped this for a few
+            # hours while the replayed graph of the step produced run-dependent gradients; the cause turned out to be packed fp32 VALU
+            # instructions next to MFMA kernels (csrc/Makefile NOPK), not the overlap.
             z_ready(); z_ready = None
         # networks.py:574-576
         x_raw, s0 = self.conve0(inputs, stats=True)
