@@ -299,6 +299,8 @@ def run_workload(a, wl, ctx, want_roofline, want_cpu):
         reducer = pkg.ddp.GradReducer(world_size=world, bucket_mb=float(os.environ.get("M1_DDP_BUCKET_MB", "64")),
                                       force=(world == 1))
         opt.attach_reducer(reducer)
+        if os.environ.get("M1_BENCH_DDP_OVERLAP") == "0":          # debug: every group is sent after the backward pass
+            reducer.overlap = False
     opt.set_lr_device()
     model.train()
     loss_buf = torch.zeros(1, device=dev)
@@ -355,6 +357,8 @@ def run_workload(a, wl, ctx, want_roofline, want_cpu):
             # process (seen in 1 of 3 ... 1 of 8 runs of the probabilistic model).  Give the watchdog time to drain its list.
             time.sleep(1.0)
         gr = torch.cuda.CUDAGraph()
+        if os.environ.get("M1_BENCH_CAPTURE_TL") in ("0", "1"):      # debug: force the capture error mode
+            thread_local = os.environ["M1_BENCH_CAPTURE_TL"] == "1"
         with torch.cuda.graph(gr, capture_error_mode="thread_local" if thread_local else "global"):
             fn()
         torch.cuda.synchronize()

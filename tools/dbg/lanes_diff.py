@@ -10,7 +10,7 @@ tmp = tempfile.mkdtemp()
 def run(tag, env_extra, port):
     out = os.path.join(tmp, tag + ".pt")
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", M1_BENCH_DUMP=out, **env_extra)
-    if not os.environ.get("NODIST"): env["M1_BENCH_FORCE_DIST"] = "1"
+    if not os.environ.get("NODIST") and not (tag == "inorder" and os.environ.get("REF_NODIST")): env["M1_BENCH_FORCE_DIST"] = "1"
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--workload", "C1P", "--steps", steps, "--warmup", "1",
                         "--no-cpu-baseline", "--no-roofline"] + (["--no-graph"] if os.environ.get("NOGRAPH") else []), env=env, capture_output=True, text=True)
     if r.returncode:
