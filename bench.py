@@ -592,6 +592,8 @@ def main():
         else:
             dist.init_process_group(backend=backend, rank=rank, world_size=world)
     torch.manual_seed(1234 + rank)                    # the latent draws of the probabilistic model come from torch's device generator
+    if os.environ.get("M1_BENCH_PAD_MB"):                              # debug: shift every later device allocation (address-dependent behaviour)
+        globals()["_PAD"] = [torch.empty(int(float(v) * (1 << 20)), dtype=torch.uint8, device=dev) for v in os.environ["M1_BENCH_PAD_MB"].split(",")]
     ctx = dict(pkg=pkg, ops=ops, dev=dev, world=world, rank=rank, backend=backend, dist_on=dist_on)
 
     out = run_workload(a, a.workload, ctx, want_roofline=not a.no_roofline, want_cpu=(not a.no_cpu_baseline and not dist_on))

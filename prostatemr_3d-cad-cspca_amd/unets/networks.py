@@ -570,6 +570,10 @@ class M1Net(nn.Module):
                     # ONE generator launch for the draws of all levels, in the activation storage type (views of one buffer)
                     sizes = [B * int(np.prod(shp)) for shp in lshape]
                     flat = torch.randn(sum(sizes), device=image.device, dtype=image.dtype)
+                    if _os.environ.get("M1_DEBUG_FIXED_EPS"):          # debug: one persistent draw instead of a generator launch per step
+                        if getattr(self, "_dbg_eps", None) is None:
+                            self._dbg_eps = flat.clone()
+                        flat = self._dbg_eps
                     eps1, off = [], 0
                     for n_, shp in zip(sizes, lshape):
                         eps1.append(flat[off:off + n_].view(B, *shp)); off += n_

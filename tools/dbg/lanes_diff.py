@@ -18,7 +18,11 @@ def run(tag, env_extra, port):
     return torch.load(out)
 ref = run("inorder", {"M1_PQ_LANES": "0", "M1_STREAMS": "0"}, 29700)
 for i in range(runs):
-    d = run(f"lanes{i}", extra, 29701 + i)
+    ex_i = dict(extra)
+    if os.environ.get("PADRAND"):                                     # a different allocation layout in every process
+        import random
+        ex_i["M1_BENCH_PAD_MB"] = ",".join(str(round(random.uniform(0.1, 700.0), 3)) for _ in range(3))
+    d = run(f"lanes{i}", ex_i, 29701 + i)
     if d is None: continue
     for k_, ents in d.get("dbg", {}).items():
         for j, (ea, eb) in enumerate(zip(ents, ref["dbg"][k_])):
