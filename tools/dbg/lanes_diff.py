@@ -27,6 +27,7 @@ for i in range(runs):
     for k_, ents in d.get("dbg", {}).items():
         for j, (ea, eb) in enumerate(zip(ents, ref["dbg"][k_])):
             print(f"run {i}: dbg {k_}[{j}]:", ["same" if torch.equal(x, y) else f"DIFF max {float((x.float() - y.float()).abs().max()):.3g} of {float(y.float().abs().max()):.3g}" for x, y in zip(ea, eb)])
+    print(f"run {i}: step {d['step'].tolist()} (ref {ref['step'].tolist()})  rng {d['rng'].tolist()} (ref {ref['rng'].tolist()})")
     for key in ("grad", "flat"):
         a, b = d[key], ref[key]
         if torch.equal(a, b): print(f"run {i}: {key} identical"); continue
