@@ -301,6 +301,8 @@ def run_workload(a, wl, ctx, want_roofline, want_cpu):
         opt.attach_reducer(reducer)
         if os.environ.get("M1_BENCH_DDP_OVERLAP") == "0":          # debug: every group is sent after the backward pass
             reducer.overlap = False
+        if os.environ.get("M1_BENCH_NO_COLLECTIVES") == "1":       # debug: the process group exists, the step issues no collective
+            reducer.force = False
     opt.set_lr_device()
     model.train()
     loss_buf = torch.zeros(1, device=dev)
