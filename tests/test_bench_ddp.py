@@ -166,6 +166,20 @@ def test_captured_step_with_lanes_equals_in_order_run_repeatedly(tmp_path):
 
 
 @pytest.mark.timeout(3 * CHILD_TIMEOUT_S)
+@pytest.mark.parametrize("victim,load", [("enc0", "part:conv3"), ("full", "prior")])
+def test_forward_next_to_another_stream_equals_forward_alone(victim, load):
+    """The reduced form of the round-4 race (tools/dbg/stress_posterior.py): the posterior's forward (its stem block / all of it), no
+    autograd, replayed 60 times inside a graph next to a load on a forked stream (the prior's conv_pw layer / the prior's whole forward)
+    must equal the same forward computed alone, bit for bit.  With packed fp32 VALU instructions in the build 20-48 / 8 of 60 replays
+    differed."""
+    env = dict(os.environ, VICTIM=victim)
+    rc, out, err = _run([sys.executable, os.path.join(ROOT, "tools", "dbg", "stress_posterior.py"), load], env)
+    line = [l for l in out.splitlines() if l.startswith("load=")]
+    assert rc == 0 and line, f"rc={rc}\n--- stdout\n{out[-1500:]}\n--- stderr\n{err[-3000:]}"
+    assert line[-1].startswith(f"load={load}: 0 of 60"), line[-1]
+
+
+@pytest.mark.timeout(3 * CHILD_TIMEOUT_S)
 def test_no_kernel_reads_memory_nobody_wrote(tmp_path):
     """Every uninitialised allocation of the step (outputs, workspaces, partial rows) starts as NaN (M1_DEBUG_POISON, hip/ops.py): a
     kernel that folds more partial rows than its producer wrote, or reads a tile edge nobody stored, turns the gradients non-finite
