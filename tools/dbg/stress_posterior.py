@@ -92,6 +92,26 @@ def load():
         else:
             for _ in range(6):
                 ops.conv3d_same([x2], net.prior.conve0.kernel, net.prior.conve0.bias, (1, 3, 3), (1, 1, 1), True)
+if os.environ.get("WITH_PG"):
+    # the open RCCL-branch issue: does the forward change once a process group exists / an RCCL kernel has run?
+    import torch.distributed as dist
+    with torch.no_grad():
+        ops._BRANCH["on"] = False
+        full = lambda: net(x3) if os.environ.get("WITH_PG") == "net" else post()
+        before = [t.clone() for t in post()]; torch.cuda.synchronize()
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29871")
+        dist.init_process_group("nccl", rank=0, world_size=1)
+        t = torch.ones(1024, device=dev); dist.all_reduce(t); dist.barrier(); torch.cuda.synchronize()
+        bad = 0
+        for it in range(40):
+            if it % 4 == 0: dist.all_reduce(t)
+            out = post(); torch.cuda.synchronize()
+            d = [i for i, (a, b) in enumerate(zip(out, before)) if not torch.equal(a, b)]
+            bad += bool(d)
+            if d and bad <= 3: print(f"eager run {it} after the process group came up: outputs {d} differ")
+        print(f"with a process group: {bad} of 40 eager forwards differ from the forward before it existed")
+        dist.destroy_process_group()
+    sys.exit(0)
 with torch.no_grad():
     ops._BRANCH["on"] = False                                    # everything of a pass in line on its stream
     main = torch.cuda.Stream()
