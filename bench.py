@@ -306,6 +306,18 @@ def run_workload(a, wl, ctx, want_roofline, want_cpu):
     opt.set_lr_device()
     model.train()
     loss_buf = torch.zeros(1, device=dev)
+    # debug (harness tools only): M1_BENCH_HIST=1 records a hash of the gradient and parameter vectors after EVERY executed step
+    # (eager warm-up, capture prelude, each replay) and, with M1_DEBUG_TRACE, the per-op checksum log of that step
+    hist_on = os.environ.get("M1_BENCH_HIST") == "1"
+    hist = []
+
+    def note(tag):
+        if not hist_on:
+            return
+        import hashlib
+        torch.cuda.synchronize()
+        h = lambda t: hashlib.sha1(t.detach().cpu().numpy().tobytes()).hexdigest()[:12]
+        hist.append({"tag": tag, "grad": h(opt.flatp.grad), "flat": h(opt.flatp.flat), "trace": ops.trace_snapshot()})
 
     def fwd_bwd():
         """forward (all core passes) + loss + backward: gradients land in the flat buffer (kernels accumulate there);
@@ -324,6 +336,7 @@ def run_workload(a, wl, ctx, want_roofline, want_cpu):
         ops.step_advance(None, model.rng_state)
 
     def step():
+        ops.trace_reset(dev)
         fwd_bwd()
         update()
 
@@ -331,6 +344,7 @@ def run_workload(a, wl, ctx, want_roofline, want_cpu):
     _dbg(f"{wl}: model built; eager warm-up")
     for _ in range(max(1, min(a.warmup, 2))):
         step()
+        note("eager")
     torch.cuda.synchronize()
     _dbg("eager warm-up done")
     # N = 1: the whole step is one hipGraph.  N > 1 over RCCL ("full"): the same, the collectives are captured on the
@@ -351,7 +365,8 @@ def run_workload(a, wl, ctx, want_roofline, want_cpu):
                 update()
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
-        if dist_on and backend == "nccl":
+        note("prelude")
+        if (dist_on and backend == "nccl" and os.environ.get("M1_BENCH_NO_SLEEP") != "1") or os.environ.get("M1_BENCH_SLEEP") == "1":
             # The process group's watchdog thread retires finished collectives by polling their end events (every ~100 ms).  The
             # collectives of the eager step above are finished, but may not have been polled yet -- and their events were recorded
             # on the group's internal stream, which JOINS THE CAPTURE with the first captured collective: HIP then refuses the
@@ -375,6 +390,7 @@ def run_workload(a, wl, ctx, want_roofline, want_cpu):
         run = step
         if a.no_graph:
             step()                       # (capture() runs one eager step before it records: both modes execute the same number of steps)
+            note("prelude")
     elif gmode == "full":
         run = graph.replay
     else:
@@ -384,17 +400,20 @@ def run_workload(a, wl, ctx, want_roofline, want_cpu):
             update()
 
     _dbg(f"graph mode={gmode} err={graph_err}; timed warm-up")
+    barriers = dist_on and os.environ.get("M1_BENCH_NO_BARRIER") != "1"      # (debug: no RCCL kernel between the replays)
     for _ in range(a.warmup):
         run()
-    if dist_on:
+        note("warm")
+    if barriers:
         dist.barrier()
     torch.cuda.synchronize()
     _dbg("timing")
     t0 = time.perf_counter()
     for _ in range(a.steps):
         run()
+        note("timed")
     torch.cuda.synchronize()
-    if dist_on:
+    if barriers:
         dist.barrier()
     dt = time.perf_counter() - t0
     exchange = None
@@ -417,7 +436,7 @@ def run_workload(a, wl, ctx, want_roofline, want_cpu):
     final_loss = float(loss_buf)
     if os.environ.get("M1_BENCH_DUMP") and rank == 0:          # harness tests: the state a run ends in (bit-compared between modes)
         torch.save({"flat": opt.flatp.flat.cpu(), "grad": opt.flatp.grad.cpu(), "m": opt.m.cpu(), "vhat": opt.vhat.cpu(),
-                    "step": opt.step_dev.cpu(), "rng": model.rng_state.cpu(),
+                    "step": opt.step_dev.cpu(), "rng": model.rng_state.cpu(), "hist": hist,
                     "layout": [({id(q): k for k, q in model.named_parameters()}.get(id(q_), "?"), q_.numel()) for q_ in opt.flatp.params]},
                    os.environ["M1_BENCH_DUMP"])
 

@@ -129,6 +129,15 @@ int m1_config_get(const char* name, int* value);
  * (device, unsigned) counts the words that changed.  Launched next to another kernel it shows whether that kernel writes LDS outside
  * its own allocation. */
 int m1_debug_lds_canary(unsigned* bad, int blocks, int spins, void* stream);
+/* debug probes (csrc/debug.hip; hip/ops.py M1_DEBUG_TRACE / M1_DEBUG_POISON=2; never launched unless a debug switch asks):
+ * m1_debug_checksum: *slot (device) = a deterministic 64-bit checksum of the nbytes at p (4-byte aligned), ONE single-block kernel --
+ * capturable into a hipGraph, so the outputs of every op of a replayed step can be compared between two processes.
+ * m1_debug_scribble: `blocks` workgroups (0 = 512) that each take a whole CU (160 KB of LDS, four waves with 256 VGPRs + 256 AGPRs)
+ * and leave the NaN pattern 0x7FC07FC0 in every LDS word and every vector register; `spins` ~microseconds each block stays resident
+ * (so that all CUs are covered).  A kernel that reads LDS or a register it never wrote then yields NaN instead of a value that
+ * depends on its predecessor on that CU. */
+int m1_debug_checksum(const void* p, long long nbytes, unsigned long long* slot, void* stream);
+int m1_debug_scribble(int blocks, int spins, void* stream);
 
 /* ---- Conv3DTranspose(padding='same') + bias : N:496-499,505-507,513-514,520,546-553 ----
  * w: Keras layout (kd,kh,kw,Cout,Cin) fp32; y: (N, D*sd, H*sh, W*sw, Cout). */

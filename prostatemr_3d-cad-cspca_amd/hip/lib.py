@@ -74,6 +74,8 @@ SIGNATURES = {
     "m1_config_unset": (_i, [C.c_char_p]),
     "m1_config_get": (_i, [C.c_char_p, C.POINTER(_i)]),
     "m1_debug_lds_canary": (_i, [_vp, _i, _i, _vp]),
+    "m1_debug_checksum": (_i, [_vp, _ll, _vp, _vp]),
+    "m1_debug_scribble": (_i, [_i, _i, _vp]),
     "m1_conv3d_wgrad": (_i, [_desc_p, _vp, _vp, _vp, _vp, _i, _vp]),
     "m1_conv3d_pair_supported": (_i, [_desc_p, _i]),
     "m1_conv3d_pair_fwd": (_i, [_desc_p, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp]),

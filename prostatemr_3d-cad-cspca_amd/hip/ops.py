@@ -26,17 +26,64 @@ def _dt(t: torch.Tensor) -> int:
     raise RuntimeError(f"unsupported activation dtype {t.dtype} (float32 / bfloat16 only)")
 
 
-if _os.environ.get("M1_DEBUG_POISON"):
-    # debug: every uninitialised allocation starts as NaN bit patterns (0xFF bytes), so that a kernel reading what no kernel wrote
-    # shows up as NaN in the results of an ordinary in-order run instead of as a run-dependent value under concurrency
+# ---- debug switches (environment, read once): never on in the product path ---------------------------------------------------
+# M1_DEBUG_POISON=1   every uninitialised allocation starts as NaN bit patterns (0xFF bytes): a kernel reading what no kernel wrote
+#                     shows up as NaN in the results of an ordinary in-order run instead of as a run-dependent value under concurrency
+# M1_DEBUG_POISON=2   additionally a scribble launch (m1_debug_scribble: NaN pattern in every LDS word, VGPR and AGPR of all CUs) in
+#                     front of every entry point: reads of LDS / registers the kernel never wrote become NaN as well
+# M1_DEBUG_TRACE=n    a 64-bit checksum of every tensor an op allocated (outputs, workspaces) into slot i of an n-slot device log,
+#                     launched right behind the entry point that wrote it -- one kernel per tensor, capturable, so two processes can be
+#                     compared op by op inside a REPLAYED graph (trace_reset / trace_snapshot; tools/dbg/first_diff.py)
+_POISON = int(_os.environ.get("M1_DEBUG_POISON", "0") or 0)
+_TRACE = {"n": int(_os.environ.get("M1_DEBUG_TRACE", "0") or 0), "log": None, "names": [], "recent": [], "i": 0}
+if _POISON or _TRACE["n"]:
     _empty, _empty_like = torch.empty, torch.empty_like
 
     def _poison(t):
         if t.is_cuda and t.numel():
-            t.fill_(float("nan") if t.is_floating_point() else (255 if t.dtype == torch.uint8 else -1))
+            if _POISON:
+                t.fill_(float("nan") if t.is_floating_point() else (255 if t.dtype == torch.uint8 else -1))
+            if _TRACE["n"]:
+                _TRACE["recent"].append(t)
         return t
     torch.empty = lambda *a, **k: _poison(_empty(*a, **k))
     torch.empty_like = lambda *a, **k: _poison(_empty_like(*a, **k))
+
+if _TRACE["n"]:
+    _check0 = L.check
+
+    def _traced_check(rc, what):
+        _check0(rc, what)
+        rec, _TRACE["recent"] = _TRACE["recent"], []
+        if _TRACE["log"] is None:
+            return
+        lib, st = L.load(), torch.cuda.current_stream().cuda_stream
+        for t in rec:
+            i = _TRACE["i"]
+            nb = t.numel() * t.element_size()
+            if i >= _TRACE["n"] or (t.data_ptr() & 3) or not t.is_contiguous():
+                continue
+            _check0(lib.m1_debug_checksum(t.data_ptr(), nb, _TRACE["log"].data_ptr() + 8 * i, st), "m1_debug_checksum")
+            _TRACE["names"].append((what, tuple(t.shape), str(t.dtype)))
+            _TRACE["i"] = i + 1
+    L.check = _traced_check
+
+
+def trace_reset(device=None) -> None:
+    """M1_DEBUG_TRACE: start a step's log (slot 0 next; the device log is zeroed by a fill on the current stream)."""
+    if not _TRACE["n"]:
+        return
+    if _TRACE["log"] is None:
+        _TRACE["log"] = torch.zeros(_TRACE["n"], dtype=torch.int64, device=device or torch.device("cuda", torch.cuda.current_device()))
+    _TRACE["names"], _TRACE["recent"], _TRACE["i"] = [], [], 0
+
+
+def trace_snapshot():
+    """M1_DEBUG_TRACE: (names, checksums) of the step the log holds -- after a synchronize."""
+    if not _TRACE["n"] or _TRACE["log"] is None:
+        return None
+    torch.cuda.synchronize()
+    return list(_TRACE["names"]), _TRACE["log"][:_TRACE["i"]].cpu().clone()
 
 
 def _req(*ts):
@@ -77,7 +124,10 @@ def _p(t: Optional[torch.Tensor]):
 
 
 def _stream():
-    return torch.cuda.current_stream().cuda_stream
+    s = torch.cuda.current_stream().cuda_stream
+    if _POISON >= 2:
+        L.load().m1_debug_scribble(0, 8, s)
+    return s
 
 
 def _ws(N: int, V: int, Cn: int, nsums: int, device) -> torch.Tensor:
