@@ -42,6 +42,8 @@ typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 #define CT3_NAS 2            // A-piece slots per wave in each of the two issue phases of a kd slice: 2 * 2 * 8 KB >= (256 + 2 W + 2) * 64 B
 
 __device__ __forceinline__ void ct3_dma(i32x4_t rs, unsigned lds, unsigned voff, unsigned soff) {
+    // (M0 is written here without a clobber: "m0" is a reserved register to hipcc -- it warns on the clobber -- and these kernels contain no
+    // compiler-generated M0 use that a stale value could reach; tools/isa_async_check.py / tests/test_build_props.py verify that on the ISA)
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" :: "s"(lds), "v"(voff), "s"(rs), "s"(soff) : "memory");
 }
 template <int N> __device__ __forceinline__ void ct3_vmwait() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }

@@ -224,6 +224,24 @@ static size_t stem_ws_bytes(const m1_conv_desc_t* d, bool T) {
     if (!stem_wanted(d, T)) return 0;
     return align256((size_t)d->N * d->D * d->H * d->W * 8 * 2) + align256((size_t)d->kd * d->kh * d->kw * 8 * d->Cout * sizeof(float));
 }
+// Zero fill as a KERNEL.  hipMemsetAsync on a capturing stream becomes a memset node of the step's hipGraph, and on this ROCm release
+// a replayed graph does not keep a memset node ordered between the kernel nodes around it (round 5: from the third replay on, the
+// padded-stem weight gradient -- zero r8, accumulate into it, read it -- differed from run to run, in order on ONE stream; eager
+// launches never; tools/probes/graph_memset_probe.py).  M1_MEMSET_KERNEL=0 restores the memset (the reproducer of that finding).
+__global__ void __launch_bounds__(256) m1_zero_kernel(uint4* __restrict__ p, long long n16, unsigned* __restrict__ tail, int ntail) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n16; i += (long long)gridDim.x * 256) p[i] = make_uint4(0, 0, 0, 0);
+    if (blockIdx.x == 0 && (int)threadIdx.x < ntail) tail[threadIdx.x] = 0u;
+}
+static int m1_zero_async(void* p, size_t bytes, hipStream_t st) {
+    if (!bytes) return M1_OK;
+    if (!M1_CFG("M1_MEMSET_KERNEL", 1) || ((uintptr_t)p & 15) || (bytes & 3))
+        return hipMemsetAsync(p, 0, bytes, st) == hipSuccess ? M1_OK : M1_ERR_LAUNCH;
+    const long long n16 = (long long)(bytes >> 4);
+    const int ntail = (int)((bytes & 15) >> 2);
+    long long g = (n16 + 255) / 256; if (g > 2048) g = 2048; if (g < 1) g = 1;
+    hipLaunchKernelGGL(m1_zero_kernel, dim3((unsigned)g), dim3(256), 0, st, (uint4*)p, n16, (unsigned*)((unsigned char*)p + (n16 << 4)), ntail);
+    return m1_check_launch();
+}
 __global__ void __launch_bounds__(256) stem_pad8_kernel(const unsigned short* __restrict__ x, uint4* __restrict__ x8, long long nvox, int C) {
     for (long long v = (long long)blockIdx.x * 256 + threadIdx.x; v < nvox; v += (long long)gridDim.x * 256) {
         unsigned short e[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -536,11 +554,11 @@ static int wgrad_common(const m1_conv_desc_t* d, bool T, const void* dy, float* 
                         int accumulate) {
     Geo q = T ? convT_geo(d) : conv_geo(d);
     const size_t nw = (size_t)d->kd * d->kh * d->kw * d->Cin * d->Cout;
-    if (!accumulate && hipMemsetAsync(dw, 0, nw * sizeof(float), st) != hipSuccess) return M1_ERR_LAUNCH;
+    if (!accumulate && m1_zero_async(dw, nw * sizeof(float), st) != M1_OK) return M1_ERR_LAUNCH;
     // Conv3D bias gradient rides on the matrix-core wgrad of the first concat member (all-ones fragment); the
     // transposed conv (its dOut is the SHIFTED operand) and the direct path keep the separate column-sum pass
     const bool fuse_db = db && !T && !g_force_direct;
-    if (fuse_db && !accumulate && hipMemsetAsync(db, 0, (size_t)d->Cout * sizeof(float), st) != hipSuccess) return M1_ERR_LAUNCH;
+    if (fuse_db && !accumulate && m1_zero_async(db, (size_t)d->Cout * sizeof(float), st) != M1_OK) return M1_ERR_LAUNCH;
     int off = 0;
     const int nbias = fuse_db ? d->Cout : 0;
     float* rx = nullptr; long long rx_floats = 0;              // partial-copy scratch: the tail of the caller's workspace
@@ -558,7 +576,7 @@ static int wgrad_common(const m1_conv_desc_t* d, bool T, const void* dy, float* 
         uint4* x8 = reinterpret_cast<uint4*>(base);
         float* r8 = reinterpret_cast<float*>(base + align256((size_t)nvox * 16));
         const size_t nw8 = (size_t)taps * CP * d->Cout;
-        if (hipMemsetAsync(r8, 0, nw8 * sizeof(float), st) != hipSuccess) return M1_ERR_LAUNCH;
+        if (m1_zero_async(r8, nw8 * sizeof(float), st) != M1_OK) return M1_ERR_LAUNCH;
         long long pb = (nvox + 255) / 256; if (pb > 8192) pb = 8192;
         if (f32) hipLaunchKernelGGL(stem_pad4f_kernel, dim3((unsigned)pb), dim3(256), 0, st, (const float*)d->src[0].ptr, reinterpret_cast<float4*>(x8), nvox, Cin);
         else hipLaunchKernelGGL(stem_pad8_kernel, dim3((unsigned)pb), dim3(256), 0, st, (const unsigned short*)d->src[0].ptr, x8, nvox, Cin);

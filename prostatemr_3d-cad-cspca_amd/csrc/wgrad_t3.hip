@@ -64,6 +64,8 @@ __device__ __forceinline__ bf16x8_t t3_frag(s16x4_t lo, s16x4_t hi) {
 // 64 lanes x 16 bytes, global (buffer resource `rs`, per-lane byte offset `voff`; out of range -> zeros) -> LDS at the
 // wave-uniform byte address `lds` + 16 * lane.  M0 carries the LDS base of an LDS-DMA.
 __device__ __forceinline__ void t3_dma(i32x4_t rs, unsigned lds, unsigned voff) {
+    // (M0 is written here without a clobber: "m0" is a reserved register to hipcc -- it warns on the clobber -- and these kernels contain no
+    // compiler-generated M0 use that a stale value could reach; tools/isa_async_check.py / tests/test_build_props.py verify that on the ISA)
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" :: "s"(lds), "v"(voff), "s"(rs) : "memory");
 }
 // at most P * (S - 2) LDS-DMA pieces of this wave still in flight (every wave issues P pieces per stage)

@@ -40,6 +40,8 @@ struct TSP {
 };
 
 __device__ __forceinline__ void ts_dma(i32x4_t rs, unsigned lds, unsigned voff) {
+    // (M0 is written here without a clobber: "m0" is a reserved register to hipcc -- it warns on the clobber -- and these kernels contain no
+    // compiler-generated M0 use that a stale value could reach; tools/isa_async_check.py / tests/test_build_props.py verify that on the ISA)
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" :: "s"(lds), "v"(voff), "s"(rs) : "memory");
 }
 

@@ -15,6 +15,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 PKG_DIR = os.path.dirname(_HERE)
 CSRC_DIR = os.path.join(PKG_DIR, "csrc")
 SO_PATH = os.path.join(PKG_DIR, "libm1hip.so")
+if os.environ.get("M1HIP_SO"):          # harness only: a bisection build of the same sources (csrc/Makefile PK_FILES), e.g. libm1hip_pk.so
+    SO_PATH = os.path.join(PKG_DIR, os.path.basename(os.environ["M1HIP_SO"]))
 HEADER = os.path.join(os.path.dirname(PKG_DIR), "include", "m1hip.h")
 
 M1_F32, M1_BF16 = 0, 1

@@ -29,3 +29,38 @@ def test_hot_kernels_use_no_scratch_memory(src):
     assert kernels, "no kernel metadata found"
     bad = [(n, int(p), int(v)) for n, p, v in kernels if (int(p) or int(v)) and "tf64" not in n]
     assert not bad, bad
+
+
+def test_library_creates_no_memset_nodes():
+    """hipMemsetAsync on a capturing stream becomes a memset node of the step's hipGraph, and a REPLAYED graph fills a memset node's
+    range with garbage on this ROCm release (round 5: the cause of the run-dependent captured step; tools/probes/graph_memset_probe.py).
+    The library zero-fills through dispatch.hip's m1_zero_async (a kernel): no other call of hipMemset* / hipMemcpy* may appear."""
+    import glob
+    hits = []
+    for f in sorted(glob.glob(os.path.join(CSRC, "*.hip")) + glob.glob(os.path.join(CSRC, "*.h"))):
+        for no, line in enumerate(open(f), 1):
+            code = line.split("//")[0]
+            if re.search(r"\bhipMem(set|cpy)\w*\s*\(", code):
+                hits.append((os.path.basename(f), no, code.strip()))
+    assert len(hits) == 1 and hits[0][0] == "dispatch.hip" and "M1_MEMSET_KERNEL" in open(os.path.join(CSRC, "dispatch.hip")).read(), hits
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not available")
+@pytest.mark.parametrize("src", ["conv_mfma.hip", "conv_t3.hip", "wgrad_tf.hip", "wgrad_t3.hip"])
+def test_no_register_of_an_inline_asm_load_is_touched_in_flight(src):
+    """hipcc's waitcnt insertion does not see loads issued from inline asm (ds_read_b128 / ds_read_b64_tr_b16 fragments): the kernels
+    wait by hand, and a register copy the allocator places between such a load and its wait would read a stale register.
+    tools/isa_async_check.py walks the control-flow graph of every kernel of the compiler's output and reports each instruction that
+    touches a destination of an asm-issued load before a wait covers it (self-test: a planted violation is found)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("isa_async_check", os.path.join(os.path.dirname(CSRC), "..", "tools", "isa_async_check.py"))
+    chk = importlib.util.module_from_spec(spec); spec.loader.exec_module(chk)
+    with tempfile.TemporaryDirectory() as td:
+        planted = os.path.join(td, "p.s")
+        open(planted, "w").write("_Zk:\n\t;;#ASMSTART\n\tds_read_b128 v[4:7], v1\n\t;;#ASMEND\n\tv_mov_b32_e32 v9, v5\n\t;;#ASMSTART\n"
+                                 "\ts_waitcnt lgkmcnt(0)\n\t;;#ASMEND\n\tv_mov_b32_e32 v10, v6\n\ts_endpgm\n")
+        assert len(chk.check_file(planted)) == 1
+    out = chk.compile_s(os.path.join(CSRC, src), chk.makefile_flags())
+    kernels = chk.split_kernels(out)
+    assert sum(1 for v in kernels.values() for it in v if it[1] != "label" and it[2] and it[1].startswith("ds_read")) > 100
+    assert chk.check_file(out) == []

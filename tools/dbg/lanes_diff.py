@@ -15,7 +15,7 @@ def run(tag, env_extra, port):
                         "--no-cpu-baseline", "--no-roofline"] + (["--no-graph"] if os.environ.get("NOGRAPH") else []), env=env, capture_output=True, text=True)
     if r.returncode:
         print(tag, "rc", r.returncode, r.stderr[-600:]); return None
-    return torch.load(out)
+    return torch.load(out, weights_only=False)
 ref = run("inorder", {"M1_PQ_LANES": "0", "M1_STREAMS": "0"}, 29700)
 for i in range(runs):
     ex_i = dict(extra)

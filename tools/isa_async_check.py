@@ -12,8 +12,8 @@ register of an asm-issued load before a wait that covers it.
 
     python tools/isa_async_check.py [file.hip ...]       (default: every csrc/*.hip, production flags of csrc/Makefile)
 
-The scan is linear per kernel (loops are walked once, pending loads survive labels and branches): conservative for
-straight-line software pipelines, which is what these kernels are.  Exit status 1 when anything is reported.
+Every kernel's basic blocks are walked along the control-flow graph (path-sensitive: the queue of outstanding loads is part of the
+state, states are memoised per block).  Exit status 1 when anything is reported.
 """
 import glob
 import os
@@ -41,13 +41,13 @@ def regs_of(text):
 
 def makefile_flags():
     mk = open(os.path.join(CSRC, "Makefile")).read()
-    nopk = re.search(r"^NOPK\s*\?=\s*(.*)$", mk, re.M).group(1).split()
+    nopk = re.search(r"^NOPK\s*:?\??=\s*(.*)$", mk, re.M).group(1).split()
     return ["-O3", "-std=c++17", "--offload-arch=gfx950"] + nopk
 
 
 def compile_s(src, flags):
     out = f"/tmp/isa_check_{os.path.basename(src)}.s"
-    subprocess.run([HIPCC, "-S", "--cuda-device-only", *flags, "-o", out, src], check=True, cwd=CSRC, stderr=subprocess.DEVNULL)
+    subprocess.run([HIPCC, "-S", "--cuda-device-only", *flags, "-o", out, os.path.abspath(src)], check=True, cwd=CSRC, stderr=subprocess.DEVNULL)
     return out
 
 
@@ -196,6 +196,11 @@ def check_file(path, max_visits=400000):
     for kernel, items in split_kernels(path).items():
         if not any(it[1] != "label" and it[2] for it in items):
             continue                                      # no inline asm in this function
+        # inline asm that writes M0 (LDS-DMA base) does not declare it: no compiler-generated instruction of the same kernel may use M0
+        if any(it[1] != "label" and it[2] and re.search(r"\bm0\b", it[1]) for it in items):
+            for it in items:
+                if it[1] != "label" and not it[2] and re.search(r"\bm0\b", it[1]):
+                    findings.add((kernel, it[0], it[1], 0, "inline asm of this kernel writes m0 undeclared", (("m", 0),)))
         blocks = build_blocks(items)
         if not blocks:
             continue
