@@ -253,6 +253,30 @@ def capture_with_fallback(gmode, dist_on, capture, reducer=None, sync=lambda: No
     return graph, gmode, err
 
 
+def drain_watchdog(timeout_s=20.0):
+    """Block until the RCCL process group's watchdog thread has retired every collective issued so far.  The flight recorder marks an
+    entry 'completed' exactly when the watchdog takes it off its list (ProcessGroupNCCL's work-cleanup loop), so polling the recorder
+    is a deterministic drain (round-4 advisor finding: the fixed 1 s sleep was a timing assumption).  Falls back to the sleep when the
+    recorder is off or unreadable.  Returns how the drain ended (for the debug log)."""
+    import pickle
+    import torch
+    torch.cuda.synchronize()                                  # the collectives themselves are finished on the GPU
+    t0 = time.time()
+    try:
+        while time.time() - t0 < timeout_s:
+            tr = pickle.loads(torch._C._distributed_c10d._dump_nccl_trace(True, False, False))
+            ents = tr.get("entries", []) if isinstance(tr, dict) else []
+            if not ents:
+                break                                         # recorder off (TORCH_NCCL_TRACE_BUFFER_SIZE=0): cannot observe the list
+            if all(e.get("state") == "completed" for e in ents):
+                return f"retired {len(ents)} collectives after {time.time() - t0:.3f} s"
+            time.sleep(0.01)
+    except Exception as e:  # noqa: BLE001 -- recorder API differs: fall back
+        _dbg(f"flight recorder unavailable ({type(e).__name__}: {e}); timed drain")
+    time.sleep(1.0)
+    return "timed (1 s)"
+
+
 def _dbg(msg):
     if os.environ.get("M1_BENCH_DEBUG"):
         print(f"[rank {os.environ.get('RANK', '0')}] {msg}", file=sys.stderr, flush=True)
@@ -366,13 +390,13 @@ def run_workload(a, wl, ctx, want_roofline, want_cpu):
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
         note("prelude")
-        if (dist_on and backend == "nccl" and os.environ.get("M1_BENCH_NO_SLEEP") != "1") or os.environ.get("M1_BENCH_SLEEP") == "1":
+        if dist_on and backend == "nccl":
             # The process group's watchdog thread retires finished collectives by polling their end events (every ~100 ms).  The
             # collectives of the eager step above are finished, but may not have been polled yet -- and their events were recorded
             # on the group's internal stream, which JOINS THE CAPTURE with the first captured collective: HIP then refuses the
             # query ("operation not permitted on an event last recorded in a capturing stream") and the watchdog aborts the
-            # process (seen in 1 of 3 ... 1 of 8 runs of the probabilistic model).  Give the watchdog time to drain its list.
-            time.sleep(1.0)
+            # process (seen in 1 of 3 ... 1 of 8 runs of the probabilistic model).  Wait until the watchdog HAS retired them.
+            _dbg("watchdog drain: " + drain_watchdog())
         gr = torch.cuda.CUDAGraph()
         if os.environ.get("M1_BENCH_CAPTURE_TL") in ("0", "1"):      # debug: force the capture error mode
             thread_local = os.environ["M1_BENCH_CAPTURE_TL"] == "1"
@@ -607,8 +631,12 @@ def main():
             # recorded in a capturing stream cannot be queried: hipErrorCapturedEvent, the watchdog then terminates the process --
             # seen once in three runs of the probabilistic model through this path).  PyTorch's CUDA-graph notes prescribe this
             # switch for whole-step capture with NCCL; both spellings, set before the group exists
-            os.environ.setdefault("TORCH_NCCL_ASYNC_ERROR_HANDLING", "0")
-            os.environ.setdefault("NCCL_ASYNC_ERROR_HANDLING", "0")
+            # -- only when the step WILL be captured with its collectives (graph mode "full"); eager / split runs keep the default
+            # (hang detection on a real multi-GPU run).  The flight recorder lets drain_watchdog() see the watchdog's list.
+            if not a.no_graph and os.environ.get("M1_DDP_GRAPH", "full") == "full":
+                os.environ.setdefault("TORCH_NCCL_ASYNC_ERROR_HANDLING", "0")
+                os.environ.setdefault("NCCL_ASYNC_ERROR_HANDLING", "0")
+            os.environ.setdefault("TORCH_NCCL_TRACE_BUFFER_SIZE", "2000")
             dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group(backend=backend, rank=rank, world_size=world)

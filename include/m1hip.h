@@ -137,6 +137,11 @@ int m1_debug_lds_canary(unsigned* bad, int blocks, int spins, void* stream);
  * (so that all CUs are covered).  A kernel that reads LDS or a register it never wrote then yields NaN instead of a value that
  * depends on its predecessor on that CU. */
 int m1_debug_checksum(const void* p, long long nbytes, unsigned long long* slot, void* stream);
+/* Kernel-choice log: which kernel the dispatch put behind the conv-like launches since the log was last cleared, as a comma-separated
+ * list ("conv_t3:bn160:ks2,wgrad_t3:kws16:big1,conv_mfma:128x128:w8:ks1", ...; valid until the next call).  mode 1 / 0: return the
+ * log, clear it and switch logging on / off; mode < 0: return it only.  Off by default.  The op tests of the special kernels assert
+ * on it: a shape the special kernel declines would otherwise compare the generic kernel with itself and stay green. */
+const char* m1_debug_kernels(int mode);
 int m1_debug_scribble(int blocks, int spins, void* stream);
 
 /* ---- Conv3DTranspose(padding='same') + bias : N:496-499,505-507,513-514,520,546-553 ----

@@ -181,6 +181,10 @@ static inline int m1_check_launch() {
 }
 static inline long long cdiv_ll(long long a, long long b) { return (a + b - 1) / b; }
 
+// kernel-choice log (prof.hip; m1_debug_kernels in include/m1hip.h): the dispatch names the kernel behind every conv-like launch so
+// that a test of a special kernel can assert it ran (a declined shape would otherwise compare the generic kernel with itself)
+void m1_note_kernel(const char* fmt, ...);
+
 // profiler hooks (prof.hip)
 struct M1ProfScope {
     int slot;

@@ -183,6 +183,7 @@ static int launch_gather(const GatherP& p, int dtype, hipStream_t st) {
     }
     const int ocTiles = (p.OC + GT_O - 1) / GT_O;
     dim3 grid((unsigned)cdiv_ll(maxQV, GT_V), classes, p.N * ocTiles);
+    m1_note_kernel("conv_gather");
     if (dtype == M1_BF16) hipLaunchKernelGGL(conv_gather_kernel<bf16_t>, grid, dim3(256), 0, st, p);
     else hipLaunchKernelGGL(conv_gather_kernel<float>, grid, dim3(256), 0, st, p);
     return m1_check_launch();
@@ -286,6 +287,7 @@ int m1_direct_wgrad(const WgradSpec& spec, hipStream_t st) {
     splits = cdiv_ll(TV, vps);
     p.vox_per_split = vps;
     dim3 grid(aTiles * bTiles, taps, (unsigned)splits);
+    m1_note_kernel("conv_wgrad_direct");
     if (dtype == M1_BF16) hipLaunchKernelGGL(conv_wgrad_kernel<bf16_t>, grid, dim3(256), 0, st, p);
     else hipLaunchKernelGGL(conv_wgrad_kernel<float>, grid, dim3(256), 0, st, p);
     return m1_check_launch();
@@ -375,6 +377,7 @@ static int skinny_launch(WgradP p, hipStream_t st) {
     blocks = cdiv_ll(TV, p.vox_per_split);
     const dim3 grid((unsigned)blocks), blk(256);
     const bool smallA = p.CA <= 4 && p.CB <= 256;
+    m1_note_kernel("wgrad_skinny");
 #define SK(NT_, SM_, SA_) hipLaunchKernelGGL((wgrad_skinny_kernel<T, NT_, SM_, SA_>), grid, blk, 0, st, p)
     if (smallA) { if (nt == 1) SK(1, 4, true); else if (nt == 9) SK(9, 4, true); else SK(27, 4, true); }
     else if (p.CB <= 4) { if (nt == 1) SK(1, 4, false); else if (nt == 9) SK(9, 4, false); else SK(27, 4, false); }

@@ -623,6 +623,7 @@ int m1_halo_conv(const MfmaP& mp, int OCpad, hipStream_t st) {
             if (ndone < 24) done[ndone++] = (const void*)kern;
         }
     }
+    m1_note_kernel(p.ncls == 4 ? "conv_halo_cls:bn%d" : "conv_halo:bn%d", p.BNh);
     hipLaunchKernelGGL(kern, dim3(slices, nsplit), dim3(p.nthr), smem, st, p);
     return m1_check_launch();
 }

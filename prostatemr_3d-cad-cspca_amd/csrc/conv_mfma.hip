@@ -919,6 +919,7 @@ static int launch_cfg_kc(const MfmaP& mp, long long maxM, int OCpad, hipStream_t
         if (hipFuncSetAttribute((const void*)conv_mfma_kernel<T, BM, BN, WM, WN, KC, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) return M1_ERR_LAUNCH;
         attr_set = true;
     }
+    m1_note_kernel("conv_mfma:%dx%d:w%d:ks%d", BM, BN, WM * WN, mp.ksplit);
     hipLaunchKernelGGL(kern, grid, dim3(WM * WN * 64), smem, st, mp);
     return m1_check_launch();
 }

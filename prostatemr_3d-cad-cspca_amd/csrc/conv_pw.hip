@@ -272,6 +272,7 @@ int m1_pw_conv(const MfmaP& mp, int OCpad, int BN, hipStream_t st) {
             if (ndone < 16) done[ndone++] = (const void*)kern;
         }
     }
+    m1_note_kernel("conv_pw:bn%d", BN);
     hipLaunchKernelGGL(kern, dim3(OCpad / BN, p.nwaves / 4), dim3(256), smem, st, p);
     return m1_check_launch();
 }

@@ -473,6 +473,7 @@ int m1_ct3_conv(const MfmaP& mp, int BN, int OCpad, hipStream_t st) {
     }
     const long long tiles = (long long)q.tps * mp.N;
     dim3 grid((unsigned)(cdiv_ll(tiles, 8) * 8), (unsigned)mp.ksplit, (unsigned)(OCpad / BN));
+    m1_note_kernel("conv_t3:bn%d:ks%d", BN, mp.ksplit);
     hipLaunchKernelGGL(kern, grid, dim3(CT3_THREADS), smem, st, mp, q);
     return m1_check_launch();
 }

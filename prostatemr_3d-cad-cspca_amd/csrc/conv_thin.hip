@@ -198,6 +198,7 @@ int m1_thin_conv_try(const GatherSpec& g, hipStream_t st, int* rc) {
         const bool stats = g.stats_out && g.stats_ws;
         if (g.stats_out && !stats) return 0;
         p.stat_partial = stats ? g.stats_ws : nullptr;
+        m1_note_kernel("thin_fwd");
         hipLaunchKernelGGL(thin_fwd_kernel, dim3((unsigned)p.nsplit), dim3(256), 0, st, p);
         *rc = m1_check_launch();
         if (!*rc && stats) *rc = m1_reduce_finalize_launch<2>(g.stats_ws, g.N, g.OC, p.nsplit, g.stats_out, Vout, g.stats_eps, st);
@@ -209,6 +210,7 @@ int m1_thin_conv_try(const GatherSpec& g, hipStream_t st, int* rc) {
         p.dy = (const bf16_t*)g.src[0]; p.dx = (bf16_t*)out; p.w = g.w; p.wSC = g.wSC; p.wSO = g.wSO; p.nvox = (long long)g.N * Vout;
         p.CC = CC; p.OC = g.OC; p.accumulate = acc;
         long long nb = cdiv_ll(p.nvox * (g.OC / 8), 256 * 4); if (nb > 4096) nb = 4096; if (nb < 1) nb = 1;
+        m1_note_kernel("thin_pw_dgrad");
         hipLaunchKernelGGL(thin_pw_dgrad_kernel, dim3((unsigned)nb), dim3(256), (size_t)CC * g.OC * sizeof(float), st, p);
         *rc = m1_check_launch();
         return 1;

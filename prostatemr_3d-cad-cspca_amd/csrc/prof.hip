@@ -4,6 +4,8 @@
 #include <string.h>
 #include <vector>
 #include <mutex>
+#include <stdarg.h>
+#include <string>
 
 namespace {
 struct Rec { char name[48]; double flops, bytes; long long launches; };
@@ -58,6 +60,23 @@ extern "C" int m1_prof_read(m1_prof_rec_t* out, int max_n) {
         out[n].total_ms = ms[i]; out[n].flops = g_recs[i].flops; out[n].bytes = g_recs[i].bytes; out[n].launches = g_recs[i].launches;
     }
     return n;
+}
+
+// ---- kernel-choice log: off until m1_debug_kernels(1) is called; names are appended, comma-separated, up to 16 KB
+namespace { bool g_klog_on = false; std::string g_klog; std::mutex g_klog_mu; }
+void m1_note_kernel(const char* fmt, ...) {
+    if (!g_klog_on) return;
+    char buf[160];
+    va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof(buf), fmt, ap); va_end(ap);
+    std::lock_guard<std::mutex> lk(g_klog_mu);
+    if (g_klog.size() < 16384) { if (!g_klog.empty()) g_klog += ','; g_klog += buf; }
+}
+extern "C" const char* m1_debug_kernels(int mode) {
+    static std::string out;
+    std::lock_guard<std::mutex> lk(g_klog_mu);
+    out = g_klog;
+    if (mode >= 0) { g_klog.clear(); g_klog_on = mode != 0; }
+    return out.c_str();
 }
 
 // ---- debug: LDS canary.  Blocks fill 31 KB of static LDS (the footprint of thin_fwd_kernel) with a pattern and re-read it `spins`

@@ -270,8 +270,10 @@ static int launch_wg(WgP p, hipStream_t st) {
     p.xcd_total = 0; p.xcd_gx = (int)grid.x; p.xcd_gy = (int)grid.y; p.xcd_gz = (int)grid.z;
     if (xr && (long long)grid.x * grid.y > 1 && splits > 1) {
         p.xcd_total = (int)(((long long)grid.x * grid.y * grid.z + 7) / 8 * 8);
+        m1_note_kernel("wgrad_mfma");
         hipLaunchKernelGGL((wgrad_mfma_kernel<T, TA, TB, KB>), dim3((unsigned)p.xcd_total), dim3(256), 0, st, p);
     } else {
+        m1_note_kernel("wgrad_mfma");
         hipLaunchKernelGGL((wgrad_mfma_kernel<T, TA, TB, KB>), grid, dim3(256), 0, st, p);
     }
     int rc = m1_check_launch(); if (rc) return rc;

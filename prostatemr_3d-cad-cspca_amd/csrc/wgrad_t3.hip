@@ -634,6 +634,7 @@ int m1_t3_wgrad(const WgradSpec& g, long long nw, int nb, hipStream_t st, int nm
             if (ndone < 20) done[ndone++] = (const void*)kern;
         }
     }
+    m1_note_kernel(f32 ? "wgrad_t3f:kws%d:big%d" : (s2 ? "wgrad_t3:s2:kws%d:big%d" : "wgrad_t3:kws%d:big%d"), p.KWs, (int)bigb);
     hipLaunchKernelGGL(kern, dim3((unsigned)gx, (unsigned)nsplit, (unsigned)(gzu * g.kd)), dim3(T3_THREADS), smem, st, p);
     int rc = m1_check_launch(); if (rc) return rc;
     for (int m = 0; m < nmem; ++m) {                      // one fold per member (its own block of R; the bias sums ride on member 0)

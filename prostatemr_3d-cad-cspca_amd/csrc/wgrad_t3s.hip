@@ -303,6 +303,7 @@ int m1_t3s_wgrad(const WgradSpec& g, long long nw, int nb, hipStream_t st) {
             if (ndone < 16) done[ndone++] = (const void*)kern;
         }
     }
+    m1_note_kernel("wgrad_t3s");
     hipLaunchKernelGGL(kern, dim3((unsigned)nbu, (unsigned)nsplit, (unsigned)(p.nau * g.kd)), dim3(TS_THREADS), smem, st, p);
     int rc = m1_check_launch(); if (rc) return rc;
     return m1_wg_rx_finish(p.Rx, stride, (int)nsplit, g, nloc, st);
@@ -459,6 +460,7 @@ int m1_pwf_wgrad(const WgradSpec& g, long long nw, int nb, hipStream_t st) {
         if (hipFuncSetAttribute((const void*)wgrad_pwf_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return M1_ERR_LAUNCH;
         attr = true;
     }
+    m1_note_kernel("wgrad_pwf");
     hipLaunchKernelGGL(wgrad_pwf_kernel, dim3((unsigned)nbu, (unsigned)nsplit, (unsigned)nau), dim3(PW_THREADS), smem, st, p);
     int rc = m1_check_launch(); if (rc) return rc;
     return m1_wg_rx_finish(p.Rx, stride, (int)nsplit, g, nloc, st);

@@ -321,8 +321,10 @@ int m1_tap_wgrad(const WgradSpec& g, long long nw, int nb, hipStream_t st) {
     p.ctiles = ctiles; p.taps = taps; p.xcd_total = 0;
     if (xr && taps > 1) {
         p.xcd_total = (int)(((long long)ctiles * nsplit * taps + 7) / 8 * 8);
+        m1_note_kernel("wgrad_tap");
         hipLaunchKernelGGL(kern, dim3((unsigned)p.xcd_total), dim3(256), smem, st, p);
     } else {
+        m1_note_kernel("wgrad_tap");
         hipLaunchKernelGGL(kern, dim3(ctiles, (unsigned)nsplit, taps), dim3(256), smem, st, p);
     }
     int rc = m1_check_launch(); if (rc) return rc;

@@ -561,6 +561,7 @@ static int tf_wgrad_launch(const WgradSpec& g, long long nw, int nb, hipStream_t
             if (ndone < 8) done[ndone++] = (const void*)kern;
         }
     }
+    m1_note_kernel("wgrad_tf");
     hipLaunchKernelGGL(kern, grid, dim3(256), smem, st, p);
     int rc = m1_check_launch(); if (rc) return rc;
     if (nmem <= 1) return m1_wg_rx_finish(p.Rx, stride, (int)nsplit, g, nloc, st);

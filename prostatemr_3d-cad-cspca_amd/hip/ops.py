@@ -1369,13 +1369,23 @@ def set_force_direct(on: bool):
     L.load().m1_set_force_direct(int(on) if not isinstance(on, bool) else (1 if on else 0))
 
 
+_CFG_OVERRIDES = {}          # switches set through config_set (name -> value): what ``config`` restores on exit
+
+
 def config_set(name: str, value: int) -> None:
-    """Set a tuning switch of libm1hip.so (m1_config_set): effective from the next launch that consults it."""
+    """Set a tuning switch of libm1hip.so (m1_config_set): effective from the next launch that consults it.  Switches such as
+    M1_CONV_T3 / M1_CT3_BN / M1_CT3_KSPLIT / M1_HALO / M1_KORDER change the K order, padding and split-K slab size of the packed weight
+    panels and the size of their workspaces, which are cached by layer geometry: every change drops the cached panels (they are
+    re-packed, and their workspaces re-sized under the new plan, at the next use)."""
     L.check(L.load().m1_config_set(name.encode(), int(value)), "m1_config_set")
+    _CFG_OVERRIDES[name] = int(value)
+    invalidate_panels()
 
 
 def config_unset(name: str) -> None:
     L.check(L.load().m1_config_unset(name.encode()), "m1_config_unset")
+    _CFG_OVERRIDES.pop(name, None)
+    invalidate_panels()
 
 
 def config_get(name: str):
@@ -1385,20 +1395,45 @@ def config_get(name: str):
 
 
 class config:
-    """``with ops.config(M1_T3_MIN_BLOCKS=1): ...`` -- switches set for the block, restored after it."""
+    """``with ops.config(M1_T3_MIN_BLOCKS=1): ...`` -- switches set for the block; on exit each one returns to what it was before the
+    block: the override an enclosing ``config`` / ``config_set`` had put there, or no override at all."""
 
     def __init__(self, **kv):
         self.kv = kv
+        self.prev = {}
 
     def __enter__(self):
         for k, v in self.kv.items():
+            self.prev[k] = _CFG_OVERRIDES.get(k)          # None = there was no override
             config_set(k, v)
         return self
 
     def __exit__(self, *exc):
         for k in self.kv:
-            config_unset(k)
+            if self.prev.get(k) is None:
+                config_unset(k)
+            else:
+                config_set(k, self.prev[k])
         return False
+
+
+class kernel_log:
+    """``with ops.kernel_log() as kl: ...; kl.names`` -- the kernels the library's dispatch launched for the conv-like entry points
+    inside the block (m1_debug_kernels), e.g. ['conv_t3:bn160:ks2', 'wgrad_t3:kws16:big1'].  ``kl.ran('conv_t3')`` is true when a
+    name starts with that prefix."""
+
+    def __enter__(self):
+        L.load().m1_debug_kernels(1)
+        self.names = []
+        return self
+
+    def __exit__(self, *exc):
+        raw = L.load().m1_debug_kernels(0)
+        self.names = [n for n in (raw.decode() if raw else "").split(",") if n]
+        return False
+
+    def ran(self, prefix: str) -> bool:
+        return any(n == prefix or n.startswith(prefix + ":") for n in self.names)
 
 
 def prof_enable(on: bool):

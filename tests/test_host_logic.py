@@ -441,9 +441,19 @@ def test_config_switches_are_set_and_restored_through_the_abi():
     assert ops.config_get("M1_NO_SUCH_SWITCH_YET") is None
     ops.config_set("M1_TEST_SWITCH", 17)
     assert ops.config_get("M1_TEST_SWITCH") == 17
+    epoch = ops._PANEL_EPOCH[0]
     with ops.config(M1_TEST_SWITCH=3):
         assert ops.config_get("M1_TEST_SWITCH") == 3
+        with ops.config(M1_TEST_SWITCH=5):                                   # nested blocks restore level by level
+            assert ops.config_get("M1_TEST_SWITCH") == 5
+        assert ops.config_get("M1_TEST_SWITCH") == 3
+    assert ops.config_get("M1_TEST_SWITCH") == 17                           # the enclosing override is back (round-4 advisor finding)
+    assert ops._PANEL_EPOCH[0] >= epoch + 4                                   # every change dropped the cached weight panels
+    ops.config_unset("M1_TEST_SWITCH")
     assert ops.config_get("M1_TEST_SWITCH") is None                     # override dropped, no default known, not in the environment
+    with ops.config(M1_TEST_SWITCH=9):
+        assert ops.config_get("M1_TEST_SWITCH") == 9
+    assert ops.config_get("M1_TEST_SWITCH") is None                     # no override before the block: none after it
     assert lib.m1_config_set(b"PATH", 1) == -1 and lib.m1_config_set(None, 1) == -1
     # the suite's environment default for the wgrad_t3 floor (conftest) is visible through the same table
     ops.config_set("M1_T3_MIN_BLOCKS", 128)
