@@ -137,6 +137,12 @@ def instance_norm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor) -> t
 
 _FORCED_PATTERN = None
 _STORE_BF16 = False
+# the classes of stored tensors bf16_storage() rounds (round 5: per-class switches, tools/bf16_class_table.py): "conv" = conv /
+# transposed-conv outputs, "act" = InstanceNorm(+LeakyReLU) outputs, "block" = SE-block outputs (behind the dropout), "gate" = the
+# attention gate's sigma, sigma*x and its output norm, "input" = the network input, "latent" = the sampled z, "weights" = the packed
+# kernels, "grad" = the data gradients flowing back through every one of those points
+BF16_CLASSES = ("conv", "act", "block", "gate", "input", "latent", "weights", "grad")
+_STORE_CLASSES = frozenset(BF16_CLASSES)
 
 
 class bf16_storage:
@@ -147,14 +153,20 @@ class bf16_storage:
     the plain oracle is the error bf16 STORAGE alone causes, the yardstick the bf16 parity tests scale their tolerance by
     ("bf16 mode gets its own (looser) tolerance").  Gradients pass straight through the rounding."""
 
+    def __init__(self, classes=None):
+        """``classes``: the subset of BF16_CLASSES to round (None = all of them, what the product stores)."""
+        self.classes = frozenset(BF16_CLASSES if classes is None else classes)
+        assert self.classes <= frozenset(BF16_CLASSES), self.classes
+
     def __enter__(self):
-        global _STORE_BF16
-        self.prev, _STORE_BF16 = _STORE_BF16, True
+        global _STORE_BF16, _STORE_CLASSES
+        self.prev, _STORE_BF16 = (_STORE_BF16, _STORE_CLASSES), True
+        _STORE_CLASSES = self.classes
         return self
 
     def __exit__(self, *exc):
-        global _STORE_BF16
-        _STORE_BF16 = self.prev
+        global _STORE_BF16, _STORE_CLASSES
+        _STORE_BF16, _STORE_CLASSES = self.prev
         return False
 
 
@@ -163,22 +175,26 @@ class _RoundBf16(torch.autograd.Function):
     product's data gradients are bf16 tensors too)."""
 
     @staticmethod
-    def forward(ctx, x):
-        return x.to(torch.bfloat16).to(x.dtype)
+    def forward(ctx, x, fwd, bwd):
+        ctx.bwd = bwd
+        return x.to(torch.bfloat16).to(x.dtype) if fwd else x.clone()
 
     @staticmethod
     def backward(ctx, g):
-        return g.to(torch.bfloat16).to(g.dtype)
+        return (g.to(torch.bfloat16).to(g.dtype) if ctx.bwd else g), None, None
 
 
-def _st(x: torch.Tensor) -> torch.Tensor:
-    """bf16 storage rounding; identity outside ``with bf16_storage():``."""
-    return _RoundBf16.apply(x) if _STORE_BF16 else x
+def _st(x: torch.Tensor, cls: str = "conv") -> torch.Tensor:
+    """bf16 storage rounding of a tensor of class ``cls`` (BF16_CLASSES); identity outside ``with bf16_storage():``."""
+    if not _STORE_BF16:
+        return x
+    fwd, bwd = cls in _STORE_CLASSES, "grad" in _STORE_CLASSES
+    return _RoundBf16.apply(x, fwd, bwd) if (fwd or bwd) else x
 
 
 def _stw(w: torch.Tensor) -> torch.Tensor:
     """bf16 weight panels: the convs multiply bf16-rounded kernels; the weight GRADIENT is an fp32 accumulator (not rounded)."""
-    return w + (w.detach().to(torch.bfloat16).to(w.dtype) - w.detach()) if _STORE_BF16 else w
+    return w + (w.detach().to(torch.bfloat16).to(w.dtype) - w.detach()) if (_STORE_BF16 and "weights" in _STORE_CLASSES) else w
 
 
 class forced_activation_pattern:
@@ -235,9 +251,9 @@ def lrelu(x: torch.Tensor, tag: Optional[str] = None) -> torch.Tensor:
             nf = int((m != (x.detach() >= 0)).sum())
             if nf:
                 _FORCED_PATTERN.flips[tag] = _FORCED_PATTERN.flips.get(tag, 0) + nf
-            return _st(torch.where(m, x, LRELU * x)) if tag is not None else torch.where(m, x, LRELU * x)
+            return _st(torch.where(m, x, LRELU * x), "act") if tag is not None else torch.where(m, x, LRELU * x)
     y = torch.where(x >= 0, x, LRELU * x)
-    return _st(y) if (tag is not None and not tag.endswith(".f")) else y        # (tagged = a stored activation; the gate's f is not)
+    return _st(y, "act") if (tag is not None and not tag.endswith(".f")) else y        # (tagged = a stored activation; the gate's f is not)
 
 
 def upsample_nearest(x: torch.Tensor, size: Sequence[int]) -> torch.Tensor:
@@ -254,7 +270,7 @@ def dropout_with_mask(x: torch.Tensor, rate: float, mask: Optional[torch.Tensor]
     if rate == 0.0:
         return x
     assert mask is not None, "oracle dropout needs an injected keep-mask"
-    return _st(x * mask / (1.0 - rate))
+    return _st(x * mask / (1.0 - rate), "block")
 
 
 # --------------------------------------------------------------------------------------------------
@@ -294,12 +310,12 @@ def grid_attention_block(P: Dict[str, torch.Tensor], pre: str, x: torch.Tensor, 
     phi = upsample_nearest(phi, scale)                                                        # B:116
     f = lrelu(theta + phi, pre + ".f")                                                        # B:117
     psi = conv3d_same(f, P[pre + ".psi.kernel"], P[pre + ".psi.bias"], (1, 1, 1))             # B:118
-    sig = _st(torch.sigmoid(psi))                                                             # B:119
+    sig = _st(torch.sigmoid(psi), "gate")                                                             # B:119
     scale = [x.shape[1 + i] // sig.shape[1 + i] for i in range(3)]                            # B:120-122
     sig = upsample_nearest(sig, scale)                                                        # B:123
-    y = _st(sig * x)                                                                          # B:124
+    y = _st(sig * x, "gate")                                                                          # B:124
     wy = conv3d_same(y, P[pre + ".W.kernel"], P[pre + ".W.bias"], (1, 1, 1))                  # B:127
-    wy = _st(instance_norm(wy, P[pre + ".normW.gamma"], P[pre + ".normW.beta"]))              # B:128
+    wy = _st(instance_norm(wy, P[pre + ".normW.gamma"], P[pre + ".normW.beta"]), "gate")              # B:128
     return wy, sig
 
 
@@ -342,7 +358,7 @@ def m1core_forward(P: Dict[str, torch.Tensor], pre: str, cfg: M1Config, inputs: 
     dm = drop_masks or {}
     if _FORCED_PATTERN is not None:
         _FORCED_PATTERN.enter_core(pre)
-    inputs = _st(inputs)
+    inputs = _st(inputs, "input")
     deep_sup = cfg.deep_supervision if deep_supervision is None else deep_supervision
     o = CoreOut()
 
@@ -432,7 +448,7 @@ def m1core_forward(P: Dict[str, torch.Tensor], pre: str, cfg: M1Config, inputs: 
                     z = mu
                 else:                                                               # N:647
                     e = next(eps_it)
-                    z = _st(mu + torch.exp(logsig_c) * e)
+                    z = _st(mu + torch.exp(logsig_c) * e, "latent")
                 o.prob_mu_logsigma.append(ml)
                 o.prob_mu.append(mu)
                 o.prob_logsig.append(logsig_c)
