@@ -371,6 +371,11 @@ def run_workload(a, wl, ctx, want_roofline, want_cpu):
         step()
         note("eager")
     torch.cuda.synchronize()
+    live_elems = None
+    if reducer is not None:
+        # layers no output of the training graph reads never receive a gradient (sersd0 / logits, the pruned posterior layers): their
+        # ranges of the flat buffer are exactly zero on every rank and stay out of the exchange
+        live_elems = opt.refresh_live_ranges()
     _dbg("eager warm-up done")
     # N = 1: the whole step is one hipGraph.  N > 1 over RCCL ("full"): the same, the collectives are captured on the
     # communication stream inside it; "split" (fallback): forward+backward are captured without collectives, the exchange
@@ -455,7 +460,9 @@ def run_workload(a, wl, ctx, want_roofline, want_cpu):
         exchange = {"backend": backend, "graph_mode": gmode, "groups": len(reducer.order), "buckets": len(reducer.order) + 1,
                     "groups_sent_during_backward": st["early_groups"], "groups_sent_after_backward": st["late_groups"],
                     "collectives_issued": st["collectives"], "host_steps": reducer._step,
-                    "bytes_per_step": 4 * opt.flatp.grad.numel(), "replicas_in_sync": bool(torch.equal(lo, hi)),
+                    "bytes_per_step": 4 * (live_elems if live_elems else opt.flatp.grad.numel()),
+                    "dead_bytes_not_exchanged": 4 * (opt.flatp.grad.numel() - live_elems) if live_elems else 0,
+                    "rs_ag": bool(reducer.rs_ag), "replicas_in_sync": bool(torch.equal(lo, hi)),
                     "note": "groups are sent from the communication stream as backward completes them (ddp.py); counters "
                             "count host-side calls (in graph mode 'full' the captured collectives replay without them)"}
     final_loss = float(loss_buf)

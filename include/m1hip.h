@@ -7,8 +7,16 @@
  *
  * Conventions
  *   - plain pointers and sizes only; the caller (PyTorch, or any host) owns every buffer, including
- *     workspaces; no allocation, no global mutable state (except the opt-in profiler), no hidden
- *     synchronisation; every launch goes to the caller's hipStream_t (graph-capturable).
+ *     workspaces; no device allocation, no hidden synchronisation; every launch goes to the caller's
+ *     hipStream_t (graph-capturable: no memset / memcpy nodes, zero fills are kernels).
+ *   - process-global host state the library DOES keep (all of it behind mutexes, none of it device memory):
+ *     the tuning-switch table (m1_config_*), the queue of deferred weight-gradient folds between m1_wgrad_defer(1)
+ *     and m1_wgrad_fold_pending / _drop (the queued jobs point into caller-owned workspaces, which the caller keeps
+ *     alive until then), the test hook m1_set_force_direct, the opt-in profiler (m1_prof_*) and the opt-in
+ *     kernel-choice log (m1_debug_kernels).  One thread drives the library at a time per process.
+ *   - results are bit-reproducible run to run in the default configuration: every reduction across blocks goes
+ *     through per-split partials folded in a fixed order.  Floating-point atomics remain compiled in behind
+ *     switches only (M1_WG_DET=0, m1_set_force_direct: the generic fp32 reference kernels of conv_direct.hip).
  *   - activations are NDHWC, C-contiguous; `dtype` selects their storage type
  *     (M1_F32 / M1_BF16); parameters, statistics, reductions and gradients of parameters are fp32.
  *   - every function returns 0 on success or a negative m1_status.

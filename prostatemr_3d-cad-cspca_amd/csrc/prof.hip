@@ -62,14 +62,14 @@ extern "C" int m1_prof_read(m1_prof_rec_t* out, int max_n) {
     return n;
 }
 
-// ---- kernel-choice log: off until m1_debug_kernels(1) is called; names are appended, comma-separated, up to 16 KB
+// ---- kernel-choice log: off until m1_debug_kernels(1) is called; names are appended, comma-separated, up to 1 MB
 namespace { bool g_klog_on = false; std::string g_klog; std::mutex g_klog_mu; }
 void m1_note_kernel(const char* fmt, ...) {
     if (!g_klog_on) return;
     char buf[160];
     va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof(buf), fmt, ap); va_end(ap);
     std::lock_guard<std::mutex> lk(g_klog_mu);
-    if (g_klog.size() < 16384) { if (!g_klog.empty()) g_klog += ','; g_klog += buf; }
+    if (g_klog.size() < (1u << 20)) { if (!g_klog.empty()) g_klog += ','; g_klog += buf; }
 }
 extern "C" const char* m1_debug_kernels(int mode) {
     static std::string out;

@@ -78,6 +78,9 @@ class GradReducer:
         self._before_send: Callable[[], None] = lambda: None
         self._on_origin: Callable[[], bool] = lambda: True
         self._deferred: List[str] = []      # groups that completed while a branch stream was current (sent from the next origin-stream hook)
+        self._live: Optional[List[Tuple[int, int]]] = None       # set_live(): the parts of the buffer that can be non-zero
+        # M1_DDP_RSAG=1: reduce-scatter + all-gather per bucket instead of one all-reduce (unmeasured: no multi-GPU node was available)
+        self.rs_ag = os.environ.get("M1_DDP_RSAG", "0") == "1"
         self.stats = {"buckets": 0, "early_groups": 0, "late_groups": 0, "collectives": 0}
 
     # ------------------------------------------------------------------------------------------------------
@@ -106,10 +109,40 @@ class GradReducer:
             self._comm = torch.cuda.Stream(device=flat_grad.device)
 
     # ------------------------------------------------------------------------------------------------------
+    def set_live(self, runs: Sequence[Tuple[int, int]]) -> None:
+        """``runs``: sorted, disjoint [lo, hi) ranges of the flat buffer that can hold a non-zero gradient (optim.FlatParams.live_ranges
+        after a first backward pass).  Everything else belongs to layers no output of the training graph reads -- zero on every rank --
+        and is left out of the exchange (sersd0 / logits and the pruned posterior layers of the probabilistic model)."""
+        self._live = [(int(a), int(b)) for a, b in runs if b > a]
+
+    def _pieces(self, lo: int, hi: int) -> List[Tuple[int, int]]:
+        """[lo, hi) cut down to its live parts (all of it when no live set is known)."""
+        if self._live is None:
+            return [(lo, hi)]
+        return [(max(lo, a), min(hi, b)) for a, b in self._live if a < hi and b > lo]
+
     def _reduce_range(self, lo: int, hi: int) -> None:
-        for a, b in bucket_bounds(hi - lo, self.bucket_elems):
-            dist.all_reduce(self.flat[lo + a:lo + b], op=dist.ReduceOp.SUM, group=self.group)
-            self.stats["collectives"] += 1
+        world = self.world_size
+        for plo, phi in self._pieces(lo, hi):
+            for a, b in bucket_bounds(phi - plo, self.bucket_elems):
+                t = self.flat[plo + a:plo + b]
+                m = (b - a) // world * world
+                if self.rs_ag and (world > 1 or self.force) and m >= 1024 * world:
+                    # reduce-scatter + all-gather in place (each rank owns 1/world of the bucket between the two): on xGMI every rank
+                    # exchanges its shard with all 7 peers directly, where a ring all-reduce relays through every rank (SURVEY 8e)
+                    c = m // world
+                    rank = dist.get_rank(self.group)
+                    shard = t[rank * c:(rank + 1) * c]
+                    dist.reduce_scatter_tensor(shard, t[:m], op=dist.ReduceOp.SUM, group=self.group)
+                    dist.all_gather_into_tensor(t[:m], shard, group=self.group)
+                    self.stats["collectives"] += 2
+                    if m < b - a:
+                        dist.all_reduce(t[m:], op=dist.ReduceOp.SUM, group=self.group)
+                        self.stats["collectives"] += 1
+                else:
+                    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+                    self.stats["collectives"] += 1
+            self.stats["elements"] = self.stats.get("elements", 0) + (phi - plo)
 
     def _send(self, key: str, early: bool) -> None:
         if key in self._sent:

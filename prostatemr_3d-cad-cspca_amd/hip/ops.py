@@ -161,6 +161,7 @@ def _sink(param: torch.Tensor, like: Optional[torch.Tensor] = None):
     autograd receives None (no per-parameter tensors, no AccumulateGrad adds, no gather pass)."""
     g = getattr(param, "_m1_gsink", None)
     if g is not None:
+        param._m1_live = True            # (a backward kernel writes this parameter's gradient: optim.FlatParams.live_ranges)
         return g, 1, None
     t = torch.empty_like(param if like is None else like, dtype=torch.float32)
     return t, 0, t

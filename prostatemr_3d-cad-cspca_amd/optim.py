@@ -99,6 +99,23 @@ class FlatParams:
             if p.grad is not None:
                 gv.add_(p.grad)
                 p.grad = None
+                p._m1_live = True
+
+    def live_ranges(self):
+        """[lo, hi) runs of the flat buffers whose parameters received a gradient in the backward passes run so far.  Layers no output
+        of the training graph reads get none -- in the hierarchical probabilistic model everything behind ``sersd0`` / ``logits`` of
+        both cores and the posterior's layers past its res2 latent head -- and their ranges stay exactly zero: a
+        data-parallel run need not exchange them (ddp.GradReducer.set_live)."""
+        runs, off = [], 0
+        for p in self.params:
+            n = p.numel()
+            if getattr(p, "_m1_live", False):
+                if runs and runs[-1][1] == off:
+                    runs[-1][1] = off + n
+                else:
+                    runs.append([off, off + n])
+            off += n
+        return [(a, b) for a, b in runs]
 
 
 class Adam:
@@ -164,6 +181,15 @@ class Adam:
             self.model.set_grad_marker(reducer.mark)
         return self
 
+    def refresh_live_ranges(self) -> int:
+        """After at least one backward pass: tell the reducer which parts of the flat gradient buffer ever receive a gradient, so
+        that the rest (dead layers: exactly zero on every rank) is left out of the exchange.  Returns the number of live elements.
+        The set is a function of the model graph, identical on every rank.  Call outside graph capture."""
+        live = self.flatp.live_ranges()
+        if self.reducer is not None and live:
+            self.reducer.set_live(live)
+        return sum(b - a for a, b in live)
+
     def exchange(self):
         """Complete the flat gradient buffer across ranks (no-op without a reducer)."""
         if self.reducer is not None:
@@ -186,3 +212,5 @@ class Adam:
         self.exchange()
         self.apply_flat()
         self.iterations += 1
+        if self.reducer is not None and self.iterations == 1 and not torch.cuda.is_current_stream_capturing():
+            self.refresh_live_ranges()       # from the second step on the dead layers' ranges (all zero) are not exchanged

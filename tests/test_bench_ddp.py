@@ -91,11 +91,13 @@ def test_bench_two_ranks_one_gpu_gloo(gmode):
 
 
 @pytest.mark.timeout(2 * CHILD_TIMEOUT_S + 60)
-def test_bench_rccl_world_of_one():
+@pytest.mark.parametrize("rs_ag", ["0", "1"])
+def test_bench_rccl_world_of_one(rs_ag):
     """bench.py's RCCL branch (init_process_group('nccl', device_id), bucketed all-reduce from the comm stream, barrier,
-    destroy) executed on one GPU: M1_BENCH_FORCE_DIST=1 makes a world of one take the N > 1 code path."""
+    destroy) executed on one GPU: M1_BENCH_FORCE_DIST=1 makes a world of one take the N > 1 code path.  rs_ag = 1: every bucket
+    as an in-place reduce-scatter + all-gather pair (M1_DDP_RSAG) -- the calls and their in-place layout run through RCCL."""
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29534", RANK="0", LOCAL_RANK="0", WORLD_SIZE="1",
-               M1_BENCH_FORCE_DIST="1", M1_BENCH_DEBUG="1")
+               M1_BENCH_FORCE_DIST="1", M1_BENCH_DEBUG="1", M1_DDP_RSAG=rs_ag)
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--workload", "C1", "--steps", "3", "--warmup", "1",
            "--no-cpu-baseline"]
     rc, out, err = _run_retrying_bringup(cmd, env)
@@ -103,6 +105,7 @@ def test_bench_rccl_world_of_one():
     ex = d["config"]["exchange"]
     assert ex["backend"] == "nccl" and ex["graph_mode"] == "full" and ex["replicas_in_sync"] is True, (ex, d["config"]["graph_error"])
     assert ex["collectives_issued"] > 0 and ex["groups_sent_during_backward"] > 0, ex
+    assert ex["rs_ag"] is (rs_ag == "1") and ex["dead_bytes_not_exchanged"] == 0, ex       # (the deterministic model has no dead layers)
 
 
 @pytest.mark.timeout(4 * CHILD_TIMEOUT_S + 60)
@@ -131,6 +134,8 @@ def test_bench_rccl_probabilistic_lanes_match_in_order_run(tmp_path):
         ex = d["config"]["exchange"]
         assert ex["backend"] == "nccl" and ex["graph_mode"] == "full" and d["config"]["graph_error"] is None, (tag, ex, d["config"]["graph_error"])
         assert ex["groups"] == 6 and ex["replicas_in_sync"] is True, (tag, ex)
+        # sersd0 / logits of both cores and the posterior's pruned layers receive no gradient: their ranges are not exchanged
+        assert 0 < ex["dead_bytes_not_exchanged"] < ex["bytes_per_step"], (tag, ex)
         if tag == "lanes":
             assert ex["groups_sent_during_backward"] > 0, ex
         import torch

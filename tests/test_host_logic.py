@@ -249,6 +249,31 @@ def test_two_rank_gloo_gradient_exchange_equals_global_batch_mean():
     assert np.array_equal(res[0][6][:16], np.full(16, 200.0)) and np.array_equal(res[1][6][:16], np.full(16, 400.0))
 
 
+def test_reducer_leaves_dead_ranges_out_of_the_exchange():
+    """GradReducer.set_live: only the parts of a group that can hold a gradient are cut into buckets (the layers no
+    output of the probabilistic training graph reads are zero on every rank)."""
+    red = PKG.ddp.GradReducer(world_size=2, bucket_mb=0.0001)
+    red.bind(torch.zeros(100), {"a": (0, 40), "b": (40, 80)}, ["a", "b"], (80, 100))
+    assert red._pieces(0, 40) == [(0, 40)]
+    red.set_live([(0, 10), (30, 50), (90, 100)])
+    assert red._pieces(0, 40) == [(0, 10), (30, 40)]
+    assert red._pieces(40, 80) == [(40, 50)]
+    assert red._pieces(80, 100) == [(90, 100)]
+    assert red._pieces(50, 90) == []
+
+
+def test_flat_params_live_ranges_merge_touched_neighbours():
+    class M(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.a, self.b, self.c, self.d = (torch.nn.Parameter(torch.zeros(n)) for n in (4, 8, 4, 12))
+    m = M()
+    f = PKG.optim.FlatParams(m)
+    assert f.live_ranges() == []
+    m.a._m1_live = True; m.b._m1_live = True; m.d._m1_live = True
+    assert f.live_ranges() == [(0, 12), (16, 28)]
+
+
 # ---- N > 1 readiness without hardware (VERDICT r02 item 8) -----------------------------------------------------------
 def _six_group_worker(rank, world, port, q, order_seed):
     """The probabilistic model's 6 exchange groups (prior a, b, c, posterior a, b, c -- completion order of M1Net.exchange_groups)
