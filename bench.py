@@ -371,11 +371,15 @@ def run_workload(a, wl, ctx, want_roofline, want_cpu):
         step()
         note("eager")
     torch.cuda.synchronize()
-    live_elems = None
+    live_elems, dead_zero = None, None
     if reducer is not None:
         # layers no output of the training graph reads never receive a gradient (sersd0 / logits, the pruned posterior layers): their
         # ranges of the flat buffer are exactly zero on every rank and stay out of the exchange
         live_elems = opt.refresh_live_ranges()
+        # ... which the gradient buffer of the warm-up step confirms: everything outside the live ranges is exactly zero
+        gabs = opt.flatp.grad.abs()
+        dead_zero = bool(float(gabs.sum() - sum(gabs[a:b].sum() for a, b in opt.flatp.live_ranges())) == 0.0) if live_elems else None
+        del gabs
     _dbg("eager warm-up done")
     # N = 1: the whole step is one hipGraph.  N > 1 over RCCL ("full"): the same, the collectives are captured on the
     # communication stream inside it; "split" (fallback): forward+backward are captured without collectives, the exchange
@@ -462,7 +466,7 @@ def run_workload(a, wl, ctx, want_roofline, want_cpu):
                     "collectives_issued": st["collectives"], "host_steps": reducer._step,
                     "bytes_per_step": 4 * (live_elems if live_elems else opt.flatp.grad.numel()),
                     "dead_bytes_not_exchanged": 4 * (opt.flatp.grad.numel() - live_elems) if live_elems else 0,
-                    "rs_ag": bool(reducer.rs_ag), "replicas_in_sync": bool(torch.equal(lo, hi)),
+                    "dead_ranges_all_zero": dead_zero, "rs_ag": bool(reducer.rs_ag), "replicas_in_sync": bool(torch.equal(lo, hi)),
                     "note": "groups are sent from the communication stream as backward completes them (ddp.py); counters "
                             "count host-side calls (in graph mode 'full' the captured collectives replay without them)"}
     final_loss = float(loss_buf)
@@ -561,7 +565,7 @@ def run_workload(a, wl, ctx, want_roofline, want_cpu):
                     for _ in range(a.prof_steps):
                         step()
                     torch.cuda.synchronize()
-                    iso = [q for q in family_of([q for q in ops.prof_read() if q["total_ms"] > 0]) if q["name"] == r["name"]]
+                    iso = [q for q in family_of([q for q in ops.prof_read() if q["total_ms"] > 0]) if set(q["entry_points"]) == set(r["entry_points"])]
                     ops.prof_enable(False)
                 finally:
                     ops._BRANCH["on"] = True

@@ -105,7 +105,9 @@ def test_bench_rccl_world_of_one(rs_ag):
     ex = d["config"]["exchange"]
     assert ex["backend"] == "nccl" and ex["graph_mode"] == "full" and ex["replicas_in_sync"] is True, (ex, d["config"]["graph_error"])
     assert ex["collectives_issued"] > 0 and ex["groups_sent_during_backward"] > 0, ex
-    assert ex["rs_ag"] is (rs_ag == "1") and ex["dead_bytes_not_exchanged"] == 0, ex       # (the deterministic model has no dead layers)
+    # layers the graph never evaluates (the dense-skip / deep-supervision convs of a model built without them) get no gradient: their
+    # ranges are left out, and the warm-up step's gradient buffer is exactly zero there
+    assert ex["rs_ag"] is (rs_ag == "1") and ex["dead_bytes_not_exchanged"] >= 0 and ex["dead_ranges_all_zero"] is True, ex
 
 
 @pytest.mark.timeout(4 * CHILD_TIMEOUT_S + 60)
@@ -135,7 +137,7 @@ def test_bench_rccl_probabilistic_lanes_match_in_order_run(tmp_path):
         assert ex["backend"] == "nccl" and ex["graph_mode"] == "full" and d["config"]["graph_error"] is None, (tag, ex, d["config"]["graph_error"])
         assert ex["groups"] == 6 and ex["replicas_in_sync"] is True, (tag, ex)
         # sersd0 / logits of both cores and the posterior's pruned layers receive no gradient: their ranges are not exchanged
-        assert 0 < ex["dead_bytes_not_exchanged"] < ex["bytes_per_step"], (tag, ex)
+        assert 0 < ex["dead_bytes_not_exchanged"] < ex["bytes_per_step"] and ex["dead_ranges_all_zero"] is True, (tag, ex)
         if tag == "lanes":
             assert ex["groups_sent_during_backward"] > 0, ex
         import torch

@@ -62,5 +62,6 @@ def test_no_register_of_an_inline_asm_load_is_touched_in_flight(src):
         assert len(chk.check_file(planted)) == 1
     out = chk.compile_s(os.path.join(CSRC, src), chk.makefile_flags())
     kernels = chk.split_kernels(out)
-    assert sum(1 for v in kernels.values() for it in v if it[1] != "label" and it[2] and it[1].startswith("ds_read")) > 100
+    n_asm_reads = sum(1 for v in kernels.values() for it in v if it[1] != "label" and it[2] and it[1].startswith("ds_read"))
+    assert n_asm_reads > 100 or src == "wgrad_t3.hip"      # (wgrad_t3's transpose reads are compiler-visible builtins; its inline asm is the LDS-DMA, checked for M0)
     assert chk.check_file(out) == []
