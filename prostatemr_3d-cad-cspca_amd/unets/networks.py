@@ -111,6 +111,17 @@ class M1Core(nn.Module):
         assert [len(s) for s in self.strides] == [3, 3, 3, 3, 3], "ERROR: Expected 5x3 Tuple/Array (3D Strides for 5 Resolutions)."
         assert [len(k) for k in self.kernel_sizes] == [3, 3, 3, 3, 3], "ERROR: Expected 5x3 Tuple/Array (3D Kernels for 5 Resolutions)."
 
+        if self.probabilistic:
+            # networks.py:534-537 index prob_latent_dims[0..3]; :645,669,693,717 read the posterior's latents as prob_z_q[level] while
+            # used_latents only grows at levels that HAVE a latent: a level without one in front of a level with one makes the
+            # reference's own training graph fail with "list index out of range".  Same error, raised where the reference builds its graph.
+            if len(self.prob_latent_dims) < 4:
+                raise IndexError("tuple index out of range: prob_latent_dims needs one entry per latent level (4), got %r"
+                                 % (self.prob_latent_dims,))
+            nz = [d != 0 for d in self.prob_latent_dims[:4]]
+            if any(nz[k + 1] and not nz[k] for k in range(3)):
+                raise IndexError("list index out of range: prob_latent_dims %r has a level without a latent in front of a level with "
+                                 "one (the reference indexes the posterior's latents by level, networks.py:645-717)" % (self.prob_latent_dims,))
         F, S, K, R = self.filters, self.strides, self.kernel_sizes, self.se_reduction
         cp = {k: v for k, v in self.conv_params.items() if k != 'padding'}
         dn = self.dense_skip

@@ -164,6 +164,102 @@ def test_c1_probabilistic_forward_kl_and_gradients(dev):
     _check_grads(m, g64, orc[torch.float32][2])
 
 
+# Other configurations of the hierarchical latent branch (networks.py:633-734 treats every level independently: ``if
+# self.prob_latent_dims[k] != 0``): the m1() / M1Core default (1,1,1,1) -- a latent at EVERY scale, full resolution included --,
+# a single coarse latent, two levels, and the model without the nested dense skips.  Same tolerances as the README configuration.
+LATENT_CONFIGS = [((1, 1, 1, 1), True, 21), ((2, 0, 0, 0), True, 22), ((2, 1, 0, 0), False, 23), ((3, 2, 1, 0), False, 24)]
+
+
+@pytest.mark.parametrize("latents,dense,seed", LATENT_CONFIGS)
+def test_c1_probabilistic_other_latent_configurations(dev, latents, dense, seed):
+    cfg = O.M1Config(input_spatial_dims=(4, 32, 32), filters=C1_FILTERS, strides=C1_STRIDES, dense_skip=dense,
+                     deep_supervision=False, probabilistic=True, prob_latent_dims=latents)
+    P = O.fixture_params(cfg, seed=seed)
+    x = rnd((1, 4, 32, 32, 3), seed + 100)
+    tgt = _ball_target((1, 4, 32, 32), seed + 200)
+    x[..., 2] = tgt[..., 1]
+    eps = [rnd((1, *s), seed + 300 + i) for i, s in enumerate(O.latent_shapes(cfg))]
+    assert len(eps) == sum(1 for d in latents if d != 0)
+    m = build_m1(cfg, dev)
+    load_params_into(m, P)
+    with activation_pattern(m) as ap:
+        det, kl = m(x.to(dev), eps_q=[e.to(dev) for e in eps])
+    orc = _oracle_loss_and_grads(cfg, P, x, tgt, eps, masks=ap.masks)
+    loss_o, o, g64 = orc[torch.float64]
+    tc = m.references.m1_model['prob_train_conv']
+    assert float((tc.double().cpu() - o["prob_train_conv"]).abs().max()) < 1e-3
+    assert abs(float(kl) - float(o["prob_kl"])) < 1e-3 * max(1.0, abs(float(o["prob_kl"])))
+    focal = PKG.losses.Focal(alpha=[0.75, 0.25], gamma=2.0).loss
+    elbo = PKG.losses.EvidenceLowerBound().loss
+    loss = focal(tgt.to(dev), det) + 10.0 * elbo(None, kl) + m.regularization_loss()
+    assert abs(float(loss) - float(loss_o)) < 1e-3 * abs(float(loss_o))
+    loss.backward()
+    _check_grads(m, g64, orc[torch.float32][2])
+
+
+def _three_class_target(shape, seed):
+    """One-hot (B,D,H,W,3): background, a ball, a second ball (the first wins where they overlap)."""
+    B, D, H, W = shape
+    rng = np.random.default_rng(seed)
+    zz, yy, xx = np.meshgrid(np.arange(D), np.arange(H), np.arange(W), indexing="ij")
+    t = np.zeros((B, D, H, W, 3), dtype=np.float32)
+    for b in range(B):
+        lab = np.zeros((D, H, W), dtype=np.int64)
+        for cls in (2, 1):
+            c = [rng.integers(0, D), rng.integers(5, H - 5), rng.integers(5, W - 5)]
+            lab[((zz - c[0]) ** 2 + (yy - c[1]) ** 2 + (xx - c[2]) ** 2) <= 25] = cls
+        for k in range(3):
+            t[b, ..., k] = lab == k
+    return torch.from_numpy(t)
+
+
+@pytest.mark.parametrize("prob", [False, True])
+def test_c1_three_classes(dev, prob):
+    """num_classes = 3: three-column heads and softmax (networks.py:627,737-757), a 3-entry Focal alpha (losses.py:32-49), and in the
+    probabilistic model the channel arithmetic of networks.py:300-301 with TWO label channels -- image = inputs[..., :C-2], label =
+    inputs[..., C-3:C-1] (the off-by-one of App. C-2 now overlaps the image), posterior input C channels, prior input C-2."""
+    nc, C = 3, (5 if prob else 3)
+    cfg = O.M1Config(input_spatial_dims=(4, 32, 32), input_channels=C, num_classes=nc, filters=C1_FILTERS, strides=C1_STRIDES,
+                     dense_skip=prob, deep_supervision=not prob, probabilistic=prob, prob_latent_dims=(2, 1, 1, 0))
+    P = O.fixture_params(cfg, seed=41 + prob)
+    x = rnd((1, 4, 32, 32, C), 42)
+    tgt = _three_class_target((1, 4, 32, 32), 43)
+    if prob:
+        x[..., C - 2:] = tgt[..., 1:]                          # the label channels ride behind the image channels
+    eps = [rnd((1, *s), 44 + i) for i, s in enumerate(O.latent_shapes(cfg))] if prob else None
+    alpha = [0.6, 0.25, 0.15]
+    m = build_m1(cfg, dev)
+    load_params_into(m, P)
+    focal = PKG.losses.Focal(alpha=alpha, gamma=2.0).loss
+    out = {}
+    import contextlib
+    with activation_pattern(m) as ap:
+        if prob:
+            det, kl = m(x.to(dev), eps_q=[e.to(dev) for e in eps])
+        else:
+            det = m(x.to(dev))
+    for dt in (torch.float64, torch.float32):
+        Pd = {k: v.to(dt).requires_grad_(True) for k, v in P.items()}
+        with O.forced_activation_pattern(ap.masks):
+            loss_o, parts, o = O.train_loss(Pd, cfg, x.to(dt), tgt.to(dt), eps_q=[e.to(dt) for e in eps] if eps else None, focal_alpha=alpha)
+        loss_o.backward()
+        out[dt] = (loss_o.detach(), o, {k: (v.grad.double() if v.grad is not None else None) for k, v in Pd.items()})
+    loss_o, o, g64 = out[torch.float64]
+    if prob:
+        tc = m.references.m1_model['prob_train_conv']
+        assert tuple(tc.shape[-1:]) == (3,) and float((tc.double().cpu() - o["prob_train_conv"]).abs().max()) < 1e-3
+        assert abs(float(kl) - float(o["prob_kl"])) < 1e-3 * max(1.0, abs(float(o["prob_kl"])))
+        loss = focal(tgt.to(dev), det) + 10.0 * PKG.losses.EvidenceLowerBound().loss(None, kl) + m.regularization_loss()
+    else:
+        lg = m.references.m1_model['logits']
+        assert tuple(lg.shape[-1:]) == (3,) and float((lg.double().cpu() - o["logits"]).abs().max()) < 1e-3
+        assert det.shape[-1] == 12 and float((det.double().cpu() - o["y_softmax"]).abs().max()) < 1e-3      # 4 heads x 3 classes
+        loss = focal(tgt.to(dev), det) + m.regularization_loss()
+    assert abs(float(loss) - float(loss_o)) < 1e-3 * abs(float(loss_o))
+    loss.backward()
+    _check_grads(m, g64, out[torch.float32][2])
+
+
 def test_golden_fixture_c1_det(dev):
     """Committed golden vectors (tests/golden/, produced by tools/make_golden.py from the oracle)."""
     path = os.path.join(os.path.dirname(__file__), "golden", "c1_det.npz")

@@ -249,6 +249,28 @@ def test_two_rank_gloo_gradient_exchange_equals_global_batch_mean():
     assert np.array_equal(res[0][6][:16], np.full(16, 200.0)) and np.array_equal(res[1][6][:16], np.full(16, 400.0))
 
 
+def test_latent_configurations_the_reference_cannot_build_raise_the_same_error():
+    """networks.py:645-717 read the posterior's latents as prob_z_q[level] while used_latents only grows at levels that have one: a
+    level WITHOUT a latent in front of a level WITH one (e.g. (3,0,1,0)) fails in the reference with IndexError when m1() builds its
+    training graph -- and so does M1's own default (3,2,1), a 3-tuple, at networks.py:537.  Same error class here, at construction;
+    the oracle restatement fails the same way (it follows the reference's indexing)."""
+    nets = PKG.unets.networks
+    kw = dict(input_spatial_dims=(4, 32, 32), input_channels=3, num_classes=2, filters=(8, 16, 32, 64, 128), probabilistic=True, summary=False)
+    for bad in ((3, 0, 1, 0), (0, 2, 0, 1), (3, 2, 1)):
+        with pytest.raises(IndexError):
+            nets.M1(prob_latent_dims=bad, **kw)
+    for ok in ((1, 1, 1, 1), (2, 0, 0, 0), (3, 2, 1, 0)):
+        nets.M1(prob_latent_dims=ok, **kw)
+    from oracle import m1_oracle as O
+    import numpy as np
+    cfg = O.M1Config(input_spatial_dims=(4, 32, 32), filters=(8, 16, 32, 64, 128), strides=((1, 1, 1), (1, 2, 2), (1, 2, 2), (2, 2, 2), (2, 2, 2)),
+                     probabilistic=True, prob_latent_dims=(3, 0, 1, 0))
+    P = O.fixture_params(cfg, seed=1)
+    x = torch.from_numpy(np.random.default_rng(0).standard_normal((1, 4, 32, 32, 3))).float()
+    with pytest.raises(IndexError):
+        O.m1_forward(P, cfg, x, eps_q=[torch.zeros(1, *s) for s in O.latent_shapes(cfg)])
+
+
 def test_reducer_leaves_dead_ranges_out_of_the_exchange():
     """GradReducer.set_live: only the parts of a group that can hold a gradient are cut into buckets (the layers no
     output of the probabilistic training graph reads are zero on every rank)."""
