@@ -260,6 +260,46 @@ def test_c1_three_classes(dev, prob):
     _check_grads(m, g64, out[torch.float32][2])
 
 
+@pytest.mark.parametrize("prob", [False, True])
+def test_c1_other_strides_gate_subsampling_and_reductions(dev, prob):
+    """Constructor arguments away from the README values: m1()'s own default strides (networks.py:237: the deepest level keeps the
+    depth, (1,2,2)), attention gates that sub-sample their theta conv ((1,2,2) / (2,2,2): B:100,111,120-124 -- kernel = stride =
+    sub_samp, sigma upsampled by repetition), per-level SE reductions (4,4,8,8,16), all-(3,3,3) kernels, a non-cubic volume."""
+    strides = ((1, 1, 1), (1, 2, 2), (1, 2, 2), (2, 2, 2), (1, 2, 2))
+    cfg = O.M1Config(input_spatial_dims=(4, 48, 32), filters=C1_FILTERS, strides=strides, kernel_sizes=((3, 3, 3),) * 5,
+                     se_reduction=(4, 4, 8, 8, 16), att_sub_samp=((1, 2, 2), (1, 2, 2), (2, 2, 2), (1, 1, 1)),
+                     dense_skip=True, deep_supervision=not prob, probabilistic=prob, prob_latent_dims=(2, 1, 0, 0))
+    P = O.fixture_params(cfg, seed=51 + prob)
+    x = rnd((1, 4, 48, 32, 3), 52)
+    tgt = _ball_target((1, 4, 48, 32), 53)
+    if prob:
+        x[..., 2] = tgt[..., 1]
+    eps = [rnd((1, *s), 54 + i) for i, s in enumerate(O.latent_shapes(cfg))] if prob else None
+    m = build_m1(cfg, dev)
+    load_params_into(m, P)
+    with activation_pattern(m) as ap:
+        if prob:
+            det, kl = m(x.to(dev), eps_q=[e.to(dev) for e in eps])
+        else:
+            det = m(x.to(dev))
+    orc = _oracle_loss_and_grads(cfg, P, x, tgt, eps, masks=ap.masks)
+    loss_o, o, g64 = orc[torch.float64]
+    focal = PKG.losses.Focal(alpha=[0.75, 0.25], gamma=2.0).loss
+    if prob:
+        tc = m.references.m1_model['prob_train_conv']
+        assert float((tc.double().cpu() - o["prob_train_conv"]).abs().max()) < 1e-3
+        assert abs(float(kl) - float(o["prob_kl"])) < 1e-3 * max(1.0, abs(float(o["prob_kl"])))
+        loss = focal(tgt.to(dev), det) + 10.0 * PKG.losses.EvidenceLowerBound().loss(None, kl) + m.regularization_loss()
+    else:
+        lg = m.references.m1_model['logits']
+        assert float((lg.double().cpu() - o["logits"]).abs().max()) < 1e-3
+        assert float((det.double().cpu() - o["y_softmax"]).abs().max()) < 1e-3
+        loss = focal(tgt.to(dev), det) + m.regularization_loss()
+    assert abs(float(loss) - float(loss_o)) < 1e-3 * abs(float(loss_o))
+    loss.backward()
+    _check_grads(m, g64, orc[torch.float32][2])
+
+
 def test_golden_fixture_c1_det(dev):
     """Committed golden vectors (tests/golden/, produced by tools/make_golden.py from the oracle)."""
     path = os.path.join(os.path.dirname(__file__), "golden", "c1_det.npz")
