@@ -1,5 +1,7 @@
 #!/bin/bash
-# round-5 hunt, batch 1: where does the process-group run first differ from the run without one?
+# round-5 hunt, batch 1 (record; outputs in profiles/r05_hunt/h1_*): where does the process-group run first differ from the run without one?
+# (lines d / e used the debug switches M1_BENCH_NO_SLEEP / M1_BENCH_SLEEP of that day's bench.py: the 1 s watchdog sleep they toggled has
+#  since been replaced by drain_watchdog(); the switches no longer exist and the lines now run the default configuration)
 cd ${GRAFT_REPO_ROOT:-.}; mkdir -p gpurun_out/h1
 export STEPS=2
 ( set -x

@@ -1,4 +1,6 @@
 #!/bin/bash
+# round-5 hunt, batch 2 (record; outputs in profiles/r05_hunt/h2_*): the stand-alone memset-node probe, then the captured step with the memset node
+# (M1_MEMSET_KERNEL=0) and with the zero-fill kernel -- without a process group, with one, and with lanes + collectives -- against eager steps
 cd ${GRAFT_REPO_ROOT:-.}; mkdir -p gpurun_out/h2
 export STEPS=3
 ( set -x

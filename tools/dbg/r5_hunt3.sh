@@ -1,5 +1,10 @@
 #!/bin/bash
-# packed fp32 re-test with the memset fix in place: does the round-4 race reproduce, and which file's packed ops does it need?
+# round-5 hunt, batch 3 (record; outputs in profiles/r05_hunt/h3_*): packed fp32 re-test with the memset fix in place -- does the round-4 race
+# reproduce, and which file's packed ops does it need?  Build the bisection libraries first (they are not kept in the tree):
+#   cd prostatemr_3d-cad-cspca_amd/csrc
+#   make BUILD=build_pk OUT=../libm1hip_pk.so PK_FILES=all
+#   make BUILD=build_pkthin OUT=../libm1hip_pkthin.so PK_FILES=conv_thin.hip
+#   make BUILD=build_pkrest OUT=../libm1hip_pkrest.so PK_FILES="$(ls *.hip | grep -v conv_thin | tr '\n' ' ')"
 cd ${GRAFT_REPO_ROOT:-.}; mkdir -p gpurun_out/h3
 for lib in libm1hip_pk.so libm1hip_pkthin.so libm1hip_pkrest.so libm1hip.so; do
   for cfg in "enc0 part:conv3" "full prior"; do
