@@ -255,8 +255,8 @@ def capture_with_fallback(gmode, dist_on, capture, reducer=None, sync=lambda: No
 
 
 def drain_watchdog(timeout_s=20.0):
-    """Block until the RCCL process group's watchdog thread has retired every collective issued so far.  The flight recorder marks an
-    entry 'completed' exactly when the watchdog takes it off its list (ProcessGroupNCCL's work-cleanup loop), so polling the recorder
+    """Block until the RCCL process group's watchdog thread has retired every collective issued so far.  The flight recorder flags an
+    entry ``retired`` when the watchdog takes the work off its list (ProcessGroupNCCL's watchdog loop), so polling the recorder
     is a deterministic drain (round-4 advisor finding: the fixed 1 s sleep was a timing assumption).  Falls back to the sleep when the
     recorder is off or unreadable.  Returns how the drain ended (for the debug log)."""
     import pickle
@@ -269,7 +269,12 @@ def drain_watchdog(timeout_s=20.0):
             ents = tr.get("entries", []) if isinstance(tr, dict) else []
             if not ents:
                 break                                         # recorder off (TORCH_NCCL_TRACE_BUFFER_SIZE=0): cannot observe the list
-            if all(e.get("state") == "completed" for e in ents):
+            # "retired" = the watchdog has taken the work off its list (the state 'completed' alone only says that the recorder's own
+            # event query -- made while dumping -- found the kernel finished: the watchdog may not have polled it yet, and an un-polled
+            # work is exactly what aborts the capture; seen once in this round's suite runs with the state-only test)
+            if all(e.get("retired", e.get("state") == "completed") for e in ents):
+                if "retired" not in ents[-1]:
+                    time.sleep(0.5)                           # recorder without the flag: completion seen, give the watchdog its poll period
                 return f"retired {len(ents)} collectives after {time.time() - t0:.3f} s"
             time.sleep(0.01)
     except Exception as e:  # noqa: BLE001 -- recorder API differs: fall back
