@@ -1202,3 +1202,88 @@ def test_conv_t3_pair_forward_and_inbwd_epilogue(dev):
         for a_, b_, nm in zip(outs["t3"][:3], outs["mfma"][:3], ("dy", "dgamma", "dbeta")):
             assert rel_err(a_, b_) < 2e-2, nm
     ops.invalidate_panels()
+
+
+# ---- seeded fuzz over conv / transposed-conv configurations ------------------------------------------------------------------------
+# The parametrised cases above are the shapes somebody thought of.  The dispatch has a dozen kernels with eligibility rules on channel
+# counts (multiples of 8 / 32 / 64), row lengths (multiples of 8 / 16 / 32), voxel counts, strides and concat layouts; a configuration
+# that falls between two rules lands on a fallback path nobody exercised.  300 random configurations (fixed seed: reproducible), every
+# one forward + data gradients + weight / bias gradients + fused statistics against the fp64 oracle, half of them with the size floors
+# of the special kernels lifted (so that small volumes reach conv_t3 / conv_halo / conv_thin / conv_pw as well).
+def _fuzz_cases(n, seed):
+    import random
+    rng = random.Random(seed)
+    cases = []
+    chan_pool = [1, 2, 3, 4, 5, 8, 8, 16, 16, 24, 32, 32, 40, 64, 64, 96, 128]
+    for i in range(n):
+        transposed = rng.random() < 0.3
+        k = rng.choice([(1, 1, 1), (1, 3, 3), (3, 3, 3), (3, 3, 3), (1, 3, 3)])
+        s = rng.choice([(1, 1, 1), (1, 1, 1), (1, 2, 2), (2, 2, 2)])
+        if k == (1, 1, 1) and rng.random() < 0.7:
+            s = (1, 1, 1)
+        nmem = rng.choice([1, 1, 1, 2, 2, 3, 5])
+        cins = [rng.choice(chan_pool) for _ in range(nmem)]
+        cout = rng.choice(chan_pool + [2, 6, 160])
+        N = rng.choice([1, 1, 2, 3])
+        D = rng.choice([1, 2, 3, 4, 5])
+        H = rng.choice([4, 6, 8, 9, 12, 16])
+        W = rng.choice([4, 8, 8, 10, 16, 16, 20, 24, 32, 40])
+        if not transposed:                                    # SAME-padded strided conv: any extent; keep the volume small
+            pass
+        dtype = rng.choice([torch.float32, torch.bfloat16, torch.bfloat16])
+        lifted = rng.random() < 0.5
+        cases.append((i, transposed, k, s, cins, cout, (N, D, H, W), dtype, lifted))
+    return cases
+
+
+_FUZZ_LIFT = dict(M1_CT3_MINM=1, M1_CT3_MINC=32, M1_CT3_MINOC=8, M1_HALO=2, M1_THIN=2)
+
+
+@pytest.mark.parametrize("chunk", range(10))
+def test_conv_fuzz_against_oracle(dev, chunk):
+    cases = _fuzz_cases(300, seed=20251003)[chunk * 30:(chunk + 1) * 30]
+    seen = set()
+    for (i, transposed, k, s, cins, cout, dims, dtype, lifted) in cases:
+        N, D, H, W = dims
+        bf = dtype == torch.bfloat16
+        xs = [rnd((N, D, H, W, c), 1000 + 7 * i + j) for j, c in enumerate(cins)]
+        cin = sum(cins)
+        sc = 1.0 / (cin * k[0] * k[1] * k[2]) ** 0.5
+        w = rnd((*k, cout, cin) if transposed else (*k, cin, cout), 2000 + i, sc); b = rnd((cout,), 3000 + i)
+        if bf:
+            xs = [x.bfloat16().float() for x in xs]
+        fo = (lambda x, w_, b_: O.conv3d_transpose_same(x, w_, b_, s)) if transposed else (lambda x, w_, b_: O.conv3d_same(x, w_, b_, s))
+        yo = fo(torch.cat(xs, -1).double(), w.double(), b.double())
+        dy = rnd(tuple(yo.shape), 4000 + i)
+        if bf:
+            dy = dy.bfloat16().float()
+        yo, (gx, gw, gb) = _oracle_grads(fo, [torch.cat(xs, -1), w, b], dy)
+        ctx = ops.config(**_FUZZ_LIFT) if lifted else ops.config()
+        with ctx, ops.kernel_log() as kl:
+            xd = [x.to(dev, dtype).requires_grad_(True) for x in xs]
+            wd, bd = w.to(dev).requires_grad_(True), b.to(dev).requires_grad_(True)
+            if transposed:
+                y = ops.conv3d_transpose_same(xd, wd, bd, k, s); st = None
+            else:
+                y, st = ops.conv3d_same(xd, wd, bd, k, s, stats=True)
+            y.backward(dy.to(dev, dtype))
+            torch.cuda.synchronize()
+        seen.update(n.split(":")[0] for n in kl.names)
+        tag = f"case {i}: T={transposed} k={k} s={s} cins={cins} cout={cout} dims={dims} {dtype} lifted={lifted} kernels={sorted(set(kl.names))}"
+        tol = 1.2e-2 if bf else 2e-4                                  # bf16: rounding of the stored output / data gradient
+        assert tuple(y.shape) == tuple(yo.shape), tag
+        assert rel_err(y, yo) < tol, (tag, rel_err(y, yo))
+        off = 0
+        for x in xd:
+            c = x.shape[-1]
+            assert rel_err(x.grad, gx[..., off:off + c]) < tol, (tag, "dx", off, rel_err(x.grad, gx[..., off:off + c]))
+            off += c
+        assert rel_err(wd.grad, gw) < (2e-4 if not bf else 2e-4), (tag, "dw", rel_err(wd.grad, gw))      # fp32 accumulation of exact bf16 products
+        assert rel_err(bd.grad, gb) < 2e-4, (tag, "db", rel_err(bd.grad, gb))
+        if st is not None:
+            yf = y.detach().float()
+            mean = yf.mean(dim=(1, 2, 3)); var = yf.var(dim=(1, 2, 3), unbiased=False)
+            assert float((st[..., 0] - mean).abs().max()) < 1e-4 * (1.0 + float(mean.abs().max())), (tag, "mean")
+            assert rel_err(st[..., 1], 1.0 / torch.sqrt(var + 1e-3)) < 1e-3, (tag, "rstd")
+    ops.invalidate_panels()
+    assert seen, "no kernel was logged"
