@@ -213,14 +213,17 @@ int m1_se_gate_bwd_batch(const m1_se_gate_job_t* jobs /* host array */, int njob
  * a pure function of (rng, layer_id, element index): backward can regenerate it.  keep_mask (optional, bf16 and
  * F % 8 == 0 only, N*V*F/8 bytes): the forward also stores the keep bits (bit idx & 7 of byte idx >> 3) and a backward
  * given the same buffer reads them instead of re-running Philox (the backward passes are instruction bound:
- * 10 Philox rounds per 4 elements were ~45 % of their instructions). */
+ * 10 Philox rounds per 4 elements were ~45 % of their instructions).
+ * stats4 == gamma4 == beta4 == NULL: the identity residual of B:63 (C_in == filters: no conv4 / norm4) -- y4 is then the block's
+ * INPUT tensor (N,V,F) and out = dropout( lrelu( IN3(y3) * g * y4 ) ). */
 int m1_se_combine_fwd(const void* y3, const void* y4, const float* stats3, const float* stats4,
                       const float* gamma3, const float* beta3, const float* gamma4, const float* beta4,
                       const float* g, void* out, int N, long long V, int F, int dtype, float drop_rate,
                       const uint64_t* rng, uint64_t layer_id, unsigned char* keep_mask, void* stream);
 /* writes dy3, dy4 (grads wrt the RAW conv outputs, i.e. through both InstanceNorms); dgamma3,dbeta3,dgamma4,
  * dbeta4 (F each) per `accumulate`; dg is scratch for m1_se_gate_bwd, F + Fr floats, first F always overwritten.
- * ws: m1_reduce_ws_floats(N,V,F,5). */
+ * ws: m1_reduce_ws_floats(N,V,F,5).  Identity residual (stats4 == gamma4 == beta4 == NULL): dy4 is the gradient wrt the block input
+ * through the residual factor (no normalisation to go back through), dgamma4 / dbeta4 are not touched (may be NULL). */
 int m1_se_combine_bwd(const void* y3, const void* y4, const float* stats3, const float* stats4,
                       const float* gamma3, const float* beta3, const float* gamma4, const float* beta4,
                       const float* g, const void* dout, void* dy3, void* dy4, float* dgamma3, float* dbeta3,

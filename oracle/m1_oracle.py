@@ -696,6 +696,11 @@ def _se_shapes(pre: str, cin: int, f: int, k, red: int) -> Dict[str, Tuple[int, 
     for name, c in (("norm1", q), ("norm2", q), ("norm3", f), ("norm4", f)):
         d[f"{pre}.{name}.gamma"] = (c,)
         d[f"{pre}.{name}.beta"] = (c,)
+    if cin == f:
+        # B:63: with C_in == filters the block never calls conv4 / norm4 -- Keras builds weights at the first call, so they own
+        # none (no trainable variables, no L2 term); the residual factor is the block input itself
+        for k_ in [k_ for k_ in d if ".conv4." in k_ or ".norm4." in k_]:
+            del d[k_]
     return d
 
 

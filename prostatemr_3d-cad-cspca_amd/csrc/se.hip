@@ -217,7 +217,14 @@ struct SeParams {
     long long V; int F;
     float drop_rate; const uint64_t* rng; uint64_t layer_id;
     unsigned char* mask;      // optional keep-mask, bit (idx & 7) of byte (idx >> 3): written by the forward, read by the backward
+    int identity4;            // network_blocks.py:63 false branch (C_in == filters): rho is the block input itself, no conv4 / norm4
 };
+// per-channel constants of the second factor: {mean, rstd, gamma, beta} of norm4, or {0, 1, 1, 0} for the identity residual --
+// (y4 - 0) * 1 * 1 + 0 is y4 exactly, and the InstanceNorm backward with zero sums and unit scale is the identity
+__device__ __forceinline__ void se_rho_consts(const SeParams& p, size_t sc, int c, float& m4, float& r4, float& g4, float& b4) {
+    if (p.identity4) { m4 = 0.f; r4 = 1.f; g4 = 1.f; b4 = 0.f; }
+    else { m4 = p.stats4[sc]; r4 = p.stats4[sc + 1]; g4 = p.gamma4[c]; b4 = p.beta4[c]; }
+}
 
 __device__ __forceinline__ void se_rng(const SeParams& p, uint64_t& seed, uint64_t& base) {
     seed = 0; base = 0;
@@ -241,7 +248,7 @@ __global__ void __launch_bounds__(256, 3) se_combine_fwd_kernel(const T* __restr
     for (int k = 0; k < VEC; ++k) {
         const int c = c0 + k; const size_t sc = ((size_t)n * F + c) * 2;
         m3[k] = p.stats3[sc]; r3[k] = p.stats3[sc + 1]; g3[k] = p.gamma3[c]; b3[k] = p.beta3[c];
-        m4[k] = p.stats4[sc]; r4[k] = p.stats4[sc + 1]; g4[k] = p.gamma4[c]; b4[k] = p.beta4[c]; gt[k] = p.g[c];
+        se_rho_consts(p, sc, c, m4[k], r4[k], g4[k], b4[k]); gt[k] = p.g[c];
     }
     auto body = [&](long long i, float* a, const float* b) {
 #pragma unroll
@@ -285,9 +292,10 @@ struct SeBwdF {
     __device__ void operator()(int n, long long v, int c, float* acc) const {
         const int F = p.F;
         const size_t idx = ((size_t)n * p.V + v) * F + c; const size_t sc = ((size_t)n * F + c) * 2;
+        float m4, r4, g4, b4; se_rho_consts(p, sc, c, m4, r4, g4, b4);
         const float xh3 = (Act<T>::ld(y3 + idx) - p.stats3[sc]) * p.stats3[sc + 1];
-        const float xh4 = (Act<T>::ld(y4 + idx) - p.stats4[sc]) * p.stats4[sc + 1];
-        const float x_ = xh3 * p.gamma3[c] + p.beta3[c], rho = xh4 * p.gamma4[c] + p.beta4[c];
+        const float xh4 = (Act<T>::ld(y4 + idx) - m4) * r4;
+        const float x_ = xh3 * p.gamma3[c] + p.beta3[c], rho = xh4 * g4 + b4;
         const float g = p.g[c], u = x_ * g * rho;
         float d = Act<T>::ld(dout + idx);
         if (p.drop_rate > 0.f) {
@@ -315,9 +323,10 @@ struct SeBwdF {
 #pragma unroll
         for (int e = 0; e < kVec; ++e) {
             const int c = c0 + e; const size_t sc = ((size_t)n * F + c) * 2;
+            float m4, r4, g4, b4; se_rho_consts(p, sc, c, m4, r4, g4, b4);
             const float xh3 = (a[e] - p.stats3[sc]) * p.stats3[sc + 1];
-            const float xh4 = (b[e] - p.stats4[sc]) * p.stats4[sc + 1];
-            const float x_ = xh3 * p.gamma3[c] + p.beta3[c], rho = xh4 * p.gamma4[c] + p.beta4[c];
+            const float xh4 = (b[e] - m4) * r4;
+            const float x_ = xh3 * p.gamma3[c] + p.beta3[c], rho = xh4 * g4 + b4;
             const float g = p.g[c], u = x_ * g * rho;
             float dd = d[e];
             if (p.drop_rate > 0.f) dd = keep[e] ? dd * keep_scale : 0.f;
@@ -347,9 +356,10 @@ __global__ void __launch_bounds__(256, MINW) se_combine_bwd_apply_kernel(const T
     for (int k = 0; k < VEC; ++k) {
         const int c = c0 + k; const size_t sc = ((size_t)n * F + c) * 2;
         m3[k] = p.stats3[sc]; r3[k] = p.stats3[sc + 1]; g3[k] = p.gamma3[c]; b3[k] = p.beta3[c];
-        m4[k] = p.stats4[sc]; r4[k] = p.stats4[sc + 1]; g4[k] = p.gamma4[c]; b4[k] = p.beta4[c]; gt[k] = p.g[c];
+        se_rho_consts(p, sc, c, m4[k], r4[k], g4[k], b4[k]); gt[k] = p.g[c];
         const float* s = sums + ((size_t)n * F + c) * 5;
         s0[k] = s[0] * invV; s1[k] = s[1] * invV; s2[k] = s[2] * invV; s3[k] = s[3] * invV;
+        if (p.identity4) { s2[k] = 0.f; s3[k] = 0.f; }            // d(residual) = d(rho): no mean terms (there is no norm4)
     }
     for (long long i = i0; i < per; i += stride) {
         float a[VEC], b[VEC], d[VEC];
@@ -402,7 +412,7 @@ static int se_bwd_impl(const void* y3, const void* y4, const void* dout, const S
     const int nchunks = m1_red_nchunks(p.V, p.F, N);
     float* sums = ws + (size_t)N * nchunks * p.F * 5;
     // parameter gradients ride on the fold: dg is scratch for the gate backward (always overwritten)
-    M1ParamOut<5> po{{dbeta3, dgamma3, dbeta4, dgamma4, dg}, {acc, acc, acc, acc, 0}};
+    M1ParamOut<5> po{{dbeta3, dgamma3, p.identity4 ? nullptr : dbeta4, p.identity4 ? nullptr : dgamma4, dg}, {acc, acc, acc, acc, 0}};
     if (masked) { SeBwdF<T, true> f{(const T*)y3, (const T*)y4, (const T*)dout, p}; rc = m1_reduce_nc_launch<5>(f, N, p.V, p.F, ws, st); }
     else { SeBwdF<T> f{(const T*)y3, (const T*)y4, (const T*)dout, p}; rc = m1_reduce_nc_launch<5>(f, N, p.V, p.F, ws, st); }
     if (rc) return rc;
@@ -427,11 +437,13 @@ extern "C" int m1_se_combine_fwd(const void* y3, const void* y4, const float* st
                                  const float* gamma3, const float* beta3, const float* gamma4, const float* beta4,
                                  const float* g, void* out, int N, long long V, int F, int dtype, float drop_rate,
                                  const uint64_t* rng, uint64_t layer_id, unsigned char* keep_mask, void* stream) {
-    if (!y3 || !y4 || !stats3 || !stats4 || !gamma3 || !beta3 || !gamma4 || !beta4 || !g || !out) return M1_ERR_BAD_ARG;
+    if (!y3 || !y4 || !stats3 || !gamma3 || !beta3 || !g || !out) return M1_ERR_BAD_ARG;
+    const bool ident = !stats4 && !gamma4 && !beta4;             // all three NULL: identity residual (network_blocks.py:63, C_in == filters)
+    if (!ident && (!stats4 || !gamma4 || !beta4)) return M1_ERR_BAD_ARG;
     if (drop_rate > 0.f && !rng) return M1_ERR_BAD_ARG;
     if (drop_rate < 0.f || drop_rate >= 1.f) return M1_ERR_BAD_ARG;
     if (keep_mask && (dtype != M1_BF16 || F % 8)) return M1_ERR_UNSUPPORTED;
-    SeParams p{stats3, stats4, gamma3, beta3, gamma4, beta4, g, V, F, drop_rate, rng, layer_id, keep_mask};
+    SeParams p{stats3, stats4, gamma3, beta3, gamma4, beta4, g, V, F, drop_rate, rng, layer_id, keep_mask, ident ? 1 : 0};
     M1ProfScope ps("se_combine_fwd", 0.0, 3.0 * N * V * F * (dtype == M1_BF16 ? 2 : 4), (hipStream_t)stream);
     return dtype == M1_BF16 ? se_fwd_impl<bf16_t>(y3, y4, p, out, N, (hipStream_t)stream)
                             : se_fwd_impl<float>(y3, y4, p, out, N, (hipStream_t)stream);
@@ -443,10 +455,12 @@ extern "C" int m1_se_combine_bwd(const void* y3, const void* y4, const float* st
                                  float* dgamma4, float* dbeta4, float* dg, int N, long long V, int F, int dtype,
                                  float drop_rate, const uint64_t* rng, uint64_t layer_id, const unsigned char* keep_mask,
                                  float* ws, int accumulate, void* stream) {
-    if (!y3 || !y4 || !dout || !dy3 || !dy4 || !dgamma3 || !dbeta3 || !dgamma4 || !dbeta4 || !dg || !ws) return M1_ERR_BAD_ARG;
+    if (!y3 || !y4 || !stats3 || !gamma3 || !beta3 || !g || !dout || !dy3 || !dy4 || !dgamma3 || !dbeta3 || !dg || !ws) return M1_ERR_BAD_ARG;
+    const bool ident = !stats4 && !gamma4 && !beta4;             // identity residual: dy4 = d(out)/d(y4) directly, dgamma4 / dbeta4 unused
+    if (!ident && (!stats4 || !gamma4 || !beta4 || !dgamma4 || !dbeta4)) return M1_ERR_BAD_ARG;
     if (drop_rate > 0.f && !rng && !keep_mask) return M1_ERR_BAD_ARG;
     if (keep_mask && (dtype != M1_BF16 || F % 8)) return M1_ERR_UNSUPPORTED;
-    SeParams p{stats3, stats4, gamma3, beta3, gamma4, beta4, g, V, F, drop_rate, rng, layer_id, const_cast<unsigned char*>(keep_mask)};
+    SeParams p{stats3, stats4, gamma3, beta3, gamma4, beta4, g, V, F, drop_rate, rng, layer_id, const_cast<unsigned char*>(keep_mask), ident ? 1 : 0};
     M1ProfScope ps("se_combine_bwd", 0.0, 8.0 * N * V * F * (dtype == M1_BF16 ? 2 : 4), (hipStream_t)stream);
     return dtype == M1_BF16
                ? se_bwd_impl<bf16_t>(y3, y4, dout, p, dy3, dy4, dgamma3, dbeta3, dgamma4, dbeta4, dg, N, ws, (hipStream_t)stream, accumulate)

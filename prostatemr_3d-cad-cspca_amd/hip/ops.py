@@ -1004,8 +1004,11 @@ class _SECombine(torch.autograd.Function):
         V = y3.numel() // (N * Fn)
         Fr = int(W6.shape[-1])
         st = _stream()
+        ident = g4 is None and b4 is None            # network_blocks.py:63 false branch: y4 is the block input, no norm4
+        if (g4 is None) != (b4 is None) or tuple(y4.shape) != tuple(y3.shape):
+            raise RuntimeError("se_combine: gamma4 / beta4 both or neither; y4 must have y3's shape")
         s3 = instnorm_stats(y3) if s3 is None else s3
-        s4 = instnorm_stats(y4) if s4 is None else s4
+        s4 = None if ident else (instnorm_stats(y4) if s4 is None else s4)
         if gate is not None:                      # evaluated up front with the other gates of the pass (se_gate_batch)
             hidden, g = gate
             if hidden.numel() != Fr or g.numel() != Fn:
@@ -1021,16 +1024,25 @@ class _SECombine(torch.autograd.Function):
             mask = torch.empty(y3.numel() // 8, dtype=torch.uint8, device=y3.device)
         L.check(lib.m1_se_combine_fwd(_p(y3), _p(y4), _p(s3), _p(s4), _p(g3), _p(b3), _p(g4), _p(b4), _p(g), _p(out), N, V, Fn,
                                       _dt(y3), float(drop_rate), _p(rng), int(layer_id), _p(mask), st), "m1_se_combine_fwd")
-        ctx.save_for_backward(y3, y4, s3, s4, g3, b3, g4, b4, W6, W7, hidden, g)
+        ctx.ident = ident
+        if ident:
+            ctx.save_for_backward(y3, y4, s3, g3, b3, W6, W7, hidden, g)
+            ctx.params = (g3, b3, W6, b6, W7, b7)
+        else:
+            ctx.save_for_backward(y3, y4, s3, s4, g3, b3, g4, b4, W6, W7, hidden, g)
+            ctx.params = (g3, b3, g4, b4, W6, b6, W7, b7)
         ctx.mask = mask
-        ctx.params = (g3, b3, g4, b4, W6, b6, W7, b7)
         ctx.rng, ctx.drop_rate, ctx.layer_id = rng, float(drop_rate), int(layer_id)
         return out
 
     @staticmethod
     def backward(ctx, dout):
         lib = L.load()
-        y3, y4, s3, s4, g3, b3, g4, b4, W6, W7, hidden, g = ctx.saved_tensors
+        if ctx.ident:
+            y3, y4, s3, g3, b3, W6, W7, hidden, g = ctx.saved_tensors
+            s4 = g4 = b4 = None
+        else:
+            y3, y4, s3, s4, g3, b3, g4, b4, W6, W7, hidden, g = ctx.saved_tensors
         dout = dout.contiguous()
         N, Fn = int(y3.shape[0]), int(y3.shape[-1])
         V = y3.numel() // (N * Fn)
@@ -1043,7 +1055,11 @@ class _SECombine(torch.autograd.Function):
         if any(sk[1] != acc for sk in sinks):
             sinks = [(t, 0, t) for t in (torch.empty_like(p, dtype=torch.float32) for p in ctx.params)]
             acc = 0
-        (bg3, _, rg3), (bb3, _, rb3), (bg4, _, rg4), (bb4, _, rb4), (bW6, _, rW6), (bb6, _, rb6), (bW7, _, rW7), (bb7, _, rb7) = sinks
+        if ctx.ident:
+            (bg3, _, rg3), (bb3, _, rb3), (bW6, _, rW6), (bb6, _, rb6), (bW7, _, rW7), (bb7, _, rb7) = sinks
+            bg4 = bb4 = rg4 = rb4 = None
+        else:
+            (bg3, _, rg3), (bb3, _, rb3), (bg4, _, rg4), (bb4, _, rb4), (bW6, _, rW6), (bb6, _, rb6), (bW7, _, rW7), (bb7, _, rb7) = sinks
         dg = torch.empty(Fn + Fr, dtype=torch.float32, device=dev)
         ws = _ws(N, V, Fn, 5, dev)
         L.check(lib.m1_se_combine_bwd(_p(y3), _p(y4), _p(s3), _p(s4), _p(g3), _p(b3), _p(g4), _p(b4), _p(g), _p(dout),
@@ -1064,7 +1080,8 @@ class _SECombine(torch.autograd.Function):
 def se_combine(y3, y4, g3, b3, g4, b4, W6, b6, W7, b7, drop_rate=0.0, rng=None, layer_id=0, stats3=None, stats4=None,
                gate=None):
     """dropout(lrelu(IN3(y3) * sigmoid(W7.lrelu(W6.beta3+b6)+b7) * IN4(y4)))  (network_blocks.py:60-78).
-    ``gate``: the (hidden, g) pair se_gate_batch computed for this block from the same parameters, else evaluated here."""
+    ``gate``: the (hidden, g) pair se_gate_batch computed for this block from the same parameters, else evaluated here.
+    ``g4 = b4 = None``: the identity residual of network_blocks.py:63 (C_in == filters) -- ``y4`` is the block's input tensor."""
     return _SECombine.apply(y3, y4, g3, b3, g4, b4, W6, b6, W7, b7, drop_rate, rng, layer_id, stats3, stats4, gate)
 
 

@@ -126,7 +126,8 @@ class SEResNetBottleNeck(nn.Module):
     """[1] J. Hu et al. (2019), "Squeeze-and-Excitation Networks".  call(): B:48-80.
 
         a   = lrelu(IN1(conv1_{k,s}(x)));  b = lrelu(IN2(conv2_{3x3x3}(a)));  x_ = IN3(conv3_{1x1x1}(b))
-        r   = IN4(conv4_{k,s}(x))                          (always: C_in != filters inside M1, B:63)
+        r   = IN4(conv4_{k,s}(x))   if C_in != filters (B:63; always the case with strictly increasing filters)
+        r   = x                      if C_in == filters: no conv4 / norm4 (and the reference only works with unit strides then)
         out = lrelu( x_ * sigmoid(conv7(lrelu(conv6(GAP(x_))))) * r )          (multiplicative, B:74-78)
     """
 
@@ -134,9 +135,14 @@ class SEResNetBottleNeck(nn.Module):
         super().__init__()
         if in_channels is None:
             raise TypeError("SEResNetBottleNeck needs in_channels (torch builds weights eagerly)")
-        if in_channels == filters:
-            raise NotImplementedError("identity-residual variant (C_in == filters, B:63) never occurs inside M1")
         self.filters, self.kernel_size, self.strides = int(filters), tuple(kernel_size), tuple(strides)
+        # B:63: conv4 / norm4 only "replicate operations with the residual connection" when the channel count changes; with C_in ==
+        # filters the residual factor is the input itself, and the multiply B:77 needs equal shapes: strides other than (1,1,1) fail
+        # in the reference at call time ("Incompatible shapes") -- same condition, raised at construction here
+        self.identity_residual = int(in_channels) == int(filters)
+        if self.identity_residual and self.strides != (1, 1, 1):
+            raise ValueError("Incompatible shapes: SEResNetBottleNeck with C_in == filters (%d) multiplies its output with its own input "
+                             "(network_blocks.py:63,77), which needs strides (1,1,1), got %r" % (self.filters, self.strides))
         self.conv_params, self.reduction = conv_params, int(reduction)
         cp = {k: v for k, v in conv_params.items() if k != "padding"}
         q = self.filters // 4
@@ -146,8 +152,10 @@ class SEResNetBottleNeck(nn.Module):
         self.norm2 = InstanceNormalization(q)
         self.conv3 = Conv3D(q, self.filters, (1, 1, 1), (1, 1, 1), **cp)
         self.norm3 = InstanceNormalization(self.filters)
-        self.conv4 = Conv3D(in_channels, self.filters, self.kernel_size, self.strides, **cp)
-        self.norm4 = InstanceNormalization(self.filters)
+        # (the reference builds conv4 / norm4 in every block, B:43-44; unused ones own no Keras weights because they are never called)
+        if not self.identity_residual:
+            self.conv4 = Conv3D(in_channels, self.filters, self.kernel_size, self.strides, **cp)
+            self.norm4 = InstanceNormalization(self.filters)
         # Keras defaults: glorot_uniform / zeros, no regulariser (B:45-46)
         self.conv6 = Conv3D(self.filters, self.filters // self.reduction, (1, 1, 1), (1, 1, 1), padding="valid")
         self.conv7 = Conv3D(self.filters // self.reduction, self.filters, (1, 1, 1), (1, 1, 1), padding="valid")
@@ -165,6 +173,8 @@ class SEResNetBottleNeck(nn.Module):
 
     def forward(self, input_tensor: Tensors, dropout: Optional[_DropoutBase] = None) -> torch.Tensor:
         members = _as_list(input_tensor)
+        if self.identity_residual:
+            return self._forward_identity(members, dropout)
         if ops.conv_pair_supported(members, self.conv1.kernel, self.conv4.kernel, self.strides):
             # conv1 || conv4 read the same input with the same kernel size and strides (B:53,64): one data gradient over [dy1 | dy4]
             y1, s1, y4, s4, br = ops.conv_pair_same(members, self.conv1.kernel, self.conv1.bias, self.conv4.kernel, self.conv4.bias,
@@ -186,6 +196,23 @@ class SEResNetBottleNeck(nn.Module):
                               self.conv6.kernel, self.conv6.bias, self.conv7.kernel, self.conv7.bias, rate,
                               dropout.rng if (dropout is not None and rate > 0.0) else None,
                               dropout.layer_id if dropout is not None else 0, s3, s4, gate)   # B:60-78 (+ following dropout)
+
+
+    def _forward_identity(self, members, dropout):
+        """C_in == filters (B:63 false branch): out = lrelu(IN3(conv3(...)) * g * x) with the block input x as the residual factor."""
+        x = members[0] if len(members) == 1 else torch.cat(members, dim=-1).contiguous()     # (a concat must exist as a tensor to be a factor)
+        x1, xr = ops.fanout(x, 2)
+        y1, s1 = self.conv1([x1], stats=True)
+        a = self.norm1(y1, 0.1, s1)
+        y2, s2 = self.conv2(a, stats=True)
+        a = self.norm2(y2, 0.1, s2)
+        y3, s3 = self.conv3(a, stats=True)
+        rate = dropout.effective_rate() if dropout is not None else 0.0
+        gate, self._gate = self._gate, None
+        return ops.se_combine(y3, xr, self.norm3.gamma, self.norm3.beta, None, None,
+                              self.conv6.kernel, self.conv6.bias, self.conv7.kernel, self.conv7.bias, rate,
+                              dropout.rng if (dropout is not None and rate > 0.0) else None,
+                              dropout.layer_id if dropout is not None else 0, s3, None, gate)
 
 
 # ---- grid attention gate (B:88-130) ---------------------------------------------------------------------

@@ -300,6 +300,48 @@ def test_c1_other_strides_gate_subsampling_and_reductions(dev, prob):
     _check_grads(m, g64, orc[torch.float32][2])
 
 
+@pytest.mark.parametrize("prob", [False, True])
+def test_c1_equal_neighbouring_filters_identity_residual(dev, prob):
+    """filters (8, 8, 16, 32, 64) with unit strides at level 1: the first encoder block maps 8 -> 8 channels, so the reference skips
+    conv4 / norm4 there (network_blocks.py:63) and multiplies with the block input itself; that block owns no conv4 / norm4 weights
+    (Keras builds weights at the first call) and contributes no L2 term for them."""
+    strides = ((1, 1, 1), (1, 1, 1), (1, 2, 2), (2, 2, 2), (2, 2, 2))
+    cfg = O.M1Config(input_spatial_dims=(4, 16, 16), filters=(8, 8, 16, 32, 64), strides=strides, dense_skip=prob,
+                     deep_supervision=not prob, probabilistic=prob, prob_latent_dims=(2, 1, 0, 0))
+    P = O.fixture_params(cfg, seed=61 + prob)
+    assert not any(".serse1.conv4." in k or ".serse1.norm4." in k for k in P) and any(".serse2.conv4." in k for k in P)
+    x = rnd((2, 4, 16, 16, 3), 62)
+    tgt = _ball_target((2, 4, 16, 16), 63) if False else torch.zeros(2, 4, 16, 16, 2)
+    tgt[..., 0] = 1.0; tgt[:, 1:3, 5:9, 6:10, 0] = 0.0; tgt[:, 1:3, 5:9, 6:10, 1] = 1.0
+    if prob:
+        x[..., 2] = tgt[..., 1]
+    eps = [rnd((2, *s), 64 + i) for i, s in enumerate(O.latent_shapes(cfg))] if prob else None
+    m = build_m1(cfg, dev)
+    names = {k.replace("m1_model.", "") for k, _ in m.named_parameters()}
+    assert names == set(P), (sorted(names - set(P))[:5], sorted(set(P) - names)[:5])          # the same parameter inventory as the oracle
+    load_params_into(m, P)
+    with activation_pattern(m) as ap:
+        if prob:
+            det, kl = m(x.to(dev), eps_q=[e.to(dev) for e in eps])
+        else:
+            det = m(x.to(dev))
+    orc = _oracle_loss_and_grads(cfg, P, x, tgt, eps, masks=ap.masks)
+    loss_o, o, g64 = orc[torch.float64]
+    focal = PKG.losses.Focal(alpha=[0.75, 0.25], gamma=2.0).loss
+    if prob:
+        tc = m.references.m1_model['prob_train_conv']
+        assert float((tc.double().cpu() - o["prob_train_conv"]).abs().max()) < 1e-3
+        assert abs(float(kl) - float(o["prob_kl"])) < 1e-3 * max(1.0, abs(float(o["prob_kl"])))
+        loss = focal(tgt.to(dev), det) + 10.0 * PKG.losses.EvidenceLowerBound().loss(None, kl) + m.regularization_loss()
+    else:
+        lg = m.references.m1_model['logits']
+        assert float((lg.double().cpu() - o["logits"]).abs().max()) < 1e-3
+        loss = focal(tgt.to(dev), det) + m.regularization_loss()
+    assert abs(float(loss) - float(loss_o)) < 1e-3 * abs(float(loss_o))
+    loss.backward()
+    _check_grads(m, g64, orc[torch.float32][2])
+
+
 def test_golden_fixture_c1_det(dev):
     """Committed golden vectors (tests/golden/, produced by tools/make_golden.py from the oracle)."""
     path = os.path.join(os.path.dirname(__file__), "golden", "c1_det.npz")
@@ -521,3 +563,54 @@ def test_side_stream_branches_do_not_change_results(dev, prob):
         assert torch.equal(gx_on, gx_off)
         for a, b in zip(gp_on, gp_off):          # parameter gradients too: no atomics, fixed-order folds
             assert torch.equal(a, b)
+
+
+# ---- seeded fuzz over constructor arguments: forward outputs of random small models against the oracle -------------------------------
+def _model_fuzz_cases(n, seed):
+    import random
+    rng = random.Random(seed)
+    out = []
+    for i in range(n):
+        prob = rng.random() < 0.5
+        filters = rng.choice([(8, 16, 32, 64, 128), (8, 8, 16, 16, 32), (16, 16, 32, 32, 64), (8, 16, 16, 32, 32)])
+        strides = rng.choice([((1, 1, 1), (1, 2, 2), (1, 2, 2), (2, 2, 2), (2, 2, 2)), ((1, 1, 1), (1, 2, 2), (1, 2, 2), (2, 2, 2), (1, 2, 2)),
+                              ((1, 1, 1), (2, 2, 2), (1, 2, 2), (1, 2, 2), (2, 2, 2))])
+        dmul = 1
+        for s_ in strides:
+            dmul *= s_[0]
+        dims = (dmul * rng.choice([1, 2]), 16 * rng.choice([2, 3]), 16 * rng.choice([2, 3]))
+        ks = rng.choice([((1, 3, 3), (1, 3, 3), (3, 3, 3), (3, 3, 3), (3, 3, 3)), ((3, 3, 3),) * 5, ((1, 3, 3),) * 5])
+        red = rng.choice([(8, 8, 8, 8, 8), (4, 4, 4, 4, 4), (2, 4, 8, 8, 16)])
+        lat = rng.choice([(3, 2, 1, 0), (1, 1, 1, 1), (2, 2, 0, 0), (4, 0, 0, 0)])
+        nc = rng.choice([2, 2, 3])
+        cin = (nc - 1) + rng.choice([1, 2, 3]) if prob else rng.choice([1, 2, 3, 4])
+        out.append(dict(i=i, prob=prob, filters=filters, strides=strides, dims=dims, ks=ks, red=red, lat=lat, nc=nc, cin=cin,
+                        dense=rng.random() < 0.6, deep=rng.random() < 0.5, B=rng.choice([1, 2])))
+    return out
+
+
+@pytest.mark.parametrize("case", _model_fuzz_cases(12, seed=77), ids=lambda c: f"m{c['i']}")
+def test_m1_forward_fuzz_against_oracle(dev, case):
+    c = case
+    cfg = O.M1Config(input_spatial_dims=c["dims"], input_channels=c["cin"], num_classes=c["nc"], filters=c["filters"], strides=c["strides"],
+                     kernel_sizes=c["ks"], se_reduction=c["red"], dense_skip=c["dense"], deep_supervision=c["deep"],
+                     probabilistic=c["prob"], prob_latent_dims=c["lat"])
+    P = O.fixture_params(cfg, seed=500 + c["i"])
+    B = c["B"]
+    x = rnd((B, *c["dims"], c["cin"]), 600 + c["i"])
+    eps = [rnd((B, *s), 700 + c["i"] + j) for j, s in enumerate(O.latent_shapes(cfg))] if c["prob"] else None
+    o = O.m1_forward({k: v.double() for k, v in P.items()}, cfg, x.double(), eps_q=[e.double() for e in eps] if eps else None)
+    m = build_m1(cfg, dev)
+    load_params_into(m, P)
+    with torch.no_grad():
+        if c["prob"]:
+            det, kl = m(x.to(dev), eps_q=[e.to(dev) for e in eps])
+            tc = m.references.m1_model['prob_train_conv']
+            assert float((tc.double().cpu() - o["prob_train_conv"]).abs().max()) < 1e-3, case
+            assert abs(float(kl) - float(o["prob_kl"])) < 1e-3 * max(1.0, abs(float(o["prob_kl"]))), (case, float(kl), float(o["prob_kl"]))
+            assert float((det.double().cpu() - o["prob_softmax"]).abs().max()) < 1e-3, case
+        else:
+            probs = m(x.to(dev))
+            lg = m.references.m1_model['logits']
+            assert float((lg.double().cpu() - o["logits"]).abs().max()) < 1e-3, case
+            assert float((probs.double().cpu() - o["y_softmax"]).abs().max()) < 1e-3, case

@@ -223,6 +223,52 @@ def test_se_combine_fwd_bwd(dev, dtype, F_, red, V):
         assert rel_err(a.grad, b) < tol * 3, n
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("F_,red,V,drop", [(16, 8, (3, 6, 5), 0.0), (32, 4, (2, 8, 8), 0.0), (8, 8, (4, 10, 10), 0.4)])
+def test_se_combine_identity_residual_fwd_bwd(dev, dtype, F_, red, V, drop):
+    """network_blocks.py:63 false branch (C_in == filters): out = dropout(lrelu(IN3(y3) * g * x)) with the block INPUT x as the residual
+    factor -- no conv4 / norm4, the gradient wrt x passes through without a normalisation (m1_se_combine_* with stats4 = gamma4 =
+    beta4 = NULL)."""
+    N = 2
+    shp = (N, *V, F_)
+    y3, x = rnd(shp, 21), rnd(shp, 22) * 1.3 + 0.1
+    if dtype == torch.bfloat16:
+        y3, x = y3.bfloat16().float(), x.bfloat16().float()
+    g3, b3 = 1 + 0.2 * rnd((F_,), 23), 0.5 * rnd((F_,), 24)
+    W6, b6 = rnd((1, 1, 1, F_, F_ // red), 27, 0.5), 0.1 * rnd((F_ // red,), 28)
+    W7, b7 = rnd((1, 1, 1, F_ // red, F_), 29, 0.5), 0.1 * rnd((F_,), 30)
+    dout = rnd(shp, 31)
+    if dtype == torch.bfloat16:
+        dout = dout.bfloat16().float()
+    rng = torch.tensor([12345, 3], dtype=torch.int64, device=dev) if drop > 0 else None
+    keep = None
+    if drop > 0:                                           # the draw of the product, reproduced on a tensor of ones (a pure function of
+        ones = torch.ones(shp, device=dev, dtype=dtype)    # (seed, step, layer id, element index))
+        keep = (ops.dropout(ones, drop, rng, 7) != 0).double().cpu()
+
+    def fn(y3_, x_in, g3_, b3_, W6_, b6_, W7_, b7_):
+        x_ = O.instance_norm(y3_, g3_, b3_)
+        gp = x_.mean(dim=(1, 2, 3), keepdim=True)
+        gp = O.lrelu(O.conv3d_same(gp, W6_, b6_, (1, 1, 1)))
+        gp = torch.sigmoid(O.conv3d_same(gp, W7_, b7_, (1, 1, 1)))
+        out = O.lrelu(x_ * gp * x_in)
+        return out * keep / (1.0 - drop) if drop > 0 else out
+    ins = [y3, x, g3, b3, W6, b6, W7, b7]
+    yo, grads = _oracle_grads(fn, ins, dout)
+    d = [t.to(dev, dtype if i < 2 else torch.float32).requires_grad_(True) for i, t in enumerate(ins)]
+    out = ops.se_combine(d[0], d[1], d[2], d[3], None, None, d[4], d[5], d[6], d[7], drop, rng, 7)
+    out.backward(dout.to(dev, dtype))
+    tol = TOL[dtype]
+    assert rel_err(out, yo) < tol
+    for n, a, b in zip("y3 x g3 b3 W6 b6 W7 b7".split(), d, grads):
+        assert rel_err(a.grad, b) < tol * 3, n
+    # the ABI rejects a half-specified second norm
+    lib = PKG.hip.lib.load()
+    assert lib.m1_se_combine_fwd(d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), None, d[2].data_ptr(), d[3].data_ptr(), d[2].data_ptr(), None,
+                                 d[2].data_ptr(), out.data_ptr(), N, V[0] * V[1] * V[2], F_, 0 if dtype == torch.float32 else 1, 0.0, None, 0, None,
+                                 torch.cuda.current_stream().cuda_stream) == -1
+
+
 def test_se_gate_backward_deferred_batch_matches_direct(dev):
     """Gradient-sink mode queues the SE gate backwards and runs them as one m1_se_gate_bwd_batch at flush_deferred();
     the sums in the sinks must equal the immediate per-block path (two passes accumulate, like prior+posterior)."""

@@ -249,6 +249,24 @@ def test_two_rank_gloo_gradient_exchange_equals_global_batch_mean():
     assert np.array_equal(res[0][6][:16], np.full(16, 200.0)) and np.array_equal(res[1][6][:16], np.full(16, 400.0))
 
 
+def test_se_block_with_equal_channel_counts_needs_unit_strides_like_the_reference():
+    """network_blocks.py:63: conv4 / norm4 only run when the channel count changes; with C_in == filters the output is multiplied with the
+    block's own input (B:77), which the reference can only do when the strides are (1,1,1) (otherwise TF raises 'Incompatible shapes' at
+    call time).  Here: ValueError at construction for the strided case, and a block without conv4 / norm4 parameters otherwise."""
+    nb = PKG.unets.network_blocks
+    cp = dict(kernel_initializer=None, bias_initializer=None, kernel_regularizer=None, bias_regularizer=None)
+    with pytest.raises(ValueError, match="Incompatible shapes"):
+        nb.SEResNetBottleNeck(16, (3, 3, 3), (1, 2, 2), cp, 8, in_channels=16)
+    blk = nb.SEResNetBottleNeck(16, (3, 3, 3), (1, 1, 1), cp, 8, in_channels=16)
+    assert blk.identity_residual and not hasattr(blk, "conv4") and not hasattr(blk, "norm4")
+    assert not any("conv4" in k or "norm4" in k for k, _ in blk.named_parameters())
+    blk2 = nb.SEResNetBottleNeck(16, (3, 3, 3), (1, 2, 2), cp, 8, in_channels=8)
+    assert not blk2.identity_residual and hasattr(blk2, "conv4")
+    # a whole model whose filters repeat at a strided level fails the same way (M1's default strides have (1,2,2) at level 1)
+    with pytest.raises(ValueError, match="Incompatible shapes"):
+        PKG.unets.networks.M1(input_spatial_dims=(4, 32, 32), input_channels=3, num_classes=2, filters=(8, 8, 16, 32, 64), summary=False)
+
+
 def test_latent_configurations_the_reference_cannot_build_raise_the_same_error():
     """networks.py:645-717 read the posterior's latents as prob_z_q[level] while used_latents only grows at levels that have one: a
     level WITHOUT a latent in front of a level WITH one (e.g. (3,0,1,0)) fails in the reference with IndexError when m1() builds its
