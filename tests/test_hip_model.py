@@ -572,7 +572,9 @@ def _model_fuzz_cases(n, seed):
     out = []
     for i in range(n):
         prob = rng.random() < 0.5
-        filters = rng.choice([(8, 16, 32, 64, 128), (8, 8, 16, 16, 32), (16, 16, 32, 32, 64), (8, 16, 16, 32, 32)])
+        # (strictly increasing filters: a level that keeps its channel count must have unit strides in the reference, network_blocks.py:63;
+        #  (8,16,24,32,48) puts 2 / 4 / 6 / 12-channel bottlenecks and 24- / 48-channel tensors on the zero-padded K-segment paths)
+        filters = rng.choice([(8, 16, 32, 64, 128), (8, 16, 24, 32, 48), (16, 32, 48, 64, 96), (8, 16, 32, 48, 64)])
         strides = rng.choice([((1, 1, 1), (1, 2, 2), (1, 2, 2), (2, 2, 2), (2, 2, 2)), ((1, 1, 1), (1, 2, 2), (1, 2, 2), (2, 2, 2), (1, 2, 2)),
                               ((1, 1, 1), (2, 2, 2), (1, 2, 2), (1, 2, 2), (2, 2, 2))])
         dmul = 1
