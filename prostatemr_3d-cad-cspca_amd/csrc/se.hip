@@ -221,8 +221,11 @@ struct SeParams {
 };
 // per-channel constants of the second factor: {mean, rstd, gamma, beta} of norm4, or {0, 1, 1, 0} for the identity residual --
 // (y4 - 0) * 1 * 1 + 0 is y4 exactly, and the InstanceNorm backward with zero sums and unit scale is the identity
+// (ID4 is a template parameter of every kernel: a run-time test of p.identity4 inside the per-element functor cost the ordinary path
+//  2-3x -- 0.54 -> 1.60 ms forward, 1.6 -> 3.3 ms backward per C3 step -- measured before this was made compile-time)
+template <bool ID4>
 __device__ __forceinline__ void se_rho_consts(const SeParams& p, size_t sc, int c, float& m4, float& r4, float& g4, float& b4) {
-    if (p.identity4) { m4 = 0.f; r4 = 1.f; g4 = 1.f; b4 = 0.f; }
+    if constexpr (ID4) { m4 = 0.f; r4 = 1.f; g4 = 1.f; b4 = 0.f; }
     else { m4 = p.stats4[sc]; r4 = p.stats4[sc + 1]; g4 = p.gamma4[c]; b4 = p.beta4[c]; }
 }
 
@@ -231,7 +234,7 @@ __device__ __forceinline__ void se_rng(const SeParams& p, uint64_t& seed, uint64
     if (p.drop_rate > 0.f) { seed = p.rng[0] + p.layer_id * 0x9E3779B97F4A7C15ull; base = p.rng[1] << 36; }
 }
 
-template <typename T, int VEC>
+template <typename T, int VEC, bool ID4 = false>
 __global__ void __launch_bounds__(256, 3) se_combine_fwd_kernel(const T* __restrict__ y3, const T* __restrict__ y4, SeParams p,
                                                              T* __restrict__ out) {
     const int n = blockIdx.y, F = p.F, cg = F / VEC;
@@ -248,7 +251,7 @@ __global__ void __launch_bounds__(256, 3) se_combine_fwd_kernel(const T* __restr
     for (int k = 0; k < VEC; ++k) {
         const int c = c0 + k; const size_t sc = ((size_t)n * F + c) * 2;
         m3[k] = p.stats3[sc]; r3[k] = p.stats3[sc + 1]; g3[k] = p.gamma3[c]; b3[k] = p.beta3[c];
-        se_rho_consts(p, sc, c, m4[k], r4[k], g4[k], b4[k]); gt[k] = p.g[c];
+        se_rho_consts<ID4>(p, sc, c, m4[k], r4[k], g4[k], b4[k]); gt[k] = p.g[c];
     }
     auto body = [&](long long i, float* a, const float* b) {
 #pragma unroll
@@ -286,13 +289,13 @@ __global__ void __launch_bounds__(256, 3) se_combine_fwd_kernel(const T* __restr
 }
 
 // ---------------- combine backward ----------------
-template <typename T, bool MASKED = false>
+template <typename T, bool MASKED = false, bool ID4 = false>
 struct SeBwdF {
     const T* y3; const T* y4; const T* dout; SeParams p;
     __device__ void operator()(int n, long long v, int c, float* acc) const {
         const int F = p.F;
         const size_t idx = ((size_t)n * p.V + v) * F + c; const size_t sc = ((size_t)n * F + c) * 2;
-        float m4, r4, g4, b4; se_rho_consts(p, sc, c, m4, r4, g4, b4);
+        float m4, r4, g4, b4; se_rho_consts<ID4>(p, sc, c, m4, r4, g4, b4);
         const float xh3 = (Act<T>::ld(y3 + idx) - p.stats3[sc]) * p.stats3[sc + 1];
         const float xh4 = (Act<T>::ld(y4 + idx) - m4) * r4;
         const float x_ = xh3 * p.gamma3[c] + p.beta3[c], rho = xh4 * g4 + b4;
@@ -323,7 +326,7 @@ struct SeBwdF {
 #pragma unroll
         for (int e = 0; e < kVec; ++e) {
             const int c = c0 + e; const size_t sc = ((size_t)n * F + c) * 2;
-            float m4, r4, g4, b4; se_rho_consts(p, sc, c, m4, r4, g4, b4);
+            float m4, r4, g4, b4; se_rho_consts<ID4>(p, sc, c, m4, r4, g4, b4);
             const float xh3 = (a[e] - p.stats3[sc]) * p.stats3[sc + 1];
             const float xh4 = (b[e] - m4) * r4;
             const float x_ = xh3 * p.gamma3[c] + p.beta3[c], rho = xh4 * g4 + b4;
@@ -337,7 +340,7 @@ struct SeBwdF {
     }
 };
 
-template <typename T, int VEC, bool MASKED = false, int MINW = 2>
+template <typename T, int VEC, bool MASKED = false, int MINW = 2, bool ID4 = false>
 __global__ void __launch_bounds__(256, MINW) se_combine_bwd_apply_kernel(const T* __restrict__ y3, const T* __restrict__ y4,
                                                                    const T* __restrict__ dout, SeParams p,
                                                                    const float* __restrict__ sums /*[N][F][5]*/,
@@ -356,10 +359,10 @@ __global__ void __launch_bounds__(256, MINW) se_combine_bwd_apply_kernel(const T
     for (int k = 0; k < VEC; ++k) {
         const int c = c0 + k; const size_t sc = ((size_t)n * F + c) * 2;
         m3[k] = p.stats3[sc]; r3[k] = p.stats3[sc + 1]; g3[k] = p.gamma3[c]; b3[k] = p.beta3[c];
-        se_rho_consts(p, sc, c, m4[k], r4[k], g4[k], b4[k]); gt[k] = p.g[c];
+        se_rho_consts<ID4>(p, sc, c, m4[k], r4[k], g4[k], b4[k]); gt[k] = p.g[c];
         const float* s = sums + ((size_t)n * F + c) * 5;
         s0[k] = s[0] * invV; s1[k] = s[1] * invV; s2[k] = s[2] * invV; s3[k] = s[3] * invV;
-        if (p.identity4) { s2[k] = 0.f; s3[k] = 0.f; }            // d(residual) = d(rho): no mean terms (there is no norm4)
+        if constexpr (ID4) { s2[k] = 0.f; s3[k] = 0.f; }          // d(residual) = d(rho): no mean terms (there is no norm4)
     }
     for (long long i = i0; i < per; i += stride) {
         float a[VEC], b[VEC], d[VEC];
@@ -393,6 +396,15 @@ __global__ void __launch_bounds__(256, MINW) se_combine_bwd_apply_kernel(const T
 template <typename T>
 static int se_fwd_impl(const void* y3, const void* y4, const SeParams& p, void* out, int N, hipStream_t st) {
     constexpr int VW = sizeof(T) == 2 ? 8 : 4;
+    if (p.identity4) {                                   // network_blocks.py:63 false branch: its own instantiations (compile-time constants)
+        if (p.F % VW == 0)
+            hipLaunchKernelGGL((se_combine_fwd_kernel<T, VW, true>), dim3(m1_grid_for(p.V * (p.F / VW), p.F / VW), N), dim3(256), 0, st, (const T*)y3,
+                               (const T*)y4, p, (T*)out);
+        else
+            hipLaunchKernelGGL((se_combine_fwd_kernel<T, 1, true>), dim3(m1_grid_for(p.V * p.F, p.F), N), dim3(256), 0, st, (const T*)y3,
+                               (const T*)y4, p, (T*)out);
+        return m1_check_launch();
+    }
     if (p.F % VW == 0)
         hipLaunchKernelGGL((se_combine_fwd_kernel<T, VW>), dim3(m1_grid_for(p.V * (p.F / VW), p.F / VW), N), dim3(256), 0, st, (const T*)y3,
                            (const T*)y4, p, (T*)out);
@@ -413,6 +425,23 @@ static int se_bwd_impl(const void* y3, const void* y4, const void* dout, const S
     float* sums = ws + (size_t)N * nchunks * p.F * 5;
     // parameter gradients ride on the fold: dg is scratch for the gate backward (always overwritten)
     M1ParamOut<5> po{{dbeta3, dgamma3, p.identity4 ? nullptr : dbeta4, p.identity4 ? nullptr : dgamma4, dg}, {acc, acc, acc, acc, 0}};
+    if (p.identity4) {
+        // the identity-residual block (a rare configuration): the plain variants, the keep bits read from the mask when there is one
+        if (masked) { SeBwdF<T, true, true> f{(const T*)y3, (const T*)y4, (const T*)dout, p}; rc = m1_reduce_nc_launch<5>(f, N, p.V, p.F, ws, st); }
+        else { SeBwdF<T, false, true> f{(const T*)y3, (const T*)y4, (const T*)dout, p}; rc = m1_reduce_nc_launch<5>(f, N, p.V, p.F, ws, st); }
+        if (rc) return rc;
+        rc = m1_reduce_finalize_params_launch<5>(ws, N, p.F, nchunks, sums, po, st); if (rc) return rc;
+        if (masked)
+            hipLaunchKernelGGL((se_combine_bwd_apply_kernel<T, VW, true, 2, true>), dim3(m1_grid_for(p.V * (p.F / VW), p.F / VW), N), dim3(256), 0, st,
+                               (const T*)y3, (const T*)y4, (const T*)dout, p, sums, (T*)dy3, (T*)dy4);
+        else if (p.F % VW == 0)
+            hipLaunchKernelGGL((se_combine_bwd_apply_kernel<T, VW, false, 2, true>), dim3(m1_grid_for(p.V * (p.F / VW), p.F / VW), N), dim3(256), 0, st,
+                               (const T*)y3, (const T*)y4, (const T*)dout, p, sums, (T*)dy3, (T*)dy4);
+        else
+            hipLaunchKernelGGL((se_combine_bwd_apply_kernel<T, 1, false, 2, true>), dim3(m1_grid_for(p.V * p.F, p.F), N), dim3(256), 0, st, (const T*)y3,
+                               (const T*)y4, (const T*)dout, p, sums, (T*)dy3, (T*)dy4);
+        return m1_check_launch();
+    }
     if (masked) { SeBwdF<T, true> f{(const T*)y3, (const T*)y4, (const T*)dout, p}; rc = m1_reduce_nc_launch<5>(f, N, p.V, p.F, ws, st); }
     else { SeBwdF<T> f{(const T*)y3, (const T*)y4, (const T*)dout, p}; rc = m1_reduce_nc_launch<5>(f, N, p.V, p.F, ws, st); }
     if (rc) return rc;
