@@ -382,9 +382,15 @@ def run_workload(a, wl, ctx, want_roofline, want_cpu):
         # ranges of the flat buffer are exactly zero on every rank and stay out of the exchange
         live_elems = opt.refresh_live_ranges()
         # ... which the gradient buffer of the warm-up step confirms: everything outside the live ranges is exactly zero
-        gabs = opt.flatp.grad.abs()
-        dead_zero = bool(float(gabs.sum() - sum(gabs[a:b].sum() for a, b in opt.flatp.live_ranges())) == 0.0) if live_elems else None
-        del gabs
+        # (exact: the largest magnitude of every slice BETWEEN the live runs must be zero -- no difference of rounded sums)
+        if live_elems:
+            gflat, pos, dead_zero = opt.flatp.grad, 0, True
+            for a_, b_ in list(opt.flatp.live_ranges()) + [(gflat.numel(), gflat.numel())]:
+                if a_ > pos and float(gflat[pos:a_].abs().max()) != 0.0:
+                    dead_zero = False
+                pos = max(pos, b_)
+        else:
+            dead_zero = None
     _dbg("eager warm-up done")
     # N = 1: the whole step is one hipGraph.  N > 1 over RCCL ("full"): the same, the collectives are captured on the
     # communication stream inside it; "split" (fallback): forward+backward are captured without collectives, the exchange
@@ -395,6 +401,8 @@ def run_workload(a, wl, ctx, want_roofline, want_cpu):
         gmode = os.environ.get("M1_DDP_GRAPH", "full" if backend == "nccl" else "off")
     else:
         gmode = "full"
+    graph_nodes = {}
+
     def capture(fn, thread_local):
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
@@ -412,11 +420,15 @@ def run_workload(a, wl, ctx, want_roofline, want_cpu):
             # query ("operation not permitted on an event last recorded in a capturing stream") and the watchdog aborts the
             # process (seen in 1 of 3 ... 1 of 8 runs of the probabilistic model).  Wait until the watchdog HAS retired them.
             _dbg("watchdog drain: " + drain_watchdog())
-        gr = torch.cuda.CUDAGraph()
+        gr = torch.cuda.CUDAGraph(keep_graph=True)                    # (the raw hipGraph_t stays: its nodes are enumerated below)
         if os.environ.get("M1_BENCH_CAPTURE_TL") in ("0", "1"):      # debug: force the capture error mode
             thread_local = os.environ["M1_BENCH_CAPTURE_TL"] == "1"
         with torch.cuda.graph(gr, capture_error_mode="thread_local" if thread_local else "global"):
             fn()
+        # the captured step -- library kernels, torch-side ops and RCCL's nodes alike -- must hold NO memset node (ROCm 7.2 executes
+        # them wrongly from the second replay on); the histogram goes into the bench line (config.graph_nodes)
+        graph_nodes.clear(); graph_nodes.update(pkg.hip.graphs.assert_no_memset_nodes(gr))
+        gr.instantiate()
         torch.cuda.synchronize()
         if fn is fwd_bwd:
             update()
@@ -475,6 +487,27 @@ def run_workload(a, wl, ctx, want_roofline, want_cpu):
                     "note": "groups are sent from the communication stream as backward completes them (ddp.py); counters "
                             "count host-side calls (in graph mode 'full' the captured collectives replay without them)"}
     final_loss = float(loss_buf)
+    if os.environ.get("M1_BENCH_TORCH_OPS") and rank == 0:
+        # debug: which torch-side (non-library) device ops one eager step issues, and from which line of this repository
+        import collections
+        from torch.profiler import ProfilerActivity, profile
+        with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True, record_shapes=True) as prof:
+            step()
+            torch.cuda.synchronize()
+        agg = collections.Counter()
+        for ev in prof.events():
+            if not ev.name.startswith("aten::") or not ev.kernels:
+                continue
+            site = "?"
+            for fr in ev.stack or []:
+                if ROOT in fr and "/torch/" not in fr:
+                    site = fr.replace(ROOT + "/", "")
+                    break
+            agg[(ev.name, str(ev.input_shapes)[:70], ",".join(sorted({k.name[:44] for k in ev.kernels})), site)] += 1
+        with open(os.environ["M1_BENCH_TORCH_OPS"], "w") as f:
+            f.write(f"{wl}: torch-side device ops of ONE eager step (count, op, shapes, kernels, innermost repository frame)\n")
+            for (name, shp, kn, site), n in sorted(agg.items(), key=lambda kv: -kv[1]):
+                f.write(f"{n:4d}  {name:20s} {shp:70s} {kn:46s} {site}\n")
     if os.environ.get("M1_BENCH_DUMP") and rank == 0:          # harness tests: the state a run ends in (bit-compared between modes)
         torch.save({"flat": opt.flatp.flat.cpu(), "grad": opt.flatp.grad.cpu(), "m": opt.m.cpu(), "vhat": opt.vhat.cpu(),
                     "step": opt.step_dev.cpu(), "rng": model.rng_state.cpu(), "hist": hist,
@@ -601,7 +634,8 @@ def run_workload(a, wl, ctx, want_roofline, want_cpu):
         "config": {"workload": WORKLOAD_NAMES[wl], "batch_per_gpu": B, "global_batch": B * world,
                    "batch_note": "train_model.py:83 default (--BATCH_SIZE 2)" if a.batch is None and B == 2 else "--batch",
                    "params": nparams, "dropout": a.dropout, "parallelism": f"dp{world}", "hip_graph": graph is not None,
-                   "graph_error": graph_err, "loss": final_loss, "exchange": exchange},
+                   "graph_error": graph_err, "graph_nodes": dict(graph_nodes) if graph is not None else None,
+                   "loss": final_loss, "exchange": exchange},
         "roofline": roof, "cpu_baseline": cpu,
     }
     # free this workload before the next one is built

@@ -12,8 +12,9 @@
  *   - process-global host state the library DOES keep (all of it behind mutexes, none of it device memory):
  *     the tuning-switch table (m1_config_*), the queue of deferred weight-gradient folds between m1_wgrad_defer(1)
  *     and m1_wgrad_fold_pending / _drop (the queued jobs point into caller-owned workspaces, which the caller keeps
- *     alive until then), the test hook m1_set_force_direct, the opt-in profiler (m1_prof_*) and the opt-in
- *     kernel-choice log (m1_debug_kernels).  One thread drives the library at a time per process.
+ *     alive until then), the test hook m1_set_force_direct, the opt-in profiler (m1_prof_*), the opt-in
+ *     kernel-choice log (m1_debug_kernels) and the cursor into the caller's ticket pool (m1_tickets_set).
+ *     One thread drives the library at a time per process.
  *   - results are bit-reproducible run to run in the default configuration: every reduction across blocks goes
  *     through per-split partials folded in a fixed order.  Floating-point atomics remain compiled in behind
  *     switches only (M1_WG_DET=0, m1_set_force_direct: the generic fp32 reference kernels of conv_direct.hip).
@@ -151,6 +152,32 @@ int m1_debug_checksum(const void* p, long long nbytes, unsigned long long* slot,
  * on it: a shape the special kernel declines would otherwise compare the generic kernel with itself and stay green. */
 const char* m1_debug_kernels(int mode);
 int m1_debug_scribble(int blocks, int spins, void* stream);
+
+/* Ticket pool of the last-block finalize (round 6; csrc/reduce.h).  Every per-(sample, channel) reduction of the path -- InstanceNorm
+ * statistics (B:54-60, N:575), the InstanceNorm / SE-combine backward sums (App. F), bias-gradient column sums -- is a grid of blocks
+ * that write partial rows plus a fold of those rows.  With a pool registered the fold runs in the block that finishes last (one
+ * self-resetting counter per sample, rows written write-through) instead of in a second launch.  `pool`: n >= 64 unsigned counters
+ * in device memory of the CURRENT device, zero-initialised by the caller, kept alive and untouched while the library is in use
+ * (counters return to zero by themselves; after an aborted launch the caller zeroes the pool again).  NULL unregisters: every
+ * reduction is followed by its finalize launch again (also with M1_RED_TAIL=0).  Results are identical either way up to the
+ * rounding of the fp64 fold order, and bit-reproducible run to run in both. */
+int m1_tickets_set(void* pool, int n);
+
+/* ---- Conv3D whose input is LeakyReLU(InstanceNorm(x)) of a raw conv output x, as ONE data pass : B:56-59 (norm2 -> relu -> conv3),
+ * SURVEY App. G; BASELINE north_star "conv3d fused with GroupNorm+SiLU" (= InstanceNorm + LeakyReLU here) ----
+ * d->src[0].ptr = x (the RAW output of the previous conv, one member), x_stats = its finished {mean, rstd} [N][Cin][2], gamma / beta
+ * the norm's parameters: the kernel applies a = lrelu(gamma*(x-mean)*rstd + beta, slope), rounded to the activation type, to its
+ * operand in registers -- the normalised tensor is never written.  Stride-1 pointwise bf16 layers with Cin % 8 == 0 that the
+ * streaming kernel takes (Cin <= 64): m1_conv3d_fwd_norm_supported says so BEFORE the caller builds its graph; anything else returns
+ * M1_ERR_UNSUPPORTED with nothing launched.  y / stats / ws / ws_packed as m1_conv3d_fwd (same workspace size, same packed panel).
+ * m1_conv3d_wgrad_norm: dw[ci][co] (+)= sum_v a[v][ci] * dy[v][co] with the SAME operand transform (a is recomputed from x), db as
+ * m1_conv3d_wgrad; ws = m1_conv_ws_bytes(d, 0, 2).  The data gradient and the norm's backward take x as they always did:
+ * m1_conv3d_dgrad_inbwd + m1_instnorm_bwd_partials. */
+int m1_conv3d_fwd_norm_supported(const m1_conv_desc_t* d);
+int m1_conv3d_fwd_norm(const m1_conv_desc_t* d, const float* x_stats, const float* gamma, const float* beta, float slope,
+                       const float* w, const float* bias, void* y, float* stats, void* ws, int ws_packed, void* stream);
+int m1_conv3d_wgrad_norm(const m1_conv_desc_t* d, const float* x_stats, const float* gamma, const float* beta, float slope,
+                         const void* dy, float* dw, float* db, void* ws, int accumulate, void* stream);
 
 /* ---- Conv3DTranspose(padding='same') + bias : N:496-499,505-507,513-514,520,546-553 ----
  * w: Keras layout (kd,kh,kw,Cout,Cin) fp32; y: (N, D*sd, H*sh, W*sw, Cout). */

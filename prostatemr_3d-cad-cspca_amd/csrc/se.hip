@@ -425,12 +425,14 @@ static int se_bwd_impl(const void* y3, const void* y4, const void* dout, const S
     float* sums = ws + (size_t)N * nchunks * p.F * 5;
     // parameter gradients ride on the fold: dg is scratch for the gate backward (always overwritten)
     M1ParamOut<5> po{{dbeta3, dgamma3, p.identity4 ? nullptr : dbeta4, p.identity4 ? nullptr : dgamma4, dg}, {acc, acc, acc, acc, 0}};
+    const M1Fin<5> fin = m1_fin_params<5>(sums, po);
+    bool fused = false;
     if (p.identity4) {
         // the identity-residual block (a rare configuration): the plain variants, the keep bits read from the mask when there is one
-        if (masked) { SeBwdF<T, true, true> f{(const T*)y3, (const T*)y4, (const T*)dout, p}; rc = m1_reduce_nc_launch<5>(f, N, p.V, p.F, ws, st); }
-        else { SeBwdF<T, false, true> f{(const T*)y3, (const T*)y4, (const T*)dout, p}; rc = m1_reduce_nc_launch<5>(f, N, p.V, p.F, ws, st); }
+        if (masked) { SeBwdF<T, true, true> f{(const T*)y3, (const T*)y4, (const T*)dout, p}; rc = m1_reduce_nc_launch<5>(f, N, p.V, p.F, ws, st, &fin, &fused); }
+        else { SeBwdF<T, false, true> f{(const T*)y3, (const T*)y4, (const T*)dout, p}; rc = m1_reduce_nc_launch<5>(f, N, p.V, p.F, ws, st, &fin, &fused); }
         if (rc) return rc;
-        rc = m1_reduce_finalize_params_launch<5>(ws, N, p.F, nchunks, sums, po, st); if (rc) return rc;
+        if (!fused) { rc = m1_reduce_finalize_params_launch<5>(ws, N, p.F, nchunks, sums, po, st); if (rc) return rc; }
         if (masked)
             hipLaunchKernelGGL((se_combine_bwd_apply_kernel<T, VW, true, 2, true>), dim3(m1_grid_for(p.V * (p.F / VW), p.F / VW), N), dim3(256), 0, st,
                                (const T*)y3, (const T*)y4, (const T*)dout, p, sums, (T*)dy3, (T*)dy4);
@@ -442,10 +444,10 @@ static int se_bwd_impl(const void* y3, const void* y4, const void* dout, const S
                                (const T*)y4, (const T*)dout, p, sums, (T*)dy3, (T*)dy4);
         return m1_check_launch();
     }
-    if (masked) { SeBwdF<T, true> f{(const T*)y3, (const T*)y4, (const T*)dout, p}; rc = m1_reduce_nc_launch<5>(f, N, p.V, p.F, ws, st); }
-    else { SeBwdF<T> f{(const T*)y3, (const T*)y4, (const T*)dout, p}; rc = m1_reduce_nc_launch<5>(f, N, p.V, p.F, ws, st); }
+    if (masked) { SeBwdF<T, true> f{(const T*)y3, (const T*)y4, (const T*)dout, p}; rc = m1_reduce_nc_launch<5>(f, N, p.V, p.F, ws, st, &fin, &fused); }
+    else { SeBwdF<T> f{(const T*)y3, (const T*)y4, (const T*)dout, p}; rc = m1_reduce_nc_launch<5>(f, N, p.V, p.F, ws, st, &fin, &fused); }
     if (rc) return rc;
-    rc = m1_reduce_finalize_params_launch<5>(ws, N, p.F, nchunks, sums, po, st); if (rc) return rc;
+    if (!fused) { rc = m1_reduce_finalize_params_launch<5>(ws, N, p.F, nchunks, sums, po, st); if (rc) return rc; }
     int w3 = M1_CFG("M1_SE_BWD_W3", 0);
     if (masked && w3)       // 3 waves per SIMD at the price of 4 spilled registers (measured: see DESIGN 5)
         hipLaunchKernelGGL((se_combine_bwd_apply_kernel<T, VW, true, 3>), dim3(m1_grid_for(p.V * (p.F / VW), p.F / VW), N), dim3(256), 0, st,

@@ -107,6 +107,9 @@ class GradReducer:
             self._on_origin = on_origin
         if flat_grad.is_cuda and self._comm is None:
             self._comm = torch.cuda.Stream(device=flat_grad.device)
+        # the reduce-scatter + all-gather pair needs a backend that implements the tensor forms (RCCL does, gloo does not)
+        self._rank = dist.get_rank(self.group) if dist.is_initialized() else 0
+        self._rsag_ok = dist.is_initialized() and dist.get_backend(self.group) == "nccl"
 
     # ------------------------------------------------------------------------------------------------------
     def set_live(self, runs: Sequence[Tuple[int, int]]) -> None:
@@ -127,11 +130,11 @@ class GradReducer:
             for a, b in bucket_bounds(phi - plo, self.bucket_elems):
                 t = self.flat[plo + a:plo + b]
                 m = (b - a) // world * world
-                if self.rs_ag and (world > 1 or self.force) and m >= 1024 * world:
+                if self.rs_ag and getattr(self, "_rsag_ok", False) and (world > 1 or self.force) and m >= 1024 * world:
                     # reduce-scatter + all-gather in place (each rank owns 1/world of the bucket between the two): on xGMI every rank
                     # exchanges its shard with all 7 peers directly, where a ring all-reduce relays through every rank
                     c = m // world
-                    rank = dist.get_rank(self.group)
+                    rank = self._rank
                     shard = t[rank * c:(rank + 1) * c]
                     dist.reduce_scatter_tensor(shard, t[:m], op=dist.ReduceOp.SUM, group=self.group)
                     dist.all_gather_into_tensor(t[:m], shard, group=self.group)

@@ -79,7 +79,11 @@ SIGNATURES = {
     "m1_debug_checksum": (_i, [_vp, _ll, _vp, _vp]),
     "m1_debug_scribble": (_i, [_i, _i, _vp]),
     "m1_debug_kernels": (C.c_char_p, [_i]),
+    "m1_tickets_set": (_i, [_vp, _i]),
     "m1_conv3d_wgrad": (_i, [_desc_p, _vp, _vp, _vp, _vp, _i, _vp]),
+    "m1_conv3d_fwd_norm_supported": (_i, [_desc_p]),
+    "m1_conv3d_fwd_norm": (_i, [_desc_p, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
+    "m1_conv3d_wgrad_norm": (_i, [_desc_p, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _i, _vp]),
     "m1_conv3d_pair_supported": (_i, [_desc_p, _i]),
     "m1_conv3d_pair_fwd": (_i, [_desc_p, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
     "m1_conv3d_pair_dgrad": (_i, [_desc_p, _vp, _vp, _i, _vp, _vp, C.POINTER(_vp), C.POINTER(_i), _vp, _i, _vp]),

@@ -123,7 +123,33 @@ def _p(t: Optional[torch.Tensor]):
     return None if t is None else t.data_ptr()
 
 
+# Ticket pools of the last-block finalize (m1_tickets_set): one zero-initialised int32 tensor per device, registered before the
+# first launch on that device and kept for the life of the process (the counters reset themselves, see include/m1hip.h).
+_TICKETS: dict = {}
+_TICKET_SLOTS = 16384
+
+
+def _ensure_tickets() -> None:
+    dev = torch.cuda.current_device()
+    if dev in _TICKETS:
+        return
+    if torch.cuda.is_current_stream_capturing():
+        raise RuntimeError("first M1 HIP op on this device inside a graph capture: run one eager step first")
+    t = torch.zeros(_TICKET_SLOTS, dtype=torch.int32, device=torch.device("cuda", dev))
+    torch.cuda.current_stream().synchronize()                 # the fill ran on this stream; launches may come from others
+    L.check(L.load().m1_tickets_set(t.data_ptr(), _TICKET_SLOTS), "m1_tickets_set")
+    _TICKETS[dev] = t
+
+
+def tickets_reset() -> None:
+    """Zero the ticket pool of the current device (after an aborted launch left counters mid-count)."""
+    t = _TICKETS.get(torch.cuda.current_device())
+    if t is not None:
+        t.zero_()
+
+
 def _stream():
+    _ensure_tickets()
     s = torch.cuda.current_stream().cuda_stream
     if _POISON >= 2:
         L.load().m1_debug_scribble(0, 8, s)
@@ -691,7 +717,7 @@ def _pair_panel_ws(w1: torch.Tensor, w4: torch.Tensor, d, role: int, need_mask=N
     return ws, 0
 
 
-def _wgrad_into_sinks(lib, d, dy, w_param, b_param, transposed: bool, st, srcs=()):
+def _wgrad_into_sinks(lib, d, dy, w_param, b_param, transposed: bool, st, srcs=(), norm=None):
     """Weight (+ bias) gradient of a conv into the parameters' sinks (or fresh tensors): returns (dw, db) for autograd.
 
     The kernels run in order on the caller's stream (weight gradients on streams of their own next to the data-gradient chain were
@@ -706,6 +732,10 @@ def _wgrad_into_sinks(lib, d, dy, w_param, b_param, transposed: bool, st, srcs=(
             bbuf = torch.empty(int(bbuf.numel()), dtype=torch.float32, device=w_param.device)
             dw, db = wbuf, bbuf
     fn = lib.m1_convT3d_wgrad if transposed else lib.m1_conv3d_wgrad
+    if norm is not None:        # the conv's input is lrelu(IN(x)) of the raw tensor in ``d``: the kernel recomputes the operand
+        xstats, gamma, beta, slope = norm
+        fn0 = lib.m1_conv3d_wgrad_norm
+        fn = lambda dd, dy_, wb, bb, ws_, acc_, st_: fn0(dd, _p(xstats), _p(gamma), _p(beta), float(slope), dy_, wb, bb, ws_, acc_, st_)
     flat = dw is None and db is None
     ws = _conv_ws(d, transposed, 2, w_param.device)
     if flat and _FOLD["on"]:
@@ -829,6 +859,88 @@ class _PairGraft(torch.autograd.Function):
     def backward(ctx, dy1, dy4):
         g = _ConvPair.backward(ctx, dy1, None, dy4, None)       # (dw1, db1, None, None, None, None, *dsrc)
         return (None, None, g[0], g[1], None, None, None, *g[6:])
+
+
+class _ConvNorm(torch.autograd.Function):
+    """y = Conv3D_{1x1x1}(lrelu(IN(x))) with the normalisation + activation applied on the conv's operand (m1_conv3d_fwd_norm):
+    norm2 -> LeakyReLU -> conv3 of an SE block (network_blocks.py:56-59) as one data pass.  The backward owns the norm's backward
+    too: weight gradient with the same operand transform, data gradient with the InstanceNorm-backward sums from its epilogue, then
+    the apply pass on x."""
+
+    @staticmethod
+    def forward(ctx, x, xstats, gamma, beta, slope, w, b, want_stats):
+        _req(x, xstats, gamma, beta, w, b)
+        lib = L.load()
+        cout = int(w.shape[4])
+        d = _desc([x], cout, (1, 1, 1), (1, 1, 1))
+        if d.Cin != int(w.shape[3]) or tuple(w.shape[:3]) != (1, 1, 1):
+            raise RuntimeError(f"kernel {tuple(w.shape)} does not match a pointwise conv over {d.Cin} channels")
+        y = torch.empty((*x.shape[:4], cout), dtype=x.dtype, device=x.device)
+        stats = torch.empty((d.N, cout, 2), dtype=torch.float32, device=x.device) if want_stats else None
+        ws, packed = _panel_ws(w, d, False, 0)
+        L.check(lib.m1_conv3d_fwd_norm(C.byref(d), _p(xstats), _p(gamma), _p(beta), float(slope), _p(w), _p(b), _p(y), _p(stats), _p(ws),
+                                       packed, _stream()), "m1_conv3d_fwd_norm")
+        ctx.save_for_backward(x, xstats, gamma, beta, w)
+        ctx.params = (gamma, beta, w, b)
+        ctx.slope, ctx.cout = float(slope), cout
+        if want_stats:
+            ctx.mark_non_differentiable(stats)
+            ctx.set_materialize_grads(False)
+            return y, stats
+        return y
+
+    @staticmethod
+    def backward(ctx, dy, *_unused):
+        lib = L.load()
+        x, xstats, gamma, beta, w = ctx.saved_tensors
+        if dy is None:
+            return (None,) * 8
+        g_param, b_param, w_param, bias_param = ctx.params
+        dy = dy.contiguous()
+        _req(dy)
+        st = _stream()
+        d = _desc([x], ctx.cout, (1, 1, 1), (1, 1, 1))
+        dw, db = _wgrad_into_sinks(lib, d, dy, w_param, bias_param, False, st, (x,), norm=(xstats, gamma, beta, ctx.slope))
+        N, Cn = int(x.shape[0]), int(x.shape[-1])
+        V = x.numel() // (N * Cn)
+        nmax = int(lib.m1_conv3d_dgrad_inbwd_rows(C.byref(d)))
+        part = torch.empty(N * nmax * Cn * 2 + N * Cn * 2 + 64, dtype=torch.float32, device=x.device)
+        nparts = C.c_int(0)
+        da = torch.empty_like(x)
+        ws, packed = _panel_ws(w_param, d, False, 1, (True,))
+        L.check(lib.m1_conv3d_dgrad_inbwd(C.byref(d), _p(w), _p(dy), _p(da), _p(x), _p(xstats), _p(gamma), _p(beta), ctx.slope,
+                                          _p(part), nmax, C.byref(nparts), _p(ws), packed, st), "m1_conv3d_dgrad_inbwd")
+        dx = torch.empty_like(x)
+        gbuf, acc, dg = _sink(g_param)
+        bbuf, acc2, dbt = _sink(b_param)
+        if acc != acc2:
+            gbuf, bbuf, acc = torch.empty_like(gamma), torch.empty_like(beta), 0
+            dg, dbt = gbuf, bbuf
+        if nparts.value > 0:
+            sums = part[part.numel() - N * Cn * 2 - 64:]
+            L.check(lib.m1_instnorm_bwd_partials(_p(x), _p(xstats), _p(gamma), _p(beta), ctx.slope, _p(da), _p(dx), _p(gbuf), _p(bbuf),
+                                                 N, V, Cn, _dt(x), _p(part), nparts.value, _p(sums), acc, st), "m1_instnorm_bwd_partials")
+            _INBWD["fused"] += 1
+        else:
+            ws2 = _ws(N, V, Cn, 2, x.device)
+            L.check(lib.m1_instnorm_bwd(_p(x), _p(xstats), _p(gamma), _p(beta), ctx.slope, _p(da), _p(dx), _p(gbuf), _p(bbuf),
+                                        N, V, Cn, _dt(x), _p(ws2), acc, st), "m1_instnorm_bwd")
+            _INBWD["plain"] += 1
+        return dx, None, dg, dbt, None, dw, db, None
+
+
+def conv_norm_supported(x: torch.Tensor, w: torch.Tensor) -> bool:
+    """Does the library apply lrelu(IN(x)) on the operand of this pointwise conv (m1_conv3d_fwd_norm_supported)?"""
+    if _FORCE_DIRECT[0] or not x.is_cuda or x.dtype != torch.bfloat16 or tuple(w.shape[:3]) != (1, 1, 1):
+        return False
+    d = _desc([x], int(w.shape[4]), (1, 1, 1), (1, 1, 1))
+    return bool(L.load().m1_conv3d_fwd_norm_supported(C.byref(d)))
+
+
+def conv3d_norm_same(x, xstats, gamma, beta, slope, w, b, stats: bool = False):
+    """Conv3D_{1x1x1}(LeakyReLU(InstanceNorm(x))) from the RAW tensor ``x`` and its finished statistics ``xstats`` (N,C,2): the
+    normalised tensor is never materialised (conv_norm_supported says whether the library can)."""
+    return _ConvNorm.apply(x, xstats, gamma, beta, float(slope), w, b, bool(stats))
 
 
 _FORCE_DIRECT = [False]

@@ -6,6 +6,7 @@ which also adds the L2-regulariser gradient 2*lambda*w (networks.py:456-460), an
 from __future__ import annotations
 
 import math
+import os as _os
 from typing import List, Optional
 
 import torch
@@ -134,6 +135,7 @@ class Adam:
         self.iterations = 0
         self.grad_scale = 1.0
         self.reducer = None          # ddp.GradReducer, optional
+        self.prune_dead = _os.environ.get("M1_DDP_PRUNE_DEAD", "0") == "1"      # step(): leave never-written gradient ranges out of the exchange
         self._lr_override: Optional[float] = None
 
     # Keras: optimizer.lr readable / assignable (callbacks.py:99,117,179)
@@ -184,10 +186,25 @@ class Adam:
     def refresh_live_ranges(self) -> int:
         """After at least one backward pass: tell the reducer which parts of the flat gradient buffer ever receive a gradient, so
         that the rest (dead layers: exactly zero on every rank) is left out of the exchange.  Returns the number of live elements.
-        The set is a function of the model graph, identical on every rank.  Call outside graph capture."""
-        live = self.flatp.live_ranges()
-        if self.reducer is not None and live:
-            self.reducer.set_live(live)
+        COLLECTIVE when a process group is active: every rank must call it at the same point of its loop.  The set is a function of
+        the model graph and should be identical on every rank, but nothing else would notice a rank that disagrees (a conditional
+        branch, another loss head) until the collective sizes mismatch -- so the per-parameter flags are max-reduced over the ranks
+        first and every rank uses the UNION.  The set only grows (a flag, once set by a backward kernel, stays).  Call outside
+        graph capture."""
+        import torch.distributed as dist
+        f = self.flatp
+        red = self.reducer
+        if red is not None and red.active and dist.is_initialized() and red.world_size > 1:
+            dev = f.grad.device if dist.get_backend(red.group) == "nccl" else torch.device("cpu")
+            flags = torch.tensor([1 if getattr(p, "_m1_live", False) else 0 for p in f.params], dtype=torch.int32, device=dev)
+            dist.all_reduce(flags, op=dist.ReduceOp.MAX, group=red.group)
+            for p, v in zip(f.params, flags.cpu().tolist()):
+                if v:
+                    p._m1_live = True
+        live = f.live_ranges()
+        if red is not None and live:
+            red.set_live(live)
+        self._live_params = sum(1 for p in f.params if getattr(p, "_m1_live", False))
         return sum(b - a for a, b in live)
 
     def exchange(self):
@@ -212,5 +229,10 @@ class Adam:
         self.exchange()
         self.apply_flat()
         self.iterations += 1
-        if self.reducer is not None and self.iterations == 1 and not torch.cuda.is_current_stream_capturing():
-            self.refresh_live_ranges()       # from the second step on the dead layers' ranges (all zero) are not exchanged
+        # Dead ranges out of the exchange: OPT-IN (``prune_dead`` / M1_DDP_PRUNE_DEAD=1; bench.py calls refresh_live_ranges itself
+        # after its warm-up).  The live set is agreed on by all ranks (union) and refreshed every 64 eager steps at the same
+        # iteration count on every rank, so a parameter that first receives a gradient later (unfreezing, another loss head) re-enters
+        # the exchange; under graph capture the exchanged ranges are frozen into the graph and nothing is refreshed.
+        if (self.reducer is not None and self.prune_dead and (self.iterations == 1 or self.iterations % 64 == 0)
+                and not torch.cuda.is_current_stream_capturing()):
+            self.refresh_live_ranges()

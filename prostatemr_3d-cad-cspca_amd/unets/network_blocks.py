@@ -187,8 +187,7 @@ class SEResNetBottleNeck(nn.Module):
             y1, s1 = self.conv1(srcs, stats=True)
         a = self.norm1(y1, 0.1, s1)                                             # B:53-55
         y2, s2 = self.conv2(a, stats=True)
-        a = self.norm2(y2, 0.1, s2)                                             # B:56-58
-        y3, s3 = self.conv3(a, stats=True)                                      # B:59
+        y3, s3 = self._norm2_conv3(y2, s2)                                      # B:56-59
         br.join(y4, s4)
         rate = dropout.effective_rate() if dropout is not None else 0.0
         gate, self._gate = self._gate, None              # evaluated up front by the owning core (precompute_gates), once per pass
@@ -198,6 +197,17 @@ class SEResNetBottleNeck(nn.Module):
                               dropout.layer_id if dropout is not None else 0, s3, s4, gate)   # B:60-78 (+ following dropout)
 
 
+    def _norm2_conv3(self, y2, s2):
+        """conv3(lrelu(norm2(y2))) (B:56-59) -> (y3, stats3).  One data pass where the library applies the normalisation and the
+        activation on the pointwise conv's operand (ops.conv3d_norm_same: the normalised tensor is never written); otherwise the
+        stand-alone apply kernel followed by the conv."""
+        # (a norm2 / conv3 module that carries forward hooks is called as a module: the hooks must see their tensors)
+        hooked = bool(self.norm2._forward_hooks or self.conv3._forward_hooks or self.conv3._forward_pre_hooks)
+        if not hooked and ops.conv_norm_supported(y2, self.conv3.kernel):
+            return ops.conv3d_norm_same(y2, s2, self.norm2.gamma, self.norm2.beta, 0.1, self.conv3.kernel, self.conv3.bias, stats=True)
+        a = self.norm2(y2, 0.1, s2)                                             # B:56-58
+        return self.conv3(a, stats=True)                                        # B:59
+
     def _forward_identity(self, members, dropout):
         """C_in == filters (B:63 false branch): out = lrelu(IN3(conv3(...)) * g * x) with the block input x as the residual factor."""
         x = members[0] if len(members) == 1 else torch.cat(members, dim=-1).contiguous()     # (a concat must exist as a tensor to be a factor)
@@ -205,8 +215,7 @@ class SEResNetBottleNeck(nn.Module):
         y1, s1 = self.conv1([x1], stats=True)
         a = self.norm1(y1, 0.1, s1)
         y2, s2 = self.conv2(a, stats=True)
-        a = self.norm2(y2, 0.1, s2)
-        y3, s3 = self.conv3(a, stats=True)
+        y3, s3 = self._norm2_conv3(y2, s2)
         rate = dropout.effective_rate() if dropout is not None else 0.0
         gate, self._gate = self._gate, None
         return ops.se_combine(y3, xr, self.norm3.gamma, self.norm3.beta, None, None,

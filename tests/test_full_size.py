@@ -314,6 +314,97 @@ def test_full_size_c3_bench_configuration_batch2_dropout(dev):
     assert not torch.equal(p1, p3)
 
 
+def test_full_size_c3_graph_replays_equal_eager_steps_and_hold_no_memset_node(dev):
+    """The headline artefact itself: the FULL-SIZE C3 bench configuration (bf16, batch 2, Monte-Carlo dropout 0.5, posterior lane, fold
+    stream, drawn latents, Adam + panel re-pack + counters) captured into one hipGraph as bench.py does.  Six replays must leave the
+    parameters, the Adam state, the step counter and the RNG state that six eager steps leave from the same start, bit for bit -- the
+    round-5 defect (a memset node executed wrongly from the second replay on) was replay-only and size-dependent kernels (conv_t3,
+    conv_halo class mode, wgrad_t3, other scratch sizes) only run at this size.  The captured graph is enumerated through the HIP graph
+    API: zero memset nodes, whoever issued them (library, torch, RCCL)."""
+    dims = (20, 160, 160)
+    init = PKG.initializers
+    PKG.unets.network_blocks.set_init_seed(0)
+    m = PKG.unets.networks.M1(
+        input_spatial_dims=dims, input_channels=3, num_classes=2, filters=(32, 64, 128, 256, 512),
+        strides=((1, 1, 1), (1, 2, 2), (1, 2, 2), (2, 2, 2), (2, 2, 2)),
+        kernel_sizes=((1, 3, 3), (1, 3, 3), (3, 3, 3), (3, 3, 3), (3, 3, 3)), se_reduction=(8, 8, 8, 8, 8),
+        att_sub_samp=((1, 1, 1),) * 4, dropout_rate=0.5, dropout_mode='monte-carlo', prob_latent_dims=(3, 2, 1, 0),
+        kernel_initializer=init.Orthogonal(1.0), bias_initializer=init.TruncatedNormal(0.0, 1e-3),
+        kernel_regularizer=init.l2(1e-4), bias_regularizer=init.l2(1e-4), cascaded=False, dense_skip=True,
+        deep_supervision=True, probabilistic=True, summary=False).to(dev)
+    m.set_compute_dtype(torch.bfloat16)
+    m.seed_dropout(2)
+    assert m.m1_model.stack_passes and ops._BRANCH["on"]
+    tgt = torch.cat([_box_target(dims), _box_target(dims).roll(17, dims=2)], dim=0)
+    x = rnd((2, *dims, 3), 11)
+    x[..., 2] = tgt[..., 1]
+    xs, ts = ops.cast(x.to(dev).contiguous(), torch.bfloat16), tgt.to(dev)
+    opt = PKG.optim.Adam(learning_rate=1e-3, amsgrad=True)
+    focal = PKG.losses.Focal(alpha=[0.75, 0.25], gamma=2.0).loss
+    m.compile(optimizer=opt, loss=[focal, PKG.losses.EvidenceLowerBound().loss], loss_weights=[1.0, 10.0])
+    opt.set_lr_device()
+    m.train()
+    loss_buf = torch.zeros(1, device=dev)
+
+    def step():                                   # bench.py's step(): fwd_bwd() + update()
+        opt.zero_grad()
+        outs = m(xs)
+        total, _ = m.compute_loss(outs, {"detection": ts})
+        total.backward()
+        opt.flatp.gather_grads()
+        loss_buf.copy_(total.detach().reshape(1))
+        opt.exchange()
+        opt.apply_flat()
+        ops.step_advance(None, m.rng_state)
+
+    state = lambda: [opt.flatp.flat, opt.m, opt.v, opt.vhat, opt.step_dev, m.rng_state]
+    step(); step()                                # eager warm-up: allocator, panel registry
+    torch.cuda.synchronize()
+    start = [t.clone() for t in state()]
+    gen0 = torch.cuda.get_rng_state(dev)
+
+    def restore():
+        with torch.no_grad():
+            for t, s0 in zip(state(), start):
+                t.copy_(s0)
+        torch.cuda.set_rng_state(gen0, dev)
+        ops.repack_all()
+        torch.cuda.synchronize()
+
+    NSTEP = 6
+    losses = {"eager": [], "graph": []}
+    for _ in range(NSTEP):
+        step(); losses["eager"].append(float(loss_buf))
+    torch.cuda.synchronize()
+    eager = [t.clone() for t in state()]
+    assert not torch.equal(eager[0], start[0]) and all(l == l and l > 0 for l in losses["eager"])
+
+    restore()
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        step()
+    torch.cuda.current_stream().wait_stream(s)
+    torch.cuda.synchronize()
+    gr = torch.cuda.CUDAGraph(keep_graph=True)
+    with torch.cuda.graph(gr):
+        step()
+    hist = PKG.hip.graphs.node_histogram(gr)
+    print("captured C3 step, nodes by type:", hist)
+    assert hist.get("memset", 0) == 0, hist
+    assert hist.get("kernel", 0) > 500, hist
+    gr.instantiate()
+    torch.cuda.synchronize()
+    restore()
+    for _ in range(NSTEP):
+        gr.replay(); losses["graph"].append(float(loss_buf))
+    torch.cuda.synchronize()
+    names = ["parameters", "adam m", "adam v", "adam vhat", "step counter", "rng state"]
+    assert losses["graph"] == losses["eager"], losses
+    for n, a, b in zip(names, eager, state()):
+        assert torch.equal(a, b), f"{n}: {int((a != b).sum())} of {a.numel()} elements differ between {NSTEP} eager steps and {NSTEP} replays"
+
+
 def test_full_size_c5_fp32_model_properties(dev):
     """C5 (BASELINE.json configs[4]): deterministic M1 at (32,256,256,3), fp32 -- App. A.1's stage shapes, parameter count,
     output simplex, finite loss and gradients, bit-identical forward run to run; the backward pass is the derivative of the

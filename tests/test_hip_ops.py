@@ -752,6 +752,60 @@ def test_instnorm_backward_sums_from_the_dgrad_epilogue(dev, dtype, dims, c, cou
         assert rel_err(a_, o_) < tol
 
 
+# ---- conv o InstanceNorm o LeakyReLU as ONE data pass (m1_conv3d_fwd_norm / m1_conv3d_wgrad_norm; network_blocks.py:56-59) ----
+@pytest.mark.parametrize("dims,c,cout", [((2, 8, 32, 32), 8, 32),        # conv3 at res0 (one 32-channel K chunk, 24 of them padding)
+                                         ((4, 4, 16, 16), 16, 64),       # res1
+                                         ((2, 4, 16, 16), 32, 128),      # res2
+                                         ((3, 2, 8, 16), 64, 256),       # res3: two K chunks
+                                         ((1, 3, 8, 12), 24, 40)])       # ragged channel counts (24 = 3 segments, 40 output columns)
+def test_conv_norm_prologue_fwd_bwd(dev, dims, c, cout):
+    """y = conv_{1x1x1}(lrelu(IN(x))) from the RAW x: the streaming kernel normalises its operand in registers, the weight gradient
+    recomputes it, the normalised tensor never exists.  Forward and every gradient against the oracle and against the unfused ops;
+    the kernel log proves which kernels ran."""
+    dtype = torch.bfloat16
+    x = rnd((*dims, c), 1).bfloat16().float(); g = 1.0 + 0.2 * rnd((c,), 2); bt = 0.1 * rnd((c,), 3)
+    w = rnd((1, 1, 1, c, cout), 4, 1.0 / c ** 0.5); b = rnd((cout,), 5)
+    dy = rnd((*dims, cout), 6).bfloat16().float()
+
+    def ref(x_, g_, b_, w_, bb_):
+        return O.conv3d_same(O.lrelu(O.instance_norm(x_, g_, b_)), w_, bb_, (1, 1, 1))
+    yo, gro = _oracle_grads(ref, [x, g, bt, w, b], dy)
+
+    def run(fused):
+        xd = x.to(dev, dtype).requires_grad_(True)
+        ps = [t.to(dev).requires_grad_(True) for t in (g, bt, w, b)]
+        st = ops.instnorm_stats(xd)
+        if fused:
+            assert ops.conv_norm_supported(xd, ps[2])
+            y, ys = ops.conv3d_norm_same(xd, st, ps[0], ps[1], 0.1, ps[2], ps[3], stats=True)
+        else:
+            y, ys = ops.conv3d_same([ops.instnorm_act(xd, ps[0], ps[1], 0.1, st)], ps[2], ps[3], (1, 1, 1), (1, 1, 1), stats=True)
+        y.backward(dy.to(dev, dtype))
+        return [y.detach(), ys, xd.grad] + [p.grad for p in ps]
+    with ops.kernel_log() as kl:
+        got = run(True)
+    assert kl.ran("conv_pw") and any(n.startswith("conv_pw:") and n.endswith(":pro") for n in kl.names), kl.names
+    assert "wgrad_mfma:pro" in kl.names, kl.names
+    base = run(False)
+    # the fused forward rounds the operand exactly as the apply kernel stores it: outputs agree to the fp32 order of the fma
+    assert rel_err(got[0], base[0]) < 1e-2
+    assert rel_err(got[1], base[1]) < 1e-2
+    assert rel_err(got[0], yo) < 4e-2
+    for a_, b_, o_ in zip(got[2:], base[2:], gro):
+        assert rel_err(a_, b_) < 2e-2
+        assert rel_err(a_, o_) < 4e-2
+    # statistics of the fused output against the stand-alone reduction over that very output
+    assert rel_err(got[1], ops.instnorm_stats(got[0])) < 1e-4
+
+
+def test_conv_norm_prologue_declines_what_no_kernel_takes(dev):
+    """fp32, 3x3x3 kernels and wide contractions are not fused: the query says so and the entry point launches nothing."""
+    x = rnd((1, 2, 8, 8, 128), 1).to(dev, torch.bfloat16)
+    assert not ops.conv_norm_supported(x, rnd((1, 1, 1, 128, 128), 2).to(dev))          # 128-deep: the matrix-core kernel's shape
+    assert not ops.conv_norm_supported(x[..., :32].contiguous(), rnd((3, 3, 3, 32, 32), 2).to(dev))
+    assert not ops.conv_norm_supported(x[..., :32].float().contiguous(), rnd((1, 1, 1, 32, 32), 2).to(dev))
+
+
 def _wgrad_kernels(kl):
     """Base names of the weight-gradient kernels a kernel log holds (ops.kernel_log): {'wgrad_t3', 'wgrad_tf', ...}."""
     return {n.split(":")[0] for n in kl.names if n.startswith("wgrad_") or n == "conv_wgrad_direct"}
