@@ -12,9 +12,8 @@
  *   - process-global host state the library DOES keep (all of it behind mutexes, none of it device memory):
  *     the tuning-switch table (m1_config_*), the queue of deferred weight-gradient folds between m1_wgrad_defer(1)
  *     and m1_wgrad_fold_pending / _drop (the queued jobs point into caller-owned workspaces, which the caller keeps
- *     alive until then), the test hook m1_set_force_direct, the opt-in profiler (m1_prof_*), the opt-in
- *     kernel-choice log (m1_debug_kernels) and the cursor into the caller's ticket pool (m1_tickets_set).
- *     One thread drives the library at a time per process.
+ *     alive until then), the test hook m1_set_force_direct, the opt-in profiler (m1_prof_*) and the opt-in
+ *     kernel-choice log (m1_debug_kernels).  One thread drives the library at a time per process.
  *   - results are bit-reproducible run to run in the default configuration: every reduction across blocks goes
  *     through per-split partials folded in a fixed order.  Floating-point atomics remain compiled in behind
  *     switches only (M1_WG_DET=0, m1_set_force_direct: the generic fp32 reference kernels of conv_direct.hip).
@@ -153,32 +152,6 @@ int m1_debug_checksum(const void* p, long long nbytes, unsigned long long* slot,
 const char* m1_debug_kernels(int mode);
 int m1_debug_scribble(int blocks, int spins, void* stream);
 
-/* Ticket pool of the last-block finalize (round 6; csrc/reduce.h).  Every per-(sample, channel) reduction of the path -- InstanceNorm
- * statistics (B:54-60, N:575), the InstanceNorm / SE-combine backward sums (App. F), bias-gradient column sums -- is a grid of blocks
- * that write partial rows plus a fold of those rows.  With a pool registered the fold runs in the block that finishes last (one
- * self-resetting counter per sample, rows written write-through) instead of in a second launch.  `pool`: n >= 64 unsigned counters
- * in device memory of the CURRENT device, zero-initialised by the caller, kept alive and untouched while the library is in use
- * (counters return to zero by themselves; after an aborted launch the caller zeroes the pool again).  NULL unregisters: every
- * reduction is followed by its finalize launch again (also with M1_RED_TAIL=0).  Results are identical either way up to the
- * rounding of the fp64 fold order, and bit-reproducible run to run in both. */
-int m1_tickets_set(void* pool, int n);
-
-/* ---- Conv3D whose input is LeakyReLU(InstanceNorm(x)) of a raw conv output x, as ONE data pass : B:56-59 (norm2 -> relu -> conv3),
- * SURVEY App. G; BASELINE north_star "conv3d fused with GroupNorm+SiLU" (= InstanceNorm + LeakyReLU here) ----
- * d->src[0].ptr = x (the RAW output of the previous conv, one member), x_stats = its finished {mean, rstd} [N][Cin][2], gamma / beta
- * the norm's parameters: the kernel applies a = lrelu(gamma*(x-mean)*rstd + beta, slope), rounded to the activation type, to its
- * operand in registers -- the normalised tensor is never written.  Stride-1 pointwise bf16 layers with Cin % 8 == 0 that the
- * streaming kernel takes (Cin <= 64): m1_conv3d_fwd_norm_supported says so BEFORE the caller builds its graph; anything else returns
- * M1_ERR_UNSUPPORTED with nothing launched.  y / stats / ws / ws_packed as m1_conv3d_fwd (same workspace size, same packed panel).
- * m1_conv3d_wgrad_norm: dw[ci][co] (+)= sum_v a[v][ci] * dy[v][co] with the SAME operand transform (a is recomputed from x), db as
- * m1_conv3d_wgrad; ws = m1_conv_ws_bytes(d, 0, 2).  The data gradient and the norm's backward take x as they always did:
- * m1_conv3d_dgrad_inbwd + m1_instnorm_bwd_partials. */
-int m1_conv3d_fwd_norm_supported(const m1_conv_desc_t* d);
-int m1_conv3d_fwd_norm(const m1_conv_desc_t* d, const float* x_stats, const float* gamma, const float* beta, float slope,
-                       const float* w, const float* bias, void* y, float* stats, void* ws, int ws_packed, void* stream);
-int m1_conv3d_wgrad_norm(const m1_conv_desc_t* d, const float* x_stats, const float* gamma, const float* beta, float slope,
-                         const void* dy, float* dw, float* db, void* ws, int accumulate, void* stream);
-
 /* ---- Conv3DTranspose(padding='same') + bias : N:496-499,505-507,513-514,520,546-553 ----
  * w: Keras layout (kd,kh,kw,Cout,Cin) fp32; y: (N, D*sd, H*sh, W*sw, Cout). */
 int m1_convT3d_fwd(const m1_conv_desc_t* d, const float* w, const float* bias, void* y, void* ws, int ws_packed,
@@ -258,6 +231,24 @@ int m1_se_combine_bwd(const void* y3, const void* y4, const float* stats3, const
                       float drop_rate, const uint64_t* rng, uint64_t layer_id, const unsigned char* keep_mask,
                       float* ws, int accumulate, void* stream);
 
+/* The same for TWO stacked passes of a core that share everything in front of their first dropout draw (round 6).  A training step
+ * evaluates each core twice on the same input (N:348-349 posterior, N:351-352 prior; here stacked along the batch axis): with
+ * Monte-Carlo dropout the two passes differ from the first SE block's dropout on (N:579-582) -- the stem and that block's convolutions
+ * and norms are the same computation twice.  y3 / y4 / stats3 / stats4 hold N samples; out (and keep_mask) hold 2N: output sample n
+ * reads input sample n % N and draws its own keep mask (the dropout stream is indexed by the OUTPUT element, exactly as if the inputs
+ * had been duplicated).  Backward: dout holds 2N samples; dy3 / dy4 (N samples) and the parameter sums take the SUM of the two halves'
+ * gradients (lrelu' and both factors are common to the halves).  Not for the identity residual. */
+int m1_se_combine_dup_fwd(const void* y3, const void* y4, const float* stats3, const float* stats4,
+                          const float* gamma3, const float* beta3, const float* gamma4, const float* beta4,
+                          const float* g, void* out, int N, long long V, int F, int dtype, float drop_rate,
+                          const uint64_t* rng, uint64_t layer_id, unsigned char* keep_mask, void* stream);
+int m1_se_combine_dup_bwd(const void* y3, const void* y4, const float* stats3, const float* stats4,
+                          const float* gamma3, const float* beta3, const float* gamma4, const float* beta4,
+                          const float* g, const void* dout, void* dy3, void* dy4, float* dgamma3, float* dbeta3,
+                          float* dgamma4, float* dbeta4, float* dg, int N, long long V, int F, int dtype,
+                          float drop_rate, const uint64_t* rng, uint64_t layer_id, const unsigned char* keep_mask,
+                          float* ws, int accumulate, void* stream);
+
 /* ---- grid attention gate pieces : B:113-124 ----
  * theta: (N, Dt,Ht,Wt, C) ; phi: (N, Dp,Hp,Wp, C) nearest-upsampled by (Dt/Dp,...) ;
  * sigma[n,v] = sigmoid( sum_c lrelu(theta+phi_up)[c]*wpsi[c] + bpsi ) : (N,Dt,Ht,Wt) stored as dtype */
@@ -284,11 +275,23 @@ int m1_latent_sample_fwd(const void* ml, const void* eps, void* z, int N, long l
                          int dtype, void* stream);
 int m1_latent_sample_bwd(const void* ml, const void* eps, const void* dz, void* dml, int N, long long V, int L,
                          int mode, int dtype, void* stream);
+/* The same with the N(0,1) draws made INSIDE the kernel (no draw tensor, no generator launch in the step): element i of the sampling
+ * pass takes Box-Muller of Philox4x32-10(seed = rng[0] + stream_id * golden, counter = (rng[1] << 36) + i), rng = the device-resident
+ * {seed, step} pair of the dropout stream (m1_step_advance moves it).  The backward regenerates the same draws from the same state:
+ * call it before the step counter advances.  stream_id: distinct per latent head. */
+int m1_latent_sample_rng_fwd(const void* ml, const uint64_t* rng, uint64_t stream_id, void* z, int N, long long V, int L, int mode,
+                             int dtype, void* stream);
+int m1_latent_sample_rng_bwd(const void* ml, const uint64_t* rng, uint64_t stream_id, const void* dz, void* dml, int N, long long V,
+                             int L, int mode, int dtype, void* stream);
 /* kl[0] = mean_n sum_v KL(q||p) (fp32, overwritten). */
 int m1_kl_fwd(const void* ml_q, const void* ml_p, float* kl, int N, long long V, int L, int dtype, void* stream);
 /* dml_q, dml_p = dkl[0] * dKL/d(ml_*)  */
 int m1_kl_bwd(const void* ml_q, const void* ml_p, const float* dkl, void* dml_q, void* dml_p, int N,
               long long V, int L, int dtype, void* stream);
+/* the same when the KL term reads only the first N of Nall samples of ml_q / ml_p (the sampling half of two stacked passes, N:348,351):
+ * dml_q / dml_p are (Nall, V, 2L); the gradient of the samples >= N is written as zeros by the kernel */
+int m1_kl_bwd_first(const void* ml_q, const void* ml_p, const float* dkl, void* dml_q, void* dml_p, int N, long long V,
+                    int L, int Nall, int dtype, void* stream);
 
 /* ---- output heads : softmax(logits) (N:754, N:388-390) with deep-supervision heads upsampled by
  *      nearest repeat (N:739-741,751).  logits_h: (N, D/u0, H/u1, W/u2, nc) per head;

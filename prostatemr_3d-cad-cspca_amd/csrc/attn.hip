@@ -182,12 +182,10 @@ static int gate_bwd_impl(const void* theta, const void* phi, const float* wpsi, 
     }
     int rc = m1_check_launch(); if (rc) return rc;
     GateWF<T> f{(const T*)theta, (const T*)phi, (const T*)sigma, (const T*)dsigma, g};
+    rc = m1_reduce_nc_launch<2>(f, g.N, Vt, g.C, ws, st); if (rc) return rc;
     const int nchunks = m1_red_nchunks(Vt, g.C, g.N);
     float* sums = ws + (size_t)g.N * nchunks * g.C * 2;
-    const M1Fin<2> fin = m1_fin_out<2>(sums, 0, 0.f);
-    bool fused = false;
-    rc = m1_reduce_nc_launch<2>(f, g.N, Vt, g.C, ws, st, &fin, &fused); if (rc) return rc;
-    if (!fused) { rc = m1_reduce_finalize_launch<2>(ws, g.N, g.C, nchunks, sums, 0, 0.f, st); if (rc) return rc; }
+    rc = m1_reduce_finalize_launch<2>(ws, g.N, g.C, nchunks, sums, 0, 0.f, st); if (rc) return rc;
     hipLaunchKernelGGL(gate_w_finalize_kernel, dim3((g.C + 255) / 256), dim3(256), 0, st, sums, g.N, g.C, dwpsi, dbpsi, acc);
     return m1_check_launch();
 }

@@ -53,30 +53,3 @@ extern "C" int m1_config_get(const char* name, int* value) {
         }
     return M1_ERR_UNSUPPORTED;
 }
-
-// ---- ticket pool of the last-block finalize (reduce.h: m1_reduce_tail) ------------------------------------------------------------
-// Caller-owned device memory (the library owns none): `n` unsigned counters, zero-initialised once by the caller; every counter
-// returns to zero when the launch that used it completes (atomicInc wraps), so the pool is handed out round-robin -- a launch takes
-// <= 9 consecutive counters, two launches can only share counters when >= n / 9 launches lie between them.  One pool per device.
-struct M1TicketPool { unsigned* base; int n; int cur; };
-static M1TicketPool g_tickets[16];
-extern "C" int m1_tickets_set(void* pool, int n) {
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return M1_ERR_BAD_ARG;
-    if ((pool && n < 64) || ((uintptr_t)pool & 3)) return M1_ERR_BAD_ARG;
-    std::lock_guard<std::mutex> lk(g_cfg_mu);
-    g_tickets[dev] = M1TicketPool{(unsigned*)pool, pool ? n : 0, 0};
-    return M1_OK;
-}
-unsigned* m1_ticket_take(int n) {
-    if (!M1_CFG("M1_RED_TAIL", 0)) return nullptr;      // (measured slower than the finalize launches, round 6: off)
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
-    std::lock_guard<std::mutex> lk(g_cfg_mu);
-    M1TicketPool& p = g_tickets[dev];
-    if (!p.base || n <= 0 || n > p.n) return nullptr;
-    if (p.cur + n > p.n) p.cur = 0;
-    unsigned* t = p.base + p.cur;
-    p.cur += n;
-    return t;
-}

@@ -38,10 +38,6 @@ struct MfmaP {
     int korder;                 // 1: K runs [64-byte chunk of the concat][tap] (needs aligned), 0: [tap][concat channel]
     const void* ib_x;           // != nullptr: stat_partial receives the InstanceNorm-BACKWARD sums {sum dy, sum dy*xh} of the (rounded)
     const float* ib_stats; const float* ib_gamma; const float* ib_beta; float ib_slope;   //   outputs instead (GatherSpec::ib_*)
-    // != nullptr (one member, pointwise streaming kernel only): the member is the RAW output x of a conv and the operand is
-    // a = lrelu(IN(x)) = lrelu(x * A + B), A = rstd*gamma, B = beta - mean*A per (sample, channel), applied in registers on
-    // the way to the MFMA (GatherSpec::pro_*; network_blocks.py:56-59: norm2 -> LeakyReLU -> conv3 as one data pass)
-    const float* pro_stats; const float* pro_gamma; const float* pro_beta; float pro_slope;
     float* stat_partial;        // fused InstanceNorm statistics: [N][stat_tiles][OC][2] = {sum, sum of squares} of the ROUNDED
     int stat_tiles;             //   outputs, one partial per 64/128-row tile (mode 0, tiles never straddle samples) or, in the
                                 //   halo kernel, per (sample, block row)

@@ -934,7 +934,7 @@ static int launch_cfg(const MfmaP& mp, long long maxM, int OCpad, hipStream_t st
 }
 
 template <typename T>
-static int run_mfma(const GatherSpec& g, void* ws, int ws_packed, hipStream_t st, bool dry = false) {
+static int run_mfma(const GatherSpec& g, void* ws, int ws_packed, hipStream_t st) {
     constexpr int SEG = MT<T>::SEG;
     MfmaP mp{}; PackP pp{};
     int CC = 0;
@@ -1014,16 +1014,6 @@ static int run_mfma(const GatherSpec& g, void* ws, int ws_packed, hipStream_t st
     int maxk = 0; for (int c = 0; c < pp.nclasses; ++c) maxk = pp.cls_kpad[c] > maxk ? pp.cls_kpad[c] : maxk;
     long long pblocks = cdiv_ll((long long)OCpad * maxk, 256); if (pblocks > 2048) pblocks = 2048; if (pblocks < 1) pblocks = 1;
     int rc = M1_OK;
-    // operand = lrelu(IN(raw member)) (GatherSpec::pro_*): only the pointwise streaming kernel transforms its operand in registers
-    mp.pro_stats = g.pro_stats; mp.pro_gamma = g.pro_gamma; mp.pro_beta = g.pro_beta; mp.pro_slope = g.pro_slope;
-    if (g.pro_stats) {
-        bool pw_ok = false;
-        if constexpr (sizeof(T) == 2)
-            pw_ok = !halo && !t3 && g.nsrc == 1 && g.mode == 0 && pl.ksplit == 1 && !g.accumulate && g.nout == 0 && !g.ib_x &&
-                    m1_pw_conv_supported(mp, OCpad, BN > 32 ? 32 : BN);
-        if (!pw_ok) return M1_ERR_UNSUPPORTED;             // (nothing launched yet)
-    }
-    if (dry) return M1_OK;
     if (!ws_packed) {          // the caller may keep the panel of an unchanged weight across calls (2+2 core passes per step)
         hipLaunchKernelGGL(pack_weights_kernel<T>, dim3((unsigned)pblocks, pp.nclasses), dim3(256), 0, st, pp, (T*)panel, reinterpret_cast<PackJob*>(ws));
         rc = m1_check_launch(); if (rc) return rc;
@@ -1137,9 +1127,7 @@ static int run_mfma(const GatherSpec& g, void* ws, int ws_packed, hipStream_t st
         }
         if (ok) {
             FinishStatsF<T> f{mp.acc32, pl.ksplit, ne, g.bias, g.bias2, g.oc_split, (T*)g.out, Vout, g.OC, fo, nullptr, nullptr, nullptr, nullptr, 0.f};
-            const M1Fin<2> fin = m1_fin_out<2>(g.stats_out, Vout, g.stats_eps, 0, g.stats_out2, g.stats_out2 ? g.oc_split : 0);
-            bool fused = false;
-            rc2 = m1_reduce_nc_launch<2>(f, g.N, Vout, g.OC, g.stats_ws, st, &fin, &fused); if (rc2 || fused) return rc2;
+            rc2 = m1_reduce_nc_launch<2>(f, g.N, Vout, g.OC, g.stats_ws, st); if (rc2) return rc2;
             return m1_reduce_finalize_launch<2>(g.stats_ws, g.N, g.OC, m1_red_nchunks(Vout, g.OC, g.N), g.stats_out, Vout, g.stats_eps, st, 0,
                                                 g.stats_out2, g.stats_out2 ? g.oc_split : 0);
         }
@@ -1150,13 +1138,8 @@ static int run_mfma(const GatherSpec& g, void* ws, int ws_packed, hipStream_t st
     return M1_OK;
 }
 
-// would m1_mfma_gather take `g` WITH its operand transform (GatherSpec::pro_*)?  Plans the launch without issuing anything.
-bool m1_mfma_pro_supported(const GatherSpec& g) {
-    if (!g.pro_stats || g.dtype != M1_BF16 || !m1_mfma_supported(g)) return false;
-    return run_mfma<bf16_t>(g, reinterpret_cast<void*>(256), 1, nullptr, true) == M1_OK;
-}
 int m1_mfma_gather(const GatherSpec& g, void* ws, int ws_packed, hipStream_t st) {
     if (!ws) return M1_ERR_WORKSPACE;
-    if (!g.pro_stats) { int rc = M1_OK; if (m1_thin_conv_try(g, st, &rc)) return rc; }
+    { int rc = M1_OK; if (m1_thin_conv_try(g, st, &rc)) return rc; }
     return g.dtype == M1_BF16 ? run_mfma<bf16_t>(g, ws, ws_packed, st) : run_mfma<float>(g, ws, ws_packed, st);
 }

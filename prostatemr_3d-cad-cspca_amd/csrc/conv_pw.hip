@@ -33,10 +33,7 @@ struct PwP {
     long long Mtot;              // voxels in all
 };
 
-// PRO: the (single) member is a raw conv output and the operand is lrelu(IN(x)) (MfmaP::pro_*): per lane the A / B of its 8 channels
-// of every K chunk live in registers (re-loaded when the walk enters the next sample) and the 16-byte fragment is unpacked,
-// fma'd, activated and re-packed (round to nearest even, exactly what the stand-alone apply kernel would have stored) before the MFMAs
-template <int TN, int NCH, bool PRO = false>
+template <int TN, int NCH>
 __global__ void __launch_bounds__(256) conv_pw_kernel(PwP p) {
     constexpr int BN = TN * 16, NW = 4;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];     // [NCH][BN][64] weights, swizzled
@@ -134,44 +131,10 @@ __global__ void __launch_bounds__(256) conv_pw_kernel(PwP p) {
             }
         }
     };
-    float pA[PRO ? NCH : 1][8], pB[PRO ? NCH : 1][8]; int pro_n = -1;
     fetch((long long)part * 32, xf);
     for (long long v0 = (long long)part * 32; v0 < p.Mtot; v0 += step) {
         if (want_stats) { const int n = (int)(v0 / p.V); for (; cur_n < n; ++cur_n) flush(cur_n); }
         fetch(v0 + step, xn);
-        if constexpr (PRO) {
-            const int n = (int)(v0 / p.V);                     // (wave-uniform: a wave tile never straddles two samples)
-            if (n != pro_n) {
-                pro_n = n;
-#pragma unroll
-                for (int q = 0; q < NCH; ++q) {
-                    const int kseg = q * 4 + fs;
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        float a = 0.f, b = 0.f;
-                        if (kseg < p.nseg) {
-                            const int c = kseg * 8 + e;
-                            const float2 ms = *reinterpret_cast<const float2*>(m.pro_stats + ((long long)n * m.CC + c) * 2);
-                            a = ms.y * m.pro_gamma[c]; b = m.pro_beta[c] - ms.x * a;
-                        }
-                        pA[q][e] = a; pB[q][e] = b;
-                    }
-                }
-            }
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int q = 0; q < NCH; ++q) {
-                    u32x4p_t x = xf[i][q];
-#pragma unroll
-                    for (int d = 0; d < 4; ++d) {
-                        const float lo = lrelu_f(__uint_as_float(x[d] << 16) * pA[q][2 * d] + pB[q][2 * d], m.pro_slope);
-                        const float hi = lrelu_f(__uint_as_float(x[d] & 0xffff0000u) * pA[q][2 * d + 1] + pB[q][2 * d + 1], m.pro_slope);
-                        x[d] = pw_cvt_pk(lo, hi);
-                    }
-                    xf[i][q] = x;
-                }
-        }
         bool vok[2];
 #pragma unroll
         for (int i = 0; i < 2; ++i) vok[i] = v0 + i * 16 + fr < p.Mtot;
@@ -269,7 +232,6 @@ static bool pw_plan(const MfmaP& m, int OCpad, int BN, PwP& p) {
     p = PwP{}; p.m = m; p.kpad = kpad; p.nseg = CC / 8;
     p.V = m.OD * m.OH * m.OW; p.Mtot = (long long)m.N * p.V;
     if (p.V % 32) return false;                   // a wave tile never straddles two samples
-    if (m.pro_stats && (m.nsrc != 1 || !m.pro_gamma || !m.pro_beta)) return false;
     return true;
 }
 static int pw_nwaves(const PwP& p, int OCpad, int BN) {
@@ -296,22 +258,21 @@ int m1_pw_conv(const MfmaP& mp, int OCpad, int BN, hipStream_t st) {
         return M1_ERR_UNSUPPORTED;
     }
     void (*kern)(PwP) = nullptr;
-    const bool pro = mp.pro_stats != nullptr;
-#define PK(TN_, NCH_) if (BN == TN_ * 16 && NCH == NCH_) kern = pro ? conv_pw_kernel<TN_, NCH_, true> : conv_pw_kernel<TN_, NCH_, false>;
+#define PK(TN_, NCH_) if (BN == TN_ * 16 && NCH == NCH_) kern = conv_pw_kernel<TN_, NCH_>;
     PK(1, 1) PK(1, 2) PK(2, 1) PK(2, 2)
 #undef PK
     if (!kern) return M1_ERR_UNSUPPORTED;
     const size_t smem = (size_t)NCH * BN * 64;
     if (smem > 48 * 1024) {
-        static const void* done[32]; static int ndone = 0;
+        static const void* done[16]; static int ndone = 0;
         bool seen = false;
         for (int q = 0; q < ndone; ++q) seen |= done[q] == (const void*)kern;
         if (!seen) {
             if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024) != hipSuccess) return M1_ERR_LAUNCH;
-            if (ndone < 32) done[ndone++] = (const void*)kern;
+            if (ndone < 16) done[ndone++] = (const void*)kern;
         }
     }
-    m1_note_kernel(pro ? "conv_pw:bn%d:pro" : "conv_pw:bn%d", BN);
+    m1_note_kernel("conv_pw:bn%d", BN);
     hipLaunchKernelGGL(kern, dim3(OCpad / BN, p.nwaves / 4), dim3(256), smem, st, p);
     return m1_check_launch();
 }

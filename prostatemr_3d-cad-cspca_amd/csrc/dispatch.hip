@@ -395,43 +395,6 @@ extern "C" int m1_conv3d_fwd(const m1_conv_desc_t* d, const float* w, const floa
     }
     return run_gather(g, ws, ws_packed, (hipStream_t)stream);
 }
-// ---- Conv3D whose input is lrelu(IN(x)) of a RAW conv output x: normalisation + activation applied on the operand --------------
-// (network_blocks.py:56-59: norm2 -> LeakyReLU -> conv3 of every SE block; north_star: "conv3d fused with GroupNorm+SiLU" = here
-// InstanceNorm + LeakyReLU).  The normalised tensor is never written: the forward reads x (pointwise streaming
-// kernel, conv_pw.hip PRO), the weight gradient recomputes the operand the same way (wgrad_mfma.hip PRO), the data gradient +
-// InstanceNorm backward already work on x (m1_conv3d_dgrad_inbwd).  Stride-1 pointwise bf16 layers of <= 64 input channels only.
-static inline int wg_pick_t(int c) { return c > 64 ? 128 : (c > 32 ? 64 : 32); }
-static bool fwd_norm_shape_ok(const m1_conv_desc_t* d) {
-    if (!desc_ok(d) || g_force_direct || !M1_CFG("M1_PW_PRO", 1)) return false;
-    if (d->dtype != M1_BF16 || d->nsrc != 1 || d->kd * d->kh * d->kw != 1 || d->sd != 1 || d->sh != 1 || d->sw != 1) return false;
-    if (d->Cin % 8 || d->N * wg_pick_t(d->Cin) > 1024) return false;                     // (wgrad_mfma PRO: its LDS table)
-    if ((long long)d->N * d->D * d->H * d->W >= (1ll << 31) - 4096) return false;
-    return true;
-}
-static GatherSpec fwd_norm_spec(const m1_conv_desc_t* d, const float* x_stats, const float* gamma, const float* beta, float slope,
-                                const float* w, const float* bias, void* y) {
-    GatherSpec g = fwd_spec(d, false, w, bias, y);
-    g.pro_stats = x_stats; g.pro_gamma = gamma; g.pro_beta = beta; g.pro_slope = slope;
-    return g;
-}
-extern "C" int m1_conv3d_fwd_norm_supported(const m1_conv_desc_t* d) {
-    if (!fwd_norm_shape_ok(d)) return 0;
-    static const float one = 1.f;                             // (any non-null address: the plan only tests the pointers)
-    return m1_mfma_pro_supported(fwd_norm_spec(d, &one, &one, &one, 0.1f, nullptr, nullptr, nullptr)) ? 1 : 0;
-}
-extern "C" int m1_conv3d_fwd_norm(const m1_conv_desc_t* d, const float* x_stats, const float* gamma, const float* beta, float slope,
-                                  const float* w, const float* bias, void* y, float* stats, void* ws, int ws_packed, void* stream) {
-    if (!desc_ok(d) || !x_stats || !gamma || !beta || !w || !y || !ws) return M1_ERR_BAD_ARG;
-    if (!fwd_norm_shape_ok(d)) return M1_ERR_UNSUPPORTED;
-    M1ProfScope ps(prof_name("conv3d_fwd", d).s, 2.0 * conv_macs(d, false), conv_bytes(d, false), (hipStream_t)stream);
-    GatherSpec g = fwd_norm_spec(d, x_stats, gamma, beta, slope, w, bias, y);
-    if (stats) {
-        g.stats_out = stats; g.stats_eps = 1e-3f;
-        g.stats_ws = reinterpret_cast<float*>((unsigned char*)ws + gather_ws_bytes(g));
-    }
-    return m1_mfma_gather(g, ws, ws_packed, (hipStream_t)stream);
-}
-
 // ---- conv1 || conv4 of an SE block (network_blocks.py:53,64: same input, same kernel size and strides) as ONE problem --------
 // Forward: one conv with C1 + C4 output columns, written to two tensors ([y1 | y4]) with their own bias vectors and InstanceNorm
 // statistics: the im2col operand is gathered once, and the C1 = F/4 columns that alone would run on a loader-bound 32-column
@@ -599,7 +562,7 @@ static bool m1_tf_wgrad_supported_stem(const m1_conv_desc_t* d, const Geo& q) {
     return d->dtype == M1_BF16 ? m1_tf_wgrad_supported(g) : m1_t3s_wgrad_supported(g);
 }
 static int wgrad_common(const m1_conv_desc_t* d, bool T, const void* dy, float* dw, float* db, void* ws, hipStream_t st,
-                        int accumulate, const GatherSpec* pro = nullptr) {
+                        int accumulate) {
     Geo q = T ? convT_geo(d) : conv_geo(d);
     const size_t nw = (size_t)d->kd * d->kh * d->kw * d->Cin * d->Cout;
     if (!accumulate && m1_zero_async(dw, nw * sizeof(float), st) != M1_OK) return M1_ERR_LAUNCH;
@@ -662,12 +625,6 @@ static int wgrad_common(const m1_conv_desc_t* d, bool T, const void* dy, float* 
         }
         int rc = M1_ERR_UNSUPPORTED;
         int wlog = M1_CFG("M1_WG_LOG", 0);
-        if (pro) {            // the x operand is lrelu(IN(raw)): the register-staged kernel transforms it (m1_conv3d_wgrad_norm)
-            g.pro_stats = pro->pro_stats; g.pro_gamma = pro->pro_gamma; g.pro_beta = pro->pro_beta; g.pro_slope = pro->pro_slope;
-            rc = m1_mfma_wgrad_ex(g, (long long)nw, nbias, st);
-            if (rc) return rc;
-            off += d->src[i].C; continue;
-        }
         // >= 64 channels on both sides, stride 1: the 64x64-tile tap-fused kernel on 32x32x16 MFMAs, one launch for a run of
         // equal-width members (dY staged once per kd slice for all of them, wgrad_t3.hip)
         if (!g_force_direct && rx && m1_t3_wgrad_supported(g)) {
@@ -734,14 +691,6 @@ extern "C" int m1_conv3d_wgrad(const m1_conv_desc_t* d, const void* dy, float* d
     if (!desc_ok(d) || !dy || !dw) return M1_ERR_BAD_ARG;
     M1ProfScope ps(prof_name("conv3d_wgrad", d).s, 2.0 * conv_macs(d, false), conv_bytes(d, false), (hipStream_t)stream);
     return wgrad_common(d, false, dy, dw, db, ws, (hipStream_t)stream, accumulate);
-}
-extern "C" int m1_conv3d_wgrad_norm(const m1_conv_desc_t* d, const float* x_stats, const float* gamma, const float* beta, float slope,
-                                    const void* dy, float* dw, float* db, void* ws, int accumulate, void* stream) {
-    if (!desc_ok(d) || !x_stats || !gamma || !beta || !dy || !dw || !ws) return M1_ERR_BAD_ARG;
-    if (!fwd_norm_shape_ok(d)) return M1_ERR_UNSUPPORTED;
-    M1ProfScope ps(prof_name("conv3d_wgrad", d).s, 2.0 * conv_macs(d, false), conv_bytes(d, false), (hipStream_t)stream);
-    GatherSpec pro{}; pro.pro_stats = x_stats; pro.pro_gamma = gamma; pro.pro_beta = beta; pro.pro_slope = slope;
-    return wgrad_common(d, false, dy, dw, db, ws, (hipStream_t)stream, accumulate, &pro);
 }
 extern "C" int m1_convT3d_wgrad(const m1_conv_desc_t* d, const void* dy, float* dw, float* db, void* ws, int accumulate,
                                 void* stream) {

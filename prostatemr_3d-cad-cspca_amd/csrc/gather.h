@@ -35,10 +35,6 @@ struct GatherSpec {
     const void* ib_x; const float* ib_stats; const float* ib_gamma; const float* ib_beta; float ib_slope;
     float* ib_partial; int* ib_nparts;
     int ib_cap;                // rows per sample `ib_partial` holds (a kernel that would write more leaves *ib_nparts = 0)
-    // optional (forward, ONE member): src[0] is the raw output x of the previous conv, the operand is lrelu(IN(x)) with the
-    // finished statistics pro_stats [N][C][2] = {mean, rstd} and the norm's gamma / beta -- applied by the kernel on its operand
-    // (m1_conv3d_fwd_norm).  Only the pointwise streaming kernel does this; any other shape: M1_ERR_UNSUPPORTED, nothing launched.
-    const float* pro_stats; const float* pro_gamma; const float* pro_beta; float pro_slope;
 };
 
 int m1_stats_internal(const void* x, int N, long long V, int C, int dtype, float eps, float* stats, float* ws, hipStream_t st);
@@ -53,9 +49,6 @@ struct WgradSpec {
     int kd, kh, kw, sd, sh, sw, pd, ph, pw;
     int dtype;
     float* rx; long long rx_floats;   // caller-owned scratch for per-split partial copies of the gradient (inside the wgrad `ws`)
-    // optional (stride-1 pointwise layers, bf16, wgrad_mfma only): A is the RAW conv output x and the operand is lrelu(IN(x))
-    // (see GatherSpec::pro_*): transformed in registers between the global load and the LDS image
-    const float* pro_stats; const float* pro_gamma; const float* pro_beta; float pro_slope;
     float* bsum;      // optional: bsum[b + b_off] += sum_v B[v][b] (bias gradient of a Conv3D, fused into the tap whose
     int bsum_tap;     // shifted partner is always inside the volume: tap index bsum_tap); NULL = off
 };
@@ -67,7 +60,6 @@ int m1_skinny_wgrad(const WgradSpec& g, hipStream_t st);
 bool m1_mfma_supported(const GatherSpec& g);
 size_t m1_mfma_ws_bytes(const GatherSpec& g);
 int m1_mfma_gather(const GatherSpec& g, void* ws, int ws_packed, hipStream_t st);
-bool m1_mfma_pro_supported(const GatherSpec& g);    // a spec with pro_* set: would the matrix-core path apply the operand transform?
 // layers with <= 4 (forward) / <= 8 (pointwise data gradient) channels on the thin side (conv_thin.hip): 1 = taken, *rc = result
 int m1_thin_conv_try(const GatherSpec& g, hipStream_t st, int* rc);
 int m1_pack_batch_internal(const void* const* jobs_dev, const int* prefix_dev, int njobs, int total_blocks, hipStream_t st);

@@ -31,10 +31,8 @@ struct StatsF {
 template <typename T>
 static int stats_impl(const void* x, int N, long long V, int C, float eps, float* stats, float* ws, hipStream_t st) {
     StatsF<T> f{(const T*)x, V, C};
-    const M1Fin<2> fin = m1_fin_out<2>(stats, V, eps);
-    bool fused = false;
-    int rc = m1_reduce_nc_launch<2>(f, N, V, C, ws, st, &fin, &fused);
-    if (rc || fused) return rc;
+    int rc = m1_reduce_nc_launch<2>(f, N, V, C, ws, st);
+    if (rc) return rc;
     return m1_reduce_finalize_launch<2>(ws, N, C, m1_red_nchunks(V, C, N), stats, V, eps, st);
 }
 
@@ -221,11 +219,9 @@ static int bwd_impl(const void* x, const float* stats, const float* gamma, const
     const int nchunks = m1_red_nchunks(V, C, N);
     float* sums = ws + (size_t)N * nchunks * C * 2;
     M1ParamOut<2> po{{dbeta, dgamma}, {accumulate, accumulate}};      // dbeta = sum_n sums[.][0], dgamma = sum_n sums[.][1]
-    const M1Fin<2> fin = m1_fin_params<2>(sums, po);
-    bool fused = false;
-    int rc = m1_reduce_nc_launch<2>(f, N, V, C, ws, st, &fin, &fused);
+    int rc = m1_reduce_nc_launch<2>(f, N, V, C, ws, st);
     if (rc) return rc;
-    if (!fused) { rc = m1_reduce_finalize_params_launch<2>(ws, N, C, nchunks, sums, po, st); if (rc) return rc; }
+    rc = m1_reduce_finalize_params_launch<2>(ws, N, C, nchunks, sums, po, st); if (rc) return rc;
     constexpr int VW = sizeof(T) == 2 ? 8 : 4;
     if (C % VW == 0) {
         long long per = V * (C / VW);
@@ -271,13 +267,9 @@ struct ColSumF {
 // Internal (used by conv wgrad): ws must hold N*nchunks*C floats.
 int m1_colsum_internal(const void* x, int N, long long V, int C, int dtype, float* out, float* ws, hipStream_t st, int accumulate) {
     int rc;
-    // (ws holds N*nchunks*C partial floats + N*C per-sample sums: m1_reduce_ws_floats(.., 1))
-    M1ParamOut<1> po{{out}, {accumulate}};
-    const M1Fin<1> fin = m1_fin_params<1>(ws + (size_t)N * m1_red_nchunks(V, C, N) * C, po, 3);
-    bool fused = false;
-    if (dtype == M1_BF16) { ColSumF<bf16_t> f{(const bf16_t*)x, V, C}; rc = m1_reduce_nc_launch<1>(f, N, V, C, ws, st, &fin, &fused); }
-    else { ColSumF<float> f{(const float*)x, V, C}; rc = m1_reduce_nc_launch<1>(f, N, V, C, ws, st, &fin, &fused); }
-    if (rc || fused) return rc;
+    if (dtype == M1_BF16) { ColSumF<bf16_t> f{(const bf16_t*)x, V, C}; rc = m1_reduce_nc_launch<1>(f, N, V, C, ws, st); }
+    else { ColSumF<float> f{(const float*)x, V, C}; rc = m1_reduce_nc_launch<1>(f, N, V, C, ws, st); }
+    if (rc) return rc;
     // partial is [N*nchunks][C][1]: fold all rows as one sample
     return m1_reduce_finalize_launch<1>(ws, 1, C, N * m1_red_nchunks(V, C, N), out, 0, 0.f, st, accumulate);
 }

@@ -218,6 +218,9 @@ struct SeParams {
     float drop_rate; const uint64_t* rng; uint64_t layer_id;
     unsigned char* mask;      // optional keep-mask, bit (idx & 7) of byte (idx >> 3): written by the forward, read by the backward
     int identity4;            // network_blocks.py:63 false branch (C_in == filters): rho is the block input itself, no conv4 / norm4
+    int dupB;                 // > 0: y3 / y4 / statistics hold dupB samples, out / dout / mask 2 * dupB -- the two stacked passes of a core
+                              // share everything in front of their first dropout draw (M1Net.forward: posterior([x; x]), prior([img; img])),
+                              // sample n of the output reads sample n % dupB of the inputs; the backward sums the two halves' gradients
 };
 // per-channel constants of the second factor: {mean, rstd, gamma, beta} of norm4, or {0, 1, 1, 0} for the identity residual --
 // (y4 - 0) * 1 * 1 + 0 is y4 exactly, and the InstanceNorm backward with zero sums and unit scale is the identity
@@ -237,9 +240,9 @@ __device__ __forceinline__ void se_rng(const SeParams& p, uint64_t& seed, uint64
 template <typename T, int VEC, bool ID4 = false>
 __global__ void __launch_bounds__(256, 3) se_combine_fwd_kernel(const T* __restrict__ y3, const T* __restrict__ y4, SeParams p,
                                                              T* __restrict__ out) {
-    const int n = blockIdx.y, F = p.F, cg = F / VEC;
+    const int n_out = blockIdx.y, n = p.dupB ? n_out % p.dupB : n_out, F = p.F, cg = F / VEC;
     const long long per = p.V * cg;
-    const size_t base = (size_t)n * p.V * F;
+    const size_t base_in = (size_t)n * p.V * F, base = (size_t)n_out * p.V * F;          // (base: output / dropout-stream / mask index)
     uint64_t seed, rbase; se_rng(p, seed, rbase);
     const float keep_scale = p.drop_rate > 0.f ? 1.f / (1.f - p.drop_rate) : 1.f;
     // the launch keeps gridDim.x*blockDim.x a multiple of the channel groups (m1_grid_for): a thread's channels never change and
@@ -277,19 +280,21 @@ __global__ void __launch_bounds__(256, 3) se_combine_fwd_kernel(const T* __restr
     long long i = i0;
     for (; i + stride < per; i += 2 * stride) {          // two vectors per tensor in flight per thread
         float a0[VEC], b0[VEC], a1[VEC], b1[VEC];
-        VecIO<T, VEC>::ld(y3 + base + i * VEC, a0); VecIO<T, VEC>::ld(y4 + base + i * VEC, b0);
-        VecIO<T, VEC>::ld(y3 + base + (i + stride) * VEC, a1); VecIO<T, VEC>::ld(y4 + base + (i + stride) * VEC, b1);
+        VecIO<T, VEC>::ld(y3 + base_in + i * VEC, a0); VecIO<T, VEC>::ld(y4 + base_in + i * VEC, b0);
+        VecIO<T, VEC>::ld(y3 + base_in + (i + stride) * VEC, a1); VecIO<T, VEC>::ld(y4 + base_in + (i + stride) * VEC, b1);
         body(i, a0, b0); body(i + stride, a1, b1);
     }
     for (; i < per; i += stride) {
         float a0[VEC], b0[VEC];
-        VecIO<T, VEC>::ld(y3 + base + i * VEC, a0); VecIO<T, VEC>::ld(y4 + base + i * VEC, b0);
+        VecIO<T, VEC>::ld(y3 + base_in + i * VEC, a0); VecIO<T, VEC>::ld(y4 + base_in + i * VEC, b0);
         body(i, a0, b0);
     }
 }
 
 // ---------------- combine backward ----------------
-template <typename T, bool MASKED = false, bool ID4 = false>
+// DUP (SeParams::dupB): d(out) holds two halves of dupB samples over the SAME (y3, y4): lrelu'(u) is common, the incoming gradients
+// (each behind its own dropout draw) add up before everything else
+template <typename T, bool MASKED = false, bool ID4 = false, bool DUP = false>
 struct SeBwdF {
     const T* y3; const T* y4; const T* dout; SeParams p;
     __device__ void operator()(int n, long long v, int c, float* acc) const {
@@ -304,6 +309,15 @@ struct SeBwdF {
         if (p.drop_rate > 0.f) {
             uint64_t seed, rbase; se_rng(p, seed, rbase);
             d = philox_keep(seed, rbase, idx, p.drop_rate) ? d / (1.f - p.drop_rate) : 0.f;
+        }
+        if constexpr (DUP) {
+            const size_t idx2 = idx + (size_t)p.dupB * p.V * F;
+            float d2 = Act<T>::ld(dout + idx2);
+            if (p.drop_rate > 0.f) {
+                uint64_t seed, rbase; se_rng(p, seed, rbase);
+                d2 = philox_keep(seed, rbase, idx2, p.drop_rate) ? d2 / (1.f - p.drop_rate) : 0.f;
+            }
+            d += d2;
         }
         const float du = d * lrelu_g(u, 0.1f);
         const float dx_ = du * g * rho, drho = du * g * x_;
@@ -323,6 +337,22 @@ struct SeBwdF {
             for (int e = 0; e < kVec; ++e) keep[e] = (m >> e) & 1u;
         } else if (p.drop_rate > 0.f) { uint64_t seed, rbase; se_rng(p, seed, rbase); philox_keep_vec<kVec, kVec % 4 == 0>(seed, rbase, idx, p.drop_rate, keep); }
         const float keep_scale = p.drop_rate > 0.f ? 1.f / (1.f - p.drop_rate) : 1.f;
+        if (p.drop_rate > 0.f) {
+#pragma unroll
+            for (int e = 0; e < kVec; ++e) d[e] = keep[e] ? d[e] * keep_scale : 0.f;
+        }
+        if constexpr (DUP) {
+            const size_t idx2 = idx + (size_t)p.dupB * p.V * F;
+            float d2[kVec];
+            VecIO<T, kVec>::ld(dout + idx2, d2);
+            if (MASKED) {
+                const unsigned m = p.mask[idx2 >> 3];
+#pragma unroll
+                for (int e = 0; e < kVec; ++e) keep[e] = (m >> e) & 1u;
+            } else if (p.drop_rate > 0.f) { uint64_t seed, rbase; se_rng(p, seed, rbase); philox_keep_vec<kVec, kVec % 4 == 0>(seed, rbase, idx2, p.drop_rate, keep); }
+#pragma unroll
+            for (int e = 0; e < kVec; ++e) d[e] += p.drop_rate > 0.f ? (keep[e] ? d2[e] * keep_scale : 0.f) : d2[e];
+        }
 #pragma unroll
         for (int e = 0; e < kVec; ++e) {
             const int c = c0 + e; const size_t sc = ((size_t)n * F + c) * 2;
@@ -331,16 +361,14 @@ struct SeBwdF {
             const float xh4 = (b[e] - m4) * r4;
             const float x_ = xh3 * p.gamma3[c] + p.beta3[c], rho = xh4 * g4 + b4;
             const float g = p.g[c], u = x_ * g * rho;
-            float dd = d[e];
-            if (p.drop_rate > 0.f) dd = keep[e] ? dd * keep_scale : 0.f;
-            const float du = dd * lrelu_g(u, 0.1f);
+            const float du = d[e] * lrelu_g(u, 0.1f);              // (d: behind the dropout, both halves summed under DUP)
             const float dx_ = du * g * rho, drho = du * g * x_;
             acc[0][e] += dx_; acc[1][e] += dx_ * xh3; acc[2][e] += drho; acc[3][e] += drho * xh4; acc[4][e] += du * x_ * rho;
         }
     }
 };
 
-template <typename T, int VEC, bool MASKED = false, int MINW = 2, bool ID4 = false>
+template <typename T, int VEC, bool MASKED = false, int MINW = 2, bool ID4 = false, bool DUP = false>
 __global__ void __launch_bounds__(256, MINW) se_combine_bwd_apply_kernel(const T* __restrict__ y3, const T* __restrict__ y4,
                                                                    const T* __restrict__ dout, SeParams p,
                                                                    const float* __restrict__ sums /*[N][F][5]*/,
@@ -375,14 +403,28 @@ __global__ void __launch_bounds__(256, MINW) se_combine_bwd_apply_kernel(const T
 #pragma unroll
             for (int k = 0; k < VEC; ++k) keep[k] = (m >> k) & 1u;
         } else if (p.drop_rate > 0.f) philox_keep_vec<VEC, VEC % 4 == 0>(seed, rbase, base + i * VEC, p.drop_rate, keep);
+        if (p.drop_rate > 0.f) {
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) d[k] = keep[k] ? d[k] * keep_scale : 0.f;
+        }
+        if constexpr (DUP) {                     // the second half's gradient (its own dropout draw) over the same (y3, y4)
+            const size_t o2 = base + (size_t)p.dupB * p.V * F + i * VEC;
+            float d2[VEC];
+            VecIO<T, VEC>::ld(dout + o2, d2);
+            if (MASKED) {
+                const unsigned m = p.mask[o2 >> 3];
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) keep[k] = (m >> k) & 1u;
+            } else if (p.drop_rate > 0.f) philox_keep_vec<VEC, VEC % 4 == 0>(seed, rbase, o2, p.drop_rate, keep);
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) d[k] += p.drop_rate > 0.f ? (keep[k] ? d2[k] * keep_scale : 0.f) : d2[k];
+        }
 #pragma unroll
         for (int k = 0; k < VEC; ++k) {
             const float xh3 = (a[k] - m3[k]) * r3[k], xh4 = (b[k] - m4[k]) * r4[k];
             const float x_ = xh3 * g3[k] + b3[k], rho = xh4 * g4[k] + b4[k];
             const float g = gt[k], u = x_ * g * rho;
-            float dd = d[k];
-            if (p.drop_rate > 0.f) dd = keep[k] ? dd * keep_scale : 0.f;
-            const float du = dd * lrelu_g(u, 0.1f);
+            const float du = d[k] * lrelu_g(u, 0.1f);
             const float dx_ = du * g * rho, drho = du * g * x_;
             a[k] = g3[k] * r3[k] * (dx_ - s0[k] - xh3 * s1[k]);
             b[k] = g4[k] * r4[k] * (drho - s2[k] - xh4 * s3[k]);
@@ -394,8 +436,9 @@ __global__ void __launch_bounds__(256, MINW) se_combine_bwd_apply_kernel(const T
 
 
 template <typename T>
-static int se_fwd_impl(const void* y3, const void* y4, const SeParams& p, void* out, int N, hipStream_t st) {
+static int se_fwd_impl(const void* y3, const void* y4, const SeParams& p, void* out, int N_in, hipStream_t st) {
     constexpr int VW = sizeof(T) == 2 ? 8 : 4;
+    const int N = p.dupB ? 2 * N_in : N_in;              // blocks walk the OUTPUT samples (SeParams::dupB: two per input sample)
     if (p.identity4) {                                   // network_blocks.py:63 false branch: its own instantiations (compile-time constants)
         if (p.F % VW == 0)
             hipLaunchKernelGGL((se_combine_fwd_kernel<T, VW, true>), dim3(m1_grid_for(p.V * (p.F / VW), p.F / VW), N), dim3(256), 0, st, (const T*)y3,
@@ -425,14 +468,12 @@ static int se_bwd_impl(const void* y3, const void* y4, const void* dout, const S
     float* sums = ws + (size_t)N * nchunks * p.F * 5;
     // parameter gradients ride on the fold: dg is scratch for the gate backward (always overwritten)
     M1ParamOut<5> po{{dbeta3, dgamma3, p.identity4 ? nullptr : dbeta4, p.identity4 ? nullptr : dgamma4, dg}, {acc, acc, acc, acc, 0}};
-    const M1Fin<5> fin = m1_fin_params<5>(sums, po);
-    bool fused = false;
     if (p.identity4) {
         // the identity-residual block (a rare configuration): the plain variants, the keep bits read from the mask when there is one
-        if (masked) { SeBwdF<T, true, true> f{(const T*)y3, (const T*)y4, (const T*)dout, p}; rc = m1_reduce_nc_launch<5>(f, N, p.V, p.F, ws, st, &fin, &fused); }
-        else { SeBwdF<T, false, true> f{(const T*)y3, (const T*)y4, (const T*)dout, p}; rc = m1_reduce_nc_launch<5>(f, N, p.V, p.F, ws, st, &fin, &fused); }
+        if (masked) { SeBwdF<T, true, true> f{(const T*)y3, (const T*)y4, (const T*)dout, p}; rc = m1_reduce_nc_launch<5>(f, N, p.V, p.F, ws, st); }
+        else { SeBwdF<T, false, true> f{(const T*)y3, (const T*)y4, (const T*)dout, p}; rc = m1_reduce_nc_launch<5>(f, N, p.V, p.F, ws, st); }
         if (rc) return rc;
-        if (!fused) { rc = m1_reduce_finalize_params_launch<5>(ws, N, p.F, nchunks, sums, po, st); if (rc) return rc; }
+        rc = m1_reduce_finalize_params_launch<5>(ws, N, p.F, nchunks, sums, po, st); if (rc) return rc;
         if (masked)
             hipLaunchKernelGGL((se_combine_bwd_apply_kernel<T, VW, true, 2, true>), dim3(m1_grid_for(p.V * (p.F / VW), p.F / VW), N), dim3(256), 0, st,
                                (const T*)y3, (const T*)y4, (const T*)dout, p, sums, (T*)dy3, (T*)dy4);
@@ -444,10 +485,25 @@ static int se_bwd_impl(const void* y3, const void* y4, const void* dout, const S
                                (const T*)y4, (const T*)dout, p, sums, (T*)dy3, (T*)dy4);
         return m1_check_launch();
     }
-    if (masked) { SeBwdF<T, true> f{(const T*)y3, (const T*)y4, (const T*)dout, p}; rc = m1_reduce_nc_launch<5>(f, N, p.V, p.F, ws, st, &fin, &fused); }
-    else { SeBwdF<T> f{(const T*)y3, (const T*)y4, (const T*)dout, p}; rc = m1_reduce_nc_launch<5>(f, N, p.V, p.F, ws, st, &fin, &fused); }
+    if (p.dupB) {
+        // two halves of d(out) over the same (y3, y4) (SeParams::dupB): sums and gradients of the N input samples, both halves added
+        if (p.F % VW) return M1_ERR_UNSUPPORTED;
+        if (masked) { SeBwdF<T, true, false, true> f{(const T*)y3, (const T*)y4, (const T*)dout, p}; rc = m1_reduce_nc_launch<5>(f, N, p.V, p.F, ws, st); }
+        else { SeBwdF<T, false, false, true> f{(const T*)y3, (const T*)y4, (const T*)dout, p}; rc = m1_reduce_nc_launch<5>(f, N, p.V, p.F, ws, st); }
+        if (rc) return rc;
+        rc = m1_reduce_finalize_params_launch<5>(ws, N, p.F, nchunks, sums, po, st); if (rc) return rc;
+        if (masked)
+            hipLaunchKernelGGL((se_combine_bwd_apply_kernel<T, VW, true, 2, false, true>), dim3(m1_grid_for(p.V * (p.F / VW), p.F / VW), N), dim3(256), 0, st,
+                               (const T*)y3, (const T*)y4, (const T*)dout, p, sums, (T*)dy3, (T*)dy4);
+        else
+            hipLaunchKernelGGL((se_combine_bwd_apply_kernel<T, VW, false, 2, false, true>), dim3(m1_grid_for(p.V * (p.F / VW), p.F / VW), N), dim3(256), 0, st,
+                               (const T*)y3, (const T*)y4, (const T*)dout, p, sums, (T*)dy3, (T*)dy4);
+        return m1_check_launch();
+    }
+    if (masked) { SeBwdF<T, true> f{(const T*)y3, (const T*)y4, (const T*)dout, p}; rc = m1_reduce_nc_launch<5>(f, N, p.V, p.F, ws, st); }
+    else { SeBwdF<T> f{(const T*)y3, (const T*)y4, (const T*)dout, p}; rc = m1_reduce_nc_launch<5>(f, N, p.V, p.F, ws, st); }
     if (rc) return rc;
-    if (!fused) { rc = m1_reduce_finalize_params_launch<5>(ws, N, p.F, nchunks, sums, po, st); if (rc) return rc; }
+    rc = m1_reduce_finalize_params_launch<5>(ws, N, p.F, nchunks, sums, po, st); if (rc) return rc;
     int w3 = M1_CFG("M1_SE_BWD_W3", 0);
     if (masked && w3)       // 3 waves per SIMD at the price of 4 spilled registers (measured: see DESIGN 5)
         hipLaunchKernelGGL((se_combine_bwd_apply_kernel<T, VW, true, 3>), dim3(m1_grid_for(p.V * (p.F / VW), p.F / VW), N), dim3(256), 0, st,
@@ -464,36 +520,68 @@ static int se_bwd_impl(const void* y3, const void* y4, const void* dout, const S
     return m1_check_launch();
 }
 
-extern "C" int m1_se_combine_fwd(const void* y3, const void* y4, const float* stats3, const float* stats4,
-                                 const float* gamma3, const float* beta3, const float* gamma4, const float* beta4,
-                                 const float* g, void* out, int N, long long V, int F, int dtype, float drop_rate,
-                                 const uint64_t* rng, uint64_t layer_id, unsigned char* keep_mask, void* stream) {
-    if (!y3 || !y4 || !stats3 || !gamma3 || !beta3 || !g || !out) return M1_ERR_BAD_ARG;
+static int se_combine_fwd_entry(const void* y3, const void* y4, const float* stats3, const float* stats4,
+                                const float* gamma3, const float* beta3, const float* gamma4, const float* beta4,
+                                const float* g, void* out, int N, long long V, int F, int dtype, float drop_rate,
+                                const uint64_t* rng, uint64_t layer_id, unsigned char* keep_mask, void* stream, int dup) {
+    if (!y3 || !y4 || !stats3 || !gamma3 || !beta3 || !g || !out || N <= 0) return M1_ERR_BAD_ARG;
     const bool ident = !stats4 && !gamma4 && !beta4;             // all three NULL: identity residual (network_blocks.py:63, C_in == filters)
     if (!ident && (!stats4 || !gamma4 || !beta4)) return M1_ERR_BAD_ARG;
     if (drop_rate > 0.f && !rng) return M1_ERR_BAD_ARG;
     if (drop_rate < 0.f || drop_rate >= 1.f) return M1_ERR_BAD_ARG;
     if (keep_mask && (dtype != M1_BF16 || F % 8)) return M1_ERR_UNSUPPORTED;
-    SeParams p{stats3, stats4, gamma3, beta3, gamma4, beta4, g, V, F, drop_rate, rng, layer_id, keep_mask, ident ? 1 : 0};
-    M1ProfScope ps("se_combine_fwd", 0.0, 3.0 * N * V * F * (dtype == M1_BF16 ? 2 : 4), (hipStream_t)stream);
+    if (dup && ident) return M1_ERR_UNSUPPORTED;
+    SeParams p{stats3, stats4, gamma3, beta3, gamma4, beta4, g, V, F, drop_rate, rng, layer_id, keep_mask, ident ? 1 : 0, dup ? N : 0};
+    M1ProfScope ps("se_combine_fwd", 0.0, (dup ? 4.0 : 3.0) * N * V * F * (dtype == M1_BF16 ? 2 : 4), (hipStream_t)stream);
     return dtype == M1_BF16 ? se_fwd_impl<bf16_t>(y3, y4, p, out, N, (hipStream_t)stream)
                             : se_fwd_impl<float>(y3, y4, p, out, N, (hipStream_t)stream);
 }
+extern "C" int m1_se_combine_fwd(const void* y3, const void* y4, const float* stats3, const float* stats4,
+                                 const float* gamma3, const float* beta3, const float* gamma4, const float* beta4,
+                                 const float* g, void* out, int N, long long V, int F, int dtype, float drop_rate,
+                                 const uint64_t* rng, uint64_t layer_id, unsigned char* keep_mask, void* stream) {
+    return se_combine_fwd_entry(y3, y4, stats3, stats4, gamma3, beta3, gamma4, beta4, g, out, N, V, F, dtype, drop_rate, rng, layer_id, keep_mask, stream, 0);
+}
+extern "C" int m1_se_combine_dup_fwd(const void* y3, const void* y4, const float* stats3, const float* stats4,
+                                     const float* gamma3, const float* beta3, const float* gamma4, const float* beta4,
+                                     const float* g, void* out, int N, long long V, int F, int dtype, float drop_rate,
+                                     const uint64_t* rng, uint64_t layer_id, unsigned char* keep_mask, void* stream) {
+    return se_combine_fwd_entry(y3, y4, stats3, stats4, gamma3, beta3, gamma4, beta4, g, out, N, V, F, dtype, drop_rate, rng, layer_id, keep_mask, stream, 1);
+}
 
+static int se_combine_bwd_entry(const void* y3, const void* y4, const float* stats3, const float* stats4,
+                                const float* gamma3, const float* beta3, const float* gamma4, const float* beta4,
+                                const float* g, const void* dout, void* dy3, void* dy4, float* dgamma3, float* dbeta3,
+                                float* dgamma4, float* dbeta4, float* dg, int N, long long V, int F, int dtype,
+                                float drop_rate, const uint64_t* rng, uint64_t layer_id, const unsigned char* keep_mask,
+                                float* ws, int accumulate, void* stream, int dup) {
+    if (N <= 0 || !y3 || !y4 || !stats3 || !gamma3 || !beta3 || !g || !dout || !dy3 || !dy4 || !dgamma3 || !dbeta3 || !dg || !ws) return M1_ERR_BAD_ARG;
+    const bool ident = !stats4 && !gamma4 && !beta4;             // identity residual: dy4 = d(out)/d(y4) directly, dgamma4 / dbeta4 unused
+    if (!ident && (!stats4 || !gamma4 || !beta4 || !dgamma4 || !dbeta4)) return M1_ERR_BAD_ARG;
+    if (drop_rate > 0.f && !rng && !keep_mask) return M1_ERR_BAD_ARG;
+    if (keep_mask && (dtype != M1_BF16 || F % 8)) return M1_ERR_UNSUPPORTED;
+    if (dup && ident) return M1_ERR_UNSUPPORTED;
+    SeParams p{stats3, stats4, gamma3, beta3, gamma4, beta4, g, V, F, drop_rate, rng, layer_id, const_cast<unsigned char*>(keep_mask), ident ? 1 : 0, dup ? N : 0};
+    M1ProfScope ps("se_combine_bwd", 0.0, (dup ? 10.0 : 8.0) * N * V * F * (dtype == M1_BF16 ? 2 : 4), (hipStream_t)stream);
+    return dtype == M1_BF16
+               ? se_bwd_impl<bf16_t>(y3, y4, dout, p, dy3, dy4, dgamma3, dbeta3, dgamma4, dbeta4, dg, N, ws, (hipStream_t)stream, accumulate)
+               : se_bwd_impl<float>(y3, y4, dout, p, dy3, dy4, dgamma3, dbeta3, dgamma4, dbeta4, dg, N, ws, (hipStream_t)stream, accumulate);
+}
 extern "C" int m1_se_combine_bwd(const void* y3, const void* y4, const float* stats3, const float* stats4,
                                  const float* gamma3, const float* beta3, const float* gamma4, const float* beta4,
                                  const float* g, const void* dout, void* dy3, void* dy4, float* dgamma3, float* dbeta3,
                                  float* dgamma4, float* dbeta4, float* dg, int N, long long V, int F, int dtype,
                                  float drop_rate, const uint64_t* rng, uint64_t layer_id, const unsigned char* keep_mask,
                                  float* ws, int accumulate, void* stream) {
-    if (!y3 || !y4 || !stats3 || !gamma3 || !beta3 || !g || !dout || !dy3 || !dy4 || !dgamma3 || !dbeta3 || !dg || !ws) return M1_ERR_BAD_ARG;
-    const bool ident = !stats4 && !gamma4 && !beta4;             // identity residual: dy4 = d(out)/d(y4) directly, dgamma4 / dbeta4 unused
-    if (!ident && (!stats4 || !gamma4 || !beta4 || !dgamma4 || !dbeta4)) return M1_ERR_BAD_ARG;
-    if (drop_rate > 0.f && !rng && !keep_mask) return M1_ERR_BAD_ARG;
-    if (keep_mask && (dtype != M1_BF16 || F % 8)) return M1_ERR_UNSUPPORTED;
-    SeParams p{stats3, stats4, gamma3, beta3, gamma4, beta4, g, V, F, drop_rate, rng, layer_id, const_cast<unsigned char*>(keep_mask), ident ? 1 : 0};
-    M1ProfScope ps("se_combine_bwd", 0.0, 8.0 * N * V * F * (dtype == M1_BF16 ? 2 : 4), (hipStream_t)stream);
-    return dtype == M1_BF16
-               ? se_bwd_impl<bf16_t>(y3, y4, dout, p, dy3, dy4, dgamma3, dbeta3, dgamma4, dbeta4, dg, N, ws, (hipStream_t)stream, accumulate)
-               : se_bwd_impl<float>(y3, y4, dout, p, dy3, dy4, dgamma3, dbeta3, dgamma4, dbeta4, dg, N, ws, (hipStream_t)stream, accumulate);
+    return se_combine_bwd_entry(y3, y4, stats3, stats4, gamma3, beta3, gamma4, beta4, g, dout, dy3, dy4, dgamma3, dbeta3, dgamma4, dbeta4, dg,
+                                N, V, F, dtype, drop_rate, rng, layer_id, keep_mask, ws, accumulate, stream, 0);
+}
+extern "C" int m1_se_combine_dup_bwd(const void* y3, const void* y4, const float* stats3, const float* stats4,
+                                     const float* gamma3, const float* beta3, const float* gamma4, const float* beta4,
+                                     const float* g, const void* dout, void* dy3, void* dy4, float* dgamma3, float* dbeta3,
+                                     float* dgamma4, float* dbeta4, float* dg, int N, long long V, int F, int dtype,
+                                     float drop_rate, const uint64_t* rng, uint64_t layer_id, const unsigned char* keep_mask,
+                                     float* ws, int accumulate, void* stream) {
+    return se_combine_bwd_entry(y3, y4, stats3, stats4, gamma3, beta3, gamma4, beta4, g, dout, dy3, dy4, dgamma3, dbeta3, dgamma4, dbeta4, dg,
+                                N, V, F, dtype, drop_rate, rng, layer_id, keep_mask, ws, accumulate, stream, 1);
 }

@@ -56,11 +56,7 @@ __device__ __forceinline__ void transpose_unit(const uint4 (&r)[8], uint4 (&o)[8
     o[3] = make_uint4(r[0].w, r[1].w, r[2].w, r[3].w);
 }
 
-// PRO (bf16, stride-1 pointwise layers): A is the RAW output x of the previous conv and the operand is a = lrelu(IN(x))
-// (WgradSpec::pro_*; conv3 of an SE block reading norm2's output, network_blocks.py:56-59, which the forward never materialised):
-// the block keeps {A, B} = {rstd*gamma, beta - mean*rstd*gamma} of its TA channels for every sample in LDS and transforms each
-// 16-byte voxel row between the global load and the register transpose, rounding to bf16 as the stand-alone apply kernel does.
-template <typename T, int TA, int TB, int KB, bool PRO = false>
+template <typename T, int TA, int TB, int KB>
 __global__ void __launch_bounds__(256) wgrad_mfma_kernel(WgP p) {
     constexpr int SEG = WT<T>::SEG;
     constexpr int KS1 = 4 * SEG;                           // voxels per 64-byte LDS row
@@ -71,8 +67,6 @@ __global__ void __launch_bounds__(256) wgrad_mfma_kernel(WgP p) {
     __shared__ __attribute__((aligned(16))) unsigned char A_s[KB * TA * 64];
     __shared__ __attribute__((aligned(16))) unsigned char B_s[KB * TB * 64];
     __shared__ long long a_off_s[KS], b_off_s[KS];
-    __shared__ float2 pro_s[PRO ? 1024 : 1];               // [n][channel of the a-tile] (host: N * TA <= 1024)
-    __shared__ int n_s[PRO ? KS : 1];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -92,18 +86,6 @@ __global__ void __launch_bounds__(256) wgrad_mfma_kernel(WgP p) {
     const int vbeg = (int)(bz * p.vox_per_split);
     int vend = vbeg + (int)p.vox_per_split; if (vend > TV) vend = TV;
     const T* A = (const T*)p.A; const T* B = (const T*)p.B;
-    if constexpr (PRO) {
-        for (int q = tid; q < p.N * TA; q += 256) {
-            const int n = q / TA, c = a0 + q % TA;
-            float2 ab = make_float2(0.f, 0.f);
-            if (c < p.CA) {
-                const float mean = p.pro_stats[((long long)n * p.CA + c) * 2], rstd = p.pro_stats[((long long)n * p.CA + c) * 2 + 1];
-                ab.x = rstd * p.pro_gamma[c]; ab.y = p.pro_beta[c] - mean * ab.x;
-            }
-            pro_s[q] = ab;
-        }
-        // (visible to all threads after the first __syncthreads() of the K loop)
-    }
 
     f32x4_t acc[TM][TN];
 #pragma unroll
@@ -136,7 +118,6 @@ __global__ void __launch_bounds__(256) wgrad_mfma_kernel(WgP p) {
                 }
             }
             a_off_s[t] = ao; b_off_s[t] = bo;
-            if constexpr (PRO) n_s[t] = v < vend ? v / BV : 0;
         }
         __syncthreads();           // also fences the previous step's fragment reads before A_s/B_s are rewritten
 #pragma unroll
@@ -161,20 +142,6 @@ __global__ void __launch_bounds__(256) wgrad_mfma_kernel(WgP p) {
 #pragma unroll
                             for (int k = 0; k < SEG; ++k) if (c0 + k < C) u.e[k] = base[off * C + c0 + k];
                             v = u.q;
-                        }
-                    }
-                    if constexpr (PRO && sizeof(T) == 2) {
-                        if (isA && off >= 0 && c0 < C) {
-                            const float2* ab = pro_s + n_s[ks * SEG + j] * TA + cg * SEG;
-                            unsigned w[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-                            for (int d = 0; d < 4; ++d) {
-                                const float2 e0 = ab[2 * d], e1 = ab[2 * d + 1];
-                                const float lo = lrelu_f(__uint_as_float(w[d] << 16) * e0.x + e0.y, p.pro_slope);
-                                const float hi = lrelu_f(__uint_as_float(w[d] & 0xffff0000u) * e1.x + e1.y, p.pro_slope);
-                                w[d] = (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16);
-                            }
-                            v = make_uint4(w[0], w[1], w[2], w[3]);
                         }
                     }
                     r[j] = v;
@@ -301,20 +268,13 @@ static int launch_wg(WgP p, hipStream_t st) {
     if (!partial) { p.Rx = nullptr; }
     int xr = M1_CFG("M1_WG_XCD", 1);
     p.xcd_total = 0; p.xcd_gx = (int)grid.x; p.xcd_gy = (int)grid.y; p.xcd_gz = (int)grid.z;
-    void (*kern)(WgP) = wgrad_mfma_kernel<T, TA, TB, KB, false>;
-    if (p.pro_stats) {
-        if constexpr (sizeof(T) == 2) {
-            if (p.N * TA > 1024 || p.CA % 8 || taps != 1 || p.sd != 1 || p.sh != 1 || p.sw != 1) return M1_ERR_UNSUPPORTED;
-            kern = wgrad_mfma_kernel<T, TA, TB, KB, true>;
-        } else return M1_ERR_UNSUPPORTED;
-    }
     if (xr && (long long)grid.x * grid.y > 1 && splits > 1) {
         p.xcd_total = (int)(((long long)grid.x * grid.y * grid.z + 7) / 8 * 8);
-        m1_note_kernel(p.pro_stats ? "wgrad_mfma:pro" : "wgrad_mfma");
-        hipLaunchKernelGGL(kern, dim3((unsigned)p.xcd_total), dim3(256), 0, st, p);
+        m1_note_kernel("wgrad_mfma");
+        hipLaunchKernelGGL((wgrad_mfma_kernel<T, TA, TB, KB>), dim3((unsigned)p.xcd_total), dim3(256), 0, st, p);
     } else {
-        m1_note_kernel(p.pro_stats ? "wgrad_mfma:pro" : "wgrad_mfma");
-        hipLaunchKernelGGL(kern, grid, dim3(256), 0, st, p);
+        m1_note_kernel("wgrad_mfma");
+        hipLaunchKernelGGL((wgrad_mfma_kernel<T, TA, TB, KB>), grid, dim3(256), 0, st, p);
     }
     int rc = m1_check_launch(); if (rc) return rc;
     if (partial) return m1_wg_rx_finish(p.Rx, stride, (int)splits, p, p.rx_bias, st);

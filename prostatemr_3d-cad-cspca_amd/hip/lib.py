@@ -79,11 +79,7 @@ SIGNATURES = {
     "m1_debug_checksum": (_i, [_vp, _ll, _vp, _vp]),
     "m1_debug_scribble": (_i, [_i, _i, _vp]),
     "m1_debug_kernels": (C.c_char_p, [_i]),
-    "m1_tickets_set": (_i, [_vp, _i]),
     "m1_conv3d_wgrad": (_i, [_desc_p, _vp, _vp, _vp, _vp, _i, _vp]),
-    "m1_conv3d_fwd_norm_supported": (_i, [_desc_p]),
-    "m1_conv3d_fwd_norm": (_i, [_desc_p, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
-    "m1_conv3d_wgrad_norm": (_i, [_desc_p, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _i, _vp]),
     "m1_conv3d_pair_supported": (_i, [_desc_p, _i]),
     "m1_conv3d_pair_fwd": (_i, [_desc_p, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
     "m1_conv3d_pair_dgrad": (_i, [_desc_p, _vp, _vp, _i, _vp, _vp, C.POINTER(_vp), C.POINTER(_i), _vp, _i, _vp]),
@@ -101,14 +97,19 @@ SIGNATURES = {
     "m1_se_gate_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
     "m1_se_combine_fwd": (_i, [_vp] * 10 + [_i, _ll, _i, _i, _f, _vp, _u64, _vp, _vp]),
     "m1_se_combine_bwd": (_i, [_vp] * 17 + [_i, _ll, _i, _i, _f, _vp, _u64, _vp, _vp, _i, _vp]),
+    "m1_se_combine_dup_fwd": (_i, [_vp] * 10 + [_i, _ll, _i, _i, _f, _vp, _u64, _vp, _vp]),
+    "m1_se_combine_dup_bwd": (_i, [_vp] * 17 + [_i, _ll, _i, _i, _f, _vp, _u64, _vp, _vp, _i, _vp]),
     "m1_gate_sigma_fwd": (_i, [_vp] * 5 + [_i] * 9 + [_vp]),
     "m1_gate_sigma_bwd": (_i, [_vp] * 9 + [_i] * 9 + [_vp, _i, _vp]),
     "m1_mul_sigma_fwd": (_i, [_vp] * 3 + [_i] * 9 + [_vp]),
     "m1_mul_sigma_bwd": (_i, [_vp] * 5 + [_i] * 10 + [_vp]),
     "m1_latent_sample_fwd": (_i, [_vp, _vp, _vp, _i, _ll, _i, _i, _i, _vp]),
     "m1_latent_sample_bwd": (_i, [_vp, _vp, _vp, _vp, _i, _ll, _i, _i, _i, _vp]),
+    "m1_latent_sample_rng_fwd": (_i, [_vp, _vp, _u64, _vp, _i, _ll, _i, _i, _i, _vp]),
+    "m1_latent_sample_rng_bwd": (_i, [_vp, _vp, _u64, _vp, _vp, _i, _ll, _i, _i, _i, _vp]),
     "m1_kl_fwd": (_i, [_vp, _vp, _vp, _i, _ll, _i, _i, _vp]),
     "m1_kl_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _ll, _i, _i, _vp]),
+    "m1_kl_bwd_first": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _ll, _i, _i, _i, _vp]),
     "m1_softmax_heads_fwd": (_i, [C.POINTER(m1_head_t), _i, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "m1_softmax_heads_bwd": (_i, [C.POINTER(m1_head_t), _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "m1_focal_ws_floats": (_sz, [_i, _ll, _i]),

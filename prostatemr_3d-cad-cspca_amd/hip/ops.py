@@ -123,33 +123,7 @@ def _p(t: Optional[torch.Tensor]):
     return None if t is None else t.data_ptr()
 
 
-# Ticket pools of the last-block finalize (m1_tickets_set): one zero-initialised int32 tensor per device, registered before the
-# first launch on that device and kept for the life of the process (the counters reset themselves, see include/m1hip.h).
-_TICKETS: dict = {}
-_TICKET_SLOTS = 16384
-
-
-def _ensure_tickets() -> None:
-    dev = torch.cuda.current_device()
-    if dev in _TICKETS:
-        return
-    if torch.cuda.is_current_stream_capturing():
-        raise RuntimeError("first M1 HIP op on this device inside a graph capture: run one eager step first")
-    t = torch.zeros(_TICKET_SLOTS, dtype=torch.int32, device=torch.device("cuda", dev))
-    torch.cuda.current_stream().synchronize()                 # the fill ran on this stream; launches may come from others
-    L.check(L.load().m1_tickets_set(t.data_ptr(), _TICKET_SLOTS), "m1_tickets_set")
-    _TICKETS[dev] = t
-
-
-def tickets_reset() -> None:
-    """Zero the ticket pool of the current device (after an aborted launch left counters mid-count)."""
-    t = _TICKETS.get(torch.cuda.current_device())
-    if t is not None:
-        t.zero_()
-
-
 def _stream():
-    _ensure_tickets()
     s = torch.cuda.current_stream().cuda_stream
     if _POISON >= 2:
         L.load().m1_debug_scribble(0, 8, s)
@@ -717,7 +691,7 @@ def _pair_panel_ws(w1: torch.Tensor, w4: torch.Tensor, d, role: int, need_mask=N
     return ws, 0
 
 
-def _wgrad_into_sinks(lib, d, dy, w_param, b_param, transposed: bool, st, srcs=(), norm=None):
+def _wgrad_into_sinks(lib, d, dy, w_param, b_param, transposed: bool, st, srcs=()):
     """Weight (+ bias) gradient of a conv into the parameters' sinks (or fresh tensors): returns (dw, db) for autograd.
 
     The kernels run in order on the caller's stream (weight gradients on streams of their own next to the data-gradient chain were
@@ -732,10 +706,6 @@ def _wgrad_into_sinks(lib, d, dy, w_param, b_param, transposed: bool, st, srcs=(
             bbuf = torch.empty(int(bbuf.numel()), dtype=torch.float32, device=w_param.device)
             dw, db = wbuf, bbuf
     fn = lib.m1_convT3d_wgrad if transposed else lib.m1_conv3d_wgrad
-    if norm is not None:        # the conv's input is lrelu(IN(x)) of the raw tensor in ``d``: the kernel recomputes the operand
-        xstats, gamma, beta, slope = norm
-        fn0 = lib.m1_conv3d_wgrad_norm
-        fn = lambda dd, dy_, wb, bb, ws_, acc_, st_: fn0(dd, _p(xstats), _p(gamma), _p(beta), float(slope), dy_, wb, bb, ws_, acc_, st_)
     flat = dw is None and db is None
     ws = _conv_ws(d, transposed, 2, w_param.device)
     if flat and _FOLD["on"]:
@@ -859,88 +829,6 @@ class _PairGraft(torch.autograd.Function):
     def backward(ctx, dy1, dy4):
         g = _ConvPair.backward(ctx, dy1, None, dy4, None)       # (dw1, db1, None, None, None, None, *dsrc)
         return (None, None, g[0], g[1], None, None, None, *g[6:])
-
-
-class _ConvNorm(torch.autograd.Function):
-    """y = Conv3D_{1x1x1}(lrelu(IN(x))) with the normalisation + activation applied on the conv's operand (m1_conv3d_fwd_norm):
-    norm2 -> LeakyReLU -> conv3 of an SE block (network_blocks.py:56-59) as one data pass.  The backward owns the norm's backward
-    too: weight gradient with the same operand transform, data gradient with the InstanceNorm-backward sums from its epilogue, then
-    the apply pass on x."""
-
-    @staticmethod
-    def forward(ctx, x, xstats, gamma, beta, slope, w, b, want_stats):
-        _req(x, xstats, gamma, beta, w, b)
-        lib = L.load()
-        cout = int(w.shape[4])
-        d = _desc([x], cout, (1, 1, 1), (1, 1, 1))
-        if d.Cin != int(w.shape[3]) or tuple(w.shape[:3]) != (1, 1, 1):
-            raise RuntimeError(f"kernel {tuple(w.shape)} does not match a pointwise conv over {d.Cin} channels")
-        y = torch.empty((*x.shape[:4], cout), dtype=x.dtype, device=x.device)
-        stats = torch.empty((d.N, cout, 2), dtype=torch.float32, device=x.device) if want_stats else None
-        ws, packed = _panel_ws(w, d, False, 0)
-        L.check(lib.m1_conv3d_fwd_norm(C.byref(d), _p(xstats), _p(gamma), _p(beta), float(slope), _p(w), _p(b), _p(y), _p(stats), _p(ws),
-                                       packed, _stream()), "m1_conv3d_fwd_norm")
-        ctx.save_for_backward(x, xstats, gamma, beta, w)
-        ctx.params = (gamma, beta, w, b)
-        ctx.slope, ctx.cout = float(slope), cout
-        if want_stats:
-            ctx.mark_non_differentiable(stats)
-            ctx.set_materialize_grads(False)
-            return y, stats
-        return y
-
-    @staticmethod
-    def backward(ctx, dy, *_unused):
-        lib = L.load()
-        x, xstats, gamma, beta, w = ctx.saved_tensors
-        if dy is None:
-            return (None,) * 8
-        g_param, b_param, w_param, bias_param = ctx.params
-        dy = dy.contiguous()
-        _req(dy)
-        st = _stream()
-        d = _desc([x], ctx.cout, (1, 1, 1), (1, 1, 1))
-        dw, db = _wgrad_into_sinks(lib, d, dy, w_param, bias_param, False, st, (x,), norm=(xstats, gamma, beta, ctx.slope))
-        N, Cn = int(x.shape[0]), int(x.shape[-1])
-        V = x.numel() // (N * Cn)
-        nmax = int(lib.m1_conv3d_dgrad_inbwd_rows(C.byref(d)))
-        part = torch.empty(N * nmax * Cn * 2 + N * Cn * 2 + 64, dtype=torch.float32, device=x.device)
-        nparts = C.c_int(0)
-        da = torch.empty_like(x)
-        ws, packed = _panel_ws(w_param, d, False, 1, (True,))
-        L.check(lib.m1_conv3d_dgrad_inbwd(C.byref(d), _p(w), _p(dy), _p(da), _p(x), _p(xstats), _p(gamma), _p(beta), ctx.slope,
-                                          _p(part), nmax, C.byref(nparts), _p(ws), packed, st), "m1_conv3d_dgrad_inbwd")
-        dx = torch.empty_like(x)
-        gbuf, acc, dg = _sink(g_param)
-        bbuf, acc2, dbt = _sink(b_param)
-        if acc != acc2:
-            gbuf, bbuf, acc = torch.empty_like(gamma), torch.empty_like(beta), 0
-            dg, dbt = gbuf, bbuf
-        if nparts.value > 0:
-            sums = part[part.numel() - N * Cn * 2 - 64:]
-            L.check(lib.m1_instnorm_bwd_partials(_p(x), _p(xstats), _p(gamma), _p(beta), ctx.slope, _p(da), _p(dx), _p(gbuf), _p(bbuf),
-                                                 N, V, Cn, _dt(x), _p(part), nparts.value, _p(sums), acc, st), "m1_instnorm_bwd_partials")
-            _INBWD["fused"] += 1
-        else:
-            ws2 = _ws(N, V, Cn, 2, x.device)
-            L.check(lib.m1_instnorm_bwd(_p(x), _p(xstats), _p(gamma), _p(beta), ctx.slope, _p(da), _p(dx), _p(gbuf), _p(bbuf),
-                                        N, V, Cn, _dt(x), _p(ws2), acc, st), "m1_instnorm_bwd")
-            _INBWD["plain"] += 1
-        return dx, None, dg, dbt, None, dw, db, None
-
-
-def conv_norm_supported(x: torch.Tensor, w: torch.Tensor) -> bool:
-    """Does the library apply lrelu(IN(x)) on the operand of this pointwise conv (m1_conv3d_fwd_norm_supported)?"""
-    if _FORCE_DIRECT[0] or not x.is_cuda or x.dtype != torch.bfloat16 or tuple(w.shape[:3]) != (1, 1, 1):
-        return False
-    d = _desc([x], int(w.shape[4]), (1, 1, 1), (1, 1, 1))
-    return bool(L.load().m1_conv3d_fwd_norm_supported(C.byref(d)))
-
-
-def conv3d_norm_same(x, xstats, gamma, beta, slope, w, b, stats: bool = False):
-    """Conv3D_{1x1x1}(LeakyReLU(InstanceNorm(x))) from the RAW tensor ``x`` and its finished statistics ``xstats`` (N,C,2): the
-    normalised tensor is never materialised (conv_norm_supported says whether the library can)."""
-    return _ConvNorm.apply(x, xstats, gamma, beta, float(slope), w, b, bool(stats))
 
 
 _FORCE_DIRECT = [False]
@@ -1109,7 +997,7 @@ def drop_deferred() -> None:
 
 class _SECombine(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, y3, y4, g3, b3, g4, b4, W6, b6, W7, b7, drop_rate, rng, layer_id, s3, s4, gate):
+    def forward(ctx, y3, y4, g3, b3, g4, b4, W6, b6, W7, b7, drop_rate, rng, layer_id, s3, s4, gate, dup=False):
         _req(y3, y4, g3, b3, g4, b4, W6, b6, W7, b7)
         lib = L.load()
         N, Fn = int(y3.shape[0]), int(y3.shape[-1])
@@ -1129,14 +1017,19 @@ class _SECombine(torch.autograd.Function):
             hidden = torch.empty(Fr, dtype=torch.float32, device=y3.device)
             g = torch.empty(Fn, dtype=torch.float32, device=y3.device)
             L.check(lib.m1_se_gate_fwd(_p(b3), _p(W6), _p(b6), _p(W7), _p(b7), Fn, Fr, _p(hidden), _p(g), st), "m1_se_gate_fwd")
-        out = torch.empty_like(y3)
+        dup = bool(dup)
+        if dup and (ident or Fn % (8 if y3.dtype == torch.bfloat16 else 4)):
+            raise RuntimeError("se_combine: the duplicating form needs a norm4 residual and whole 16-byte channel vectors")
+        # dup: the two stacked passes of a core share (y3, y4); the output holds both, each behind its own dropout draw
+        out = torch.empty((2 * N, *y3.shape[1:]), dtype=y3.dtype, device=y3.device) if dup else torch.empty_like(y3)
         # keep bits of the fused dropout, stored for the backward (bf16, F % 8 == 0: one byte per 16-byte vector)
         mask = None
         if drop_rate > 0.0 and y3.dtype == torch.bfloat16 and Fn % 8 == 0 and any(ctx.needs_input_grad):
-            mask = torch.empty(y3.numel() // 8, dtype=torch.uint8, device=y3.device)
-        L.check(lib.m1_se_combine_fwd(_p(y3), _p(y4), _p(s3), _p(s4), _p(g3), _p(b3), _p(g4), _p(b4), _p(g), _p(out), N, V, Fn,
-                                      _dt(y3), float(drop_rate), _p(rng), int(layer_id), _p(mask), st), "m1_se_combine_fwd")
-        ctx.ident = ident
+            mask = torch.empty(out.numel() // 8, dtype=torch.uint8, device=y3.device)
+        fwd = lib.m1_se_combine_dup_fwd if dup else lib.m1_se_combine_fwd
+        L.check(fwd(_p(y3), _p(y4), _p(s3), _p(s4), _p(g3), _p(b3), _p(g4), _p(b4), _p(g), _p(out), N, V, Fn,
+                    _dt(y3), float(drop_rate), _p(rng), int(layer_id), _p(mask), st), "m1_se_combine_fwd")
+        ctx.ident, ctx.dup = ident, dup
         if ident:
             ctx.save_for_backward(y3, y4, s3, g3, b3, W6, W7, hidden, g)
             ctx.params = (g3, b3, W6, b6, W7, b7)
@@ -1174,9 +1067,10 @@ class _SECombine(torch.autograd.Function):
             (bg3, _, rg3), (bb3, _, rb3), (bg4, _, rg4), (bb4, _, rb4), (bW6, _, rW6), (bb6, _, rb6), (bW7, _, rW7), (bb7, _, rb7) = sinks
         dg = torch.empty(Fn + Fr, dtype=torch.float32, device=dev)
         ws = _ws(N, V, Fn, 5, dev)
-        L.check(lib.m1_se_combine_bwd(_p(y3), _p(y4), _p(s3), _p(s4), _p(g3), _p(b3), _p(g4), _p(b4), _p(g), _p(dout),
-                                      _p(dy3), _p(dy4), _p(bg3), _p(bb3), _p(bg4), _p(bb4), _p(dg), N, V, Fn, _dt(y3),
-                                      ctx.drop_rate, _p(ctx.rng), ctx.layer_id, _p(ctx.mask), _p(ws), acc, st), "m1_se_combine_bwd")
+        bwd = lib.m1_se_combine_dup_bwd if ctx.dup else lib.m1_se_combine_bwd
+        L.check(bwd(_p(y3), _p(y4), _p(s3), _p(s4), _p(g3), _p(b3), _p(g4), _p(b4), _p(g), _p(dout),
+                    _p(dy3), _p(dy4), _p(bg3), _p(bb3), _p(bg4), _p(bb4), _p(dg), N, V, Fn, _dt(y3),
+                    ctx.drop_rate, _p(ctx.rng), ctx.layer_id, _p(ctx.mask), _p(ws), acc, st), "m1_se_combine_bwd")
         if acc == 1:
             # parameter gradients only, accumulated into the optimiser's flat buffer: nothing downstream in this backward
             # reads them, so the job is queued and all SE blocks' gate backwards run as one batch (flush_deferred)
@@ -1186,15 +1080,17 @@ class _SECombine(torch.autograd.Function):
         else:
             L.check(lib.m1_se_gate_bwd(_p(b3), _p(W6), _p(W7), _p(hidden), _p(g), _p(dg), Fn, Fr, _p(bb3), _p(bW6), _p(bb6),
                                        _p(bW7), _p(bb7), acc, st), "m1_se_gate_bwd")
-        return dy3, dy4, rg3, rb3, rg4, rb4, rW6, rb6, rW7, rb7, None, None, None, None, None, None
+        return dy3, dy4, rg3, rb3, rg4, rb4, rW6, rb6, rW7, rb7, None, None, None, None, None, None, None
 
 
 def se_combine(y3, y4, g3, b3, g4, b4, W6, b6, W7, b7, drop_rate=0.0, rng=None, layer_id=0, stats3=None, stats4=None,
-               gate=None):
+               gate=None, dup=False):
     """dropout(lrelu(IN3(y3) * sigmoid(W7.lrelu(W6.beta3+b6)+b7) * IN4(y4)))  (network_blocks.py:60-78).
     ``gate``: the (hidden, g) pair se_gate_batch computed for this block from the same parameters, else evaluated here.
-    ``g4 = b4 = None``: the identity residual of network_blocks.py:63 (C_in == filters) -- ``y4`` is the block's input tensor."""
-    return _SECombine.apply(y3, y4, g3, b3, g4, b4, W6, b6, W7, b7, drop_rate, rng, layer_id, stats3, stats4, gate)
+    ``g4 = b4 = None``: the identity residual of network_blocks.py:63 (C_in == filters) -- ``y4`` is the block's input tensor.
+    ``dup``: the output holds TWO samples per input sample (n and n + N), each behind its own dropout draw: the two stacked passes of
+    a core share everything in front of their first draw (M1Core.forward ``dup_first``); the backward sums the halves' gradients."""
+    return _SECombine.apply(y3, y4, g3, b3, g4, b4, W6, b6, W7, b7, drop_rate, rng, layer_id, stats3, stats4, gate, bool(dup))
 
 
 def se_gate_batch(params):
@@ -1323,37 +1219,76 @@ class _LatentSample(torch.autograd.Function):
         return dml, None, None
 
 
-def latent_sample(ml, eps, mean: bool, stacked: bool = False):
+class _LatentSampleRng(torch.autograd.Function):
+    """latent_sample with the draws made in the kernel from the device-resident {seed, step} state (m1_latent_sample_rng_*)."""
+
+    @staticmethod
+    def forward(ctx, ml, rng, stream_id, mode):
+        _req(ml, rng)
+        N = int(ml.shape[0]); Lc = int(ml.shape[-1]) // 2
+        V = ml.numel() // (N * 2 * Lc)
+        if int(mode) == 2 and N % 2:
+            raise RuntimeError("latent_sample: stacked mode needs an even batch")
+        z = torch.empty((*ml.shape[:-1], Lc), dtype=ml.dtype, device=ml.device)
+        L.check(L.load().m1_latent_sample_rng_fwd(_p(ml), _p(rng), int(stream_id), _p(z), N, V, Lc, int(mode), _dt(ml), _stream()),
+                "m1_latent_sample_rng_fwd")
+        ctx.save_for_backward(ml)
+        ctx.rng, ctx.stream_id, ctx.mode = rng, int(stream_id), int(mode)
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        (ml,) = ctx.saved_tensors
+        dz = dz.contiguous()
+        N = int(ml.shape[0]); Lc = int(ml.shape[-1]) // 2
+        V = ml.numel() // (N * 2 * Lc)
+        dml = torch.empty_like(ml)
+        L.check(L.load().m1_latent_sample_rng_bwd(_p(ml), _p(ctx.rng), ctx.stream_id, _p(dz), _p(dml), N, V, Lc, ctx.mode, _dt(ml),
+                                                  _stream()), "m1_latent_sample_rng_bwd")
+        return dml, None, None, None
+
+
+def latent_sample(ml, eps, mean: bool, stacked: bool = False, rng=None, stream_id: int = 0):
     """z = mu + exp(clip(logsigma,+-0.1))*eps, or mu when ``mean`` (networks.py:640-647).  ``stacked``: the batch holds the
-    sampling pass and the prob_mean pass of the reference one after the other; ``eps`` covers the first half only."""
+    sampling pass and the prob_mean pass of the reference one after the other; ``eps`` covers the first half only.
+    ``eps=None`` with ``rng`` (device int64[2] = {seed, step}): the draws are made inside the kernel, a pure function of
+    (seed, step, stream_id, element index) that the backward regenerates."""
+    if eps is None and not mean and rng is not None:
+        return _LatentSampleRng.apply(ml, rng, int(stream_id), 2 if stacked else 0)
     return _LatentSample.apply(ml, eps, 2 if stacked else (1 if mean else 0))
 
 
 class _KL(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, mq, mp):
+    def forward(ctx, mq, mp, first):
         _req(mq, mp)
-        N = int(mq.shape[0]); Lc = int(mq.shape[-1]) // 2
-        V = mq.numel() // (N * 2 * Lc)
+        Nall = int(mq.shape[0]); Lc = int(mq.shape[-1]) // 2
+        N = Nall if first is None else int(first)
+        if not (0 < N <= Nall) or mq.shape != mp.shape:
+            raise RuntimeError("kl_mvn_diag: both heads must have one shape, `first` within the batch")
+        V = mq.numel() // (Nall * 2 * Lc)
         kl = torch.empty(1, dtype=torch.float32, device=mq.device)
         L.check(L.load().m1_kl_fwd(_p(mq), _p(mp), _p(kl), N, V, Lc, _dt(mq), _stream()), "m1_kl_fwd")
         ctx.save_for_backward(mq, mp)
+        ctx.first = N
         return kl
 
     @staticmethod
     def backward(ctx, dkl):
         mq, mp = ctx.saved_tensors
         dkl = dkl.contiguous().float()
-        N = int(mq.shape[0]); Lc = int(mq.shape[-1]) // 2
-        V = mq.numel() // (N * 2 * Lc)
+        Nall = int(mq.shape[0]); Lc = int(mq.shape[-1]) // 2
+        V = mq.numel() // (Nall * 2 * Lc)
         dq, dp = torch.empty_like(mq), torch.empty_like(mp)
-        L.check(L.load().m1_kl_bwd(_p(mq), _p(mp), _p(dkl), _p(dq), _p(dp), N, V, Lc, _dt(mq), _stream()), "m1_kl_bwd")
-        return dq, dp
+        L.check(L.load().m1_kl_bwd_first(_p(mq), _p(mp), _p(dkl), _p(dq), _p(dp), ctx.first, V, Lc, Nall, _dt(mq), _stream()), "m1_kl_bwd")
+        return dq, dp, None
 
 
-def kl_mvn_diag(ml_q, ml_p):
-    """mean_b sum_voxels KL(q||p) of one level (networks.py:375-377) -> tensor of shape (1,)."""
-    return _KL.apply(ml_q, ml_p)
+def kl_mvn_diag(ml_q, ml_p, first: Optional[int] = None):
+    """mean_b sum_voxels KL(q||p) of one level (networks.py:375-377) -> tensor of shape (1,).  ``first``: only the first ``first``
+    samples of the two (contiguous) heads enter the term (the sampling half of two stacked passes); their gradient comes back at full
+    size with zeros behind -- no slice, so no zero-fill + copy of autograd's slice backward."""
+    return _KL.apply(ml_q, ml_p, first)
 
 
 # ---------------------------------------------------------------------------------------------------------

@@ -171,9 +171,13 @@ class SEResNetBottleNeck(nn.Module):
         for blk, pair in zip(blocks, ops.se_gate_batch([b.gate_params() for b in blocks])):
             blk._gate = pair
 
-    def forward(self, input_tensor: Tensors, dropout: Optional[_DropoutBase] = None) -> torch.Tensor:
+    def forward(self, input_tensor: Tensors, dropout: Optional[_DropoutBase] = None, dup: bool = False) -> torch.Tensor:
+        """``dup``: the result holds two samples per input sample (n, n + N), each behind its own dropout draw -- the two stacked
+        passes of a core that share this block's input (M1Core.forward ``dup_first``) run its convolutions and norms once."""
         members = _as_list(input_tensor)
         if self.identity_residual:
+            if dup:
+                members = [torch.cat([t, t], dim=0) for t in members]
             return self._forward_identity(members, dropout)
         if ops.conv_pair_supported(members, self.conv1.kernel, self.conv4.kernel, self.strides):
             # conv1 || conv4 read the same input with the same kernel size and strides (B:53,64): one data gradient over [dy1 | dy4]
@@ -187,26 +191,16 @@ class SEResNetBottleNeck(nn.Module):
             y1, s1 = self.conv1(srcs, stats=True)
         a = self.norm1(y1, 0.1, s1)                                             # B:53-55
         y2, s2 = self.conv2(a, stats=True)
-        y3, s3 = self._norm2_conv3(y2, s2)                                      # B:56-59
+        a = self.norm2(y2, 0.1, s2)                                             # B:56-58
+        y3, s3 = self.conv3(a, stats=True)                                      # B:59
         br.join(y4, s4)
         rate = dropout.effective_rate() if dropout is not None else 0.0
         gate, self._gate = self._gate, None              # evaluated up front by the owning core (precompute_gates), once per pass
         return ops.se_combine(y3, y4, self.norm3.gamma, self.norm3.beta, self.norm4.gamma, self.norm4.beta,
                               self.conv6.kernel, self.conv6.bias, self.conv7.kernel, self.conv7.bias, rate,
                               dropout.rng if (dropout is not None and rate > 0.0) else None,
-                              dropout.layer_id if dropout is not None else 0, s3, s4, gate)   # B:60-78 (+ following dropout)
+                              dropout.layer_id if dropout is not None else 0, s3, s4, gate, dup=dup)   # B:60-78 (+ following dropout)
 
-
-    def _norm2_conv3(self, y2, s2):
-        """conv3(lrelu(norm2(y2))) (B:56-59) -> (y3, stats3).  One data pass where the library applies the normalisation and the
-        activation on the pointwise conv's operand (ops.conv3d_norm_same: the normalised tensor is never written); otherwise the
-        stand-alone apply kernel followed by the conv."""
-        # (a norm2 / conv3 module that carries forward hooks is called as a module: the hooks must see their tensors)
-        hooked = bool(self.norm2._forward_hooks or self.conv3._forward_hooks or self.conv3._forward_pre_hooks)
-        if not hooked and ops.conv_norm_supported(y2, self.conv3.kernel):
-            return ops.conv3d_norm_same(y2, s2, self.norm2.gamma, self.norm2.beta, 0.1, self.conv3.kernel, self.conv3.bias, stats=True)
-        a = self.norm2(y2, 0.1, s2)                                             # B:56-58
-        return self.conv3(a, stats=True)                                        # B:59
 
     def _forward_identity(self, members, dropout):
         """C_in == filters (B:63 false branch): out = lrelu(IN3(conv3(...)) * g * x) with the block input x as the residual factor."""
@@ -215,7 +209,8 @@ class SEResNetBottleNeck(nn.Module):
         y1, s1 = self.conv1([x1], stats=True)
         a = self.norm1(y1, 0.1, s1)
         y2, s2 = self.conv2(a, stats=True)
-        y3, s3 = self._norm2_conv3(y2, s2)
+        a = self.norm2(y2, 0.1, s2)
+        y3, s3 = self.conv3(a, stats=True)
         rate = dropout.effective_rate() if dropout is not None else 0.0
         gate, self._gate = self._gate, None
         return ops.se_combine(y3, xr, self.norm3.gamma, self.norm3.beta, None, None,

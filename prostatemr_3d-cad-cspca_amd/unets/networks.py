@@ -186,6 +186,13 @@ class M1Core(nn.Module):
                 setattr(self, "sersp" + sfx, SE(fr[lvl + 1] + skipc[lvl], fr[lvl + 1], kr[lvl + 1], (1, 1, 1), rr[lvl + 1]))
                 setattr(self, "dropp" + sfx, DropoutFunc(self.dropout_rate))
         self._shapes: Dict[str, tuple] = {}
+        # sampling stream of the latent heads: the owning M1 attaches its device-resident {seed, step} state (as it does for the
+        # dropout layers); every core draws on stream ids of its own (level lvl: latent_stream_id + lvl)
+        self.rng: Optional[torch.Tensor] = None
+        self.latent_stream_id = 0x4C415400 + 8 * M1Core._next_latent_id[0]
+        M1Core._next_latent_id[0] += 1
+
+    _next_latent_id = [0]
 
     # ---------------------------------------------------------------------------------------------------------
     def latent_shapes(self, dims):
@@ -208,7 +215,8 @@ class M1Core(nn.Module):
         return [(prefix + "a", plist(dec)), (prefix + "b", plist(mid)), (prefix + "c", plist(enc))]
 
     def forward(self, inputs, prob_mean=False, prob_z_q=None, eps: Optional[List[torch.Tensor]] = None, mark=None,
-                need: str = "full", tail_from: Optional[int] = None, eps_first_half: bool = False, z_ready=None):
+                need: str = "full", tail_from: Optional[int] = None, eps_first_half: bool = False, z_ready=None,
+                dup_first: bool = False):
         """M1Core.__call__(inputs, prob_mean, prob_z_q) (networks.py:568-759).  ``inputs`` is an NDHWC tensor or
         a list of tensors forming a virtual channel concat.  ``eps``: optional injected N(0,1) draws per level
         (MultivariateNormalDiag.sample() = mu + sigma*eps).  ``mark(group, tensor)``: data-parallel runs register the
@@ -229,7 +237,13 @@ class M1Core(nn.Module):
         first half only: the latent kernel takes the mean for the second half (no zero-padded draw tensors).
 
         ``z_ready``: called once before the first ``prob_z_q`` entry is read (the pass that produced it may still be running on
-        another stream: M1Net.forward)."""
+        another stream: M1Net.forward).
+
+        ``dup_first``: ``inputs`` holds B samples and stands for the stacked batch [inputs; inputs] of two passes of the reference over
+        the SAME input (networks.py:348-349, 351-352).  With Monte-Carlo dropout the two passes are the same computation up to the first
+        dropout draw -- behind ``serse1`` (networks.py:579-582) -- so the stem and ``serse1``'s convolutions and norms run ONCE on B
+        samples and the block's last kernel writes both halves, each behind its own draw (SEResNetBottleNeck.forward ``dup``); their
+        backward runs once on the sum of the halves' gradients.  From ``conv1`` on the batch is 2B as if the input had been stacked."""
         outputs = {}
         mark = mark if mark is not None else (lambda *_: None)
         S = self.strides
@@ -270,7 +284,7 @@ class M1Core(nn.Module):
         split = lambda t, on: fo(t, 2) if on else (t, None)
         # networks.py:579-582 (dropout fused into the block's last kernel)
         x_e, x_a = split(x, n_stage > 3)
-        conv1 = self.serse1(x_e, dropout=self.drope1)
+        conv1 = self.serse1(x_e, dropout=self.drope1, dup=dup_first)
         c1_e, c1_a = split(conv1, n_stage > 2)
         conv2 = self.serse2(c1_e, dropout=self.drope2)
         c2_e, c2_a = split(conv2, n_stage > 1)
@@ -290,7 +304,12 @@ class M1Core(nn.Module):
         for k, (gate, src) in enumerate(((self.att3, c3_a), (self.att2, c2_a), (self.att1, c1_a), (self.att0, x_a))):
             if n_stage > k:
                 with ops.branch(dvc, 1 + k) as br:
-                    att_conv[k], _ = gate(X(src, -1, k), X(m_use.pop(), -1, k))
+                    if k == 3 and dup_first:
+                        # the stem output holds B samples: it IS the batch slice of the second stacked pass, else both halves
+                        xg = src if tl(k) else torch.cat([src, src], dim=0)
+                    else:
+                        xg = X(src, -1, k)
+                    att_conv[k], _ = gate(xg, X(m_use.pop(), -1, k))
                 brs[k] = br
         att_conv3, att_conv2, att_conv1, att_conv0 = att_conv
         heads_on = self.deep_supervision and not prob
@@ -403,7 +422,10 @@ class M1Core(nn.Module):
                         z = prob_z_q[lvl]
                     elif prob_mean:                                                # networks.py:646
                         z = ops.latent_sample(ml, None, True)
-                    else:                                                          # networks.py:647
+                    elif eps is None and getattr(self, "rng", None) is not None:   # networks.py:647, the draw made in the kernel
+                        z = ops.latent_sample(ml, None, False, stacked=eps_first_half, rng=self.rng,
+                                              stream_id=self.latent_stream_id + lvl)
+                    else:                                                          # networks.py:647 with injected (or host-made) draws
                         nb = int(ml.shape[0]) // 2 if eps_first_half else int(ml.shape[0])
                         e = eps[zi] if eps is not None else torch.randn((nb, *ml.shape[1:-1], Ld), device=ml.device,
                                                                          dtype=torch.float32)
@@ -573,10 +595,20 @@ class M1Net(nn.Module):
                 B = int(image.shape[0])
                 mq, mp = self._marker("posterior."), self._marker("prior.")
                 dup = lambda t: torch.cat([t, t], dim=0)
-                post2 = dup(post_in) if isinstance(post_in, torch.Tensor) else [dup(t) for t in post_in]
+                # both halves of a stacked pass read the SAME input: everything in front of the first dropout draw (stem + serse1 up to
+                # its last kernel) is one computation, run once on B samples (M1Core.forward dup_first; M1_DEDUP_PREFIX=0: stack the input)
+                vec = 8 if image.dtype == torch.bfloat16 else 4
+                share = (_os.environ.get("M1_DEDUP_PREFIX", "1") != "0" and all(
+                    (not c.serse1.identity_residual) and c.serse1.filters % vec == 0 for c in (self.prior, self.posterior)))
+                if share:
+                    post2 = post_in
+                else:
+                    post2 = dup(post_in) if isinstance(post_in, torch.Tensor) else [dup(t) for t in post_in]
                 lshape = self.posterior.latent_shapes(image.shape[1:4])
                 if eps_q is not None:
                     eps1 = [e for e in eps_q]
+                elif getattr(self.posterior, "rng", None) is not None and _os.environ.get("M1_LATENT_RNG", "1") != "0":
+                    eps1 = None                     # the latent kernels draw for themselves (ops.latent_sample rng=...)
                 else:
                     # ONE generator launch for the draws of all levels, in the activation storage type (views of one buffer)
                     sizes = [B * int(np.prod(shp)) for shp in lshape]
@@ -591,19 +623,20 @@ class M1Net(nn.Module):
                 # The prior core reads the posterior's latents only in its latent decoder (dec_hi / sersp): its U-Net -- encoder,
                 # gates, nested decoder -- is independent of the posterior pass, which therefore runs on a side stream next to
                 # it (and so do their backward passes); the prior joins where it first reads a z.
-                img2 = dup(image)
-                post_kw = dict(prob_mean=False, prob_z_q=None, eps=eps1, mark=mq, need="latents", eps_first_half=True)
+                img2 = image if share else dup(image)
+                post_kw = dict(prob_mean=False, prob_z_q=None, eps=eps1, mark=mq, need="latents", eps_first_half=True, dup_first=share)
                 if _PQ_LANES:
                     with ops.branch(image.device, 8) as lane:
                         q = self.posterior(post2, **post_kw)
                     z_ready = lambda: lane.join(*q['prob_used_latents'], *q['prob_distributions'])
                 else:
                     q, z_ready = self.posterior(post2, **post_kw), None
-                p = self.prior(img2, prob_mean=False, prob_z_q=q['prob_used_latents'], mark=mp, need="full", tail_from=B, z_ready=z_ready)
+                p = self.prior(img2, prob_mean=False, prob_z_q=q['prob_used_latents'], mark=mp, need="full", tail_from=B, z_ready=z_ready,
+                               dup_first=share)
                 train_conv = self.stitch(p['prob_decoder_features'])                                    # networks.py:356 (p_z_qm)
                 kl = None                                                                               # networks.py:373-385
                 for lvl, (qd, pd) in enumerate(zip(q['prob_distributions'], p['prob_distributions'])):
-                    k = ops.kl_mvn_diag(qd[:B], pd[:B])                                                 # (q_sample, p_z_q)
+                    k = ops.kl_mvn_diag(qd, pd, first=B)                                                # (q_sample, p_z_q): the first halves
                     kl = k if kl is None else kl + k
                     if lvl == 0 and mp is not None:
                         mp("a", pd)          # the prior's coarsest latent head is reached through its KL term only
@@ -771,7 +804,7 @@ class M1(LoadableModel):
     # ---- plumbing ------------------------------------------------------------------------------------------
     def _attach_rng(self):
         for m in self.modules():
-            if isinstance(m, _DropoutBase):
+            if isinstance(m, (_DropoutBase, M1Core)):
                 m.rng = self.rng_state
 
     def _apply(self, fn, *a, **k):

@@ -269,6 +269,41 @@ def test_se_combine_identity_residual_fwd_bwd(dev, dtype, F_, red, V, drop):
                                  torch.cuda.current_stream().cuda_stream) == -1
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("F_,V,drop", [(16, (3, 6, 5), 0.0), (32, (2, 8, 8), 0.5), (64, (4, 10, 10), 0.3)])
+def test_se_combine_dup_equals_the_duplicated_inputs(dev, dtype, F_, V, drop):
+    """m1_se_combine_dup_*: out[n], out[n + N] from ONE (y3[n], y4[n]) -- the two stacked passes of a core share everything in front of
+    their first dropout draw.  Forward: bit-identical to the plain kernel on the duplicated tensors (the dropout stream is indexed by the
+    output element).  Backward: dy3 / dy4 and every parameter gradient equal the SUM over the two halves of what the plain kernel
+    returns for the duplicated tensors."""
+    N, red = 2, 4
+    y3 = rnd((N, *V, F_), 1); y4 = rnd((N, *V, F_), 2)
+    if dtype == torch.bfloat16:
+        y3, y4 = y3.bfloat16().float(), y4.bfloat16().float()
+    ps = [1.0 + 0.2 * rnd((F_,), 3), 0.1 * rnd((F_,), 4), 1.0 + 0.2 * rnd((F_,), 5), 0.1 * rnd((F_,), 6),
+          rnd((1, 1, 1, F_, F_ // red), 7, 0.3), 0.1 * rnd((F_ // red,), 8), rnd((1, 1, 1, F_ // red, F_), 9, 0.3), 0.1 * rnd((F_,), 10)]
+    dout = rnd((2 * N, *V, F_), 11)
+    if dtype == torch.bfloat16:
+        dout = dout.bfloat16().float()
+    rng = torch.tensor([77, 3], dtype=torch.int64, device=dev)
+
+    def run(dup):
+        a = y3.to(dev, dtype).requires_grad_(True); b = y4.to(dev, dtype).requires_grad_(True)
+        pd = [t.to(dev).requires_grad_(True) for t in ps]
+        if dup:
+            out = ops.se_combine(a, b, *pd, drop, rng if drop > 0 else None, 5, None, None, None, dup=True)
+        else:
+            a2, b2 = torch.cat([a, a], 0), torch.cat([b, b], 0)
+            out = ops.se_combine(a2, b2, *pd, drop, rng if drop > 0 else None, 5)
+        out.backward(dout.to(dev, dtype))
+        return [out.detach(), a.grad, b.grad] + [t.grad for t in pd]
+    got, ref = run(True), run(False)
+    assert got[0].shape[0] == 2 * N and torch.equal(got[0], ref[0])
+    tol = 1e-5 if dtype == torch.float32 else 2e-2          # (bf16: the plain path rounds each half's gradient before autograd adds them)
+    for g_, r_ in zip(got[1:], ref[1:]):
+        assert rel_err(g_, r_) < tol
+
+
 def test_se_gate_backward_deferred_batch_matches_direct(dev):
     """Gradient-sink mode queues the SE gate backwards and runs them as one m1_se_gate_bwd_batch at flush_deferred();
     the sums in the sinks must equal the immediate per-block path (two passes accumulate, like prior+posterior)."""
@@ -420,6 +455,40 @@ def test_latent_sample_and_kl(dev, L):
     assert rel_err(qd.grad, gq) < 1e-5 and rel_err(pd.grad, gp) < 1e-5
     k0 = ops.kl_mvn_diag(mq.to(dev), mq.to(dev))                  # KAT-5: KL(q||q) = 0
     assert abs(float(k0)) < 1e-6
+
+
+def test_latent_sample_draws_made_in_the_kernel(dev):
+    """m1_latent_sample_rng_*: the N(0,1) draw is a pure function of (seed, step, stream id, element index).  The implied draw
+    eps = (z - mu) / sigma is standard normal (moments, tails), the same state gives the same draw, another step / stream id another
+    one, the stacked mode draws for the first half of the batch exactly what the plain mode draws, and the backward pass regenerates the
+    forward's draw: d z / d logsigma = sigma * eps = z - mu inside the clip band."""
+    L_, N, V = 3, 4, (10, 20, 20)
+    ml = (rnd((N, *V, 2 * L_), 1) * 0.05).to(dev)                 # log-sigma inside the +-0.1 band (4 sigma = 0.2 ... a few outside)
+    rng = torch.tensor([1234, 7], dtype=torch.int64, device=dev)
+    mld = ml.clone().requires_grad_(True)
+    z = ops.latent_sample(mld, None, False, rng=rng, stream_id=5)
+    sig = torch.exp(torch.clamp(ml[..., L_:], -0.1, 0.1))
+    eps = ((z.detach() - ml[..., :L_]) / sig).double().flatten()
+    n = eps.numel()
+    assert n == 48000
+    assert abs(float(eps.mean())) < 4.0 / n ** 0.5 and abs(float(eps.var()) - 1.0) < 0.03
+    assert abs(float((eps ** 3).mean())) < 0.05 and abs(float((eps ** 4).mean()) - 3.0) < 0.15
+    assert 0.04 < float((eps.abs() > 2.0).double().mean()) < 0.051 and float(eps.abs().max()) < 6.0
+    assert torch.equal(z, ops.latent_sample(ml, None, False, rng=rng, stream_id=5))                # same state, same draw
+    assert not torch.equal(z, ops.latent_sample(ml, None, False, rng=rng, stream_id=6))            # another latent head
+    rng2 = rng.clone(); ops.step_advance(None, rng2)
+    assert int(rng2[1]) == 8 and not torch.equal(z, ops.latent_sample(ml, None, False, rng=rng2, stream_id=5))   # the next step
+    dz = rnd((N, *V, L_), 4).to(dev)
+    z.backward(dz)
+    inside = (ml[..., L_:].abs() <= 0.1).float()
+    assert rel_err(mld.grad[..., :L_], dz) < 1e-7
+    assert rel_err(mld.grad[..., L_:], dz * (z.detach() - ml[..., :L_]) * inside) < 1e-5
+    # stacked: [sampling pass; prob_mean pass], the first half draws what the plain mode draws for that half
+    ml2 = torch.cat([ml[:2], ml[:2]], 0).contiguous()
+    z2 = ops.latent_sample(ml2, None, False, stacked=True, rng=rng, stream_id=5)
+    assert torch.equal(z2[:2], ops.latent_sample(ml[:2].contiguous(), None, False, rng=rng, stream_id=5)) and torch.equal(z2[2:], ml2[2:, ..., :L_])
+    zb = ops.latent_sample(ml.bfloat16(), None, False, rng=rng, stream_id=5)                       # bf16 storage: the same draws, rounded
+    assert rel_err(zb.float(), z.detach()) < 2e-2
 
 
 def test_kl_clip_saturation(dev):
@@ -750,60 +819,6 @@ def test_instnorm_backward_sums_from_the_dgrad_epilogue(dev, dtype, dims, c, cou
     for a_, b_, o_ in zip(got, base, gro):
         assert rel_err(a_, b_) < (2e-5 if dtype == torch.float32 else 2e-2)
         assert rel_err(a_, o_) < tol
-
-
-# ---- conv o InstanceNorm o LeakyReLU as ONE data pass (m1_conv3d_fwd_norm / m1_conv3d_wgrad_norm; network_blocks.py:56-59) ----
-@pytest.mark.parametrize("dims,c,cout", [((2, 8, 32, 32), 8, 32),        # conv3 at res0 (one 32-channel K chunk, 24 of them padding)
-                                         ((4, 4, 16, 16), 16, 64),       # res1
-                                         ((2, 4, 16, 16), 32, 128),      # res2
-                                         ((3, 2, 8, 16), 64, 256),       # res3: two K chunks
-                                         ((1, 3, 8, 12), 24, 40)])       # ragged channel counts (24 = 3 segments, 40 output columns)
-def test_conv_norm_prologue_fwd_bwd(dev, dims, c, cout):
-    """y = conv_{1x1x1}(lrelu(IN(x))) from the RAW x: the streaming kernel normalises its operand in registers, the weight gradient
-    recomputes it, the normalised tensor never exists.  Forward and every gradient against the oracle and against the unfused ops;
-    the kernel log proves which kernels ran."""
-    dtype = torch.bfloat16
-    x = rnd((*dims, c), 1).bfloat16().float(); g = 1.0 + 0.2 * rnd((c,), 2); bt = 0.1 * rnd((c,), 3)
-    w = rnd((1, 1, 1, c, cout), 4, 1.0 / c ** 0.5); b = rnd((cout,), 5)
-    dy = rnd((*dims, cout), 6).bfloat16().float()
-
-    def ref(x_, g_, b_, w_, bb_):
-        return O.conv3d_same(O.lrelu(O.instance_norm(x_, g_, b_)), w_, bb_, (1, 1, 1))
-    yo, gro = _oracle_grads(ref, [x, g, bt, w, b], dy)
-
-    def run(fused):
-        xd = x.to(dev, dtype).requires_grad_(True)
-        ps = [t.to(dev).requires_grad_(True) for t in (g, bt, w, b)]
-        st = ops.instnorm_stats(xd)
-        if fused:
-            assert ops.conv_norm_supported(xd, ps[2])
-            y, ys = ops.conv3d_norm_same(xd, st, ps[0], ps[1], 0.1, ps[2], ps[3], stats=True)
-        else:
-            y, ys = ops.conv3d_same([ops.instnorm_act(xd, ps[0], ps[1], 0.1, st)], ps[2], ps[3], (1, 1, 1), (1, 1, 1), stats=True)
-        y.backward(dy.to(dev, dtype))
-        return [y.detach(), ys, xd.grad] + [p.grad for p in ps]
-    with ops.kernel_log() as kl:
-        got = run(True)
-    assert kl.ran("conv_pw") and any(n.startswith("conv_pw:") and n.endswith(":pro") for n in kl.names), kl.names
-    assert "wgrad_mfma:pro" in kl.names, kl.names
-    base = run(False)
-    # the fused forward rounds the operand exactly as the apply kernel stores it: outputs agree to the fp32 order of the fma
-    assert rel_err(got[0], base[0]) < 1e-2
-    assert rel_err(got[1], base[1]) < 1e-2
-    assert rel_err(got[0], yo) < 4e-2
-    for a_, b_, o_ in zip(got[2:], base[2:], gro):
-        assert rel_err(a_, b_) < 2e-2
-        assert rel_err(a_, o_) < 4e-2
-    # statistics of the fused output against the stand-alone reduction over that very output
-    assert rel_err(got[1], ops.instnorm_stats(got[0])) < 1e-4
-
-
-def test_conv_norm_prologue_declines_what_no_kernel_takes(dev):
-    """fp32, 3x3x3 kernels and wide contractions are not fused: the query says so and the entry point launches nothing."""
-    x = rnd((1, 2, 8, 8, 128), 1).to(dev, torch.bfloat16)
-    assert not ops.conv_norm_supported(x, rnd((1, 1, 1, 128, 128), 2).to(dev))          # 128-deep: the matrix-core kernel's shape
-    assert not ops.conv_norm_supported(x[..., :32].contiguous(), rnd((3, 3, 3, 32, 32), 2).to(dev))
-    assert not ops.conv_norm_supported(x[..., :32].float().contiguous(), rnd((1, 1, 1, 32, 32), 2).to(dev))
 
 
 def _wgrad_kernels(kl):

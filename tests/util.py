@@ -81,18 +81,24 @@ class activation_pattern:
         for name, mod in self.model.named_modules():
             if isinstance(mod, NW.M1Net) and mod.probabilistic and mod.stack_passes and not mod.show_summary:
                 stacked |= {self._tag(name + ".prior"), self._tag(name + ".posterior")}
-        batch = {}
+        batch, dupped = {}, {}
+
+        shared = (".norme0", ".serse1.norm1", ".serse1.norm2")      # layers in front of the first dropout draw (M1Core.forward dup_first)
 
         def add(tag, m, store=None):
             store = self.masks if store is None else store
             core = next(c for c in sorted(cores, key=len, reverse=True) if tag.startswith(c + "."))
             m = m.cpu()
             if core in stacked and self.passes[core] == 0:
-                # one stacked pass = the oracle's passes 0 and 1: [0:B] / [B:2B]; a tensor of the tail slice belongs to pass 1
+                # one stacked pass = the oracle's passes 0 and 1: [0:B] / [B:2B]; a tensor of the tail slice belongs to pass 1;
+                # a layer the two passes SHARE (dup_first: run once on B samples) has the same pattern in both
                 B2 = batch[core]
                 if m.shape[0] == B2:
                     store.setdefault(tag, {})[0] = m[:B2 // 2]
                     store[tag][1] = m[B2 // 2:]
+                elif dupped.get(core) and any(tag == core + sfx for sfx in shared):
+                    store.setdefault(tag, {})[0] = m
+                    store[tag][1] = m
                 else:
                     store.setdefault(tag, {})[1] = m
                 return
@@ -104,11 +110,12 @@ class activation_pattern:
             if isinstance(mod, NW.M1Core):
                 cores[tag] = mod
                 self.passes[tag] = -1
-                def pre(m_, i_, tag=tag):
+                def pre(m_, i_, kw_, tag=tag):
                     self.passes[tag] += 1
                     t0 = i_[0][0] if isinstance(i_[0], (list, tuple)) else i_[0]
-                    batch[tag] = int(t0.shape[0])
-                self.handles.append(mod.register_forward_pre_hook(pre))
+                    dupped[tag] = bool(kw_.get("dup_first"))
+                    batch[tag] = int(t0.shape[0]) * (2 if dupped[tag] else 1)
+                self.handles.append(mod.register_forward_pre_hook(pre, with_kwargs=True))
             elif isinstance(mod, NB.InstanceNormalization):
                 def h(mod, inp, out, tag=tag):
                     if len(inp) > 1 and float(inp[1]) == 0.1:           # (x, slope, stats): LeakyReLU(0.1) follows
