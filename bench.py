@@ -335,7 +335,8 @@ def run_workload(a, wl, ctx, want_roofline, want_cpu):
             reducer.force = False
     opt.set_lr_device()
     model.train()
-    loss_buf = torch.zeros(1, device=dev)
+    loss_ref = [None]            # the loss scalar of the last executed step: a REFERENCE to the tensor the step produced (inside a captured
+                                 # graph it lives in the graph's pool and is rewritten by every replay) -- no copy node in the step
     # debug (harness tools only): M1_BENCH_HIST=1 records a hash of the gradient and parameter vectors after EVERY executed step
     # (eager warm-up, capture prelude, each replay) and, with M1_DEBUG_TRACE, the per-op checksum log of that step
     hist_on = os.environ.get("M1_BENCH_HIST") == "1"
@@ -357,7 +358,7 @@ def run_workload(a, wl, ctx, want_roofline, want_cpu):
         total, _ = model.compute_loss(outs, {"detection": tgt})
         total.backward()
         opt.flatp.gather_grads()
-        loss_buf.copy_(total.detach().reshape(1))
+        loss_ref[0] = total.detach()
 
     def update():
         """rest of the gradient exchange (N > 1) + fused Adam-amsgrad/L2 + counters."""
@@ -486,7 +487,7 @@ def run_workload(a, wl, ctx, want_roofline, want_cpu):
                     "dead_ranges_all_zero": dead_zero, "rs_ag": bool(reducer.rs_ag), "replicas_in_sync": bool(torch.equal(lo, hi)),
                     "note": "groups are sent from the communication stream as backward completes them (ddp.py); counters "
                             "count host-side calls (in graph mode 'full' the captured collectives replay without them)"}
-    final_loss = float(loss_buf)
+    final_loss = float(loss_ref[0])
     if os.environ.get("M1_BENCH_TORCH_OPS") and rank == 0:
         # debug: which torch-side (non-library) device ops one eager step issues, and from which line of this repository
         import collections

@@ -410,6 +410,26 @@ class _Fanout(torch.autograd.Function):
     @staticmethod
     def backward(ctx, *gs):
         slot = ctx.slot
+        if isinstance(slot, _TailRef):
+            # aliases of a batch_tail() output: the consumers wrote (and summed) their shares straight into the tail of the parent
+            # tensor's gradient buffer; hand that view on -- _BatchTail.backward recognises it and no slice backward runs
+            ref, slot = slot, slot.slot
+            full = slot.buf
+            buf = None
+            if full is not None and tuple(full.shape) == ref.full_shape and slot.tail_init:
+                if slot.event is not None and slot.stream != torch.cuda.current_stream():
+                    torch.cuda.current_stream().wait_event(slot.event)
+                    full.record_stream(torch.cuda.current_stream())
+                buf = full[ref.start:]
+            rest = None
+            for g in gs:
+                if g is None or (buf is not None and g.data_ptr() == buf.data_ptr() and g.shape == buf.shape):
+                    continue
+                if buf is not None:
+                    buf.add_(g)
+                else:
+                    rest = g if rest is None else rest + g
+            return (buf if buf is not None else rest), None, None, None
         buf = slot.buf
         if buf is not None and slot.event is not None and slot.stream != torch.cuda.current_stream():
             # the last share was added on another stream than this node's (a gate branch, the posterior lane): the readers of the
@@ -435,6 +455,15 @@ def fanout(x: torch.Tensor, k: int):
     used by exactly one consumer.  Nested use (a module forks an alias it was handed) shares the outer buffer."""
     if k <= 1 or not torch.is_grad_enabled() or not x.requires_grad:
         return (x,) * k
+    tref = getattr(x, "_m1_gslot_tail", None)
+    if tref is not None:
+        # x is the batch slice of a tensor with a shared gradient buffer (batch_tail): its consumers accumulate into the TAIL of that
+        # buffer (a gate forks the slice for its theta conv and the sigma product -- without this the fork opened a buffer of its own
+        # and autograd's slice backward added a zero-filled full-size tensor: a fill, a copy and an add over a res1 skip tensor)
+        outs = _Fanout.apply(x, k, tref, False)
+        for o in outs:
+            o._m1_gslot_tail = tref
+        return outs
     slot = getattr(x, "_m1_gslot", None)
     owner = slot is None
     if owner:
