@@ -973,7 +973,7 @@ static int run_mfma(const GatherSpec& g, void* ws, int ws_packed, hipStream_t st
     // (the staged-run kernel tiles every sample on its own: its tiles never straddle samples)
     bool fuse_stats = g.stats_out && g.stats_ws && g.mode == 0 && pl.ksplit == 1 && (g.N == 1 || Vout % bm_eff == 0 || t3) &&
                       !g.accumulate;           // (this kernel's statistics come from its own tile, before the add)
-    const int tiles_ps = t3 ? m1_ct3_tiles_ps(g) : (int)cdiv_ll(Vout, bm_eff);      // epilogue partial rows per sample
+    const int tiles_ps = t3 ? m1_ct3_tiles_per_sample(g.OD, g.OH, g.OW) : (int)cdiv_ll(Vout, bm_eff);      // epilogue partial rows per sample
     if (fuse_stats) { mp.stat_partial = g.stats_ws; mp.stat_tiles = tiles_ps; }
     // InstanceNorm-backward sums from the epilogue of a data gradient (GatherSpec::ib_*): one output tensor, one parity class
     // (rows run sample-major like a forward conv's), tiles that do not straddle samples

@@ -4,6 +4,5 @@
 
 // the shapes the kernel takes and how it tiles them (columns per block, K splits); false: conv_mfma / conv_halo keep the problem
 bool m1_ct3_plan(const GatherSpec& g, int* BN, int* ksplit);
-int m1_ct3_tiles_per_sample(int D, int H, int W);      // = rows per sample of its statistics partials (stride-1 form)
-int m1_ct3_tiles_ps(const GatherSpec& g);              // the same for the form m1_ct3_plan chose for g (stride 1 / stride 2)
+int m1_ct3_tiles_per_sample(int D, int H, int W);      // = rows per sample of its statistics partials
 int m1_ct3_conv(const MfmaP& mp, int BN, int OCpad, hipStream_t st);

@@ -59,11 +59,6 @@ struct Ct3P {
     int cps;                 // chunks per K split
     int OCpad;
     int smax;                // stages of a block at most (cps * KD): the descriptor tables are sized by it
-    // stride-2 forward form (S2: strides (1|2, 2, 2), TF-SAME on even extents = no padding in front): an output tile is TR whole
-    // rows of ONE output plane (TR * OW <= 128 voxels); the staged run of a kd slice is the 2 TR + 1 input rows under it, stored
-    // DE-INTERLEAVED (even columns of a row, then its odd columns) so that the voxels a tap reads for consecutive outputs are
-    // consecutive LDS rows again (stride-2 row addresses hit every bank twice)
-    int s2, Vout, OW, OH, TR, tpp, sd, pd;     // tpp = tiles per output plane
 };
 
 // compile-time loop: f(std::integral_constant<int, I>{}) for I = 0 .. N - 1 (immediates of the inline-asm reads must be constants)
@@ -77,30 +72,25 @@ template <int IMM> __device__ __forceinline__ void ct3_rd(u32x4_t& v, unsigned a
 }
 
 #define CT3_ASTRIDE (22 * 1024)      // bytes of one A buffer (compile time: the buffer parity is an immediate of the reads): W <= 44
-#define CT3_ASTRIDE_S2 (37 * 1024)   // the stride-2 form: (2 TR + 1) W + 1 rows of 64 bytes, <= 591 rows
-#define CT3_NAS_S2 3                 // its A-piece slots per wave and phase: 2 * 3 * 8 KB
 
-template <int NJ0, int NJ1, bool S2 = false>
+template <int NJ0, int NJ1>
 __global__ void __launch_bounds__(CT3_THREADS, 2) conv_t3_kernel(MfmaP p, Ct3P q) {
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr int BN = 32 * (NJ0 + NJ1), NJ = NJ0 > NJ1 ? NJ0 : NJ1;
-    constexpr int NI = S2 ? 1 : 2;                                // 32-voxel row blocks of a wave: tiles of 256 (stride 1) / 128 (stride 2) voxels
-    constexpr int BMk = 128 * NI;
-    constexpr int ASTR = S2 ? CT3_ASTRIDE_S2 : CT3_ASTRIDE, NAS = S2 ? CT3_NAS_S2 : CT3_NAS;
     constexpr int BT = BN * 64;                                  // bytes of one tap's weight tile (BN rows of 64 bytes)
     constexpr int BSTAGE = 3 * BT;                               // one kh row: 3 taps
     constexpr int NB = 3 * BN / 16;                              // its 1 KB pieces
     constexpr int NBS = (NB + 7) / 8;                            // piece slots per wave
-    constexpr int NR = NI + NJ;                                  // fragment reads per k-step
+    constexpr int NR = 2 + NJ;                                   // fragment reads per k-step
     constexpr int RING = BN >= 256 ? 2 : 3;                      // weight stages in LDS (256 columns: 48 KB each, two fit)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     int* const s_tap = reinterpret_cast<int*>(smem);             // [27] panel tap index of (dd,dh,dw), -1 = no such tap
     int* const outrow = reinterpret_cast<int*>(smem + 128);      // [256] output voxel (global row) or -1
     unsigned char* const A_s = smem + 128 + CT3_BM * 4;
     const unsigned lds0 = (unsigned)(unsigned long long)(lptr_t)smem;
-    const unsigned ldsA = lds0 + 128 + CT3_BM * 4, ldsB = ldsA + 2 * ASTR, trash = ldsB + RING * BSTAGE;
+    const unsigned ldsA = lds0 + 128 + CT3_BM * 4, ldsB = ldsA + 2 * CT3_ASTRIDE, trash = ldsB + RING * BSTAGE;
     // descriptor tables behind the scratch KB: per stage (chunk, kd slice) the A resource + run shift, per interval the 3 panel offsets
-    int4* const tabA = reinterpret_cast<int4*>(smem + 128 + CT3_BM * 4 + 2 * ASTR + RING * BSTAGE + 1024);     // [S + 2][2]
+    int4* const tabA = reinterpret_cast<int4*>(smem + 128 + CT3_BM * 4 + 2 * CT3_ASTRIDE + RING * BSTAGE + 1024);     // [S + 2][2]
     int4* const tabB = tabA + 2 * (q.smax + 2);                                                                     // [Q + 3]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -108,32 +98,21 @@ __global__ void __launch_bounds__(CT3_THREADS, 2) conv_t3_kernel(MfmaP p, Ct3P q
     const int oc0 = blockIdx.z * BN, ksp = blockIdx.y;
     const long long tile = (long long)(blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);      // XCD b & 7 owns a contiguous range of tiles
     if (tile >= (long long)q.tps * p.N) return;
-    const int n = (int)(tile / q.tps), m0 = S2 ? 0 : (int)(tile % q.tps) * CT3_BM;
+    const int n = (int)(tile / q.tps), m0 = (int)(tile % q.tps) * CT3_BM;
     const int W = p.IW, H = p.IH;
     const int nt = p.cls_ntaps[0];
-    // S2: the tile is rows oh0 .. oh0 + TR - 1 of output plane od
-    const int tl_ = (int)(tile % q.tps), od = S2 ? tl_ / q.tpp : 0, oh0 = S2 ? (tl_ % q.tpp) * q.TR : 0;
 
     if (tid < 27) {
         const int dd = tid / 9 - 1, dh = (tid / 3) % 3 - 1, dw = tid % 3 - 1;
         int found = -1;
         for (int t = 0; t < nt; ++t) {
-            // (S2: the table is indexed by the kernel position itself, (kd | 1, kh, kw) -> slot (dd + 1, dh + 1, dw + 1))
-            const int ed = S2 ? (int)p.tdd[t] - (q.KD == 3 ? 1 : 0) : (p.mode == 0 ? (int)p.tdd[t] - p.pd : (int)p.tdd[t]),
-                      eh = S2 ? (int)p.tdh[t] - 1 : (p.mode == 0 ? (int)p.tdh[t] - p.ph : (int)p.tdh[t]),
-                      ew = S2 ? (int)p.tdw[t] - 1 : (p.mode == 0 ? (int)p.tdw[t] - p.pw : (int)p.tdw[t]);
+            const int ed = p.mode == 0 ? (int)p.tdd[t] - p.pd : (int)p.tdd[t], eh = p.mode == 0 ? (int)p.tdh[t] - p.ph : (int)p.tdh[t],
+                      ew = p.mode == 0 ? (int)p.tdw[t] - p.pw : (int)p.tdw[t];
             if (ed == dd && eh == dh && ew == dw) found = t;
         }
         s_tap[tid] = found;
     }
-    if constexpr (S2) {
-        if (tid < BMk) {
-            const int rl = tid / q.OW, ow = tid - rl * q.OW;
-            outrow[tid] = (rl < q.TR && oh0 + rl < q.OH) ? n * q.Vout + (od * q.OH + oh0 + rl) * q.OW + ow : -1;
-        }
-    } else {
-        if (tid < CT3_BM) outrow[tid] = m0 + tid < q.V ? n * q.V + m0 + tid : -1;
-    }
+    if (tid < CT3_BM) outrow[tid] = m0 + tid < q.V ? n * q.V + m0 + tid : -1;
     // K range of this block: chunks [c_beg, c_end) x kd slices -> stages; a stage = 3 intervals (kh rows)
     const int c_beg = ksp * q.cps, c_end = c_beg + q.cps < q.nchunks ? c_beg + q.cps : q.nchunks;
     const int S = (c_end > c_beg ? c_end - c_beg : 0) * q.KD, Q = 3 * S;
@@ -147,9 +126,7 @@ __global__ void __launch_bounds__(CT3_THREADS, 2) conv_t3_kernel(MfmaP p, Ct3P q
             const int Cs = p.srcC[m];
             const unsigned long long base = (unsigned long long)((const bf16_t*)p.src[m] + (long long)n * q.V * Cs);
             e0 = make_int4((int)(unsigned)base, (int)((unsigned)(base >> 32) & 0xffffu), q.V * Cs * 2, 0x00020000);
-            // run origin (voxel of the sample), row pitch, channel byte offset.  S2: input plane od * sd + kd - pd, first input row 2 oh0
-            const int org = S2 ? (od * q.sd + (q.KD == 3 ? st % 3 : 0) - q.pd) * q.HW + 2 * oh0 * W : m0 - q.halo + dd * q.HW;
-            e1 = make_int4(org, Cs * 2, ch * 2, 0);
+            e1 = make_int4(m0 - q.halo + dd * q.HW, Cs * 2, ch * 2, 0);          // run origin (voxel), row pitch, channel byte offset
         }
         tabA[2 * st] = e0; tabA[2 * st + 1] = e1;
     }
@@ -168,24 +145,9 @@ __global__ void __launch_bounds__(CT3_THREADS, 2) conv_t3_kernel(MfmaP p, Ct3P q
     //      shift that leaves the plane (TF-SAME padding) points at the zero row behind the run.
     //      B: column rows of the wave's tiles in the three ring slots. ----
     const int kh8 = lane >> 5;                                   // which 8 of a 16-deep k-step this lane supplies
-    unsigned aad[9][NI];
+    unsigned aad[9][2];
 #pragma unroll
-    for (int i = 0; i < NI; ++i) {
-        if constexpr (S2) {
-            // output voxel (row rl of the tile, column ow) reads input row 2 rl + kh, column 2 ow + kw of the staged rows: LDS row
-            // (2 rl + kh) W + parity * W/2 + (column >> 1); beyond the volume (the one row / column of TF-SAME padding behind it,
-            // rows of the tile that do not exist): the zero row
-            const int loc = wm * 32 + (lane & 31);
-            const int rl = loc / q.OW, ow = loc - rl * q.OW;
-            const bool vox_ok = rl < q.TR && oh0 + rl < q.OH;
-#pragma unroll
-            for (int t = 0; t < 9; ++t) {
-                const int hr = 2 * rl + t / 3, ww = 2 * ow + t % 3;
-                const bool ok = vox_ok && 2 * oh0 + hr < H && ww < W;
-                const int r = ok ? hr * W + (ww & 1) * (W >> 1) + (ww >> 1) : q.arows;
-                aad[t][i] = ldsA + (unsigned)(r * 64 + ((((r >> 2) & 3) ^ kh8) << 4));
-            }
-        } else {
+    for (int i = 0; i < 2; ++i) {
         const int loc = wm * 64 + i * 32 + (lane & 31), m = m0 + loc;
         const int hw = m % q.HW, h = hw / W, w = hw - h * W;
 #pragma unroll
@@ -194,7 +156,6 @@ __global__ void __launch_bounds__(CT3_THREADS, 2) conv_t3_kernel(MfmaP p, Ct3P q
             const bool ok = (unsigned)hh < (unsigned)H && (unsigned)ww < (unsigned)W;
             const int r = ok ? q.halo + loc + (t / 3 - 1) * W + (t % 3 - 1) : q.arows;
             aad[t][i] = ldsA + (unsigned)(r * 64 + ((((r >> 2) & 3) ^ kh8) << 4));
-        }
         }
     }
     const int bcol0 = wn == 0 ? 0 : NJ0 * 32;
@@ -210,20 +171,14 @@ __global__ void __launch_bounds__(CT3_THREADS, 2) conv_t3_kernel(MfmaP p, Ct3P q
     // ---- DMA slots of this lane.  A piece = 16 rows x 64 B of the staged run; B piece = 16 panel rows x 64 B of one tap.
     //      A slot past the pieces fetches nothing into the scratch KB (the counts stay uniform, no branches). ----
     constexpr unsigned OOB = 0x80000000u;
-    int a_vox[2][NAS]; unsigned a_dst[2][NAS]; int a_ssl[2][NAS];
+    int a_vox[2][CT3_NAS]; unsigned a_dst[2][CT3_NAS]; int a_ssl[2][CT3_NAS];
 #pragma unroll
     for (int ph = 0; ph < 2; ++ph)
 #pragma unroll
-        for (int sl = 0; sl < NAS; ++sl) {
-            const int j = (ph * NAS + sl) * 8 + wave;
+        for (int sl = 0; sl < CT3_NAS; ++sl) {
+            const int j = (ph * CT3_NAS + sl) * 8 + wave;
             const int r = j * 16 + (lane >> 2);
             a_vox[ph][sl] = j < q.nA && r < q.arows ? r : -(1 << 22);      // row of the run (behind it, the zero row included: far below zero -> zeros)
-            if constexpr (S2) {
-                // LDS row r = input row hr of the staged rows, parity par, position idx: source voxel hr W + 2 idx + par (relative to
-                // the stage's origin); a row below the volume (TF-SAME padding behind an even extent) reads zeros
-                const int hr = r / W, rem = r - hr * W, par = rem >= (W >> 1) ? 1 : 0, idx = rem - par * (W >> 1);
-                a_vox[ph][sl] = (j < q.nA && r < q.arows && 2 * oh0 + hr < H) ? hr * W + 2 * idx + par : -(1 << 22);
-            }
             a_dst[ph][sl] = j < q.nA ? ldsA + (unsigned)(j * 1024) : trash;
             a_ssl[ph][sl] = (((lane & 3) ^ ((r >> 2) & 3)) << 4);
         }
@@ -251,12 +206,10 @@ __global__ void __launch_bounds__(CT3_THREADS, 2) conv_t3_kernel(MfmaP p, Ct3P q
         rs.z = __builtin_amdgcn_readfirstlane(e0.z); rs.w = 0x00020000;
         const int vsh = e1.x, Cs2 = e1.y, cb = e1.z;                   // (vector registers: every lane read the same entry)
 #pragma unroll
-        for (int sl = 0; sl < NAS; ++sl) {
+        for (int sl = 0; sl < CT3_NAS; ++sl) {
             const int g = a_vox[ph][sl] + vsh;                   // voxel of the sample (negative / beyond it: out of range -> zeros)
             const unsigned vo = (unsigned)(__mul24(g, Cs2) + cb + a_ssl[ph][sl]);
-            // (S2: a padded input plane in front of the sample has a negative origin, but a row far inside the tile could still land at
-            //  a non-negative voxel: the whole stage is out of range when its origin is)
-            ct3_dma(rs, a_dst[ph][sl] == trash ? trash : a_dst[ph][sl] + (unsigned)(par * ASTR), (g < 0 || (S2 && vsh < 0)) ? OOB : vo, 0);
+            ct3_dma(rs, a_dst[ph][sl] == trash ? trash : a_dst[ph][sl] + (unsigned)(par * CT3_ASTRIDE), g < 0 ? OOB : vo, 0);
         }
     };
     // weights of interval qi into ring slot `slot`: taps (dd, dh, -1..1) of its chunk
@@ -271,9 +224,9 @@ __global__ void __launch_bounds__(CT3_THREADS, 2) conv_t3_kernel(MfmaP p, Ct3P q
         }
     };
 
-    f32x16_t acc[NI][NJ];
+    f32x16_t acc[2][NJ];
 #pragma unroll
-    for (int i = 0; i < NI; ++i)
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < NJ; ++j)
 #pragma unroll
@@ -284,11 +237,11 @@ __global__ void __launch_bounds__(CT3_THREADS, 2) conv_t3_kernel(MfmaP p, Ct3P q
     auto compute = [&](auto parc, auto dhc, auto&& pre) {
         constexpr int PAR = decltype(parc)::value, DHI = decltype(dhc)::value;
         constexpr int SLOT = RING == 3 ? DHI : ((PAR + DHI) & 1);       // interval 3 st + dh: st = (even) + PAR
-        u32x4_t fa[2][NI], fb[2][NJ];
+        u32x4_t fa[2][2], fb[2][NJ];
         auto reads = [&](auto kc) {                               // k-step K = 2 tap + half
             constexpr int K = decltype(kc)::value, DWI = K >> 1, KS = K & 1, BUF = K & 1;
 #pragma unroll
-            for (int i = 0; i < NI; ++i) ct3_rd<PAR * ASTR>(fa[BUF][i], KS ? aad[DHI * 3 + DWI][i] ^ 32u : aad[DHI * 3 + DWI][i]);
+            for (int i = 0; i < 2; ++i) ct3_rd<PAR * CT3_ASTRIDE>(fa[BUF][i], KS ? aad[DHI * 3 + DWI][i] ^ 32u : aad[DHI * 3 + DWI][i]);
 #pragma unroll
             for (int j = 0; j < NJ; ++j) ct3_rd<DWI * BT>(fb[BUF][j], KS ? bad[SLOT][j] ^ 32u : bad[SLOT][j]);
         };
@@ -300,22 +253,16 @@ __global__ void __launch_bounds__(CT3_THREADS, 2) conv_t3_kernel(MfmaP p, Ct3P q
             // return of an inline-asm read and would otherwise schedule the MFMAs in front of the wait
             if constexpr (K + 1 < 6) reads(std::integral_constant<int, K + 1>{});
             constexpr int LEFT = K + 1 < 6 ? NR : 0;
-            if constexpr (NI == 1) {
-                if constexpr (NJ == 2) asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(fa[BUF][0]), "+v"(fb[BUF][0]), "+v"(fb[BUF][1]) : "n"(LEFT) : "memory");
-                else if constexpr (NJ == 4) asm volatile("s_waitcnt lgkmcnt(%5)" : "+v"(fa[BUF][0]), "+v"(fb[BUF][0]), "+v"(fb[BUF][1]), "+v"(fb[BUF][2]), "+v"(fb[BUF][3]) : "n"(LEFT) : "memory");
-                else asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(fa[BUF][0]), "+v"(fb[BUF][0]), "+v"(fb[BUF][1]), "+v"(fb[BUF][2]) : "n"(LEFT) : "memory");
-            } else {
-            if constexpr (NJ == 2) asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(fa[BUF][0]), "+v"(fa[BUF][NI - 1]), "+v"(fb[BUF][0]), "+v"(fb[BUF][1]) : "n"(LEFT) : "memory");
-            else if constexpr (NJ == 4) asm volatile("s_waitcnt lgkmcnt(%6)" : "+v"(fa[BUF][0]), "+v"(fa[BUF][NI - 1]), "+v"(fb[BUF][0]), "+v"(fb[BUF][1]), "+v"(fb[BUF][2]), "+v"(fb[BUF][3]) : "n"(LEFT) : "memory");
-            else asm volatile("s_waitcnt lgkmcnt(%5)" : "+v"(fa[BUF][0]), "+v"(fa[BUF][NI - 1]), "+v"(fb[BUF][0]), "+v"(fb[BUF][1]), "+v"(fb[BUF][2]) : "n"(LEFT) : "memory");
-            }
+            if constexpr (NJ == 2) asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(fa[BUF][0]), "+v"(fa[BUF][1]), "+v"(fb[BUF][0]), "+v"(fb[BUF][1]) : "n"(LEFT) : "memory");
+            else if constexpr (NJ == 4) asm volatile("s_waitcnt lgkmcnt(%6)" : "+v"(fa[BUF][0]), "+v"(fa[BUF][1]), "+v"(fb[BUF][0]), "+v"(fb[BUF][1]), "+v"(fb[BUF][2]), "+v"(fb[BUF][3]) : "n"(LEFT) : "memory");
+            else asm volatile("s_waitcnt lgkmcnt(%5)" : "+v"(fa[BUF][0]), "+v"(fa[BUF][1]), "+v"(fb[BUF][0]), "+v"(fb[BUF][1]), "+v"(fb[BUF][2]) : "n"(LEFT) : "memory");
             // (NJ0 != NJ1, the 3 + 2 split of the 160-column tile: ONE code path -- the narrow column wave reads the fragment of its
             //  last tile a second time, so that the lgkmcnt counts stay the same, and skips the MFMAs of the tile it does not have)
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
                 if (NJ0 != NJ1 && j >= NJ1 && wn != 0) continue;
 #pragma unroll
-                for (int i = 0; i < NI; ++i)
+                for (int i = 0; i < 2; ++i)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, fa[BUF][i]), __builtin_bit_cast(bf16x8_t, fb[BUF][j]), acc[i][j], 0, 0, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -340,7 +287,7 @@ __global__ void __launch_bounds__(CT3_THREADS, 2) conv_t3_kernel(MfmaP p, Ct3P q
                         // ring of 3: only the group issued one interval ago may be in flight; ring of 2: nothing (the weights of this
                         // interval were issued one interval ago)
                         if constexpr (RING == 2) ct3_vmwait<0>();
-                        else if constexpr (DHI == 0) ct3_vmwait<NBS>(); else ct3_vmwait<NBS + NAS>();
+                        else if constexpr (DHI == 0) ct3_vmwait<NBS>(); else ct3_vmwait<NBS + CT3_NAS>();
                         __builtin_amdgcn_s_barrier();
                         compute(parc, dhc, [&]() {
                             if constexpr (RING == 3) issue_b(qi + 2, (DHI + 2) % 3); else issue_b(qi + 1, (PAR + DHI + 1) & 1);
@@ -356,18 +303,18 @@ __global__ void __launch_bounds__(CT3_THREADS, 2) conv_t3_kernel(MfmaP p, Ct3P q
 
     // ---- D of a 32x32 tile: lane holds column (lane & 31), rows (e & 3) + 8 (e >> 2) + 4 (lane >> 5) ----
     const int NJw = wn == 0 ? NJ0 : NJ1;
-    const int a_bytes = ASTR;
+    const int a_bytes = CT3_ASTRIDE;
     if (p.ksplit > 1) {
         float* slab = p.acc32 + (long long)ksp * p.slab_elems;
 #pragma unroll
-        for (int i = 0; i < NI; ++i)
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
                 if (j >= NJw) continue;
                 const int oc = oc0 + bcol0 + j * 32 + (lane & 31);
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
-                    const int orow = outrow[wm * (32 * NI) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5)];
+                    const int orow = outrow[wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5)];
                     if (orow >= 0 && oc < p.OCn) slab[(long long)orow * p.OC + oc] = acc[i][j][e];
                 }
             }
@@ -376,7 +323,7 @@ __global__ void __launch_bounds__(CT3_THREADS, 2) conv_t3_kernel(MfmaP p, Ct3P q
     constexpr int CP = BN + 8;
     bf16_t* const C_s = reinterpret_cast<bf16_t*>(A_s);
 #pragma unroll
-    for (int i = 0; i < NI; ++i)
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
             if (j >= NJw) continue;
@@ -384,7 +331,7 @@ __global__ void __launch_bounds__(CT3_THREADS, 2) conv_t3_kernel(MfmaP p, Ct3P q
             const float bv = (oc0 + col < p.OCn) ? m1_bias_at(p, oc0 + col) : 0.f;
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                const int row = wm * (32 * NI) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+                const int row = wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
                 C_s[row * CP + col] = f2bf(acc[i][j][e] + bv);
             }
         }
@@ -400,7 +347,7 @@ __global__ void __launch_bounds__(CT3_THREADS, 2) conv_t3_kernel(MfmaP p, Ct3P q
                 const float mean = p.ib_stats[((long long)n * p.OC + oc) * 2], rstd = p.ib_stats[((long long)n * p.OC + oc) * 2 + 1];
                 const float gm = p.ib_gamma[oc], bt = p.ib_beta[oc];
                 const bf16_t* xb = (const bf16_t*)p.ib_x + oc;
-                for (int row = rg; row < BMk; row += G) {
+                for (int row = rg; row < CT3_BM; row += G) {
                     const int orow = outrow[row];
                     if (orow >= 0) {
                         const float xh = (bf2f(xb[(long long)orow * p.OC]) - mean) * rstd;
@@ -409,7 +356,7 @@ __global__ void __launch_bounds__(CT3_THREADS, 2) conv_t3_kernel(MfmaP p, Ct3P q
                     }
                 }
             } else {
-                for (int row = rg; row < BMk; row += G)
+                for (int row = rg; row < CT3_BM; row += G)
                     if (outrow[row] >= 0) { const float v = bf2f(C_s[row * CP + col]); s += v; ss += v * v; }
             }
         }
@@ -422,7 +369,7 @@ __global__ void __launch_bounds__(CT3_THREADS, 2) conv_t3_kernel(MfmaP p, Ct3P q
         }
     }
     constexpr int SPR = BN / 8;
-    for (int e = tid; e < BMk * SPR; e += CT3_THREADS) {
+    for (int e = tid; e < CT3_BM * SPR; e += CT3_THREADS) {
         const int row = e / SPR, cs = e % SPR;
         const int orow = outrow[row];
         const int oc = oc0 + cs * 8;
@@ -444,57 +391,16 @@ __global__ void __launch_bounds__(CT3_THREADS, 2) conv_t3_kernel(MfmaP p, Ct3P q
 }
 
 // ---- host ----
-static inline size_t ct3_smem(int BN, int smax, bool s2 = false) {
+static inline size_t ct3_smem(int BN, int smax) {
     size_t tab = (size_t)(smax + 2) * 32 + (size_t)(3 * smax + 3) * 16;           // descriptor tables
     if (tab < CT3_THREADS * 2 * sizeof(float)) tab = CT3_THREADS * 2 * sizeof(float);      // (the statistics scratch reuses the region)
-    return 128 + CT3_BM * 4 + 2 * (size_t)(s2 ? CT3_ASTRIDE_S2 : CT3_ASTRIDE) + (BN >= 256 ? 2 : 3) * 3 * (size_t)BN * 64 + 1024 + tab;
-}
-
-// ---- the stride-2 forward form (conv_t3_kernel<.., S2 = true>): strided Conv3D forwards and Conv3DTranspose data gradients of the
-//      matrix-core levels (res1 -> res2 -> res3 -> res4: networks.py:476-487, 496-520), which conv_mfma gathers tap by tap ----
-struct Ct3S2Geo { int TR, tpp, arows, nA; };
-static bool ct3_s2_geo(const GatherSpec& g, Ct3S2Geo* o) {
-    if (g.mode != 0 || g.sh != 2 || g.sw != 2 || (g.sd != 1 && g.sd != 2)) return false;
-    if (!(g.kh == 3 && g.kw == 3 && (g.kd == 3 || g.kd == 1))) return false;
-    if (g.IH % 2 || g.IW % 2 || g.OH != g.IH / 2 || g.OW != g.IW / 2 || g.ph != 0 || g.pw != 0) return false;      // TF-SAME on even extents
-    if (g.sd == 2 ? (g.ID % 2 || g.OD != g.ID / 2 || g.pd != 0) : (g.OD != g.ID || g.pd != (g.kd == 3 ? 1 : 0))) return false;
-    if (g.OW > 128) return false;
-    int TR = 128 / g.OW; if (TR > g.OH) TR = g.OH;
-    const int arows = (2 * TR + 1) * g.IW, nA = (arows + 16) / 16;
-    if (nA * 1024 > CT3_ASTRIDE_S2 || nA > 2 * CT3_NAS_S2 * 8) return false;
-    o->TR = TR; o->tpp = (g.OH + TR - 1) / TR; o->arows = arows; o->nA = nA;
-    return true;
-}
-static bool ct3_s2_plan(const GatherSpec& g, int* BN_out, int* ksplit_out) {
-    if (!M1_CFG("M1_CONV_T3_S2", 1)) return false;
-    Ct3S2Geo ge;
-    if (!ct3_s2_geo(g, &ge)) return false;
-    int CC = 0;
-    for (int i = 0; i < g.nsrc; ++i) { if (g.srcC[i] % 32) return false; CC += g.srcC[i]; }
-    if (g.OC % 8) return false;
-    for (int i = 0; i < g.nout; ++i) if (g.outC[i] % 8) return false;
-    const long long Vin = (long long)g.ID * g.IH * g.IW, Vout = (long long)g.OD * g.OH * g.OW;
-    if (Vin * 768 * 2 >= (1ll << 31) || (long long)(g.ID + 2) * g.IH * g.IW >= (1 << 23)) return false;
-    for (int i = 0; i < g.nsrc; ++i) if (Vin * g.srcC[i] * 2 >= (1ll << 31) - 4096) return false;
-    const int minc = M1_CFG("M1_CT3S2_MINC", 64), minoc = M1_CFG("M1_CT3S2_MINOC", 64);
-    const long long minm = M1_CFG("M1_CT3S2_MINM", 2000);
-    if (CC < minc || g.OC < minoc || (long long)g.N * Vout < minm) return false;
-    const int BN = 128, nchunks = CC / 32;
-    const long long tiles = (long long)g.N * g.OD * ge.tpp, ntile = (g.OC + BN - 1) / BN;
-    // K splits: enough blocks for one round of the chip while a split keeps >= 4 chunks
-    int ks = 1;
-    while (tiles * ntile * ks < 192 && nchunks / (ks + 1) >= 4 && ks < 8) ++ks;
-    { const int fks = M1_CFG("M1_CT3S2_KSPLIT", 0); if (fks >= 1) ks = fks; }
-    if (ct3_smem(BN, (nchunks + ks - 1) / ks * g.kd, true) > 160 * 1024) return false;
-    *BN_out = BN; *ksplit_out = ks;
-    return true;
+    return 128 + CT3_BM * 4 + 2 * (size_t)CT3_ASTRIDE + (BN >= 256 ? 2 : 3) * 3 * (size_t)BN * 64 + 1024 + tab;
 }
 
 // the shapes this kernel takes, and how: BN (columns per block), K splits.  false: conv_mfma / conv_halo keep the problem.
 bool m1_ct3_plan(const GatherSpec& g, int* BN_out, int* ksplit_out) {
     const int en = M1_CFG("M1_CONV_T3", 1);
     if (!en || g.dtype != M1_BF16) return false;
-    if (g.sh == 2 && g.sw == 2) return ct3_s2_plan(g, BN_out, ksplit_out);
     if (g.sd != 1 || g.sh != 1 || g.sw != 1) return false;
     if (!(g.kh == 3 && g.kw == 3 && (g.kd == 3 || g.kd == 1))) return false;
     if (g.ID != g.OD || g.IH != g.OH || g.IW != g.OW) return false;
@@ -545,43 +451,8 @@ bool m1_ct3_plan(const GatherSpec& g, int* BN_out, int* ksplit_out) {
 
 // tiles (= statistics partial rows) per sample: runs of 256 voxels
 int m1_ct3_tiles_per_sample(int D, int H, int W) { return (int)cdiv_ll((long long)D * H * W, CT3_BM); }
-// the same for whichever form m1_ct3_plan chose for `g`
-int m1_ct3_tiles_ps(const GatherSpec& g) {
-    Ct3S2Geo ge;
-    if (g.sh == 2 && g.sw == 2 && ct3_s2_geo(g, &ge)) return g.OD * ge.tpp;
-    return m1_ct3_tiles_per_sample(g.OD, g.OH, g.OW);
-}
-
-static int ct3_s2_conv(const MfmaP& mp, int BN, int OCpad, hipStream_t st) {
-    GatherSpec g{};      // (geometry only)
-    g.mode = mp.mode; g.sd = mp.sd; g.sh = mp.sh; g.sw = mp.sw; g.pd = mp.pd; g.ph = mp.ph; g.pw = mp.pw;
-    g.ID = mp.ID; g.IH = mp.IH; g.IW = mp.IW; g.OD = mp.OD; g.OH = mp.OH; g.OW = mp.OW;
-    const int nt = mp.cls_ntaps[0];
-    if (nt != 27 && nt != 9) return M1_ERR_UNSUPPORTED;
-    g.kd = nt == 27 ? 3 : 1; g.kh = 3; g.kw = 3;
-    Ct3S2Geo ge;
-    if (BN != 128 || !ct3_s2_geo(g, &ge)) return M1_ERR_UNSUPPORTED;
-    Ct3P q{};
-    q.s2 = 1; q.V = mp.ID * mp.IH * mp.IW; q.Vout = mp.OD * mp.OH * mp.OW; q.HW = mp.IH * mp.IW;
-    q.OW = mp.OW; q.OH = mp.OH; q.TR = ge.TR; q.tpp = ge.tpp; q.sd = mp.sd; q.pd = mp.pd;
-    q.tps = mp.OD * ge.tpp; q.halo = 0; q.arows = ge.arows; q.nA = ge.nA;
-    q.KD = g.kd; q.nchunks = mp.CC / 32; q.cps = (q.nchunks + mp.ksplit - 1) / mp.ksplit; q.OCpad = OCpad; q.smax = q.cps * q.KD;
-    const size_t smem = ct3_smem(BN, q.smax, true);
-    void (*kern)(MfmaP, Ct3P) = conv_t3_kernel<2, 2, true>;
-    static bool attr = false;
-    if (!attr) {
-        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return M1_ERR_LAUNCH;
-        attr = true;
-    }
-    const long long tiles = (long long)q.tps * mp.N;
-    dim3 grid((unsigned)(cdiv_ll(tiles, 8) * 8), (unsigned)mp.ksplit, (unsigned)(OCpad / BN));
-    m1_note_kernel("conv_t3:s2:bn%d:ks%d", BN, mp.ksplit);
-    hipLaunchKernelGGL(kern, grid, dim3(CT3_THREADS), smem, st, mp, q);
-    return m1_check_launch();
-}
 
 int m1_ct3_conv(const MfmaP& mp, int BN, int OCpad, hipStream_t st) {
-    if (mp.sh == 2 && mp.sw == 2) return ct3_s2_conv(mp, BN, OCpad, st);
     Ct3P q{};
     const long long V = (long long)mp.OD * mp.OH * mp.OW;
     q.V = (int)V; q.HW = mp.IH * mp.IW; q.tps = (int)cdiv_ll(V, CT3_BM);

@@ -1087,73 +1087,6 @@ def test_conv_t3_staged_run_kernel(dev, case):
     ops.invalidate_panels()
 
 
-# ---- the stride-2 form of the staged-run kernel (conv_t3_kernel<.., S2>, round 6): strided Conv3D forwards and Conv3DTranspose data
-#      gradients of the matrix-core levels -- output tiles of whole rows of one plane, input rows staged de-interleaved ----
-CT3S2_LOW = dict(M1_CT3S2_MINM=1, M1_CT3S2_MINC=32, M1_CT3S2_MINOC=8)
-CT3S2_CASES = [  # dims of the HIGH-resolution side (N, D, H, W), channels high side, channels low side, k, s, transposed, extra
-    ((2, 4, 16, 24), [64], 160, (3, 3, 3), (1, 2, 2), False, {}),                    # serse2's conv1 || conv4 shape class: 64 -> 160, s122
-    ((1, 6, 12, 20), [32, 96], 136, (3, 3, 3), (2, 2, 2), False, {}),                # s222, two members, a partial column tile, 10 output columns
-    ((2, 4, 8, 40), [128], 128, (3, 3, 3), (2, 2, 2), False, {"M1_CT3S2_KSPLIT": 2}),  # split-K slabs, 20 output columns (6 rows per tile, 4 rows exist)
-    ((1, 3, 20, 16), [64], 96, (1, 3, 3), (1, 2, 2), False, {}),                     # (1,3,3) kernel
-    ((2, 2, 6, 160), [32], 64, (3, 3, 3), (1, 2, 2), False, {}),                     # 80 output columns: one row per tile
-    ((2, 4, 16, 24), [64], 128, (3, 3, 3), (2, 2, 2), True, {}),                     # Conv3DTranspose 128 -> 64: its DATA GRADIENT is the strided conv
-    ((1, 2, 20, 20), [32, 64], 256, (3, 3, 3), (1, 2, 2), True, {}),                 # ... over a two-member concat on the low side
-]
-
-
-@pytest.mark.parametrize("case", CT3S2_CASES)
-def test_conv_t3_stride2_form(dev, case):
-    dims, chi, clo, k, s, transposed, extra = case
-    N, D, H, W = dims
-    lo = (N, D // s[0], H // s[1], W // s[2])
-    if not transposed:        # y(lo) = conv_s(x(hi)): forward on the stride-2 form
-        xs = [rnd((*dims, c), 70 + i).bfloat16().float() for i, c in enumerate(chi)]
-        w = rnd((*k, sum(chi), clo), 6, 1.0 / (sum(chi) * k[0] * k[1] * k[2]) ** 0.5); b = rnd((clo,), 7)
-        fn = lambda x, w_, b_: O.conv3d_same(x, w_, b_, s)
-        run = lambda xd, wd, bd: ops.conv3d_same(xd, wd, bd, k, s, stats=True)
-    else:                     # y(hi) = convT_s(x(lo)): its data gradient d x(lo) = conv_s(d y(hi)) runs on the stride-2 form
-        xs = [rnd((*lo, c), 70 + i).bfloat16().float() for i, c in enumerate(chi)]
-        w = rnd((*k, clo, sum(chi)), 6, 1.0 / (sum(chi) * k[0] * k[1] * k[2]) ** 0.5); b = rnd((clo,), 7)
-        fn = lambda x, w_, b_: O.conv3d_transpose_same(x, w_, b_, s)
-        run = lambda xd, wd, bd: (ops.conv3d_transpose_same(xd, wd, bd, k, s), None)
-    yo = fn(torch.cat(xs, -1).double(), w.double(), b.double())
-    dy = rnd(tuple(yo.shape), 8).bfloat16().float()
-    yo, (gx, gw, gb) = _oracle_grads(fn, [torch.cat(xs, -1), w, b], dy)
-    res = {}
-    for tag, cfg in (("s2", dict(CT3S2_LOW, **extra)), ("mfma", dict(M1_CONV_T3_S2=0))):
-        with ops.config(**cfg), ops.kernel_log() as kl:
-            xd = [x.to(dev, torch.bfloat16).requires_grad_(True) for x in xs]
-            wd, bd = w.to(dev).requires_grad_(True), b.to(dev).requires_grad_(True)
-            y, st = run(xd, wd, bd)
-            y.backward(dy.to(dev, torch.bfloat16))
-            torch.cuda.synchronize()
-            res[tag] = (y.detach(), st, [x.grad for x in xd], wd.grad)
-        t3 = [n for n in kl.names if n.startswith("conv_t3:s2:")]
-        if tag == "s2":
-            assert len(t3) == 1, kl.names                 # the forward (strided conv) or the data gradient (transposed conv), not both
-            if "M1_CT3S2_KSPLIT" in extra:
-                assert t3[0].endswith(f":ks{extra['M1_CT3S2_KSPLIT']}"), kl.names
-        else:
-            assert not t3, kl.names
-    y, st, gxd, gwd = res["s2"]
-    tol = 1e-2
-    assert rel_err(y, yo) < tol, "y"
-    off = 0
-    for x, g in zip(xs, gxd):
-        c = x.shape[-1]
-        assert rel_err(g, gx[..., off:off + c]) < tol, ("dx", off)
-        off += c
-    assert rel_err(gwd, gw) < 1e-4
-    if st is not None:
-        yf = y.float()
-        assert rel_err(st[..., 0], yf.mean(dim=(1, 2, 3))) < 1e-4 and rel_err(st[..., 1], 1.0 / torch.sqrt(yf.var(dim=(1, 2, 3), unbiased=False) + 1e-3)) < 1e-4
-    y2, _, gx2, _ = res["mfma"]
-    assert rel_err(y, y2) < 1e-2 and float((y.float() - y2.float()).abs().mean()) < 2e-4 * float(y2.float().abs().mean()) + 1e-6
-    for a_, b_ in zip(gxd, gx2):
-        assert rel_err(a_, b_) < 1e-2 and float((a_.float() - b_.float()).abs().mean()) < 3e-4 * float(b_.float().abs().mean()) + 1e-6
-    ops.invalidate_panels()
-
-
 # the eight stride-1 matrix-core layers of a C3 step (stacked batch 4; tools/bench_ct3.py, profiles/r04_conv_t3_layers.txt) and the tiling
 # m1_ct3_plan's cost model gives them: (columns per block, K splits).  The model is a table of measured microseconds fitted on one box at
 # 256 CUs (conv_t3.hip): a shape or constant change that silently re-plans one of these layers changes the headline number, so it is
