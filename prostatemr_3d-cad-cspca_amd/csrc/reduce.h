@@ -27,6 +27,11 @@ static inline int m1_red_chunkV(long long V, int C, int N) {
 }
 static inline int m1_red_nchunks(long long V, int C, int N) { return (int)cdiv_ll(V, m1_red_chunkV(V, C, N)); }
 
+// Block barrier behind LDS traffic only.  __syncthreads() also waits vmcnt(0): a barrier that follows the partial-row stores of a fold
+// step waits for their round trip to memory (~3 us per step, measured: the 5-sum SE backward reduction of a (4,10,20,20,128) tensor
+// took 21 us next to a 9.5 us apply pass over the same data).
+__device__ __forceinline__ void m1_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 static inline int m1_pow2_ge(int c) { int p = 1; while (p < c) p <<= 1; return p; }
 
 template <int NS> struct M1ParamOut { float* ptr[NS]; int acc[NS]; };
@@ -59,7 +64,7 @@ __global__ void __launch_bounds__(M1_RED_THREADS) m1_reduce_nc_kernel(F f, long 
                 partial[(((size_t)n * nchunks + chunk) * C + c) * NS + k] = s;
             }
         }
-        __syncthreads();
+        m1_lds_barrier();                                  // (not __syncthreads: the stores above need not have landed)
     }
 }
 
@@ -154,14 +159,68 @@ __global__ void __launch_bounds__(256) m1_reduce_finalize_params_kernel(const fl
             if (po.ptr[k]) po.ptr[k][c] = (po.acc[k] ? po.ptr[k][c] : 0.f) + (float)tot[k];
     }
 }
+// The same for MANY partial rows per sample (the per-tile rows of a res0 / res1 conv epilogue: up to ~4,000): one BLOCK per channel,
+// 256 lanes stride the rows of up to 4 samples at a time.  One wave per channel walked 4,000 rows in 62 dependent L2 round trips with
+// 2 - 8 blocks on the whole chip (25 us at C = 8, 10.6 us at C = 16; round 6).
+template <int NS>
+__global__ void __launch_bounds__(256) m1_reduce_finalize_params_wide_kernel(const float* __restrict__ partial, int N, int C, int nchunks,
+                                                                             float* __restrict__ out, M1ParamOut<NS> po) {
+    constexpr int NB = 4;
+    __shared__ double red[4][NB][NS];
+    const int c = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double tot[NS];
+#pragma unroll
+    for (int k = 0; k < NS; ++k) tot[k] = 0.0;
+    for (int n0 = 0; n0 < N; n0 += NB) {
+        double s[NB][NS];
+#pragma unroll
+        for (int q = 0; q < NB; ++q)
+#pragma unroll
+            for (int k = 0; k < NS; ++k) s[q][k] = 0.0;
+        for (int j = threadIdx.x; j < nchunks; j += 256) {
+#pragma unroll
+            for (int q = 0; q < NB; ++q)
+                if (n0 + q < N) {
+#pragma unroll
+                    for (int k = 0; k < NS; ++k) s[q][k] += (double)partial[(((size_t)(n0 + q) * nchunks + j) * C + c) * NS + k];
+                }
+        }
+#pragma unroll
+        for (int q = 0; q < NB; ++q)
+#pragma unroll
+            for (int k = 0; k < NS; ++k) { s[q][k] = wave_sum_d(s[q][k]); if (lane == 0) red[wave][q][k] = s[q][k]; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+#pragma unroll
+            for (int q = 0; q < NB; ++q)
+                if (n0 + q < N) {
+#pragma unroll
+                    for (int k = 0; k < NS; ++k) {
+                        const float v = (float)((red[0][q][k] + red[1][q][k]) + (red[2][q][k] + red[3][q][k]));
+                        out[((size_t)(n0 + q) * C + c) * NS + k] = v; tot[k] += (double)v;
+                    }
+                }
+        }
+        m1_lds_barrier();
+    }
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int k = 0; k < NS; ++k)
+            if (po.ptr[k]) po.ptr[k][c] = (po.acc[k] ? po.ptr[k][c] : 0.f) + (float)tot[k];
+    }
+}
 template <int NS>
 static inline int m1_reduce_finalize_params_launch(const float* partial, int N, int C, int nchunks, float* out,
                                                    const M1ParamOut<NS>& po, hipStream_t st) {
+    if (nchunks > M1_CFG("M1_FINP_WIDE", 128)) {
+        hipLaunchKernelGGL((m1_reduce_finalize_params_wide_kernel<NS>), dim3(C), dim3(256), 0, st, partial, N, C, nchunks, out, po);
+        return m1_check_launch();
+    }
     hipLaunchKernelGGL((m1_reduce_finalize_params_kernel<NS>), dim3((C + 3) / 4), dim3(256), 0, st, partial, N, C, nchunks, out, po);
     return m1_check_launch();
 }
 
-template <typename F, typename = void> struct M1RedUnroll { static constexpr int value = 1; };
+template <typename F, typename = void> struct M1RedUnroll { static constexpr int value = 2; };
 template <typename F> struct M1RedUnroll<F, decltype((void)F::kUnroll)> { static constexpr int value = F::kUnroll; };
 
 // Vector variant: a lane owns VEC consecutive channels (one 16-byte load per tensor per voxel) instead of one.
@@ -169,7 +228,7 @@ template <typename F> struct M1RedUnroll<F, decltype((void)F::kUnroll)> { static
 template <int NS, int VEC, typename F>
 __global__ void __launch_bounds__(M1_RED_THREADS) m1_reduce_nc_vec_kernel(F f, long long V, int C, int chunkV,
                                                                           int nchunks, float* __restrict__ partial) {
-    __shared__ float red[M1_RED_THREADS * VEC];                      // one sum at a time (NS passes)
+    __shared__ __attribute__((aligned(16))) float red[NS][M1_RED_THREADS * VEC];   // all NS sums at once: ONE barrier per fold
     const int n = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
     const long long v0 = (long long)chunk * chunkV;
     long long v1 = v0 + chunkV; if (v1 > V) v1 = V;
@@ -197,30 +256,51 @@ __global__ void __launch_bounds__(M1_RED_THREADS) m1_reduce_nc_vec_kernel(F f, l
             for (; v < v1; v += nvs) f.vec(n, v, gi * VEC, acc);
         }
         // fold the voxel sub-lanes: xor-shuffles inside a wave (lanes cpad apart share a channel group), then the
-        // 4 waves (or, for >= 64 channel groups, the voxel sub-lane rows) through LDS, one sum at a time
+        // 4 waves (or, for >= 64 channel groups, the voxel sub-lane rows) through LDS -- every sum in its own LDS plane, one barrier,
+        // and the row-0 lanes write their NS x VEC results as 16-byte stores (round 6: the fold used to run one sum at a time with
+        // two __syncthreads each, and every barrier waited for the 4-byte partial stores in front of it)
         const int wcol = cpad < 64 ? cpad : 64;                      // distinct channel groups per wave
         const int rows = M1_RED_THREADS / (cpad < 64 ? 64 : cpad);
         const int row = cpad < 64 ? (tid >> 6) : vs;
         const bool writer = cpad >= 64 || (tid & 63) < cpad;
+        // (the shuffle distance is the OUTER loop: the NS x VEC exchanges of one distance are independent and pipeline; with the
+        //  distance loop inside, each of the 40 sums of the SE backward ran its own serial chain of ds_bpermute + wait -- 80 - 120
+        //  dependent LDS round trips, ~10 us of a 20 us launch on the deep levels' tensors)
+        if (wcol < 64) {
+            for (int o = 32; o >= wcol; o >>= 1) {
 #pragma unroll
-        for (int k = 0; k < NS; ++k) {
+                for (int k = 0; k < NS; ++k)
 #pragma unroll
-            for (int e = 0; e < VEC; ++e) {
-                float s = acc[k][e];
-                for (int o = 32; o >= wcol && wcol < 64; o >>= 1) s += __shfl_xor(s, o, 64);
-                if (writer) red[(row * cpad + cl) * VEC + e] = s;
+                    for (int e = 0; e < VEC; ++e) acc[k][e] += __shfl_xor(acc[k][e], o, 64);
             }
-            __syncthreads();
-            if (writer && row == 0 && gi < cg) {
-#pragma unroll
-                for (int e = 0; e < VEC; ++e) {
-                    float s = 0.f;
-                    for (int j = 0; j < rows; ++j) s += red[(j * cpad + cl) * VEC + e];
-                    partial[(((size_t)n * nchunks + chunk) * C + gi * VEC + e) * NS + k] = s;
-                }
-            }
-            __syncthreads();
         }
+        if (writer) {
+#pragma unroll
+            for (int k = 0; k < NS; ++k)
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) red[k][(row * cpad + cl) * VEC + e] = acc[k][e];
+        }
+        m1_lds_barrier();
+        if (writer && row == 0 && gi < cg) {
+            float o[VEC * NS];                                        // [e][k]: the partial row's layout for channels gi*VEC..
+#pragma unroll
+            for (int q = 0; q < VEC * NS; ++q) o[q] = 0.f;
+            for (int j = 0; j < rows; ++j) {                          // (rows outside: the NS x VEC reads of one row are independent)
+#pragma unroll
+                for (int k = 0; k < NS; ++k)
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) o[e * NS + k] += red[k][(j * cpad + cl) * VEC + e];
+            }
+            float* dst = partial + (((size_t)n * nchunks + chunk) * C + (size_t)gi * VEC) * NS;
+            if constexpr ((VEC * NS) % 4 == 0) {                      // (VEC is 4 or 8: dst is 16-byte aligned)
+#pragma unroll
+                for (int q = 0; q < VEC * NS; q += 4) *reinterpret_cast<float4*>(dst + q) = make_float4(o[q], o[q + 1], o[q + 2], o[q + 3]);
+            } else {
+#pragma unroll
+                for (int q = 0; q < VEC * NS; ++q) dst[q] = o[q];
+            }
+        }
+        if (gbase + cpad < cg) m1_lds_barrier();
     }
 }
 

@@ -324,7 +324,7 @@ struct SeBwdF {
         acc[0] += dx_; acc[1] += dx_ * xh3; acc[2] += drho; acc[3] += drho * xh4; acc[4] += du * x_ * rho;
     }
     static constexpr int kVec = sizeof(T) == 2 ? 8 : 4;
-    static constexpr int kUnroll = 1;
+    static constexpr int kUnroll = MASKED ? 2 : 1;      // (the Philox form keeps one voxel in flight: its registers)
     __device__ void vec(int n, long long v, int c0, float (*acc)[kVec]) const {
         const int F = p.F;
         const size_t idx = ((size_t)n * p.V + v) * F + c0;
