@@ -107,8 +107,16 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_mfma_kernel(MfmaP p) {
         const long long m = m0 + r;
         int4 ri = make_int4(-1, 0, 0, 0); int orow = -1;
         if (m < Mtot) {
-            const int n = (int)(m / QV); long long lin = m % QV;
-            const int qw = (int)(lin % QW); lin /= QW; const int qh = (int)(lin % QH); const int qd = (int)(lin / QH);
+            int n, qw, qh, qd;
+            if (Mtot < (1ll << 31)) {         // (every tensor the 31-bit LDS-DMA offsets can address: 32-bit divisions, ~4x fewer instructions)
+                const unsigned mm = (unsigned)m, qv = (unsigned)QV;
+                n = (int)(mm / qv); const unsigned lin = mm - (unsigned)n * qv;
+                const unsigned t1 = lin / (unsigned)QW; qw = (int)(lin - t1 * (unsigned)QW);
+                qd = (int)(t1 / (unsigned)QH); qh = (int)(t1 - (unsigned)qd * (unsigned)QH);
+            } else {
+                n = (int)(m / QV); long long lin = m % QV;
+                qw = (int)(lin % QW); lin /= QW; qh = (int)(lin % QH); qd = (int)(lin / QH);
+            }
             if (p.mode == 0) {
                 ri = make_int4(n, qd * p.sd - p.pd, qh * p.sh - p.ph, qw * p.sw - p.pw);
                 orow = (int)m;
@@ -187,19 +195,23 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_mfma_kernel(MfmaP p) {
         tap_db = __builtin_amdgcn_readfirstlane(s_tdl[st_tap]) * __builtin_amdgcn_readfirstlane(s_srcC[st_s]) * (int)sizeof(T);
     };
     if constexpr (GLDS) {
+        // tap validity per row: the taps are the OUTER loop (one LDS read per tap, not per (row, tap)); tap offsets are -1 .. 2
+        int4 ris[A_LD];
 #pragma unroll
-        for (int i = 0; i < A_LD; ++i) {
-            const int4 ri = rowinfo[lrow + (NTHR / 4) * i];
-            unsigned mk = 0;
-            for (int t = 0; t < ntaps; ++t) {
-                const int tp = s_tap[t];
-                const int id = ri.y + (signed char)(tp & 0xff), ih = ri.z + (signed char)((tp >> 8) & 0xff), iw = ri.w + (signed char)((tp >> 16) & 0xff);
-                const bool ok = ri.x >= 0 && (unsigned)id < (unsigned)p.ID && (unsigned)ih < (unsigned)p.IH && (unsigned)iw < (unsigned)p.IW;
-                mk |= (ok ? 1u : 0u) << t;
+        for (int i = 0; i < A_LD; ++i) { ris[i] = rowinfo[lrow + (NTHR / 4) * i]; rmask[i] = 0; }
+#pragma unroll 9
+        for (int t = 0; t < ntaps; ++t) {
+            const int tp = s_tap[t];
+            const int dd = (signed char)(tp & 0xff), dh = (signed char)((tp >> 8) & 0xff), dw = (signed char)((tp >> 16) & 0xff);
+#pragma unroll
+            for (int i = 0; i < A_LD; ++i) {
+                const bool ok = ris[i].x >= 0 && (unsigned)(ris[i].y + dd) < (unsigned)p.ID && (unsigned)(ris[i].z + dh) < (unsigned)p.IH &&
+                                (unsigned)(ris[i].w + dw) < (unsigned)p.IW;
+                rmask[i] |= (ok ? 1u : 0u) << t;
             }
-            rmask[i] = mk;
-            rvox[i] = ((ri.x * p.ID + ri.y) * p.IH + ri.z) * p.IW + ri.w;
         }
+#pragma unroll
+        for (int i = 0; i < A_LD; ++i) rvox[i] = ((ris[i].x * p.ID + ris[i].y) * p.IH + ris[i].z) * p.IW + ris[i].w;
     }
     if constexpr (GLDS) {
 #pragma unroll

@@ -133,6 +133,7 @@ __global__ void __launch_bounds__(256) m1_reduce_finalize_params_kernel(const fl
         for (int q = 0; q < NB; ++q)
 #pragma unroll
             for (int k = 0; k < NS; ++k) s[q][k] = 0.0;
+#pragma unroll 2
         for (int j = lane; j < nchunks; j += 64) {
 #pragma unroll
             for (int q = 0; q < NB; ++q)
