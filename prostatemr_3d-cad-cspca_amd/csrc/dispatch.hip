@@ -682,7 +682,9 @@ static int wgrad_common(const m1_conv_desc_t* d, bool T, const void* dy, float* 
     }
     if (db && !fuse_db) {
         if (!ws) return M1_ERR_WORKSPACE;
-        return m1_colsum_internal(dy, d->N, (long long)q.OD * q.OH * q.OW, d->Cout, d->dtype, db, (float*)ws, st, accumulate);
+        const long long Vd = (long long)q.OD * q.OH * q.OW;
+        if (!g_force_direct && m1_fold_defer_get() && m1_colsum_defer(dy, d->N, Vd, d->Cout, d->dtype, db, (float*)ws, accumulate)) return M1_OK;
+        return m1_colsum_internal(dy, d->N, Vd, d->Cout, d->dtype, db, (float*)ws, st, accumulate);
     }
     return M1_OK;
 }

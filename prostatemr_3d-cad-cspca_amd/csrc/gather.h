@@ -91,3 +91,8 @@ int m1_colsum_internal(const void* x, int N, long long V, int C, int dtype, floa
 
 // deferred-fold switch of m1_wg_rx_finish (wgrad_tf.hip): returns the previous setting
 int m1_fold_defer_set(int on);
+int m1_fold_defer_get();
+// deferred bias gradients of the transposed convs (norm.hip): queued under m1_wgrad_defer, launched by m1_wgrad_fold_pending
+bool m1_colsum_defer(const void* x, int N, long long V, int C, int dtype, float* out, float* ws, int accumulate);
+int m1_colsum_launch_pending(hipStream_t st);
+void m1_colsum_drop_pending();

@@ -273,3 +273,80 @@ int m1_colsum_internal(const void* x, int N, long long V, int C, int dtype, floa
     // partial is [N*nchunks][C][1]: fold all rows as one sample
     return m1_reduce_finalize_launch<1>(ws, 1, C, N * m1_red_nchunks(V, C, N), out, 0, 0.f, st, accumulate);
 }
+
+// ---- deferred bias gradients of the transposed convolutions (round 6) ------------------------------------------------------------
+// db[c] (+)= sum_{n,v} dy[n,v,c] is a reduction + a fold of its own per Conv3DTranspose (m1_convT3d_wgrad cannot fuse it: d(out) is the
+// shifted operand there): 19 + 19 launches of 4 - 12 us on the data-gradient chain of a C3 step, read by nobody before the optimiser.
+// Under m1_wgrad_defer they are queued like the folds of the weight-gradient copies and run as TWO batched launches from
+// m1_wgrad_fold_pending (the caller keeps dy and the workspace alive until then, as it does for the copies).
+#include <mutex>
+#include <vector>
+#define CS_MAX 24
+struct ColSumJob { const void* x; long long V; int C, N, chunkV, nchunks; float* partial; float* out; int acc; };
+struct ColSumBatch { int n; int pref[CS_MAX + 1]; ColSumJob j[CS_MAX]; };
+static_assert(sizeof(ColSumBatch) <= 3800, "batch must fit the kernel argument segment");
+template <typename T>
+__global__ void __launch_bounds__(M1_RED_THREADS) colsum_batch_kernel(ColSumBatch B) {
+    constexpr int VEC = ColSumF<T>::kVec;
+    __shared__ __attribute__((aligned(16))) float red[1][M1_RED_THREADS * VEC];
+    int k = 0;
+    while (k + 1 < B.n && (int)blockIdx.x >= B.pref[k + 1]) ++k;
+    const ColSumJob& q = B.j[k];
+    const int b = blockIdx.x - B.pref[k], n = b / q.nchunks, chunk = b - n * q.nchunks;
+    ColSumF<T> f{(const T*)q.x, q.V, q.C};
+    m1_reduce_nc_vec_body<1, VEC, ColSumF<T>>(f, q.V, q.C, q.chunkV, q.nchunks, q.partial, n, chunk, red);
+}
+// one block per (job, channel): the N * nchunks partial rows in fp64, as m1_reduce_finalize_kernel<1> folds them
+__global__ void __launch_bounds__(256) colsum_finalize_batch_kernel(ColSumBatch B) {
+    __shared__ double red[4];
+    int k = 0;
+    while (k + 1 < B.n && (int)blockIdx.x >= B.pref[k + 1]) ++k;
+    const ColSumJob& q = B.j[k];
+    const int c = blockIdx.x - B.pref[k], rows = q.N * q.nchunks, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double s = 0.0;
+    for (int j = threadIdx.x; j < rows; j += 256) s += (double)q.partial[(size_t)j * q.C + c];
+    s = wave_sum_d(s);
+    if (lane == 0) red[wave] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) q.out[c] = (q.acc ? q.out[c] : 0.f) + (float)((red[0] + red[1]) + (red[2] + red[3]));
+}
+static std::mutex g_cs_mu;
+static std::vector<ColSumJob> g_cs_pending[2];          // [bf16, fp32]
+// true: queued (nothing launched); false: the caller runs the reduction now (shape outside the vector kernel, or a second gradient
+// into the same db in this batch -- two read-modify-writes of db must not share a launch)
+bool m1_colsum_defer(const void* x, int N, long long V, int C, int dtype, float* out, float* ws, int accumulate) {
+    if (!M1_CFG("M1_BIAS_DEFER", 1)) return false;
+    const int VEC = dtype == M1_BF16 ? 8 : 4;
+    if (C % VEC || (long long)N * m1_red_nchunks(V, C, N) >= (1 << 20)) return false;
+    std::lock_guard<std::mutex> lk(g_cs_mu);
+    std::vector<ColSumJob>& v = g_cs_pending[dtype == M1_BF16 ? 0 : 1];
+    for (const ColSumJob& q : g_cs_pending[0]) if (q.out == out) return false;
+    for (const ColSumJob& q : g_cs_pending[1]) if (q.out == out) return false;
+    v.push_back(ColSumJob{x, V, C, N, m1_red_chunkV(V, C, N), m1_red_nchunks(V, C, N), ws, out, accumulate});
+    return true;
+}
+int m1_colsum_launch_pending(hipStream_t st) {
+    std::lock_guard<std::mutex> lk(g_cs_mu);
+    int rc = M1_OK;
+    for (int t = 0; t < 2 && rc == M1_OK; ++t) {
+        std::vector<ColSumJob>& v = g_cs_pending[t];
+        size_t i = 0;
+        while (i < v.size() && rc == M1_OK) {
+            ColSumBatch B{}, Fb{}; B.pref[0] = 0; Fb.pref[0] = 0;
+            while (i < v.size() && B.n < CS_MAX) {
+                const ColSumJob& q = v[i++];
+                B.j[B.n] = q; B.pref[B.n + 1] = B.pref[B.n] + q.N * q.nchunks; ++B.n;
+                Fb.j[Fb.n] = q; Fb.pref[Fb.n + 1] = Fb.pref[Fb.n] + q.C; ++Fb.n;
+            }
+            if (t == 0) hipLaunchKernelGGL(colsum_batch_kernel<bf16_t>, dim3((unsigned)B.pref[B.n]), dim3(M1_RED_THREADS), 0, st, B);
+            else hipLaunchKernelGGL(colsum_batch_kernel<float>, dim3((unsigned)B.pref[B.n]), dim3(M1_RED_THREADS), 0, st, B);
+            rc = m1_check_launch(); if (rc) break;
+            hipLaunchKernelGGL(colsum_finalize_batch_kernel, dim3((unsigned)Fb.pref[Fb.n]), dim3(256), 0, st, Fb);
+            rc = m1_check_launch();
+        }
+        v.clear();
+    }
+    g_cs_pending[0].clear(); g_cs_pending[1].clear();
+    return rc;
+}
+void m1_colsum_drop_pending() { std::lock_guard<std::mutex> lk(g_cs_mu); g_cs_pending[0].clear(); g_cs_pending[1].clear(); }

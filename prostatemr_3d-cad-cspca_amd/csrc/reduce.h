@@ -226,11 +226,11 @@ template <typename F> struct M1RedUnroll<F, decltype((void)F::kUnroll)> { static
 
 // Vector variant: a lane owns VEC consecutive channels (one 16-byte load per tensor per voxel) instead of one.
 // Functor contract:  static constexpr int kVec;  __device__ void vec(int n, long long v, int c0, float (*acc)[kVec]) const;
+// (body: block (n, chunk) of the reduction -- the batched launches of norm.hip walk several reductions with it)
 template <int NS, int VEC, typename F>
-__global__ void __launch_bounds__(M1_RED_THREADS) m1_reduce_nc_vec_kernel(F f, long long V, int C, int chunkV,
-                                                                          int nchunks, float* __restrict__ partial) {
-    __shared__ __attribute__((aligned(16))) float red[NS][M1_RED_THREADS * VEC];   // all NS sums at once: ONE barrier per fold
-    const int n = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
+__device__ __forceinline__ void m1_reduce_nc_vec_body(const F& f, long long V, int C, int chunkV, int nchunks, float* __restrict__ partial,
+                                                      int n, int chunk, float (*red)[M1_RED_THREADS * VEC]) {
+    const int tid = threadIdx.x;
     const long long v0 = (long long)chunk * chunkV;
     long long v1 = v0 + chunkV; if (v1 > V) v1 = V;
     const int cg = C / VEC;
@@ -303,6 +303,12 @@ __global__ void __launch_bounds__(M1_RED_THREADS) m1_reduce_nc_vec_kernel(F f, l
         }
         if (gbase + cpad < cg) m1_lds_barrier();
     }
+}
+template <int NS, int VEC, typename F>
+__global__ void __launch_bounds__(M1_RED_THREADS) m1_reduce_nc_vec_kernel(F f, long long V, int C, int chunkV,
+                                                                          int nchunks, float* __restrict__ partial) {
+    __shared__ __attribute__((aligned(16))) float red[NS][M1_RED_THREADS * VEC];   // all NS sums at once: ONE barrier per fold
+    m1_reduce_nc_vec_body<NS, VEC, F>(f, V, C, chunkV, nchunks, partial, blockIdx.y, blockIdx.x, red);
 }
 
 template <typename F, typename = void> struct M1RedVec { static constexpr int value = 0; };

@@ -463,10 +463,14 @@ static int fold_launch_pending_locked(hipStream_t st) {
 }
 int m1_fold_defer_set(int on) { std::lock_guard<std::mutex> lk(g_fold_mu); const int was = g_fold_defer; g_fold_defer = on ? 1 : 0; return was; }
 extern "C" int m1_wgrad_defer(int on) { std::lock_guard<std::mutex> lk(g_fold_mu); g_fold_defer = on ? 1 : 0; return M1_OK; }
-extern "C" int m1_wgrad_fold_drop(void) { std::lock_guard<std::mutex> lk(g_fold_mu); g_fold_pending.clear(); return M1_OK; }
+int m1_fold_defer_get() { std::lock_guard<std::mutex> lk(g_fold_mu); return g_fold_defer; }
+extern "C" int m1_wgrad_fold_drop(void) { { std::lock_guard<std::mutex> lk(g_fold_mu); g_fold_pending.clear(); } m1_colsum_drop_pending(); return M1_OK; }
 extern "C" int m1_wgrad_fold_pending(void* stream) {
-    std::lock_guard<std::mutex> lk(g_fold_mu);
-    return fold_launch_pending_locked((hipStream_t)stream);
+    {
+        std::lock_guard<std::mutex> lk(g_fold_mu);
+        const int rc = fold_launch_pending_locked((hipStream_t)stream); if (rc) return rc;
+    }
+    return m1_colsum_launch_pending((hipStream_t)stream);        // (the transposed convs' bias gradients queued with the folds)
 }
 
 // shared with the per-tap kernel (wgrad_mfma.hip), which uses the same partial-copy scheme for small weight tensors

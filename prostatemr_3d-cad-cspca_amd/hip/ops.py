@@ -744,6 +744,9 @@ def _wgrad_into_sinks(lib, d, dy, w_param, b_param, transposed: bool, st, srcs=(
         finally:
             lib.m1_wgrad_defer(0)
         _FOLD["keep"].append((ws, torch.cuda.current_stream(w_param.device)))
+        if transposed and bbuf is not None:
+            # the bias gradient of a transposed conv is queued with the folds (norm.hip: m1_colsum_defer): d(out) is read at the fold
+            _FOLD["keep"].append((dy, torch.cuda.current_stream(w_param.device)))
         _FOLD["bytes"] += ws.numel() * ws.element_size()
         if _BRANCH["on"] and ((_FOLD["async"] > 0 and len(_FOLD["keep"]) >= _FOLD["async"]) or
                               (_FOLD["async_mb"] > 0 and _FOLD["bytes"] >= _FOLD["async_mb"] << 20)):
