@@ -199,6 +199,7 @@ static int make_geo(Geo& g, int N, int Dt, int Ht, int Wt, int Dp, int Hp, int W
 
 extern "C" int m1_gate_sigma_fwd(const void* theta, const void* phi, const float* wpsi, const float* bpsi, void* sigma,
                                  int N, int Dt, int Ht, int Wt, int Dp, int Hp, int Wp, int C, int dtype, void* stream) {
+    if (m1_debug_skip("gate")) return M1_OK;
     if (!theta || !phi || !wpsi || !bpsi || !sigma) return M1_ERR_BAD_ARG;
     Geo g; int rc = make_geo(g, N, Dt, Ht, Wt, Dp, Hp, Wp, C); if (rc) return rc;
     M1ProfScope ps("gate_sigma_fwd", 0.0, (double)N * Dt * Ht * Wt * C * (dtype == M1_BF16 ? 2 : 4), (hipStream_t)stream);
@@ -210,6 +211,7 @@ extern "C" int m1_gate_sigma_bwd(const void* theta, const void* phi, const float
                                  const void* dsigma, void* dtheta, void* dphi, float* dwpsi, float* dbpsi, int N, int Dt,
                                  int Ht, int Wt, int Dp, int Hp, int Wp, int C, int dtype, float* ws, int accumulate,
                                  void* stream) {
+    if (m1_debug_skip("gate")) return M1_OK;
     if (!theta || !phi || !wpsi || !sigma || !dsigma || !dtheta || !dphi || !dwpsi || !dbpsi || !ws) return M1_ERR_BAD_ARG;
     Geo g; int rc = make_geo(g, N, Dt, Ht, Wt, Dp, Hp, Wp, C); if (rc) return rc;
     M1ProfScope ps("gate_sigma_bwd", 0.0, 4.0 * N * Dt * Ht * Wt * C * (dtype == M1_BF16 ? 2 : 4), (hipStream_t)stream);
@@ -301,6 +303,7 @@ static int mul_fwd_impl(const void* x, const void* sigma, void* y, const MulGeo&
 
 extern "C" int m1_mul_sigma_fwd(const void* x, const void* sigma, void* y, int N, int D, int H, int W, int C, int s0, int s1,
                                 int s2, int dtype, void* stream) {
+    if (m1_debug_skip("gate")) return M1_OK;
     if (!x || !sigma || !y) return M1_ERR_BAD_ARG;
     MulGeo g; int rc = make_mulgeo(g, N, D, H, W, C, s0, s1, s2); if (rc) return rc;
     M1ProfScope ps("mul_sigma_fwd", 0.0, 2.0 * N * D * H * W * C * (dtype == M1_BF16 ? 2 : 4), (hipStream_t)stream);
@@ -327,6 +330,7 @@ static int mul_bwd_impl(const void* x, const void* sigma, const void* dy, void* 
 
 extern "C" int m1_mul_sigma_bwd(const void* x, const void* sigma, const void* dy, void* dx, void* dsigma, int N, int D, int H,
                                 int W, int C, int s0, int s1, int s2, int dtype, int accumulate_dx, void* stream) {
+    if (m1_debug_skip("gate")) return M1_OK;
     if (!x || !sigma || !dy || !dx || !dsigma) return M1_ERR_BAD_ARG;
     MulGeo g; int rc = make_mulgeo(g, N, D, H, W, C, s0, s1, s2); if (rc) return rc;
     M1ProfScope ps("mul_sigma_bwd", 0.0, 4.0 * N * D * H * W * C * (dtype == M1_BF16 ? 2 : 4), (hipStream_t)stream);

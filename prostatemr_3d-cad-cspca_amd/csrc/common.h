@@ -93,6 +93,7 @@ template <> struct VecIO<bf16_t, 8> {
 // it back (tests run the same op under several settings in one process).  The call site keeps a pointer to its table entry: one load.
 struct M1CfgEntry { char name[40]; int def; int def_known; int env; int env_set; int ovr; int has_ovr; volatile int v; };
 M1CfgEntry* m1_cfg_entry(const char* name, int def);
+bool m1_debug_skip(const char* name);
 #define M1_CFG(NAME, DEF) ([]() -> int { static M1CfgEntry* const e_ = m1_cfg_entry(NAME, DEF); return e_->v; }())
 
 // blocks of 256 threads for `per` vector elements whose channel group is (index % cg): at most ~2048 blocks, and

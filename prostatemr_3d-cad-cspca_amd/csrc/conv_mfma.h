@@ -38,6 +38,8 @@ struct MfmaP {
     int korder;                 // 1: K runs [64-byte chunk of the concat][tap] (needs aligned), 0: [tap][concat channel]
     const void* ib_x;           // != nullptr: stat_partial receives the InstanceNorm-BACKWARD sums {sum dy, sum dy*xh} of the (rounded)
     const float* ib_stats; const float* ib_gamma; const float* ib_beta; float ib_slope;   //   outputs instead (GatherSpec::ib_*)
+    int tps;                    // > 0 (conv_mfma_kernel only, one class): the M tiles run PER SAMPLE, tps of them each, so that no tile straddles two
+                                //   samples and the per-tile statistics stay per-sample when V % BM != 0 (round 6)
     float* stat_partial;        // fused InstanceNorm statistics: [N][stat_tiles][OC][2] = {sum, sum of squares} of the ROUNDED
     int stat_tiles;             //   outputs, one partial per 64/128-row tile (mode 0, tiles never straddle samples) or, in the
                                 //   halo kernel, per (sample, block row)

@@ -60,10 +60,16 @@ __device__ __forceinline__ unsigned lds_addr_of(const void* p) { return (unsigne
 // (global_load_lds_dwordx4), no staging registers and no ds_write pass -- the VGPR -> LDS store path (<= 85 B/clk/CU)
 // was the bound of the register-staged loop.  The DMA writes lane-linear, so the XOR swizzle is applied on the SOURCE
 // side: the lane that owns LDS slot (row, s) fetches K-segment s ^ swz(row).
-template <typename T, int BM, int BN, int WM, int WN, int KC, bool GLDS>
-__global__ void __launch_bounds__(WM * WN * 64) conv_mfma_kernel(MfmaP p) {
+// KG > 1 (round 6, LDS-DMA path): K GROUPS inside the block instead of split-K across blocks for the deep levels' small launches
+// (M = 4,000 / 500 voxels per sample: a few hundred tiles).  The block carries KG wave groups of WM x WN waves; group g walks the g-th
+// K range of the tile with its own pipeline buffers, the groups' accumulators are added through LDS in group order, and group 0 runs
+// the ordinary epilogue -- InstanceNorm statistics (or InstanceNorm-backward sums) included.  Against split-K over blockIdx.y: the same
+// waves per CU, no fp32 slabs, no finish / statistics pass over them (FinishStatsF: 20 launches of 15-26 us per C3 step).
+template <typename T, int BM, int BN, int WM, int WN, int KC, bool GLDS, int KG = 1>
+__global__ void __launch_bounds__(WM * WN * 64 * KG) conv_mfma_kernel(MfmaP p) {
 #if defined(__HIP_DEVICE_COMPILE__)      // (buffer-resource builtins do not exist in the host pass)
-    constexpr int NTHR = WM * WN * 64, NW = WM * WN;        // 4 waves, or 8 for the 128x128 tile of the deep layers
+    constexpr int NTHR = WM * WN * 64, NW = WM * WN;        // threads / waves of ONE K group: 4 waves, or 8 for the 128x128 tile of the deep layers
+    static_assert(KG == 1 || GLDS, "K groups: LDS-DMA path only");
     constexpr int SEG = MT<T>::SEG;
     constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
     constexpr int A_BYTES = BM * 64, B_BYTES = BN * 64;
@@ -81,12 +87,15 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_mfma_kernel(MfmaP p) {
     int* s_tap = s_srcSeg + M1_MAX_SRC;                                            // [27] packed dd|dh|dw
     int* s_tdl = s_tap + MF_MAX_TAPS;                                              // [27] the same as a linear voxel delta
     constexpr int TBL_BYTES = (BM * 20 + M1_MAX_SRC * 16 + 2 * MF_MAX_TAPS * 4 + 15) / 16 * 16;
-    unsigned char* A_s = smem + TBL_BYTES;               // [2][KC][BM][64]
+    // (tid, wave: inside the K group -- everything below is group-local; the tables are written by every group with the same values)
+    const int kg = KG > 1 ? __builtin_amdgcn_readfirstlane((int)threadIdx.x / NTHR) : 0;
+    const int tid = KG > 1 ? (int)threadIdx.x - kg * NTHR : (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int GROUP_BYTES = 2 * KC * (A_BYTES + B_BYTES);
+    unsigned char* A_s = smem + TBL_BYTES + kg * GROUP_BYTES;   // [2][KC][BM][64]
     unsigned char* B_s = A_s + 2 * KC * A_BYTES;         // [2][KC][BN][64]
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
-    const int cls = blockIdx.y / p.ksplit, ksp = blockIdx.y % p.ksplit;
+    const int cls = blockIdx.y / p.ksplit, ksp = (blockIdx.y % p.ksplit) * KG + kg;     // K range of this group: ksp of ksplit * KG
     const int oc0 = blockIdx.z * BN;
 
     int pdc = 0, phc = 0, pwc = 0, QD = p.OD, QH = p.OH, QW = p.OW;
@@ -100,13 +109,18 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_mfma_kernel(MfmaP p) {
     // Workgroups go to the 8 XCDs round-robin (block b -> XCD b & 7): hand each XCD one contiguous range of M tiles so
     // that the halo voxels neighbouring tiles gather are shared through that XCD's L2.  gridDim.x = 8 * ceil(tiles / 8).
     const long long tile = (long long)(blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
-    const long long m0 = tile * BM;
+    long long m0 = tile * BM, m_end = Mtot;
+    if (p.tps > 0) {               // tiles per sample: the last tile of a sample is cut at the sample's end
+        if (tile >= (long long)p.tps * p.N) return;
+        const long long tn = tile / p.tps;
+        m0 = tn * QV + (tile - tn * p.tps) * BM; m_end = (tn + 1) * QV;
+    }
     if (m0 >= Mtot) return;
 
     for (int r = tid; r < BM; r += NTHR) {
         const long long m = m0 + r;
         int4 ri = make_int4(-1, 0, 0, 0); int orow = -1;
-        if (m < Mtot) {
+        if (m < m_end) {
             int n, qw, qh, qd;
             if (Mtot < (1ll << 31)) {         // (every tensor the 31-bit LDS-DMA offsets can address: 32-bit divisions, ~4x fewer instructions)
                 const unsigned mm = (unsigned)m, qv = (unsigned)QV;
@@ -139,7 +153,7 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_mfma_kernel(MfmaP p) {
     const int spt = p.spt;                               // segments per tap
     const int nseg = ntaps * spt;
     const int nchunks_all = (nseg + 3) >> 2;
-    const int cps = (nchunks_all + p.ksplit - 1) / p.ksplit;        // chunks per split
+    const int cps = (nchunks_all + p.ksplit * KG - 1) / (p.ksplit * KG);        // chunks per split
     const int c_beg = ksp * cps;
     const int nchunks = (c_beg + cps <= nchunks_all ? cps : nchunks_all - c_beg);   // may be <= 0 for a trailing split
     const int kpad = p.cls_kpad[cls];
@@ -371,7 +385,8 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_mfma_kernel(MfmaP p) {
     // fragment read addresses of tile (i or j) = base + 1024*tile (16 rows x 64 B; the swizzle term is tile-invariant)
     const unsigned a_rd = lds_addr_of(A_s) + (wm * (BM / WM) + fr) * 64 + swz(fr, fs) * 16;
     const unsigned b_rd = lds_addr_of(B_s) + (wn * (BN / WN) + fr) * 64 + swz(fr, fs) * 16;
-    const int nstages = (nchunks + KC - 1) / KC;
+    // (K groups share the block's barriers: every group runs the stages of a FULL range; beyond its own range a group stages zeros)
+    const int nstages = KG > 1 ? (cps + KC - 1) / KC : (nchunks + KC - 1) / KC;
     if (nstages > 0) {
         if constexpr (GLDS) issue(0, 0);
         else { prefetch_stage(0); stage(0); }
@@ -450,6 +465,27 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_mfma_kernel(MfmaP p) {
         __syncthreads();          // (GLDS: the barrier's fence also waits for the stage in flight, vmcnt(0))
     }
 
+    if constexpr (KG > 1) {        // add the groups' accumulators in group order (fixed: deterministic); groups > 0 are done then
+        float* const xr = reinterpret_cast<float*>(smem + TBL_BYTES);          // [(KG - 1)][NTHR][TM * TN * 4]: the pipeline buffers are free
+        if (kg > 0) {
+            float* dst = xr + ((size_t)(kg - 1) * NTHR + tid) * (TM * TN * 4);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) *reinterpret_cast<f32x4_t*>(dst + (i * TN + j) * 4) = acc[i][j];
+        }
+        __syncthreads();
+        if (kg > 0) return;
+#pragma unroll
+        for (int g = 1; g < KG; ++g) {
+            const float* src = xr + ((size_t)(g - 1) * NTHR + tid) * (TM * TN * 4);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] += *reinterpret_cast<const f32x4_t*>(src + (i * TN + j) * 4);
+        }
+        __syncthreads();           // (group 0 alone from here: the epilogue tile overwrites what was just read)
+    }
     if (p.ksplit > 1) {            // partial K range: plain stores into this split's own fp32 slab; the finish kernel adds the
                                    // slabs in a fixed order (run-to-run deterministic, unlike fp32 atomics).  A trailing split
                                    // with no chunks stores its zeros, so the slabs need no memset.
@@ -484,7 +520,7 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_mfma_kernel(MfmaP p) {
         }
     __syncthreads();
     if (p.stat_partial) {          // per-tile column sums of the stored (rounded) values -> deterministic partials
-        constexpr int EPI_BYTES = (int)((BM * CP * sizeof(T) + 15) / 16 * 16), PIPE_BYTES = 2 * KC * (A_BYTES + B_BYTES);
+        constexpr int EPI_BYTES = (int)((BM * CP * sizeof(T) + 15) / 16 * 16), PIPE_BYTES = 2 * KC * (A_BYTES + B_BYTES) * KG;
         float* red = reinterpret_cast<float*>(A_s + (PIPE_BYTES > EPI_BYTES ? PIPE_BYTES : EPI_BYTES));   // 2 KB scratch behind both
         constexpr int G = NTHR / BN;                      // row groups
         const int col = tid % BN, rg = tid / BN;
@@ -573,10 +609,10 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_mfma_kernel(MfmaP p) {
 #endif
 }
 
-template <typename T, int BM, int BN, int KC, int NTHR>
+template <typename T, int BM, int BN, int KC, int NTHR, int KG = 1>
 static constexpr size_t mfma_smem_bytes() {
     size_t tbl = (BM * 20 + M1_MAX_SRC * 16 + 2 * MF_MAX_TAPS * 4 + 15) / 16 * 16;      // = TBL_BYTES of the kernel
-    size_t pipe = (size_t)KC * (2 * BM * 64 + 2 * BN * 64);
+    size_t pipe = (size_t)KC * (2 * BM * 64 + 2 * BN * 64) * KG;
     size_t epi = ((size_t)BM * (BN + MT<T>::SEG) * sizeof(T) + 15) / 16 * 16;
     return tbl + (pipe > epi ? pipe : epi) + NTHR * 2 * sizeof(float);
 }
@@ -936,9 +972,36 @@ static int launch_cfg_kc(const MfmaP& mp, long long maxM, int OCpad, hipStream_t
     return m1_check_launch();
 }
 
+// K groups inside the block (conv_mfma_kernel<.., KG>): the small 64-row tiles of the deep levels, bf16, LDS-DMA path, two chunks per stage
+template <typename T, int BM, int BN, int WM, int WN, int KG>
+static int launch_cfg_kg(const MfmaP& mp, long long maxM, int OCpad, hipStream_t st) {
+    constexpr size_t smem = mfma_smem_bytes<T, BM, BN, 2, WM * WN * 64, KG>();
+    if constexpr (sizeof(T) != 2 || smem > 160 * 1024 - 256 || WM * WN * 64 * KG > 1024) return M1_ERR_UNSUPPORTED;
+    else {
+        dim3 grid((unsigned)(cdiv_ll(cdiv_ll(maxM, BM), 8) * 8), mp.nclasses * mp.ksplit, OCpad / BN);
+        static bool attr_set = false;     // per instantiation
+        if (!attr_set) {
+            if (hipFuncSetAttribute((const void*)conv_mfma_kernel<T, BM, BN, WM, WN, 2, true, KG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) return M1_ERR_LAUNCH;
+            attr_set = true;
+        }
+        m1_note_kernel("conv_mfma:%dx%d:w%d:ks%d:kg%d", BM, BN, WM * WN, mp.ksplit, KG);
+        hipLaunchKernelGGL((conv_mfma_kernel<T, BM, BN, WM, WN, 2, true, KG>), grid, dim3(WM * WN * 64 * KG), smem, st, mp);
+        return m1_check_launch();
+    }
+}
+// the K groups a tile shape can carry in 160 KB of LDS / 1,024 threads (0: none)
+static inline int mfma_kg_max(int BM, int BN, int nthr) {
+    const int group = 2 * 2 * (BM + BN) * 64;             // two stages of two chunks
+    int k = (150 * 1024) / group; if (k > 1024 / nthr) k = 1024 / nthr; if (k > 4) k = 4;
+    return k >= 2 ? k : 0;
+}
+
 // two 64-byte K-chunks per pipeline stage (one barrier per 64 bf16 / 32 fp32 of K) once the K loop is long enough
 template <typename T, int BM, int BN, int WM, int WN>
-static int launch_cfg(const MfmaP& mp, long long maxM, int OCpad, hipStream_t st) {
+static int launch_cfg(const MfmaP& mp, long long maxM, int OCpad, hipStream_t st, int kg = 1) {
+    if (kg == 2) return launch_cfg_kg<T, BM, BN, WM, WN, 2>(mp, maxM, OCpad, st);
+    if (kg == 3) return launch_cfg_kg<T, BM, BN, WM, WN, 3>(mp, maxM, OCpad, st);
+    if (kg == 4) return launch_cfg_kg<T, BM, BN, WM, WN, 4>(mp, maxM, OCpad, st);
     int minchunks = 1 << 30;
     for (int c = 0; c < mp.nclasses; ++c) { const int n = mp.cls_kpad[c] / (4 * MT<T>::SEG) / mp.ksplit; if (n < minchunks) minchunks = n; }
     return minchunks >= 6 ? launch_cfg_kc<T, BM, BN, WM, WN, 2>(mp, maxM, OCpad, st)
@@ -969,6 +1032,18 @@ static int run_mfma(const GatherSpec& g, void* ws, int ws_packed, hipStream_t st
     int t3bn = 0, t3ks = 1;
     const bool t3 = sizeof(T) == 2 && m1_ct3_plan(g, &t3bn, &t3ks);
     if (t3) { pl.BN = t3bn; pl.BM = 256; pl.ksplit = t3ks; }
+    // K groups inside the block instead of split-K across blocks (conv_mfma_kernel<.., KG>): the 64-row tiles of the deep levels whose
+    // split the plan put at 2..4 (one kind of tile per launch: every class then has >= 8 chunks per group).  M1_MFMA_KG=0: split-K slabs
+    int kgroups = 1;
+    if (sizeof(T) == 2 && !t3 && pl.BM == 64 && (pl.BN == 64 || pl.BN == 128) && pl.ksplit >= 2 && M1_CFG("M1_MFMA_KG", 1)) {
+        bool al = true;
+        for (int i = 0; i < g.nsrc; ++i) al = al && g.srcC[i] % (4 * SEG) == 0;
+        const int kmax = mfma_kg_max(64, pl.BN, 256);
+        // (only where the unsplit tiles already cover the chip: the groups of a block share its CU, split-K blocks spread over CUs --
+        //  on the 32..128 tiles of the (5,10,10) level the in-block form was 40-60 % slower)
+        const long long tiles64 = cdiv_ll(spec_maxM(g), 64) * spec_ncls(g) * ((g.OC + pl.BN - 1) / pl.BN);
+        if (al && kmax >= 2 && pl.ksplit <= 4 && tiles64 >= 200) { kgroups = pl.ksplit < kmax ? pl.ksplit : kmax; pl.ksplit = 1; }
+    }
     const int BN = pl.BN, OCpad = (g.OC + BN - 1) / BN * BN;
     long long tot = 0;
     build_classes(g, CC, SEG, OCpad, &mp, &pp, &tot);
@@ -979,20 +1054,25 @@ static int run_mfma(const GatherSpec& g, void* ws, int ws_packed, hipStream_t st
     // its data gradient, neutral end to end; with the stacked passes (4 volumes per launch): 647 -> 624 us forward, 613 -> 557 us
     // data gradient, -1.7 % per C3 step, C2 neutral.  256x128 tiles on 8 waves (one block per CU) were slower (702 / 678 us).
     int c8 = M1_CFG("M1_CONV8", 1);
-    const bool use8 = !t3 && c8 && BN == 128 && (pl.ksplit == 1 || (c8 >= 2 && pl.BM == 128)) &&
+    const bool use8 = !t3 && kgroups == 1 && c8 && BN == 128 && (pl.ksplit == 1 || (c8 >= 2 && pl.BM == 128)) &&
                       cdiv_ll(spec_maxM(g), 128) * spec_ncls(g) * (OCpad / 128) * pl.ksplit >= 160;
     const int bm_eff = t3 ? 256 : (use8 ? 128 : pl.BM);
     // (the staged-run kernel tiles every sample on its own: its tiles never straddle samples)
-    bool fuse_stats = g.stats_out && g.stats_ws && g.mode == 0 && pl.ksplit == 1 && (g.N == 1 || Vout % bm_eff == 0 || t3) &&
-                      !g.accumulate;           // (this kernel's statistics come from its own tile, before the add)
+    // (the implicit-GEMM kernel tiles the samples one by one when V is no multiple of the tile -- MfmaP::tps, round 6: the deep levels'
+    //  4,000 / 500 voxels per sample; the halo / pointwise kernels have their own rows and ignore it)
     const int tiles_ps = t3 ? m1_ct3_tiles_per_sample(g.OD, g.OH, g.OW) : (int)cdiv_ll(Vout, bm_eff);      // epilogue partial rows per sample
+    const bool per_sample = !t3 && g.N > 1 && Vout % bm_eff != 0 && spec_ncls(g) == 1 && pl.ksplit == 1 && M1_CFG("M1_MFMA_TPS", 1) &&
+                            (long long)tiles_ps * bm_eff * g.N < (1ll << 31);
+    bool fuse_stats = g.stats_out && g.stats_ws && g.mode == 0 && pl.ksplit == 1 && (g.N == 1 || Vout % bm_eff == 0 || t3 || per_sample) &&
+                      !g.accumulate;           // (this kernel's statistics come from its own tile, before the add)
     if (fuse_stats) { mp.stat_partial = g.stats_ws; mp.stat_tiles = tiles_ps; }
     // InstanceNorm-backward sums from the epilogue of a data gradient (GatherSpec::ib_*): one output tensor, one parity class
     // (rows run sample-major like a forward conv's), tiles that do not straddle samples
     const bool ib_want = g.ib_x && g.ib_partial && g.ib_nparts && !g.stats_out && !g.accumulate && g.nout <= 1 && spec_ncls(g) == 1 &&
                          (g.nout == 0 || (g.outs[0] && !g.outAcc[0] && g.outC[0] == g.OC));
     if (g.ib_nparts) *g.ib_nparts = 0;
-    bool ib_epi = ib_want && pl.ksplit == 1 && (g.N == 1 || Vout % bm_eff == 0 || t3) && tiles_ps <= g.ib_cap;
+    bool ib_epi = ib_want && pl.ksplit == 1 && (g.N == 1 || Vout % bm_eff == 0 || t3 || per_sample) && tiles_ps <= g.ib_cap;
+    mp.tps = (per_sample && (fuse_stats || ib_epi)) ? tiles_ps : 0;
     if (ib_epi) {
         mp.stat_partial = g.ib_partial; mp.stat_tiles = tiles_ps;
         mp.ib_x = g.ib_x; mp.ib_stats = g.ib_stats; mp.ib_gamma = g.ib_gamma; mp.ib_beta = g.ib_beta; mp.ib_slope = g.ib_slope;
@@ -1007,7 +1087,7 @@ static int run_mfma(const GatherSpec& g, void* ws, int ws_packed, hipStream_t st
         mp.slab_elems = (long long)out_elems(g);
     }
     // wide, shallow bf16 layers: the halo-tile kernel (conv_halo.hip) stages every input voxel once per tile, not per tap
-    const long long maxM = spec_maxM(g);
+    const long long maxM = mp.tps > 0 ? (long long)mp.tps * g.N * bm_eff : spec_maxM(g);      // (conv_mfma launches size their grid by it)
     bool halo = false;
     if constexpr (sizeof(T) == 2) {
         int hen = M1_CFG("M1_HALO", 1);
@@ -1080,7 +1160,7 @@ static int run_mfma(const GatherSpec& g, void* ws, int ws_packed, hipStream_t st
     else
     switch (BN) {
         case 128: rc2 = use8 ? launch_cfg<T, 128, 128, 2, 4>(mp, maxM, OCpad, st)
-                             : (small ? launch_cfg<T, 64, 128, 1, 4>(mp, maxM, OCpad, st) : launch_cfg<T, 128, 128, 2, 2>(mp, maxM, OCpad, st)); break;
+                             : (small ? launch_cfg<T, 64, 128, 1, 4>(mp, maxM, OCpad, st, mp.aligned ? kgroups : 1) : launch_cfg<T, 128, 128, 2, 2>(mp, maxM, OCpad, st)); break;
         case 160: if constexpr (sizeof(T) == 2) rc2 = launch_cfg<T, 128, 160, 2, 2>(mp, maxM, OCpad, st); else rc2 = M1_ERR_UNSUPPORTED; break;
         case 64: {
             // 64 / 32 columns on 8 waves of 32x32 / 32x16 instead of 4 waves of 32x64 / 32x32 (M1_F32_W8: bit 0 fp32, bit 1 bf16).  fp32: an
@@ -1089,7 +1169,7 @@ static int run_mfma(const GatherSpec& g, void* ws, int ws_packed, hipStream_t st
             // 7.86 -> 7.59 ms, C3 neutral
             int w8 = M1_CFG("M1_F32_W8", 3);
             if (((sizeof(T) == 4 && (w8 & 1)) || (sizeof(T) == 2 && (w8 & 2))) && !small) rc2 = launch_cfg<T, 128, 64, 4, 2>(mp, maxM, OCpad, st);
-            else rc2 = small ? launch_cfg<T, 64, 64, 2, 2>(mp, maxM, OCpad, st) : launch_cfg<T, 128, 64, 4, 1>(mp, maxM, OCpad, st);
+            else rc2 = small ? launch_cfg<T, 64, 64, 2, 2>(mp, maxM, OCpad, st, mp.aligned ? kgroups : 1) : launch_cfg<T, 128, 64, 4, 1>(mp, maxM, OCpad, st);
             break; }
         case 32: {
             int w8 = M1_CFG("M1_F32_W8", 3);

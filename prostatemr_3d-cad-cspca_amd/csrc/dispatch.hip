@@ -356,6 +356,7 @@ extern "C" int m1_conv_pack_jobs(const m1_conv_desc_t* d, int transposed, int ro
     return n;
 }
 extern "C" int m1_pack_batch(const void* const* jobs_dev, const int* block_prefix_dev, int njobs, int total_blocks, void* stream) {
+    if (m1_debug_skip("pack")) return M1_OK;
     if (njobs < 0 || (njobs > 0 && !jobs_dev) || (block_prefix_dev && total_blocks < njobs)) return M1_ERR_BAD_ARG;
     M1ProfScope ps("pack_batch", 0.0, 0.0, (hipStream_t)stream);
     return m1_pack_batch_internal(jobs_dev, block_prefix_dev, njobs, total_blocks, (hipStream_t)stream);
@@ -364,6 +365,7 @@ extern "C" int m1_pack_batch(const void* const* jobs_dev, const int* block_prefi
 // ---- Conv3D ------------------------------------------------------------------------------------------------------
 extern "C" int m1_conv3d_fwd(const m1_conv_desc_t* d, const float* w, const float* bias, void* y, float* stats, void* ws,
                              int ws_packed, void* stream) {
+    if (m1_debug_skip("conv_fwd")) return M1_OK;
     if (!desc_ok(d) || !w || !y) return M1_ERR_BAD_ARG;
     M1ProfScope ps(prof_name("conv3d_fwd", d).s, 2.0 * conv_macs(d, false), conv_bytes(d, false), (hipStream_t)stream);
     FwdGroups fg;
@@ -408,6 +410,7 @@ static bool pair_ok(const m1_conv_desc_t* d, int C1) {
 }
 extern "C" int m1_conv3d_pair_fwd(const m1_conv_desc_t* d, const float* w1, const float* b1, const float* w4, const float* b4, int C1,
                                   void* y1, void* y4, float* stats1, float* stats4, void* ws, int ws_packed, void* stream) {
+    if (m1_debug_skip("conv_fwd")) return M1_OK;
     if (!d || !w1 || !w4 || !y1 || !y4 || !ws || (stats1 == nullptr) != (stats4 == nullptr)) return M1_ERR_BAD_ARG;
     FwdGroups fg;
     if (!pair_ok(d, C1) || fwd_groups(d, false, &fg)) return M1_ERR_UNSUPPORTED;
@@ -426,6 +429,7 @@ extern "C" int m1_conv3d_pair_fwd(const m1_conv_desc_t* d, const float* w1, cons
 }
 extern "C" int m1_conv3d_pair_dgrad(const m1_conv_desc_t* d, const float* w1, const float* w4, int C1, const void* dy1, const void* dy4,
                                     void* const* dx, const int* accumulate, void* ws, int ws_packed, void* stream) {
+    if (m1_debug_skip("conv_dgrad")) return M1_OK;
     if (!d || !w1 || !w4 || !dy1 || !dy4 || !dx || !ws) return M1_ERR_BAD_ARG;
     if (!pair_ok(d, C1)) return M1_ERR_UNSUPPORTED;
     M1ProfScope ps(prof_name("conv3d_dgrad", d).s, 2.0 * conv_macs(d, false), conv_bytes(d, false), (hipStream_t)stream);
@@ -470,6 +474,7 @@ extern "C" int m1_conv3d_pair_supported(const m1_conv_desc_t* d, int C1) {
 
 extern "C" int m1_convT3d_fwd(const m1_conv_desc_t* d, const float* w, const float* bias, void* y, void* ws, int ws_packed,
                               void* stream) {
+    if (m1_debug_skip("conv_fwd")) return M1_OK;
     if (!desc_ok(d) || !w || !y) return M1_ERR_BAD_ARG;
     M1ProfScope ps(prof_name("convT3d_fwd", d).s, 2.0 * conv_macs(d, true), conv_bytes(d, true), (hipStream_t)stream);
     FwdGroups fg;
@@ -508,6 +513,7 @@ static int dgrad_common(const m1_conv_desc_t* d, bool T, const float* w, const v
 }
 extern "C" int m1_conv3d_dgrad(const m1_conv_desc_t* d, const float* w, const void* dy, void* const* dx, const int* accumulate,
                                void* ws, int ws_packed, void* stream) {
+    if (m1_debug_skip("conv_dgrad")) return M1_OK;
     if (!desc_ok(d) || !w || !dy || !dx) return M1_ERR_BAD_ARG;
     M1ProfScope ps(prof_name("conv3d_dgrad", d).s, 2.0 * conv_macs(d, false), conv_bytes(d, false), (hipStream_t)stream);
     return dgrad_common(d, false, w, dy, dx, accumulate, ws, ws_packed, (hipStream_t)stream);
@@ -538,6 +544,7 @@ extern "C" int m1_conv3d_dgrad_inbwd(const m1_conv_desc_t* d, const float* w, co
 }
 extern "C" int m1_convT3d_dgrad(const m1_conv_desc_t* d, const float* w, const void* dy, void* const* dx, const int* accumulate,
                                 void* ws, int ws_packed, void* stream) {
+    if (m1_debug_skip("conv_dgrad")) return M1_OK;
     if (!desc_ok(d) || !w || !dy || !dx) return M1_ERR_BAD_ARG;
     M1ProfScope ps(prof_name("convT3d_dgrad", d).s, 2.0 * conv_macs(d, true), conv_bytes(d, true), (hipStream_t)stream);
     return dgrad_common(d, true, w, dy, dx, accumulate, ws, ws_packed, (hipStream_t)stream);
@@ -690,12 +697,14 @@ static int wgrad_common(const m1_conv_desc_t* d, bool T, const void* dy, float* 
 }
 extern "C" int m1_conv3d_wgrad(const m1_conv_desc_t* d, const void* dy, float* dw, float* db, void* ws, int accumulate,
                                void* stream) {
+    if (m1_debug_skip("conv_wgrad")) return M1_OK;
     if (!desc_ok(d) || !dy || !dw) return M1_ERR_BAD_ARG;
     M1ProfScope ps(prof_name("conv3d_wgrad", d).s, 2.0 * conv_macs(d, false), conv_bytes(d, false), (hipStream_t)stream);
     return wgrad_common(d, false, dy, dw, db, ws, (hipStream_t)stream, accumulate);
 }
 extern "C" int m1_convT3d_wgrad(const m1_conv_desc_t* d, const void* dy, float* dw, float* db, void* ws, int accumulate,
                                 void* stream) {
+    if (m1_debug_skip("conv_wgrad")) return M1_OK;
     if (!desc_ok(d) || !dy || !dw) return M1_ERR_BAD_ARG;
     M1ProfScope ps(prof_name("convT3d_wgrad", d).s, 2.0 * conv_macs(d, true), conv_bytes(d, true), (hipStream_t)stream);
     return wgrad_common(d, true, dy, dw, db, ws, (hipStream_t)stream, accumulate);

@@ -97,3 +97,19 @@ extern "C" int m1_debug_lds_canary(unsigned* bad, int blocks, int spins, void* s
     hipLaunchKernelGGL(m1_lds_canary_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, bad, spins);
     return m1_check_launch();
 }
+
+// M1_DEBUG_SKIP=name[,name...] (measurement aid, results are garbage): the named entry points return M1_OK without launching anything --
+// what a family of kernels costs the REPLAYED step, next to what its kernels cost alone (tools/dbg/skip_families.sh)
+#include <string.h>
+#include <stdlib.h>
+bool m1_debug_skip(const char* name) {
+    static const char* env = getenv("M1_DEBUG_SKIP");
+    if (!env || !*env) return false;
+    const size_t n = strlen(name);
+    for (const char* p = env; *p;) {
+        const char* e = strchr(p, ','); const size_t len = e ? (size_t)(e - p) : strlen(p);
+        if (len == n && !strncmp(p, name, n)) return true;
+        p += len; if (*p == ',') ++p;
+    }
+    return false;
+}

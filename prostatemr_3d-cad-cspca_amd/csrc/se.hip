@@ -540,12 +540,14 @@ extern "C" int m1_se_combine_fwd(const void* y3, const void* y4, const float* st
                                  const float* gamma3, const float* beta3, const float* gamma4, const float* beta4,
                                  const float* g, void* out, int N, long long V, int F, int dtype, float drop_rate,
                                  const uint64_t* rng, uint64_t layer_id, unsigned char* keep_mask, void* stream) {
+    if (m1_debug_skip("se_fwd")) return M1_OK;
     return se_combine_fwd_entry(y3, y4, stats3, stats4, gamma3, beta3, gamma4, beta4, g, out, N, V, F, dtype, drop_rate, rng, layer_id, keep_mask, stream, 0);
 }
 extern "C" int m1_se_combine_dup_fwd(const void* y3, const void* y4, const float* stats3, const float* stats4,
                                      const float* gamma3, const float* beta3, const float* gamma4, const float* beta4,
                                      const float* g, void* out, int N, long long V, int F, int dtype, float drop_rate,
                                      const uint64_t* rng, uint64_t layer_id, unsigned char* keep_mask, void* stream) {
+    if (m1_debug_skip("se_fwd")) return M1_OK;
     return se_combine_fwd_entry(y3, y4, stats3, stats4, gamma3, beta3, gamma4, beta4, g, out, N, V, F, dtype, drop_rate, rng, layer_id, keep_mask, stream, 1);
 }
 
@@ -573,6 +575,7 @@ extern "C" int m1_se_combine_bwd(const void* y3, const void* y4, const float* st
                                  float* dgamma4, float* dbeta4, float* dg, int N, long long V, int F, int dtype,
                                  float drop_rate, const uint64_t* rng, uint64_t layer_id, const unsigned char* keep_mask,
                                  float* ws, int accumulate, void* stream) {
+    if (m1_debug_skip("se_bwd")) return M1_OK;
     return se_combine_bwd_entry(y3, y4, stats3, stats4, gamma3, beta3, gamma4, beta4, g, dout, dy3, dy4, dgamma3, dbeta3, dgamma4, dbeta4, dg,
                                 N, V, F, dtype, drop_rate, rng, layer_id, keep_mask, ws, accumulate, stream, 0);
 }
@@ -582,6 +585,7 @@ extern "C" int m1_se_combine_dup_bwd(const void* y3, const void* y4, const float
                                      float* dgamma4, float* dbeta4, float* dg, int N, long long V, int F, int dtype,
                                      float drop_rate, const uint64_t* rng, uint64_t layer_id, const unsigned char* keep_mask,
                                      float* ws, int accumulate, void* stream) {
+    if (m1_debug_skip("se_bwd")) return M1_OK;
     return se_combine_bwd_entry(y3, y4, stats3, stats4, gamma3, beta3, gamma4, beta4, g, dout, dy3, dy4, dgamma3, dbeta3, dgamma4, dbeta4, dg,
                                 N, V, F, dtype, drop_rate, rng, layer_id, keep_mask, ws, accumulate, stream, 1);
 }

@@ -288,7 +288,7 @@ __global__ void __launch_bounds__(256) wgrad_tf_kernel(TfP p) {
 // A block owns EL consecutive elements; its 256/EL lane rows stride the copies, fold through LDS, and ONE lane adds the
 // total into R -- fixed order, no atomics: the weight gradient of these layers is run-to-run deterministic.
 struct TfFin { float* Rx; long long stride; int ncopies; float* R; int NT, CA, CB; long long RT, RSA; int a_off, b_off;
-               float* bsum; long long rx_bias; int nb; int EL; };
+               float* bsum; long long rx_bias; int nb; int EL; int bias_serial; };
 // (bodies take the block index / block count of THEIR fold, so that one launch can serve many folds: tf_finish_batch_kernel)
 __device__ __forceinline__ void tf_fold_generic(const TfFin& f, unsigned vb, float* red) {
     const long long n = (long long)f.NT * f.CA * f.CB;
@@ -365,12 +365,35 @@ __device__ __forceinline__ void tf_fold_wide(const TfFin& f, unsigned vb, float4
         float* dst = f.R + (long long)t * f.RT + (long long)(a + f.a_off) * f.RSA + b + f.b_off;
         dst[0] += s.x; dst[1] += s.y; dst[2] += s.z; dst[3] += s.w;
     }
-    if (vb == 0)
+    // bias sums (block 0 of the fold): the copies are spread over the lane rows -- 256 / nbp rows stride the copies with four loads in
+    // flight, then fold through LDS in row order.  (Round 6: one thread per bias element used to walk ALL copies, 512 dependent loads
+    // of a single block -- the tail of a batched launch of thousands of blocks, 100-160 us.)
+    if (vb == 0 && f.bias_serial) {                        // (M1_TF_BIAS_SERIAL=1: the round-5 form, for A/B)
         for (int j = threadIdx.x; j < f.nb; j += 256) {
             float sb = 0.f;
             for (int c = 0; c < f.ncopies; ++c) sb += f.Rx[(long long)c * f.stride + n + j];
             f.bsum[j + f.b_off] += sb;
         }
+    } else if (vb == 0 && f.nb > 0) {
+        __syncthreads();                                   // (red is reused)
+        float* const rb = reinterpret_cast<float*>(red);   // 256 floats
+        int nbp = 1; while (nbp < f.nb && nbp < 256) nbp <<= 1;
+        const int rows = 256 / nbp, j = threadIdx.x % nbp, r0 = threadIdx.x / nbp;
+        for (int j0 = 0; j0 < f.nb; j0 += nbp) {
+            float sb = 0.f;
+            if (j0 + j < f.nb) {
+#pragma unroll 4
+                for (int c = r0; c < f.ncopies; c += rows) sb += f.Rx[(long long)c * f.stride + n + j0 + j];
+            }
+            rb[threadIdx.x] = sb;
+            __syncthreads();
+            if (r0 == 0 && j0 + j < f.nb) {
+                for (int q = 1; q < rows; ++q) sb += rb[q * nbp + j];
+                f.bsum[j0 + j + f.b_off] += sb;
+            }
+            __syncthreads();
+        }
+    }
 }
 __global__ void __launch_bounds__(256) tf_finish_wide_kernel(TfFin f) {
     __shared__ float4 red[4][64];
@@ -466,6 +489,7 @@ extern "C" int m1_wgrad_defer(int on) { std::lock_guard<std::mutex> lk(g_fold_mu
 int m1_fold_defer_get() { std::lock_guard<std::mutex> lk(g_fold_mu); return g_fold_defer; }
 extern "C" int m1_wgrad_fold_drop(void) { { std::lock_guard<std::mutex> lk(g_fold_mu); g_fold_pending.clear(); } m1_colsum_drop_pending(); return M1_OK; }
 extern "C" int m1_wgrad_fold_pending(void* stream) {
+    if (m1_debug_skip("fold")) return m1_wgrad_fold_drop();
     {
         std::lock_guard<std::mutex> lk(g_fold_mu);
         const int rc = fold_launch_pending_locked((hipStream_t)stream); if (rc) return rc;
@@ -475,7 +499,8 @@ extern "C" int m1_wgrad_fold_pending(void* stream) {
 
 // shared with the per-tap kernel (wgrad_mfma.hip), which uses the same partial-copy scheme for small weight tensors
 int m1_wg_rx_finish(float* rx, long long stride, int ncopies, const WgradSpec& g, long long nw, hipStream_t st) {
-    TfFin f{rx, stride, ncopies, g.R, g.kd * g.kh * g.kw, g.CA, g.CB, g.RT, g.RSA, g.a_off, g.b_off, g.bsum, nw, g.bsum ? g.CB : 0, 32};
+    TfFin f{rx, stride, ncopies, g.R, g.kd * g.kh * g.kw, g.CA, g.CB, g.RT, g.RSA, g.a_off, g.b_off, g.bsum, nw, g.bsum ? g.CB : 0, 32,
+            M1_CFG("M1_TF_BIAS_SERIAL", 0)};
     const long long n = (long long)f.NT * f.CA * f.CB + f.nb;
     int mode = 0; long long blocks;
     if (ncopies <= 16 && f.CB % 4 == 0 && n >= (1 << 16)) {
