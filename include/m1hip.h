@@ -263,6 +263,12 @@ int m1_gate_sigma_bwd(const void* theta, const void* phi, const float* wpsi, con
 /* y = sigma_up * x : x (N,D,H,W,C), sigma (N,D/ss0,H/ss1,W/ss2) */
 int m1_mul_sigma_fwd(const void* x, const void* sigma, void* y, int N, int D, int H, int W, int C, int s0,
                      int s1, int s2, int dtype, void* stream);
+/* Both of the above as ONE launch (B:113-124): sigma (N,Dt,Ht,Wt) is written AND y = sigma_up * x with the stored (rounded) sigma;
+ * x, y (N,D,H,W,Cx), Ci = channels of theta / phi, (Dt,Ht,Wt) = (D/s0, H/s1, W/s2).  M1_ERR_UNSUPPORTED (nothing launched) for channel
+ * counts that are no multiple of a 16-byte vector or a mismatching sigma grid: take the two calls. */
+int m1_gate_sigma_mul_fwd(const void* theta, const void* phi, const float* wpsi, const float* bpsi, void* sigma, const void* x,
+                          void* y, int N, int Dt, int Ht, int Wt, int Dp, int Hp, int Wp, int Ci, int D, int H, int W, int Cx,
+                          int s0, int s1, int s2, int dtype, void* stream);
 /* accumulate_dx != 0: dx += sigma_up * dy (x also feeds other layers, see m1_conv3d_dgrad); dsigma is always overwritten */
 int m1_mul_sigma_bwd(const void* x, const void* sigma, const void* dy, void* dx, void* dsigma, int N, int D,
                      int H, int W, int C, int s0, int s1, int s2, int dtype, int accumulate_dx, void* stream);

@@ -102,6 +102,7 @@ SIGNATURES = {
     "m1_gate_sigma_fwd": (_i, [_vp] * 5 + [_i] * 9 + [_vp]),
     "m1_gate_sigma_bwd": (_i, [_vp] * 9 + [_i] * 9 + [_vp, _i, _vp]),
     "m1_mul_sigma_fwd": (_i, [_vp] * 3 + [_i] * 9 + [_vp]),
+    "m1_gate_sigma_mul_fwd": (_i, [_vp] * 7 + [_i] * 16 + [_vp]),
     "m1_mul_sigma_bwd": (_i, [_vp] * 5 + [_i] * 10 + [_vp]),
     "m1_latent_sample_fwd": (_i, [_vp, _vp, _vp, _i, _ll, _i, _i, _i, _vp]),
     "m1_latent_sample_bwd": (_i, [_vp, _vp, _vp, _vp, _i, _ll, _i, _i, _i, _vp]),

@@ -1214,6 +1214,71 @@ def mul_sigma(x, sigma, ss=(1, 1, 1)):
     return _MulSigma.apply(x, sigma, tuple(ss))
 
 
+class _GateSigmaMul(torch.autograd.Function):
+    """sigma = gate_sigma(theta, phi, psi) and y = mul_sigma(x, sigma) as ONE forward launch (m1_gate_sigma_mul_fwd, B:113-124); the
+    backward runs the two backward entry points in order (the product first: it produces d(sigma))."""
+
+    @staticmethod
+    def forward(ctx, theta, phi, wpsi, bpsi, x, ss):
+        _req(theta, phi, x)
+        N, Dt, Ht, Wt, Ci = (int(v) for v in theta.shape)
+        Dp, Hp, Wp = (int(v) for v in phi.shape[1:4])
+        _, D, H, W, Cx = (int(v) for v in x.shape)
+        sigma = torch.empty((N, Dt, Ht, Wt), dtype=theta.dtype, device=theta.device)
+        y = torch.empty_like(x)
+        L.check(L.load().m1_gate_sigma_mul_fwd(_p(theta), _p(phi), _p(wpsi), _p(bpsi), _p(sigma), _p(x), _p(y), N, Dt, Ht, Wt, Dp, Hp, Wp,
+                                               Ci, D, H, W, Cx, int(ss[0]), int(ss[1]), int(ss[2]), _dt(x), _stream()),
+                "m1_gate_sigma_mul_fwd")
+        ctx.save_for_backward(theta, phi, wpsi, sigma, x)
+        ctx.w_param, ctx.b_param = wpsi, bpsi
+        ctx.ss = tuple(int(v) for v in ss)
+        ctx.gslot = _slot_of(x)
+        ctx.set_materialize_grads(False)                     # (an unused output's gradient arrives as None, not as a zero tensor)
+        return y, sigma
+
+    @staticmethod
+    def backward(ctx, dy, dsigma_out):
+        theta, phi, wpsi, sigma, x = ctx.saved_tensors
+        if dy is None:                                       # (only sigma was used downstream)
+            dy = torch.zeros_like(x)
+        dy = dy.contiguous()
+        lib = L.load()
+        N, D, H, W, Cx = (int(v) for v in x.shape)
+        dsig = torch.empty_like(sigma)
+        dx, acc_x = _slot_target(ctx.gslot, x)
+        L.check(lib.m1_mul_sigma_bwd(_p(x), _p(sigma), _p(dy), _p(dx), _p(dsig), N, D, H, W, Cx, *ctx.ss, _dt(x), acc_x, _stream()),
+                "m1_mul_sigma_bwd")
+        _slot_written(ctx.gslot)
+        if dsigma_out is not None:                           # sigma is an output of the block too (B:130): its own gradient, if any
+            dsig = dsig + dsigma_out.to(dsig.dtype)
+        _, Dt, Ht, Wt, Ci = (int(v) for v in theta.shape)
+        Dp, Hp, Wp = (int(v) for v in phi.shape[1:4])
+        dtheta, dphi = torch.empty_like(theta), torch.empty_like(phi)
+        wbuf, acc, dw = _sink(ctx.w_param)
+        bbuf, acc_b, db = _sink(ctx.b_param)
+        if acc_b != acc:
+            wbuf, bbuf, acc = torch.empty_like(wpsi), torch.empty(1, dtype=torch.float32, device=theta.device), 0
+            dw, db = wbuf, bbuf
+        ws = _ws(N, Dt * Ht * Wt, Ci, 2, theta.device)
+        L.check(lib.m1_gate_sigma_bwd(_p(theta), _p(phi), _p(wpsi), _p(sigma), _p(dsig), _p(dtheta), _p(dphi), _p(wbuf), _p(bbuf),
+                                      N, Dt, Ht, Wt, Dp, Hp, Wp, Ci, _dt(theta), _p(ws), acc, _stream()), "m1_gate_sigma_bwd")
+        return dtheta, dphi, dw, db, dx, None
+
+
+_GATE_FUSED = {"on": _os.environ.get("M1_GATE_FWD_FUSED", "1") != "0"}
+
+
+def gate_sigma_mul(theta, phi, wpsi, bpsi, x, ss=(1, 1, 1)):
+    """(y, sigma) of a grid attention gate's non-GEMM part: one launch where the shapes allow it, else gate_sigma + mul_sigma."""
+    vec = 8 if theta.dtype == torch.bfloat16 else 4
+    ok = (_GATE_FUSED["on"] and theta.shape[-1] % vec == 0 and x.shape[-1] % vec == 0 and
+          all(int(x.shape[1 + i]) == int(theta.shape[1 + i]) * int(ss[i]) for i in range(3)))
+    if ok:
+        return _GateSigmaMul.apply(theta, phi, wpsi, bpsi, x, tuple(ss))
+    sigma = gate_sigma(theta, phi, wpsi, bpsi)
+    return mul_sigma(x, sigma, ss), sigma
+
+
 # ---------------------------------------------------------------------------------------------------------
 # latent sample / KL
 # ---------------------------------------------------------------------------------------------------------

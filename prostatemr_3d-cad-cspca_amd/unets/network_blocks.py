@@ -241,8 +241,7 @@ class GridAttentionBlock3D(nn.Module):
         x_t, x = ops.fanout(conv_tensor, 2)                                            # theta conv and the sigma product
         theta_x = self.theta(x_t)                                                      # B:111
         phi_g = self.phi(g)                                                            # B:112
-        sigma = ops.gate_sigma(theta_x, phi_g, self.psi.kernel, self.psi.bias)         # B:113-119
-        y = ops.mul_sigma(x, sigma, self.sub_samp)                                     # B:120-124
+        y, sigma = ops.gate_sigma_mul(theta_x, phi_g, self.psi.kernel, self.psi.bias, x, self.sub_samp)   # B:113-124, one launch
         Wy_raw, sW = self.W(y, stats=True)
         W_y = self.normW(Wy_raw, 1.0, sW)                                              # B:127-128
         return W_y, sigma
