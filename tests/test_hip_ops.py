@@ -420,6 +420,77 @@ def test_mul_sigma_fwd_bwd(dev, dtype, C, dims, ss):
     assert rel_err(sd.grad, gs) < tol * 2
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("Ci,Cx,dims,ss,coarse", [(8, 16, (4, 8, 8), (1, 2, 2), (2, 2, 2)), (32, 32, (2, 4, 6), (1, 1, 1), (1, 2, 3)),
+                                                  (16, 8, (4, 8, 4), (2, 2, 2), (1, 2, 1))])
+def test_gate_sigma_mul_is_the_two_calls_in_one_launch(dev, dtype, Ci, Cx, dims, ss, coarse):
+    """m1_gate_sigma_mul_fwd (round 6; network_blocks.py:113-124): sigma and y = sigma_up * x from ONE launch are BIT-identical to
+    gate_sigma followed by mul_sigma (the product reads the stored, rounded sigma), and the fused backward passes (product: dx and
+    d(sigma) in one pass; sigma: d(theta), d(phi), d(w_psi), d(b_psi) in one pass + one fold) match the oracle."""
+    N = 2
+    tdims = tuple(d // s_ for d, s_ in zip(dims, ss))                       # theta / sigma grid
+    pdims = tuple(t // c for t, c in zip(tdims, coarse))                    # phi grid
+    theta, phi, x = rnd((N, *tdims, Ci), 1), rnd((N, *pdims, Ci), 2), rnd((N, *dims, Cx), 3)
+    w, b = rnd((1, 1, 1, Ci, 1), 4, 0.3), rnd((1,), 5)
+    dy = rnd((N, *dims, Cx), 6)
+    if dtype == torch.bfloat16:
+        theta, phi, x, dy = (t.bfloat16().float() for t in (theta, phi, x, dy))
+
+    def fn(t_, p_, w_, b_, x_):
+        f = O.lrelu(t_ + O.upsample_nearest(p_, coarse))
+        sg = torch.sigmoid(O.conv3d_same(f, w_, b_, (1, 1, 1)))
+        if dtype == torch.bfloat16:
+            sg = sg + (sg.detach().float().bfloat16().double() - sg.detach())     # the product sees the stored sigma
+        return O.upsample_nearest(sg, ss) * x_
+    yo, (gt, gp, gw, gb, gx) = _oracle_grads(fn, [theta, phi, w, b, x], dy)
+
+    def run(fused):
+        td, pd, xd = (t.to(dev, dtype).requires_grad_(True) for t in (theta, phi, x))
+        wd, bd = w.to(dev).requires_grad_(True), b.to(dev).requires_grad_(True)
+        with ops.config(M1_GATE_FWD_FUSED=int(fused), M1_GATE_MUL_BWD_FUSED=int(fused), M1_GATE_BWD_FUSED=int(fused)):
+            if fused:
+                y, sg = ops._GateSigmaMul.apply(td, pd, wd, bd, xd, ss)
+            else:
+                sg = ops.gate_sigma(td, pd, wd, bd); y = ops.mul_sigma(xd, sg, ss)
+            y.backward(dy.to(dev, dtype))
+        return y.detach(), sg.detach(), [t.grad for t in (td, pd, wd, bd, xd)]
+    y1, s1, g1 = run(True)
+    y0, s0, g0 = run(False)
+    assert torch.equal(y1, y0) and torch.equal(s1, s0)
+    assert torch.equal(g1[0], g0[0]) and torch.equal(g1[1], g0[1]) and torch.equal(g1[4], g0[4])      # d(theta), d(phi), dx: same arithmetic
+    tol = TOL[dtype]
+    assert rel_err(y1, yo) < tol
+    for got, want, name in zip(g1, (gt, gp, gw, gb, gx), ("dtheta", "dphi", "dw", "db", "dx")):
+        assert rel_err(got, want) < tol * 2, name
+
+
+def test_conv_mfma_k_groups_inside_the_block(dev):
+    """conv_mfma_kernel<.., KG> (round 6): the (10,20,20) level's 64 -> 64 3x3x3 convs carry their K split as wave groups of one block
+    (no slabs, no finish pass), tile the samples one by one (4,000 voxels are no multiple of 64) and emit the InstanceNorm statistics
+    from their epilogue: forward + statistics + data gradient against the oracle, kernel asserted; the slab path gives the same."""
+    N, dims, C = 4, (10, 20, 20), 64
+    x = rnd((N, *dims, C), 1).bfloat16().float()
+    w = rnd((3, 3, 3, C, C), 2, 1.0 / (27 * C) ** 0.5); b = rnd((C,), 3)
+    dy = rnd((N, *dims, C), 4).bfloat16().float()
+    wq = w.bfloat16().float()
+    yo, (gx,) = _oracle_grads(lambda x_: O.conv3d_same(x_, wq.double(), b.double(), (1, 1, 1)), [x], dy)
+    outs = []
+    for kg in (1, 0):
+        xd = x.to(dev, torch.bfloat16).requires_grad_(True)
+        wd, bd = w.to(dev), b.to(dev)
+        with ops.config(M1_MFMA_KG=kg), ops.kernel_log() as kl:
+            y, st = ops.conv3d_same([xd], wd, bd, (3, 3, 3), (1, 1, 1), True)
+            y.backward(dy.to(dev, torch.bfloat16))
+        names = [n for n in kl.names if n.startswith("conv_mfma")]
+        assert names and all((":kg" in n) == bool(kg) for n in names), kl.names
+        assert rel_err(y, yo) < TOL[torch.bfloat16] and rel_err(xd.grad, gx) < TOL[torch.bfloat16] * 2
+        yr = y.detach().float().cpu().double()
+        mean = yr.reshape(N, -1, C).mean(1)
+        assert float((st[..., 0].cpu().double() - mean).abs().max()) < 1e-4
+        outs.append((y.detach(), st.detach()))
+    assert rel_err(outs[0][0], outs[1][0]) < 1e-2 and rel_err(outs[0][1], outs[1][1]) < 1e-3
+
+
 @pytest.mark.parametrize("L", [1, 2, 3])
 def test_latent_sample_and_kl(dev, L):
     N, V = 2, (3, 4, 5)
