@@ -1,4 +1,5 @@
 #!/bin/bash
+# NOTE: the knobs this script sweeps exist only with profiles/r06_conv_mfma_ring_and_chunk_table.patch applied (prototype measured and not kept, round 6)
 # conv_mfma chunk-table loader A/B (M1_MFMA_CTAB=0 / 1): kernel time from a trace, per layer
 R=${GRAFT_REPO_ROOT:-$(pwd)}; out=${1:-$R/gpurun_out/mfma_ctab.txt}; : > $out
 cd /tmp; export TMPDIR=/tmp

@@ -1,4 +1,5 @@
 #!/bin/bash
+# NOTE: the knobs this script sweeps exist only with profiles/r06_conv_mfma_ring_and_chunk_table.patch applied (prototype measured and not kept, round 6)
 # which part of conv_mfma costs what (kernel time from a trace): M1_MFMA_DBG bit 0 = no fragment reads / MFMAs, 2 = no DMA, 4 = no loader
 # bookkeeping, 8 = return before the K loop, 16 = return before the epilogue (results are garbage)
 R=${GRAFT_REPO_ROOT:-$(pwd)}; out=${1:-$R/gpurun_out/mfma_dbg.txt}; : > $out

@@ -1,4 +1,5 @@
 #!/bin/bash
+# NOTE: the knobs this script sweeps exist only with profiles/r06_conv_mfma_ring_and_chunk_table.patch applied (prototype measured and not kept, round 6)
 # conv_mfma LDS-DMA ring depth A/B on the layers of the C3 step that run on the implicit-GEMM kernel (strided, transposed, small 3x3x3)
 # usage (GPU box): bash tools/dbg/mfma_stages.sh [outfile]
 cd "$(dirname "$0")/../.."
