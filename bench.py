@@ -195,7 +195,7 @@ def hbm_traffic(wl, dtype, B, recs, family, prof_steps):
     FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).  None when no committed measurement matches."""
     pdir = os.path.join(ROOT, "profiles")
     path = None
-    for rnd in ("r05", "r04", "r03", "r02", "r01"):
+    for rnd in ("r06", "r05", "r04", "r03", "r02", "r01"):
         cand = os.path.join(pdir, f"{rnd}_{wl.lower()}_{dtype}_hbm_traffic.json")
         if os.path.exists(cand):
             path = cand
