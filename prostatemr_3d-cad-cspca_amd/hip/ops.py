@@ -260,6 +260,35 @@ _FOLD = {"on": _os.environ.get("M1_WG_FOLD_BATCH", "1") != "0", "keep": [],
          "async_mb": int(_os.environ.get("M1_FOLD_ASYNC_MB", "0")), "bytes": 0}
 
 
+# Deferred weight gradients of the deep levels (round 6).  A weight gradient feeds nothing before the optimiser, and the skip test of
+# round 6 showed that the replayed step is the SUM of its kernels -- except for what runs on the fold stream, which rides for free next
+# to the data-gradient chain.  Weight gradients are therefore not launched where autograd calls them: they are queued (operands kept
+# alive) and launched, in call order, on the fold stream with the next batch of folds -- no fork / join per op (weight gradients on
+# streams of their own WITH a fork and a join each were measured slower in rounds 2, 3 and 6).  M1_WG_DEFER_VOX limits this to layers
+# with at most that many input voxels per launch (0 = launch in place, round 5).  Same box, C3: in place 22.76 ms, <= 16,000 voxels
+# 22.6, <= 520,000 22.29, all 22.00 ms (90.9 volumes/s) at a batch interval of 11-13 (M1_FOLD_ASYNC; 8: 23.6, 16: 22.8, 24: 22.8);
+# profiles/r06_ab_deferred_weight_gradients.txt.
+_WGP = {"maxvox": int(_os.environ.get("M1_WG_DEFER_VOX", str(1 << 40)) or 0), "jobs": [], "extra": []}
+
+
+def _run_deferred_wgrads(stream_handle, stream) -> None:
+    """Launch the queued weight gradients (in call order) on ``stream``; the caller has ordered it behind their operands."""
+    jobs, _WGP["jobs"] = _WGP["jobs"], []
+    if not jobs:
+        return
+    lib = L.load()
+    lib.m1_wgrad_defer(1)
+    try:
+        for fn, d, dy, wbuf, bbuf, ws, acc_w, _srcs in jobs:
+            L.check(fn(C.byref(d), _p(dy), _p(wbuf), _p(bbuf), _p(ws), acc_w, stream_handle), "m1_conv3d_wgrad (deferred)")
+    finally:
+        lib.m1_wgrad_defer(0)
+    for t, made_on in _WGP["extra"]:
+        if made_on != stream:
+            t.record_stream(stream)
+    _WGP["extra"] = []
+
+
 def fold_async_default(n: int) -> None:
     """Model-level default of the M1_FOLD_ASYNC interval (the environment variable wins).  Measured optimum, same box: 10-12 for
     the hierarchical probabilistic model (~130 weight gradients per step: 26.7 ms against 27.3 at 24, 27.7 without, 27.6-27.9
@@ -285,6 +314,7 @@ def _fold_async() -> None:
     _BRANCH["used"].add(fs)
     try:
         with torch.cuda.stream(fs):
+            _run_deferred_wgrads(fs.cuda_stream, fs)
             L.check(L.load().m1_wgrad_fold_pending(fs.cuda_stream), "m1_wgrad_fold_pending")
         for ws, made_on in _FOLD["keep"]:
             if made_on != fs:
@@ -297,6 +327,7 @@ def fold_pending() -> None:
     """Run the queued weight-gradient folds on the current stream (which must be ordered behind the weight-gradient kernels)."""
     if _FOLD["keep"]:
         try:
+            _run_deferred_wgrads(_stream(), torch.cuda.current_stream())
             L.check(L.load().m1_wgrad_fold_pending(_stream()), "m1_wgrad_fold_pending")
             cur = torch.cuda.current_stream()
             for ws, made_on in _FOLD["keep"]:
@@ -338,6 +369,7 @@ def exchange_streams():
 
 
 def fold_drop() -> None:
+    _WGP["jobs"], _WGP["extra"] = [], []
     if _FOLD["keep"]:
         L.load().m1_wgrad_fold_drop()
         _FOLD["keep"].clear(); _FOLD["bytes"] = 0
@@ -738,12 +770,19 @@ def _wgrad_into_sinks(lib, d, dy, w_param, b_param, transposed: bool, st, srcs=(
     flat = dw is None and db is None
     ws = _conv_ws(d, transposed, 2, w_param.device)
     if flat and _FOLD["on"]:
-        lib.m1_wgrad_defer(1)
-        try:
-            L.check(fn(C.byref(d), _p(dy), _p(wbuf), _p(bbuf), _p(ws), acc_w, st), "m1_conv3d_wgrad")
-        finally:
-            lib.m1_wgrad_defer(0)
-        _FOLD["keep"].append((ws, torch.cuda.current_stream(w_param.device)))
+        cur_ = torch.cuda.current_stream(w_param.device)
+        if (_WGP["maxvox"] > 0 and _BRANCH["on"] and _BRANCH.get("origin") is not None and
+                int(d.N) * int(d.D) * int(d.H) * int(d.W) <= _WGP["maxvox"]):
+            # queued: launched on the fold stream with the next batch (operands referenced until then, see _run_deferred_wgrads)
+            _WGP["jobs"].append((fn, d, dy, wbuf, bbuf, ws, acc_w, tuple(srcs)))
+            _WGP["extra"].extend((t, cur_) for t in (dy, *srcs))
+        else:
+            lib.m1_wgrad_defer(1)
+            try:
+                L.check(fn(C.byref(d), _p(dy), _p(wbuf), _p(bbuf), _p(ws), acc_w, st), "m1_conv3d_wgrad")
+            finally:
+                lib.m1_wgrad_defer(0)
+        _FOLD["keep"].append((ws, cur_))
         if transposed and bbuf is not None:
             # the bias gradient of a transposed conv is queued with the folds (norm.hip: m1_colsum_defer): d(out) is read at the fold
             _FOLD["keep"].append((dy, torch.cuda.current_stream(w_param.device)))

@@ -520,7 +520,7 @@ class M1Net(nn.Module):
         self._summarised = False
         self.grad_marker = None          # ddp.GradReducer.mark of a data-parallel run (M1.set_grad_marker)
         self.stack_passes = True         # probabilistic training graph: 4 core passes as 2 stacked along the batch axis
-        ops.fold_async_default(12 if self.probabilistic else 24)
+        ops.fold_async_default(12)       # (round 6, with the weight gradients themselves on the fold stream: 11-13 for both model kinds)
         self.last: Dict[str, torch.Tensor] = {}
         common = dict(num_classes=num_classes, dropout_mode=dropout_mode, dropout_rate=dropout_rate, filters=filters,
                       strides=strides, kernel_sizes=kernel_sizes, se_reduction=se_reduction, att_sub_samp=att_sub_samp,
