@@ -1135,13 +1135,15 @@ static int run_mfma(const GatherSpec& g, void* ws, int ws_packed, hipStream_t st
         pwBN = BN > 32 ? 32 : BN;
         if (!halo && !t3 && m1_pw_conv_supported(mp, OCpad, pwBN)) {
             int parts = m1_pw_conv_stat_parts(mp, OCpad, pwBN);
-            const int cap = (int)((Vout + 63) / 64) / 4 * 4;          // what the statistics workspace holds per sample
+            const int cap = (int)m1_stats_rows_cap(Vout) / 4 * 4;     // what the statistics workspace holds per sample
             if (parts > cap) parts = cap;
             // InstanceNorm-backward sums from the streaming kernel's register epilogue (round 4): one partial row per (sample, wave)
-            const bool ib_pw = ib_want && pl.ksplit == 1 && g.OC % 4 == 0 && Vout % 32 == 0 && parts >= 4 && parts <= g.ib_cap;
+            // (its rows go to the caller's partial buffer: as many waves as THAT holds)
+            const int parts_ib = parts < g.ib_cap / 4 * 4 ? parts : g.ib_cap / 4 * 4;
+            const bool ib_pw = ib_want && pl.ksplit == 1 && g.OC % 4 == 0 && Vout % 32 == 0 && parts_ib >= 4;
             if (ib_pw) {
                 mp.ib_x = g.ib_x; mp.ib_stats = g.ib_stats; mp.ib_gamma = g.ib_gamma; mp.ib_beta = g.ib_beta; mp.ib_slope = g.ib_slope;
-                mp.stat_partial = g.ib_partial; mp.stat_tiles = parts; ib_epi = true; fuse_stats = false;
+                mp.stat_partial = g.ib_partial; mp.stat_tiles = parts_ib; ib_epi = true; fuse_stats = false;
             } else {
                 if (ib_epi) { ib_epi = false; mp.ib_x = nullptr; }
                 if (g.stats_out && g.stats_ws && g.mode == 0 && !g.accumulate && parts >= 4) {

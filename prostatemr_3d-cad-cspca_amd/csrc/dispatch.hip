@@ -527,7 +527,7 @@ extern "C" int m1_conv3d_dgrad(const m1_conv_desc_t* d, const float* w, const vo
 extern "C" int m1_conv3d_dgrad_inbwd_rows(const m1_conv_desc_t* d) {
     if (!desc_ok(d)) return 0;
     const long long V = (long long)d->D * d->H * d->W;
-    const long long tiles = cdiv_ll(V, 64), chunks = m1_red_nchunks(V, d->Cin, d->N);
+    const long long tiles = m1_stats_rows_cap(V), chunks = m1_red_nchunks(V, d->Cin, d->N);     // (>= one row per 64 voxels)
     const long long r = tiles > chunks ? tiles : chunks;
     return r > 0x3fffffff ? 0x3fffffff : (int)r;
 }

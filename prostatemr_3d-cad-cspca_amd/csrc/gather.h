@@ -90,6 +90,7 @@ int m1_pwf_wgrad(const WgradSpec& g, long long nw, int nb, hipStream_t st);
 int m1_colsum_internal(const void* x, int N, long long V, int C, int dtype, float* out, float* ws, hipStream_t st, int accumulate);
 
 // deferred-fold switch of m1_wg_rx_finish (wgrad_tf.hip): returns the previous setting
+long long m1_stats_rows_cap(long long V);       // partial rows per sample of a statistics workspace (norm.hip)
 int m1_fold_defer_set(int on);
 int m1_fold_defer_get();
 // deferred bias gradients of the transposed convs (norm.hip): queued under m1_wgrad_defer, launched by m1_wgrad_fold_pending

@@ -39,9 +39,17 @@ static int stats_impl(const void* x, int N, long long V, int C, float eps, float
 int m1_stats_internal(const void* x, int N, long long V, int C, int dtype, float eps, float* stats, float* ws, hipStream_t st) {
     return dtype == M1_BF16 ? stats_impl<bf16_t>(x, N, V, C, eps, stats, ws, st) : stats_impl<float>(x, N, V, C, eps, stats, ws, st);
 }
+// Partial rows per sample a statistics workspace holds: one per 64 voxels, and on small volumes up to 256 (one per 16 voxels) so that
+// the pointwise kernel -- one row per (sample, wave) -- is not held to 8 / 60 waves per column slice on the (5,10,10) / (10,20,20)
+// levels by the capacity of its own statistics rows (round 6: 64 -> 256 at (4,10,20,20) ran 8 tiles per wave in a row, 27-32 us).
+long long m1_stats_rows_cap(long long V) {
+    const long long a = (V + 63) / 64; long long b = (V + 15) / 16; if (b > 256) b = 256;
+    if (!M1_CFG("M1_STATS_ROWS_SMALL", 1)) b = 0;          // (0: one row per 64 voxels everywhere, round 5)
+    return a > b ? a : b;
+}
 // floats needed by either the fused-epilogue partials (one per 64-row tile at worst) or the stand-alone reduction
 size_t m1_stats_ws_floats(int N, long long V, int C) {
-    const size_t fused = (size_t)N * (size_t)((V + 63) / 64) * C * 2;
+    const size_t fused = (size_t)N * (size_t)m1_stats_rows_cap(V) * C * 2;
     const size_t alone = m1_reduce_ws_floats(N, V, C, 2);
     return (fused > alone ? fused : alone) + 64;
 }
